@@ -1,0 +1,191 @@
+/*
+ * pokerrl_hip.h -- C ABI of libpokerrl_hip.so, the MI355X (gfx950) native replacement for PokerRL's tabular hot path:
+ * public-tree CFR / exact best response, range-vs-range terminal equity, the 7-card hand evaluator and the card/hand
+ * index look-up tables.
+ *
+ * Boundary rules:
+ *   - plain C, `extern "C"`, pointers + sizes only; no torch / numpy / C++ types cross it;
+ *   - every host buffer is allocated AND owned by the caller, the callee only reads inputs and fills outputs;
+ *   - device memory lives behind opaque handles created / destroyed explicitly;
+ *   - new entry points return an int32 status (PRL_OK == 0, negative = error) and set prl_last_error(); nothing aborts;
+ *   - a handle is not thread-safe, different handles are; each handle owns its HIP stream.
+ *
+ * Each group below cites the reference interface it replaces (paths under the upstream PokerRL repository).
+ */
+#ifndef POKERRL_HIP_H
+#define POKERRL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* constants                                                                                                         */
+/* ---------------------------------------------------------------------------------------------------------------- */
+#define PRL_MAX_BET_SIZES 96
+
+/* status codes */
+#define PRL_OK 0
+#define PRL_ERR_ARG (-1)
+#define PRL_ERR_NO_DEVICE (-2)
+#define PRL_ERR_HIP (-3)
+#define PRL_ERR_UNSUPPORTED (-4)
+#define PRL_ERR_OOM (-5)
+#define PRL_ERR_STATE (-6)
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* plain-old-data descriptions of a game (reference: PokerRL/game/games.py:18-269, game_rules.py:15-312)              */
+/* ---------------------------------------------------------------------------------------------------------------- */
+typedef struct PrlRules {
+    int32_t n_hole_cards;            /* 1 (Leduc family) or 2 (Hold'em family) */
+    int32_t n_ranks;
+    int32_t n_suits;
+    int32_t n_cards;                 /* n_ranks * n_suits */
+    int32_t range_size;              /* C(n_cards, n_hole_cards) */
+    int32_t n_rounds;                /* len(ALL_ROUNDS_LIST) */
+    int32_t board_cards_in_round[4]; /* cards dealt in the transition TO round r */
+    int32_t n_board_cards;
+    int32_t btn_first_postflop;
+    int32_t rank_rule;               /* 0 Leduc (100 + rank), 1 BigLeduc (10000 + rank), 2 52-card hold'em evaluator */
+} PrlRules;
+
+typedef struct PrlGame {
+    int32_t game_type;               /* 0 fixed-limit, 1 discretized no-limit, 2 no-limit */
+    int32_t n_rounds;
+    int32_t small_blind, big_blind, ante;
+    int32_t small_bet, big_bet;
+    int32_t round_big_bet_starts;
+    int32_t max_raises[4];
+    int32_t first_action_no_call;
+    int32_t btn_first_postflop;
+    int32_t pot_size_raise;          /* Flop5Holdem: every raise is pot-sized (games.py:253-254) */
+    int32_t n_bet_sizes;
+    int32_t start_stack[2];
+    double bet_fracs[PRL_MAX_BET_SIZES]; /* ascending */
+} PrlGame;
+
+/* public betting state of one heads-up env (reference: PokerEnv.state_dict, PokerEnv.py:1161-1197, HU subset) */
+typedef struct PrlEnvState {
+    int32_t round;
+    int32_t main_pot;
+    int32_t bet[2];
+    int32_t stack[2];
+    int8_t allin[2];
+    int8_t folded[2];
+    int8_t acted[2];
+    int8_t cur;                 /* seat to act */
+    int8_t last_raiser;         /* -1 = None */
+    int8_t capped_happened;
+    int8_t capped_raiser;       /* -1 = None */
+    int8_t capped_cant_reopen;  /* -1 = None */
+    int8_t pad0;
+    int32_t n_actions_ep;       /* counts raises only (PokerEnv.py:724) */
+    int32_t n_raises_round;
+    int32_t last_action[3];     /* type, amount, seat (-1 = None) */
+} PrlEnvState;
+
+/* result of one step: the `info` dict of PokerEnv._step with RETURN_PRE_TRANSITION_STATE_IN_INFO (PokerEnv.py:737-787) */
+typedef struct PrlStepInfo {
+    int32_t is_terminal;
+    int32_t chance_acts;        /* round transition: cards must be dealt before play continues */
+    int32_t terminal_is_fold;   /* only one player left */
+    int32_t rundown;            /* terminal reached through an all-in run-out */
+    int32_t pot_before_payout;  /* main pot after the bet sweep, before any payout */
+    int32_t fixed_type, fixed_amount; /* the action after _get_fixed_action */
+} PrlStepInfo;
+
+const char* prl_last_error(void);
+/* 1 if a HIP device is usable by this library build, else 0 (never throws) */
+int32_t prl_device_available(void);
+/* compile-time identification: "hip-gfx950" for the product build */
+const char* prl_build_flavor(void);
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* 1. Legacy symbols: drop-in for the reference's binary-only lib_luts.so / lib_hand_eval.so                           */
+/*    (ctypes call sites: PokerRL/game/_/cpp_wrappers/CppLUT.py:16-94, CppHandeval.py:19-65;                           */
+/*     2-D arrays arrive as vectors of ROW POINTERS, PokerRL/_/CppWrapper.py:14,24-27).                                 */
+/*    Signatures are the reference's; sizes are fixed by the 52-card deck.                                             */
+/* ---------------------------------------------------------------------------------------------------------------- */
+int8_t get_1d_card(const int8_t* card_2d);                       /* CppLUT.py:73-82   rank*4+suit          */
+void get_2d_card(int8_t card_1d, int8_t* out_card_2d);           /* CppLUT.py:84-94   (c/4, c%4)           */
+void get_idx_2_hole_card_lut(int8_t** out_1326x2);               /* CppLUT.py:38-41                          */
+void get_hole_card_2_idx_lut(int16_t** out_52x52);               /* CppLUT.py:43-47   upper triangle only   */
+/* CppHandeval.py:34-43: hand_2d[2][2], board_2d[5][2] as (rank, suit) rows. Scalar call -> host evaluator. */
+int32_t get_hand_rank_52_holdem(int8_t** hand_2d, int8_t** board_2d);
+/* CppHandeval.py:45-65: out[N][1326] pre-filled with -1 by the caller; boards_1d[N][5]; the two LUT arguments of the
+ * reference are accepted and ignored (the library owns identical tables). Runs on the GPU. */
+void get_hand_rank_all_hands_on_given_boards_52_holdem(int32_t** out, int8_t** boards_1d, int32_t n_boards,
+                                                       int8_t** lut_idx_2_hole_cards, int8_t** lut_1d_2_2d);
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* 2. Flat-pointer LUT / evaluator API (what new callers bind)                                                        */
+/*    replaces look_up_table.py:95-134,191-220 and game_rules.py:213-223                                               */
+/* ---------------------------------------------------------------------------------------------------------------- */
+int32_t prl_lut_idx_2_hole_cards(const PrlRules* rules, int8_t* out /* [range_size][n_hole_cards] */);
+int32_t prl_lut_hole_cards_2_idx(const PrlRules* rules, int16_t* out /* [n_cards][n_cards], -2 where undefined */);
+int32_t prl_lut_card_in_what_range_idxs(const PrlRules* rules, int32_t* out /* [n_cards][n_cards-1] or [n_cards][1] */);
+/* host scalar evaluator: 7 cards of the 52-card deck as 1d cards */
+int32_t prl_hand_rank_7(const int8_t* board_1d /*[5]*/, int8_t c1, int8_t c2);
+/* batched evaluator on the GPU, host buffers in and out: ranks[n][1326] int32, -1 for hands blocked by the board */
+int32_t prl_hand_rank_boards(const int8_t* boards_1d /*[n][5]*/, int32_t n_boards, int32_t* out_ranks);
+/* same, device pointers in and out (no copies); stream = hipStream_t or NULL */
+int32_t prl_hand_rank_boards_device(const void* d_boards_1d, int32_t n_boards, void* d_out_ranks, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* 3. Public tree (host): replaces PublicTree.build_tree (PokerRL/game/_/tree/PublicTree.py:111-126,161-293)           */
+/* ---------------------------------------------------------------------------------------------------------------- */
+typedef struct prl_tree prl_tree_t;
+
+/* boards: the chance outcomes, one row of `board_len` 1d cards per board, in child order */
+int32_t prl_tree_build(const PrlGame* game, const PrlRules* rules, const int8_t* boards, int32_t n_boards,
+                       int32_t board_len, prl_tree_t** out_tree);
+void prl_tree_destroy(prl_tree_t* tree);
+
+enum {
+    PRL_TI_N_NODES = 0, PRL_TI_N_COLS = 1, PRL_TI_N_BOARDS = 2, PRL_TI_BOARD_LEN = 3, PRL_TI_N_LEVELS = 4,
+    PRL_TI_RANGE_SIZE = 5, PRL_TI_N_DECISION = 6, PRL_TI_N_TERMINAL = 7, PRL_TI_COUNT = 8
+};
+int32_t prl_tree_info(const prl_tree_t* tree, int32_t* out_info /* [PRL_TI_COUNT] */);
+
+enum {
+    PRL_TF_KIND = 0,        /* 0 decision, 1 chance, 2 terminal fold, 3 terminal showdown            [n_nodes] */
+    PRL_TF_ACTOR = 1,       /* seat to act, -1 for chance / terminal                                 [n_nodes] */
+    PRL_TF_PARENT = 2,
+    PRL_TF_CHILD_IDX = 3,   /* position in the parent's child list                                    */
+    PRL_TF_ACTION = 4,      /* env action int that produced the node, -1 for "CHANCE"/root            */
+    PRL_TF_ACTED_LAST = 5,  /* seat that produced the node, -2 chance, -1 root                        */
+    PRL_TF_ROUND = 6,
+    PRL_TF_BOARD_ID = 7,    /* row of the board table, -1 before the deal                             */
+    PRL_TF_MAIN_POT = 8,
+    PRL_TF_DEPTH = 9,
+    PRL_TF_N_CHILDREN = 10,
+    PRL_TF_FIRST_COL = 11,  /* first action column of a decision node, -1 otherwise                   */
+    PRL_TF_SUBTREE_SIZE = 12,
+    PRL_TF_CHILD_START = 13, /* CSR offsets                                                   [n_nodes+1] */
+    PRL_TF_CHILD_LIST = 14,  /* CSR payload                                                   [n_nodes-1] */
+    PRL_TF_COL_ACTION = 15,  /* env action int of each action column                            [n_cols] */
+    PRL_TF_COL_NODE = 16,    /* owning decision node of each action column                      [n_cols] */
+    PRL_TF_LEVEL_START = 17, /*                                                               [n_levels+1] */
+    PRL_TF_LEVEL_NODES = 18  /* node ids grouped by depth                                       [n_nodes] */
+};
+int32_t prl_tree_get(const prl_tree_t* tree, int32_t field, int32_t* out);
+
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* 4. Heads-up betting engine, one env on the host (tree construction, tests, Python PokerEnv facade).                 */
+/*    replaces PokerEnv.{reset,step,get_legal_actions} public-state semantics (PokerEnv.py:681-789,885-941,1075-1122;  */
+/*    LimitPokerEnv.py:27-59; DiscretizedPokerEnv.py:44-135). Cards are dealt by the caller.                           */
+/* ---------------------------------------------------------------------------------------------------------------- */
+int32_t prl_env_reset_host(const PrlGame* game, PrlEnvState* state);
+int32_t prl_env_step_host(const PrlGame* game, PrlEnvState* state, int32_t action_int, PrlStepInfo* out_info);
+/* processed (type, amount) form == PokerEnv.step_from_processed_tuple */
+int32_t prl_env_step_processed_host(const PrlGame* game, PrlEnvState* state, int32_t type, int32_t amount, PrlStepInfo* out_info);
+int32_t prl_env_legal_actions_host(const PrlGame* game, const PrlEnvState* state, int32_t* out_actions, int32_t* out_n);
+int32_t prl_env_fraction_of_pot_raise_host(const PrlEnvState* state, double fraction, int32_t seat, int32_t* out_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POKERRL_HIP_H */

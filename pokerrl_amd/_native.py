@@ -1,0 +1,251 @@
+"""
+ctypes binding of libpokerrl_hip.so (C ABI declared in include/pokerrl_hip.h).
+
+This is the ONLY way the package reaches the hot path. There is no Python / NumPy / CPU fallback: if the shared library
+is missing the import raises, and every device entry point raises `NativeError` when no HIP device is usable. (Same role
+as the reference's PokerRL/_/CppWrapper.py:10-27, but with flat pointers + explicit sizes and int32 status codes.)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("POKERRL_AMD_LIB", os.path.join(_HERE, "lib", "libpokerrl_hip.so"))
+
+PRL_MAX_BET_SIZES = 96
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class PrlRules(ctypes.Structure):
+    _fields_ = [
+        ("n_hole_cards", ctypes.c_int32), ("n_ranks", ctypes.c_int32), ("n_suits", ctypes.c_int32),
+        ("n_cards", ctypes.c_int32), ("range_size", ctypes.c_int32), ("n_rounds", ctypes.c_int32),
+        ("board_cards_in_round", ctypes.c_int32 * 4), ("n_board_cards", ctypes.c_int32),
+        ("btn_first_postflop", ctypes.c_int32), ("rank_rule", ctypes.c_int32),
+    ]
+
+
+class PrlGame(ctypes.Structure):
+    _fields_ = [
+        ("game_type", ctypes.c_int32), ("n_rounds", ctypes.c_int32),
+        ("small_blind", ctypes.c_int32), ("big_blind", ctypes.c_int32), ("ante", ctypes.c_int32),
+        ("small_bet", ctypes.c_int32), ("big_bet", ctypes.c_int32), ("round_big_bet_starts", ctypes.c_int32),
+        ("max_raises", ctypes.c_int32 * 4), ("first_action_no_call", ctypes.c_int32),
+        ("btn_first_postflop", ctypes.c_int32), ("pot_size_raise", ctypes.c_int32), ("n_bet_sizes", ctypes.c_int32),
+        ("start_stack", ctypes.c_int32 * 2), ("bet_fracs", ctypes.c_double * PRL_MAX_BET_SIZES),
+    ]
+
+
+class PrlEnvState(ctypes.Structure):
+    _fields_ = [
+        ("round", ctypes.c_int32), ("main_pot", ctypes.c_int32), ("bet", ctypes.c_int32 * 2),
+        ("stack", ctypes.c_int32 * 2), ("allin", ctypes.c_int8 * 2), ("folded", ctypes.c_int8 * 2),
+        ("acted", ctypes.c_int8 * 2), ("cur", ctypes.c_int8), ("last_raiser", ctypes.c_int8),
+        ("capped_happened", ctypes.c_int8), ("capped_raiser", ctypes.c_int8), ("capped_cant_reopen", ctypes.c_int8),
+        ("pad0", ctypes.c_int8), ("n_actions_ep", ctypes.c_int32), ("n_raises_round", ctypes.c_int32),
+        ("last_action", ctypes.c_int32 * 3),
+    ]
+
+
+class PrlStepInfo(ctypes.Structure):
+    _fields_ = [
+        ("is_terminal", ctypes.c_int32), ("chance_acts", ctypes.c_int32), ("terminal_is_fold", ctypes.c_int32),
+        ("rundown", ctypes.c_int32), ("pot_before_payout", ctypes.c_int32), ("fixed_type", ctypes.c_int32),
+        ("fixed_amount", ctypes.c_int32),
+    ]
+
+
+# tree info / field ids (include/pokerrl_hip.h)
+TI_N_NODES, TI_N_COLS, TI_N_BOARDS, TI_BOARD_LEN, TI_N_LEVELS, TI_RANGE_SIZE, TI_N_DECISION, TI_N_TERMINAL, TI_COUNT = range(9)
+TREE_FIELDS = dict(kind=0, actor=1, parent=2, child_idx=3, action=4, acted_last=5, round=6, board_id=7, main_pot=8,
+                   depth=9, n_children=10, first_col=11, subtree_size=12, child_start=13, child_list=14, col_action=15,
+                   col_node=16, level_start=17, level_nodes=18)
+
+_lib = None
+
+
+def _ptr(a, ctype=None):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def lib():
+    """Loads the shared library once. Raises NativeError (never falls back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise NativeError(
+            "pokerrl_amd: native library %s not found. Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.prl_last_error.restype = ctypes.c_char_p
+    L.prl_build_flavor.restype = ctypes.c_char_p
+    L.prl_device_available.restype = ctypes.c_int32
+    for name in ("prl_lut_idx_2_hole_cards", "prl_lut_hole_cards_2_idx", "prl_lut_card_in_what_range_idxs"):
+        getattr(L, name).argtypes = [ctypes.POINTER(PrlRules), ctypes.c_void_p]
+        getattr(L, name).restype = ctypes.c_int32
+    L.prl_hand_rank_7.argtypes = [ctypes.c_void_p, ctypes.c_int8, ctypes.c_int8]
+    L.prl_hand_rank_7.restype = ctypes.c_int32
+    L.prl_hand_rank_boards.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    L.prl_hand_rank_boards.restype = ctypes.c_int32
+    L.prl_hand_rank_boards_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    L.prl_hand_rank_boards_device.restype = ctypes.c_int32
+    L.prl_tree_build.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), ctypes.c_void_p, ctypes.c_int32,
+                                 ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+    L.prl_tree_build.restype = ctypes.c_int32
+    L.prl_tree_destroy.argtypes = [ctypes.c_void_p]
+    L.prl_tree_destroy.restype = None
+    L.prl_tree_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.prl_tree_info.restype = ctypes.c_int32
+    L.prl_tree_get.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    L.prl_tree_get.restype = ctypes.c_int32
+    L.prl_env_reset_host.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlEnvState)]
+    L.prl_env_reset_host.restype = ctypes.c_int32
+    L.prl_env_step_host.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlEnvState), ctypes.c_int32,
+                                    ctypes.POINTER(PrlStepInfo)]
+    L.prl_env_step_host.restype = ctypes.c_int32
+    L.prl_env_step_processed_host.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlEnvState), ctypes.c_int32,
+                                              ctypes.c_int32, ctypes.POINTER(PrlStepInfo)]
+    L.prl_env_step_processed_host.restype = ctypes.c_int32
+    L.prl_env_legal_actions_host.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlEnvState), ctypes.c_void_p,
+                                             ctypes.POINTER(ctypes.c_int32)]
+    L.prl_env_legal_actions_host.restype = ctypes.c_int32
+    L.prl_env_fraction_of_pot_raise_host.argtypes = [ctypes.POINTER(PrlEnvState), ctypes.c_double, ctypes.c_int32,
+                                                     ctypes.POINTER(ctypes.c_int32)]
+    L.prl_env_fraction_of_pot_raise_host.restype = ctypes.c_int32
+    _bind_solver(L)
+    _lib = L
+    return L
+
+
+def _bind_solver(L):
+    """Device-side solver entry points (declared in include/pokerrl_hip.h section 5)."""
+    if not hasattr(L, "prl_solver_create"):
+        return
+    vp, i32, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_double
+    L.prl_solver_create.argtypes = [vp, i32, i32, ctypes.POINTER(vp)]
+    L.prl_solver_create.restype = i32
+    L.prl_solver_destroy.argtypes = [vp]
+    L.prl_solver_destroy.restype = None
+    for name, args in {
+        "prl_solver_reset": [vp],
+        "prl_solver_iteration": [vp],
+        "prl_solver_iterations": [vp, i32],
+        "prl_solver_fill_uniform": [vp],
+        "prl_solver_set_strategy": [vp, vp, i32],
+        "prl_solver_update_reach": [vp],
+        "prl_solver_compute_ev": [vp],
+        "prl_solver_get": [vp, i32, vp],
+        "prl_solver_exploitability": [vp, vp],
+        "prl_solver_eval_avg": [vp, vp],
+        "prl_solver_sync": [vp],
+        "prl_solver_set_option": [vp, i32, i32],
+        "prl_solver_timing": [vp, vp],
+    }.items():
+        if hasattr(L, name):
+            getattr(L, name).argtypes = args
+            getattr(L, name).restype = i32
+
+
+def check(status):
+    if status != 0:
+        raise NativeError("libpokerrl_hip error %d: %s" % (status, lib().prl_last_error().decode("utf-8", "replace")))
+
+
+def device_available():
+    return bool(lib().prl_device_available())
+
+
+def require_device():
+    if not device_available():
+        raise NativeError("pokerrl_amd: no usable HIP device (MI355X / gfx950 required). There is no CPU fallback for "
+                          "the hot path; tests that need the GPU are marked @pytest.mark.gpu.")
+
+
+def build_flavor():
+    return lib().prl_build_flavor().decode()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# thin wrappers
+# ---------------------------------------------------------------------------------------------------------------------
+def lut_idx_2_hole_cards(rules):
+    out = np.empty((rules.range_size, rules.n_hole_cards), dtype=np.int8)
+    check(lib().prl_lut_idx_2_hole_cards(ctypes.byref(rules), _ptr(out)))
+    return out
+
+
+def lut_hole_cards_2_idx(rules):
+    shape = (rules.n_cards, 1) if rules.n_hole_cards == 1 else (rules.n_cards, rules.n_cards)
+    out = np.empty(shape, dtype=np.int16)
+    check(lib().prl_lut_hole_cards_2_idx(ctypes.byref(rules), _ptr(out)))
+    return out
+
+
+def lut_card_in_what_range_idxs(rules):
+    shape = (rules.n_cards, 1) if rules.n_hole_cards == 1 else (rules.n_cards, rules.n_cards - 1)
+    out = np.empty(shape, dtype=np.int32)
+    check(lib().prl_lut_card_in_what_range_idxs(ctypes.byref(rules), _ptr(out)))
+    return out
+
+
+def hand_rank_7(board_1d, c1, c2):
+    b = np.ascontiguousarray(board_1d, dtype=np.int8)
+    assert b.shape == (5,)
+    return int(lib().prl_hand_rank_7(_ptr(b), int(c1), int(c2)))
+
+
+def hand_rank_boards(boards_1d):
+    """[n, 5] int8 boards -> [n, 1326] int32 ranks (-1 = blocked) on the GPU."""
+    require_device()
+    b = np.ascontiguousarray(boards_1d, dtype=np.int8)
+    assert b.ndim == 2 and b.shape[1] == 5
+    out = np.empty((b.shape[0], 1326), dtype=np.int32)
+    check(lib().prl_hand_rank_boards(_ptr(b), b.shape[0], _ptr(out)))
+    return out
+
+
+class NativeTree:
+    """Owns a prl_tree_t* (host-side flat public tree)."""
+
+    def __init__(self, game, rules, boards_1d):
+        boards = np.ascontiguousarray(boards_1d, dtype=np.int8)
+        assert boards.ndim == 2
+        self._h = ctypes.c_void_p()
+        self._game, self._rules = game, rules
+        check(lib().prl_tree_build(ctypes.byref(game), ctypes.byref(rules), _ptr(boards), boards.shape[0],
+                                   boards.shape[1], ctypes.byref(self._h)))
+        info = np.zeros(TI_COUNT, dtype=np.int32)
+        check(lib().prl_tree_info(self._h, _ptr(info)))
+        self.info = info
+        self.n_nodes, self.n_cols = int(info[TI_N_NODES]), int(info[TI_N_COLS])
+        self.n_boards, self.board_len = int(info[TI_N_BOARDS]), int(info[TI_BOARD_LEN])
+        self.n_levels, self.range_size = int(info[TI_N_LEVELS]), int(info[TI_RANGE_SIZE])
+        self.n_decision, self.n_terminal = int(info[TI_N_DECISION]), int(info[TI_N_TERMINAL])
+        self.boards = boards
+        self._cache = {}
+
+    @property
+    def handle(self):
+        return self._h
+
+    def field(self, name):
+        if name not in self._cache:
+            n = {"child_start": self.n_nodes + 1, "child_list": max(self.n_nodes - 1, 0), "col_action": self.n_cols,
+                 "col_node": self.n_cols, "level_start": self.n_levels + 1}.get(name, self.n_nodes)
+            out = np.empty(n, dtype=np.int32)
+            check(lib().prl_tree_get(self._h, TREE_FIELDS[name], _ptr(out)))
+            self._cache[name] = out
+        return self._cache[name]
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().prl_tree_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -1,0 +1,90 @@
+// SIMT emulator for the CPU test-suite (TEST INFRASTRUCTURE -- never part of the product).
+//
+// Runs the package's HIP kernel SOURCES (pokerrl_amd/csrc/*.hip compiled with g++ -x c++ -DPRL_EMU) on the host so that
+// kernel logic (indexing, barriers, wave-level scans) can be checked against the oracle in the GPU-less CI container.
+// One OS thread; every GPU thread is a ucontext fiber; blocks run one after another; `prl_sync()` and the wave64
+// cross-lane ops are rendezvous points of the fibers of a block / wave. It models lock-step wave64 semantics only --
+// no memory model, no performance. libpokerrl_hip.so is never built this way and pokerrl_amd/ never loads this build.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+
+namespace prl_emu {
+struct Ctx {
+    unsigned tid, bid, bdim, gdim;
+    char* smem;
+};
+extern thread_local Ctx* g_ctx;
+void launch(const std::function<void()>& body, unsigned grid, unsigned block, size_t smem_bytes);
+void block_barrier();
+uint64_t wave_exchange(uint64_t my_value, int src_lane);  // returns the value contributed by src_lane (0 if it exited)
+uint64_t wave_ballot(int pred);
+}  // namespace prl_emu
+
+#define PRL_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    prl_emu::launch([=]() { kernel(__VA_ARGS__); }, (unsigned)(grid), (unsigned)(block), (size_t)(smem))
+
+inline unsigned prl_tid() { return prl_emu::g_ctx->tid; }
+inline unsigned prl_bid() { return prl_emu::g_ctx->bid; }
+inline unsigned prl_nthreads() { return prl_emu::g_ctx->bdim; }
+inline unsigned prl_nblocks() { return prl_emu::g_ctx->gdim; }
+inline unsigned prl_lane() { return prl_emu::g_ctx->tid & 63u; }
+inline void prl_sync() { prl_emu::block_barrier(); }
+inline char* prl_smem() { return prl_emu::g_ctx->smem; }
+
+inline float prl_shfl(float v, int src_lane) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    uint32_t r = (uint32_t)prl_emu::wave_exchange(u, src_lane & 63);
+    float f;
+    memcpy(&f, &r, 4);
+    return f;
+}
+inline float prl_shfl_up(float v, unsigned delta) {
+    int lane = (int)prl_lane();
+    int src = lane - (int)delta;
+    float r = prl_shfl(v, src < 0 ? lane : src);
+    return src < 0 ? v : r;  // HIP semantics: lanes below delta keep their own value
+}
+inline int prl_shfl_i(int v, int src_lane) { return (int)(uint32_t)prl_emu::wave_exchange((uint32_t)v, src_lane & 63); }
+inline int prl_shfl_up_i(int v, unsigned delta) {
+    int lane = (int)prl_lane();
+    int src = lane - (int)delta;
+    int r = prl_shfl_i(v, src < 0 ? lane : src);
+    return src < 0 ? v : r;
+}
+inline unsigned long long prl_ballot(int pred) { return prl_emu::wave_ballot(pred); }
+
+// ---- the sliver of the HIP runtime API the C-ABI layer uses, mapped onto the host heap ---------------------------------
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef struct prl_emu_event* hipEvent_t;
+#define hipSuccess 0
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToHost 2
+#define hipMemcpyDeviceToDevice 3
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
+inline hipError_t hipFree(void* p) { free(p); return 0; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+struct prl_emu_event { double t; };
+double prl_emu_now_ms();
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new prl_emu_event{0}; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = prl_emu_now_ms(); return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }

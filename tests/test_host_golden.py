@@ -1,0 +1,246 @@
+"""
+CPU tests of the host-side C-ABI entry points against fixtures captured from the reference (tests/golden/*.npz):
+index LUTs (lib_luts.so), the scalar 7-card evaluator (lib_hand_eval.so), the heads-up betting engine (PokerEnv) and the
+public-tree builder (PublicTree.build_tree).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from helpers import GAMES, all_single_card_boards, env_args, golden, native_tree
+from pokerrl_amd import _native
+from pokerrl_amd.game import bet_sets
+from pokerrl_amd.game import games as G
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LUTs: test/game/test_look_up_table.py:14-167 pins the layouts; here the full tables are compared
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("game", ["StandardLeduc", "BigLeduc", "DiscretizedNLHoldem", "Flop5Holdem"])
+def test_luts_match_reference(game):
+    g = golden("luts.npz")
+    lh = getattr(G, game).get_lut_holder()
+    for k in ("IDX_2_HOLE_CARDS", "HOLE_CARDS_2_IDX", "CARD_IN_WHAT_RANGE_IDXS", "1DCARD_2_2DCARD", "2DCARD_2_1DCARD"):
+        ref = g["%s_%s" % (game, k)]
+        mine = getattr(lh, "LUT_" + k)
+        assert mine.shape == ref.shape, k
+        assert mine.dtype == ref.dtype, (k, mine.dtype, ref.dtype)
+        assert np.array_equal(mine, ref), k
+
+
+def test_lut_invariants():
+    lh = G.DiscretizedNLHoldem.get_lut_holder()
+    n = 0
+    for c1 in range(52):
+        for c2 in range(c1 + 1, 52):  # lexicographic counter (test_look_up_table.py:136-143)
+            assert lh.LUT_HOLE_CARDS_2_IDX[c1, c2] == n
+            assert tuple(lh.LUT_IDX_2_HOLE_CARDS[n]) == (c1, c2)
+            n += 1
+    assert n == 1326
+    counts = np.bincount(lh.LUT_CARD_IN_WHAT_RANGE_IDXS.ravel(), minlength=1326)
+    assert np.all(counts == 2)  # every hand appears in exactly two card rows (test_look_up_table.py:44-56)
+    assert lh.get_1d_card(np.array([-127, -127])) == -127
+    assert np.array_equal(lh.get_1d_cards(lh.get_2d_cards(np.array([0, 51, -127, 17]))), [0, 51, -127, 17])
+
+
+def test_legacy_lut_symbols_row_pointer_convention():
+    """The reference's ctypes wrappers pass 2-D arrays as vectors of row pointers (CppWrapper.py:24-27)."""
+    L = _native.lib()
+
+    def rows(a):
+        return (a.__array_interface__["data"][0] + np.arange(a.shape[0]) * a.strides[0]).astype(np.intp)
+
+    idx2hc = np.full((1326, 2), -2, np.int8)
+    L.get_idx_2_hole_card_lut(rows(idx2hc).ctypes.data_as(ctypes.c_void_p))
+    hc2idx = np.full((52, 52), -2, np.int16)
+    L.get_hole_card_2_idx_lut(rows(hc2idx).ctypes.data_as(ctypes.c_void_p))
+    g = golden("luts.npz")
+    assert np.array_equal(idx2hc, g["DiscretizedNLHoldem_IDX_2_HOLE_CARDS"])
+    assert np.array_equal(hc2idx, g["DiscretizedNLHoldem_HOLE_CARDS_2_IDX"])
+    L.get_1d_card.restype = ctypes.c_int8
+    c2 = np.array([7, 3], np.int8)
+    assert L.get_1d_card(c2.ctypes.data_as(ctypes.c_void_p)) == 31
+    out = np.zeros(2, np.int8)
+    L.get_2d_card(ctypes.c_int8(31), out.ctypes.data_as(ctypes.c_void_p))
+    assert tuple(out) == (7, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# scalar hand evaluator vs the reference binary (values captured by tests/golden/make_golden.py:make_handrank)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_hand_rank_known_answers():
+    g = golden("handrank.npz")
+    L = _native.lib()
+    L.get_hand_rank_52_holdem.restype = ctypes.c_int32
+
+    def rows(a):
+        return (a.__array_interface__["data"][0] + np.arange(a.shape[0]) * a.strides[0]).astype(np.intp)
+
+    for hand, board, rank in zip(g["known_hands"], g["known_boards"], g["known_ranks"]):
+        assert _native.hand_rank_7(board, hand[0], hand[1]) == rank
+        h2 = np.stack([hand // 4, hand % 4], axis=1).astype(np.int8)
+        b2 = np.stack([board // 4, board % 4], axis=1).astype(np.int8)
+        got = L.get_hand_rank_52_holdem(rows(h2).ctypes.data_as(ctypes.c_void_p), rows(b2).ctypes.data_as(ctypes.c_void_p))
+        assert got == rank
+    # survey's table: the quads kicker is the sorted neighbour, not the best card
+    assert g["known_ranks"][-1] == 1240704
+
+
+def test_hand_rank_scalar_matches_reference_on_64_boards():
+    g = golden("handrank.npz")
+    lut = G.DiscretizedNLHoldem.get_lut_holder().LUT_IDX_2_HOLE_CARDS
+    for b, ref in zip(g["boards"], g["ranks"]):
+        for h in range(0, 1326):
+            c1, c2 = lut[h]
+            if c1 in b or c2 in b:
+                assert ref[h] == -1
+            else:
+                assert _native.hand_rank_7(b, c1, c2) == ref[h], (b, h)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# heads-up betting engine vs the reference PokerEnv on random (legal and illegal) action sequences
+# ---------------------------------------------------------------------------------------------------------------------
+ENV_FUZZ = {
+    "StandardLeduc": (G.StandardLeduc, 13, [0.0]),
+    "BigLeduc": (G.BigLeduc, 100, [0.0]),
+    "BigLeduc_short": (G.BigLeduc, 9, [0.0]),
+    "NoLimitLeduc_short": (G.NoLimitLeduc, 700, [0.0]),
+    "DiscretizedNLLeduc_B3": (G.DiscretizedNLLeduc, 20000, bet_sets.B_3),
+    "DiscretizedNLLeduc_B5_short": (G.DiscretizedNLLeduc, 900, bet_sets.B_5),
+    "LimitHoldem": (G.LimitHoldem, 48, [0.0]),
+    "LimitHoldem_short": (G.LimitHoldem, 11, [0.0]),
+    "DiscretizedNLHoldem_B5": (G.DiscretizedNLHoldem, 20000, bet_sets.B_5),
+    "DiscretizedNLHoldem_OT11_short": (G.DiscretizedNLHoldem, 2300, bet_sets.OFF_TREE_11),
+    "NoLimitHoldem_short": (G.NoLimitHoldem, 1700, [0.0]),
+    "Flop5Holdem": (G.Flop5Holdem, 20000, [0.0]),
+    "Flop5Holdem_short": (G.Flop5Holdem, 1100, [0.0]),
+}
+
+
+def _state_row(s):
+    return [s.round, s.main_pot, s.bet[0], s.bet[1], s.stack[0], s.stack[1], s.allin[0], s.allin[1], s.folded[0],
+            s.folded[1], s.acted[0], s.acted[1], s.cur, s.last_raiser, s.capped_happened, s.capped_raiser,
+            s.capped_cant_reopen, s.n_actions_ep, s.n_raises_round, s.last_action[0], s.last_action[1], s.last_action[2]]
+
+
+@pytest.mark.parametrize("name", sorted(ENV_FUZZ))
+def test_env_matches_reference_fuzz(name):
+    cls, stack, bets = ENV_FUZZ[name]
+    rows = golden("env_fuzz.npz")[name]
+    game = cls.native_game(env_args(cls, stack, bets))
+    L = _native.lib()
+    st, info = _native.PrlEnvState(), _native.PrlStepInfo()
+    legal = np.zeros(128, np.int32)
+    n_legal = ctypes.c_int32()
+    is_limit = cls.IS_FIXED_LIMIT_GAME
+    is_nl = cls._GAME_TYPE == G.GAME_NOLIMIT
+    MAXL = 16
+    n_steps = 0
+    for r in rows:
+        kind, act, amount, nl = int(r[1]), int(r[2]), int(r[3]), int(r[4])
+        ref_legal = [int(x) for x in r[5:5 + min(nl, MAXL)]]
+        term, chance, pot_before = int(r[5 + MAXL]), int(r[6 + MAXL]), int(r[7 + MAXL])
+        ref_state = [int(x) for x in r[8 + MAXL:]]
+        if kind == 0:
+            _native.check(L.prl_env_reset_host(ctypes.byref(game), ctypes.byref(st)))
+        else:
+            if is_nl:
+                _native.check(L.prl_env_step_processed_host(ctypes.byref(game), ctypes.byref(st), act, amount, ctypes.byref(info)))
+            else:
+                _native.check(L.prl_env_step_host(ctypes.byref(game), ctypes.byref(st), act, ctypes.byref(info)))
+            n_steps += 1
+            assert info.is_terminal == term
+            assert info.chance_acts == chance
+            if term:
+                assert info.pot_before_payout == pot_before
+                continue
+        _native.check(L.prl_env_legal_actions_host(ctypes.byref(game), ctypes.byref(st), legal.ctypes.data_as(ctypes.c_void_p),
+                                                   ctypes.byref(n_legal)))
+        assert n_legal.value == nl
+        assert list(legal[:min(nl, MAXL)]) == ref_legal
+        mine = _state_row(st)
+        if not is_limit:
+            ref_state[18] = mine[18]  # n_raises_this_round exists only in fixed-limit games (PokerEnv.py:1196-1197)
+        assert mine == ref_state, (n_steps, mine, ref_state)
+    assert n_steps > 200
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# public-tree structure vs the reference's PublicTree (and vs a walk of the reference env for Flop5Holdem)
+# ---------------------------------------------------------------------------------------------------------------------
+TREE_FIELDS = ("kind", "actor", "parent", "child_idx", "action", "acted_last", "round", "main_pot", "depth", "n_children",
+               "first_col", "col_action")
+
+
+@pytest.mark.parametrize("name", sorted(GAMES))
+def test_tree_matches_reference(name):
+    cls, stack, bets = GAMES[name]
+    ref = golden("tree_%s.npz" % name)
+    t = native_tree(cls, stack, bets, all_single_card_boards(cls))
+    assert t.n_nodes == len(ref["kind"])
+    for f in TREE_FIELDS:
+        assert np.array_equal(t.field(f), ref[f]), f
+    assert np.array_equal(t.field("board_id"), ref["board_card"])  # board table = all cards ascending
+    # reference counters (PublicTree.n_nodes excludes the root: PublicTree.py:60,163)
+    assert t.n_decision + t.n_terminal + int(np.sum(t.field("kind") == 1)) == t.n_nodes
+
+
+def test_tree_flop5holdem_structure():
+    ref = golden("tree_Flop5Holdem_1board.npz")
+    boards = np.array([[0, 5, 10, 15, 20], [1, 2, 3, 50, 51], [7, 8, 9, 30, 44]], np.int8)
+    t = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)
+    # expand the 1-board reference walk to 3 boards: trunk nodes + 3 copies of the board subtree
+    kind = ref["kind"]
+    ch = int(np.where(kind == 1)[0][0])
+    sub = int(ref["n_children"].shape[0]) - (ch + 1)  # board subtree is the tail of the DFS order ...
+    first_board_child = ch + 1
+    # ... unless trunk nodes follow it; verify through parents
+    size = 1
+    stack_ = [first_board_child]
+    members = set()
+    while stack_:
+        x = stack_.pop()
+        members.add(x)
+        stack_.extend(int(i) for i in np.where(ref["parent"] == x)[0])
+    sub_ids = sorted(members)
+    assert sub_ids == list(range(first_board_child, first_board_child + len(sub_ids)))
+    T = len(sub_ids)
+    assert t.n_nodes == len(kind) + 2 * T
+    for f in ("kind", "actor", "action", "acted_last", "round", "main_pot", "depth", "n_children"):
+        mine = t.field(f)
+        assert np.array_equal(mine[:first_board_child + T], ref[f][:first_board_child + T] if f != "n_children" else
+                              np.where(np.arange(first_board_child + T) == ch, 3, ref[f][:first_board_child + T])), f
+        for b in (1, 2):
+            lo = first_board_child + b * T
+            assert np.array_equal(mine[lo:lo + T], ref[f][first_board_child:first_board_child + T]), (f, b)
+        tail_ref = ref[f][first_board_child + T:]
+        assert np.array_equal(mine[first_board_child + 3 * T:], tail_ref), f
+    # per board 6 decision + 4 fold + 5 showdown nodes, sum of actions 14; 2 pre-flop decision nodes
+    k = t.field("kind")[first_board_child:first_board_child + T]
+    assert (int(np.sum(k == 0)), int(np.sum(k == 2)), int(np.sum(k == 3))) == (6, 4, 5)
+    assert int(np.sum(t.field("n_children")[first_board_child:first_board_child + T])) == 14
+    bid = t.field("board_id")
+    assert np.all(bid[:first_board_child] == -1)
+    assert np.all(bid[first_board_child + T:first_board_child + 2 * T] == 1)
+
+
+def test_tree_rejects_multi_street_games():
+    with pytest.raises(_native.NativeError):
+        native_tree(G.LimitHoldem, 48, [0.0], np.array([[0, 1, 2]], np.int8))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """include/pokerrl_hip.h is the contract: every prototype it declares must be exported by the shared library."""
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "pokerrl_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b([a-z][a-z0-9_]*)\s*\(", hdr))
+    names = {n for n in names if n.startswith(("prl_", "get_"))}
+    assert len(names) > 20
+    L = _native.lib()
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+    assert _native.build_flavor() == "hip-gfx950"
