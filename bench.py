@@ -1,0 +1,149 @@
+"""
+bench.py -- CFR+ node-updates/s on a synthetic Flop5Holdem public tree (BASELINE.json metric), one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B] [--engine fused|levels] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one CFRBase.iteration() (reference semantics, PokerRL/cfr/_CFRBase.py:122-134: both seats updated, EVs
+recomputed, current-strategy exploitability available) of CFR+ (delay 0) on the Flop5Holdem betting tree (blinds 50/100,
+stacks 20000, pot-size raises; PokerRL/game/games.py:222-254) x B seeded boards per GPU, 1326-hand ranges, float32 state
+with the reference's float64 average strategy. Inputs are resident in HBM before the timed region. Prints ONE JSON line.
+
+node-updates/s = (tree nodes incl. root) x iterations / s  (SURVEY.md section 8d).
+roofline: algorithmic bytes per iteration = 20*R*sum(A) + 8*R*N_boards / measured device time.
+cpu_baseline: the CPU oracle (plain-C restatement of the reference, 1 thread) on a bounded sample of the same workload --
+the reference itself cannot run 2-hole-card public trees.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def seeded_boards(n, seed, offset=0):
+    """n distinct sorted 5-card boards from numpy.random.RandomState(seed)."""
+    rng = np.random.RandomState(seed)
+    seen, out = set(), []
+    while len(out) < offset + n:
+        b = tuple(sorted(int(x) for x in rng.choice(52, 5, replace=False)))
+        if b not in seen:
+            seen.add(b)
+            out.append(b)
+    return np.array(out[offset:offset + n], dtype=np.int8)
+
+
+def cpu_baseline(n_boards, n_iters):
+    """CFR+ on the same kind of tree with the CPU oracle (1 thread): node-updates/s on a bounded sample."""
+    import oracle
+    from helpers import native_tree
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    boards = seeded_boards(n_boards, 0)
+    t = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)  # host-side tree builder only
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, 2, 52, 4, 2)
+    o.cfr_reset(1, 0)
+    t0 = time.perf_counter()
+    for _ in range(n_iters):
+        o.cfr_iteration()
+    dt = time.perf_counter() - t0
+    return {"value": t.n_nodes * n_iters / dt, "unit": "node-updates/s", "cores": 1, "kind": "port",
+            "sample": "CFR+ delay 0, Flop5Holdem tree x %d boards (%d nodes), %d iterations, oracle/prl_oracle.c, 1 thread, %.1f s"
+                      % (n_boards, t.n_nodes, n_iters, dt),
+            "final_exploitability_mbb_per_g": float(np.mean(o.exploitability) * 10.0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--boards", type=int, default=int(os.environ.get("PRL_BENCH_BOARDS", "8192")), help="boards per GPU")
+    ap.add_argument("--engine", default=os.environ.get("PRL_BENCH_ENGINE", "levels"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-boards", type=int, default=192)
+    ap.add_argument("--cpu-iters", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    from helpers import native_tree
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+
+    _native.require_device()
+    # every rank owns its own shard of boards (weak scaling: fixed boards per GPU)
+    boards = seeded_boards(args.boards, 0, offset=rank * args.boards)
+    tree = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)
+    solver = _native.NativeSolver(tree, "plus", 0)
+    solver.sync()
+
+    def barrier():
+        torch.cuda.synchronize()
+        solver.sync()
+        if dist is not None:
+            dist.barrier()
+
+    solver.iterations(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    dev_ms = solver.time_iterations(args.steps)  # HIP events on the solver's stream + the K iterations
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    n_nodes_total = tree.n_nodes * world
+    value = n_nodes_total * args.steps / dt
+    R, sum_a = tree.range_size, tree.n_cols
+    bytes_iter = 20.0 * R * sum_a + 8.0 * R * args.boards
+    achieved = bytes_iter * args.steps / (dev_ms * 1e-3) / 1e9
+    expl = solver.exploitability()
+    out = {
+        "metric": "CFR+ node-updates/sec on FHP public tree",
+        "value": value, "unit": "node-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "CFR+ (delay 0) full-width iterations on the Flop5Holdem public tree (blinds 50/100, stacks 20000, "
+                        "pot-size raises), %d seeded boards per GPU, 1326-hand ranges" % args.boards,
+            "boards_per_gpu": args.boards, "nodes_per_gpu": tree.n_nodes, "action_columns_per_gpu": sum_a,
+            "engine": args.engine, "parallelism": "boards sharded over %d GPU(s)" % world,
+            "iterations_done": solver.iter, "exploitability_mbb_per_g": float(np.mean(expl) * 10.0),
+            "hbm_bytes_allocated": int(solver.get("bytes_allocated")[0]),
+        },
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "bytes_per_iteration_algorithmic": bytes_iter, "device_ms_per_iteration": dev_ms / args.steps},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_boards, args.cpu_iters)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -130,6 +130,9 @@ int32_t prl_lut_card_in_what_range_idxs(const PrlRules* rules, int32_t* out /* [
 int32_t prl_hand_rank_7(const int8_t* board_1d /*[5]*/, int8_t c1, int8_t c2);
 /* batched evaluator on the GPU, host buffers in and out: ranks[n][1326] int32, -1 for hands blocked by the board */
 int32_t prl_hand_rank_boards(const int8_t* boards_1d /*[n][5]*/, int32_t n_boards, int32_t* out_ranks);
+/* verification aid: one order-sensitive u64 checksum of the rank table per `chunk` boards, computed on the GPU without
+ * materialising the table (an exhaustive C(52,5) sweep is 13.8 GB); definition in csrc/prl_handeval_kernels.hip */
+int32_t prl_hand_rank_checksums(const int8_t* boards_1d, int32_t n_boards, int32_t chunk, uint64_t* out_checksums);
 /* same, device pointers in and out (no copies); stream = hipStream_t or NULL */
 int32_t prl_hand_rank_boards_device(const void* d_boards_1d, int32_t n_boards, void* d_out_ranks, void* stream);
 
@@ -184,6 +187,53 @@ int32_t prl_env_step_host(const PrlGame* game, PrlEnvState* state, int32_t actio
 int32_t prl_env_step_processed_host(const PrlGame* game, PrlEnvState* state, int32_t type, int32_t amount, PrlStepInfo* out_info);
 int32_t prl_env_legal_actions_host(const PrlGame* game, const PrlEnvState* state, int32_t* out_actions, int32_t* out_n);
 int32_t prl_env_fraction_of_pot_raise_host(const PrlEnvState* state, double fraction, int32_t seat, int32_t* out_total);
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* 5. Device-resident tabular solver: public-tree CFR / CFR+ / Linear CFR and exact best response on one GPU.          */
+/*    replaces  PokerRL/cfr/_CFRBase.py:110-262 (+ VanillaCFR.py, CFRPlus.py, LinearCFR.py),                           */
+/*              PokerRL/game/_/tree/_/StrategyFiller.py:17-169, ValueFiller.py:21-175,                                 */
+/*              PokerRL/eval/br/LocalBRMaster.py:67-80 (fill strategy -> compute_ev -> root exploitability).           */
+/*    Array layout: per-node vectors float32 [n_nodes][2][R]; per-action-column arrays [n_cols][R] where column        */
+/*    first_col[node] + a is the reference's node.strategy[:, a]; nodes in DFS pre-order (prl_tree_get).               */
+/*    All calls are asynchronous on the solver's stream except the ones that copy results to the host.                 */
+/* ---------------------------------------------------------------------------------------------------------------- */
+typedef struct prl_solver prl_solver_t;
+
+enum { PRL_VARIANT_VANILLA = 0, PRL_VARIANT_PLUS = 1, PRL_VARIANT_LINEAR = 2 };
+
+/* create = upload tree + build showdown plans + CFRBase.reset(); `delay` is CFR+'s linear-averaging delay */
+int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay, prl_solver_t** out_solver);
+void prl_solver_destroy(prl_solver_t* solver);
+int32_t prl_solver_reset(prl_solver_t* solver);                        /* _CFRBase.reset            :110-120 */
+int32_t prl_solver_iteration(prl_solver_t* solver);                    /* _CFRBase.iteration        :122-134 (w/o avg eval) */
+int32_t prl_solver_iterations(prl_solver_t* solver, int32_t n);
+int32_t prl_solver_eval_avg(prl_solver_t* solver, float* out_expl2);   /* _evaluate_avg_strats      :218-262 */
+int32_t prl_solver_fill_uniform(prl_solver_t* solver);                 /* PublicTree.fill_uniform_random     */
+int32_t prl_solver_set_strategy(prl_solver_t* solver, const void* strategy_cols, int32_t is_f64); /* fill_with_agent_policy */
+int32_t prl_solver_update_reach(prl_solver_t* solver);                 /* PublicTree.update_reach_probs      */
+int32_t prl_solver_compute_ev(prl_solver_t* solver);                   /* PublicTree.compute_ev              */
+int32_t prl_solver_exploitability(prl_solver_t* solver, float* out_expl2); /* root.exploitability, raw float32 per seat */
+int32_t prl_solver_sync(prl_solver_t* solver);
+/* runs n iterations between two HIP events recorded on the solver's stream; elapsed device time in milliseconds */
+int32_t prl_solver_time_iterations(prl_solver_t* solver, int32_t n, float* out_ms);
+
+enum {
+    PRL_SF_REACH = 0,        /* float32 [n_nodes][2][R]  node.reach_probs                      */
+    PRL_SF_EV = 1,           /* float32 [n_nodes][2][R]  node.ev                               */
+    PRL_SF_EV_BR = 2,        /* float32 [n_nodes][2][R]  node.ev_br                            */
+    PRL_SF_STRATEGY = 3,     /* float64 [n_cols][R]      node.strategy.T                       */
+    PRL_SF_STRAT_F64 = 4,    /* uint8   [n_nodes]        1 where the strategy dtype is float64 */
+    PRL_SF_REGRET = 5,       /* float32 [n_cols][R]      node.data["regret"].T                 */
+    PRL_SF_AVG = 6,          /* float64 [n_cols][R]      node.data["avg_strat"].T              */
+    PRL_SF_AVG_F64 = 7,      /* uint8   [n_nodes]                                              */
+    PRL_SF_AVG_SUM = 8,      /* float32 [n_cols][R]      node.data["avg_strat_sum"].T          */
+    PRL_SF_BR_IDX = 9,       /* int32   [n_nodes][R]     br_a_idx_in_child_arr_for_each_hand   */
+    PRL_SF_EXPL_HISTORY = 10, /* float32 [iter+1][2]     current-strategy exploitability after every iteration */
+    PRL_SF_ITER = 11,        /* int32                    iteration counter                     */
+    PRL_SF_CONSTANTS = 12,   /* float32 [2]              chance probability, equity constant   */
+    PRL_SF_BYTES_ALLOCATED = 13 /* int64                 HBM bytes held by the solver          */
+};
+int32_t prl_solver_get(prl_solver_t* solver, int32_t field, void* out);
 
 #ifdef __cplusplus
 }

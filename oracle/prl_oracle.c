@@ -546,16 +546,27 @@ static void compute_ev(Orc* o, int node) {
     if (o->kind[node] >= K_FOLD) { terminal_values(o, node); return; }
     for (int i = 0; i < A; ++i) compute_ev(o, child_of(o, node, i));
     if (o->kind[node] == K_CHANCE) {
+        /* ValueFiller.py:76-78 sums the chance children in child order (NumPy outer-axis reduce = running add). The
+         * canonical order here is the same running add, nested: blocks of 32 children, groups of 32 blocks, then the
+         * groups -- identical to the reference for <= 32 boards (every Leduc game) and independent of how many GPUs
+         * share the boards of a big tree (each GPU owns whole groups; DESIGN.md "multi-GPU"). */
         for (int p = 0; p < 2; ++p)
-            for (int h = 0; h < R; ++h) {
-                float s = V2(o, ev, child_of(o, node, 0), p)[h], sb = V2(o, ev_br, child_of(o, node, 0), p)[h];
-                for (int i = 1; i < A; ++i) {
-                    s = s + V2(o, ev, child_of(o, node, i), p)[h];
-                    sb = sb + V2(o, ev_br, child_of(o, node, i), p)[h];
+            for (int h = 0; h < R; ++h)
+                for (int which = 0; which < 2; ++which) {
+                    float* arr = which ? o->ev_br : o->ev;
+                    float total = 0.f;
+                    for (int g0 = 0, gi = 0; g0 < A; g0 += 32 * 32, ++gi) {
+                        float gsum = 0.f;
+                        for (int b0 = g0, bi = 0; b0 < A && b0 < g0 + 32 * 32; b0 += 32, ++bi) {
+                            float bsum = arr[((size_t)child_of(o, node, b0) * 2 + p) * R + h];
+                            for (int i = b0 + 1; i < A && i < b0 + 32; ++i)
+                                bsum = bsum + arr[((size_t)child_of(o, node, i) * 2 + p) * R + h];
+                            gsum = bi == 0 ? bsum : gsum + bsum;
+                        }
+                        total = gi == 0 ? gsum : total + gsum;
+                    }
+                    arr[((size_t)node * 2 + p) * R + h] = total;
                 }
-                V2(o, ev, node, p)[h] = s;
-                V2(o, ev_br, node, p)[h] = sb;
-            }
         return;
     }
     const int pl = o->actor[node], op = 1 - pl;

@@ -75,13 +75,18 @@ def _ptr(a, ctype=None):
 def lib():
     """Loads the shared library once. Raises NativeError (never falls back) if it is absent."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.isfile(LIB_PATH):
+    if _lib is None:
+        _lib = bind(LIB_PATH)
+    return _lib
+
+
+def bind(path):
+    """dlopen + prototype declaration. The package itself only ever binds LIB_PATH (the hipcc build)."""
+    if not os.path.isfile(path):
         raise NativeError(
             "pokerrl_amd: native library %s not found. Build it with `python -c 'import __graft_entry__ as g; "
-            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
-    L = ctypes.CDLL(LIB_PATH)
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    L = ctypes.CDLL(path)
     L.prl_last_error.restype = ctypes.c_char_p
     L.prl_build_flavor.restype = ctypes.c_char_p
     L.prl_device_available.restype = ctypes.c_int32
@@ -118,7 +123,6 @@ def lib():
                                                      ctypes.POINTER(ctypes.c_int32)]
     L.prl_env_fraction_of_pot_raise_host.restype = ctypes.c_int32
     _bind_solver(L)
-    _lib = L
     return L
 
 
@@ -128,6 +132,8 @@ def _bind_solver(L):
         return
     vp, i32, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_double
     L.prl_solver_create.argtypes = [vp, i32, i32, ctypes.POINTER(vp)]
+    L.prl_solver_get.argtypes = [vp, i32, vp]
+    L.prl_solver_get.restype = i32
     L.prl_solver_create.restype = i32
     L.prl_solver_destroy.argtypes = [vp]
     L.prl_solver_destroy.restype = None
@@ -144,16 +150,17 @@ def _bind_solver(L):
         "prl_solver_eval_avg": [vp, vp],
         "prl_solver_sync": [vp],
         "prl_solver_set_option": [vp, i32, i32],
-        "prl_solver_timing": [vp, vp],
+        "prl_solver_time_iterations": [vp, i32, vp],
     }.items():
         if hasattr(L, name):
             getattr(L, name).argtypes = args
             getattr(L, name).restype = i32
 
 
-def check(status):
+def check(status, L=None):
     if status != 0:
-        raise NativeError("libpokerrl_hip error %d: %s" % (status, lib().prl_last_error().decode("utf-8", "replace")))
+        L = L or lib()
+        raise NativeError("libpokerrl_hip error %d: %s" % (status, L.prl_last_error().decode("utf-8", "replace")))
 
 
 def device_available():
@@ -212,15 +219,16 @@ def hand_rank_boards(boards_1d):
 class NativeTree:
     """Owns a prl_tree_t* (host-side flat public tree)."""
 
-    def __init__(self, game, rules, boards_1d):
+    def __init__(self, game, rules, boards_1d, _lib=None):
         boards = np.ascontiguousarray(boards_1d, dtype=np.int8)
         assert boards.ndim == 2
+        self._L = _lib or lib()
         self._h = ctypes.c_void_p()
         self._game, self._rules = game, rules
-        check(lib().prl_tree_build(ctypes.byref(game), ctypes.byref(rules), _ptr(boards), boards.shape[0],
-                                   boards.shape[1], ctypes.byref(self._h)))
+        check(self._L.prl_tree_build(ctypes.byref(game), ctypes.byref(rules), _ptr(boards), boards.shape[0],
+                                     boards.shape[1], ctypes.byref(self._h)), self._L)
         info = np.zeros(TI_COUNT, dtype=np.int32)
-        check(lib().prl_tree_info(self._h, _ptr(info)))
+        check(self._L.prl_tree_info(self._h, _ptr(info)), self._L)
         self.info = info
         self.n_nodes, self.n_cols = int(info[TI_N_NODES]), int(info[TI_N_COLS])
         self.n_boards, self.board_len = int(info[TI_N_BOARDS]), int(info[TI_BOARD_LEN])
@@ -238,14 +246,109 @@ class NativeTree:
             n = {"child_start": self.n_nodes + 1, "child_list": max(self.n_nodes - 1, 0), "col_action": self.n_cols,
                  "col_node": self.n_cols, "level_start": self.n_levels + 1}.get(name, self.n_nodes)
             out = np.empty(n, dtype=np.int32)
-            check(lib().prl_tree_get(self._h, TREE_FIELDS[name], _ptr(out)))
+            check(self._L.prl_tree_get(self._h, TREE_FIELDS[name], _ptr(out)), self._L)
             self._cache[name] = out
         return self._cache[name]
 
     def __del__(self):
         try:
             if self._h:
-                lib().prl_tree_destroy(self._h)
+                self._L.prl_tree_destroy(self._h)
                 self._h = None
         except Exception:
             pass
+
+
+# solver field ids (include/pokerrl_hip.h)
+SF = dict(reach=0, ev=1, ev_br=2, strategy=3, strat_f64=4, regret=5, avg=6, avg_f64=7, avg_sum=8, br_idx=9,
+          expl_history=10, iter=11, constants=12, bytes_allocated=13)
+VARIANTS = {"vanilla": 0, "plus": 1, "linear": 2}
+
+
+class NativeSolver:
+    """Owns a prl_solver_t* : the device-resident CFR / best-response solver of one public tree."""
+
+    def __init__(self, tree, variant, delay=0, _lib=None):
+        self._L = _lib or tree._L
+        if _lib is None and self._L is lib():
+            require_device()
+        self.tree = tree
+        self._h = ctypes.c_void_p()
+        v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
+        check(self._L.prl_solver_create(tree.handle, v, int(delay), ctypes.byref(self._h)), self._L)
+        self.n_nodes, self.n_cols, self.R = tree.n_nodes, tree.n_cols, tree.range_size
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.prl_solver_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        check(getattr(self._L, name)(self._h, *args), self._L)
+
+    def reset(self):
+        self._call("prl_solver_reset")
+
+    def iteration(self):
+        self._call("prl_solver_iteration")
+
+    def iterations(self, n):
+        self._call("prl_solver_iterations", int(n))
+
+    def fill_uniform(self):
+        self._call("prl_solver_fill_uniform")
+
+    def set_strategy(self, strategy_cols):
+        a = np.ascontiguousarray(strategy_cols)
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float32)
+        assert a.shape == (self.n_cols, self.R), (a.shape, (self.n_cols, self.R))
+        self._call("prl_solver_set_strategy", _ptr(a), int(a.dtype == np.float64))
+
+    def update_reach(self):
+        self._call("prl_solver_update_reach")
+
+    def compute_ev(self):
+        self._call("prl_solver_compute_ev")
+
+    def sync(self):
+        self._call("prl_solver_sync")
+
+    def time_iterations(self, n):
+        """n iterations bracketed by HIP events on the solver's stream -> elapsed device milliseconds."""
+        ms = ctypes.c_float()
+        self._call("prl_solver_time_iterations", int(n), ctypes.byref(ms))
+        return float(ms.value)
+
+    def exploitability(self):
+        out = np.zeros(2, np.float32)
+        self._call("prl_solver_exploitability", _ptr(out))
+        return out
+
+    def eval_avg(self):
+        out = np.zeros(2, np.float32)
+        self._call("prl_solver_eval_avg", _ptr(out))
+        return out
+
+    @property
+    def iter(self):
+        out = np.zeros(1, np.int32)
+        self._call("prl_solver_get", SF["iter"], _ptr(out))
+        return int(out[0])
+
+    def get(self, name):
+        n, c, R = self.n_nodes, self.n_cols, self.R
+        shape, dtype = {
+            "reach": ((n, 2, R), np.float32), "ev": ((n, 2, R), np.float32), "ev_br": ((n, 2, R), np.float32),
+            "strategy": ((c, R), np.float64), "strat_f64": ((n,), np.uint8), "regret": ((c, R), np.float32),
+            "avg": ((c, R), np.float64), "avg_f64": ((n,), np.uint8), "avg_sum": ((c, R), np.float32),
+            "br_idx": ((n, R), np.int32), "constants": ((2,), np.float32), "bytes_allocated": ((1,), np.int64),
+        }.get(name, (None, None))
+        if name == "expl_history":
+            shape, dtype = (self.iter + 1, 2), np.float32
+        out = np.zeros(shape, dtype)
+        self._call("prl_solver_get", SF[name], _ptr(out))
+        return out

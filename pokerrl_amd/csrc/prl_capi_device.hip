@@ -83,6 +83,29 @@ int32_t prl_hand_rank_boards(const int8_t* boards_1d, int32_t n_boards, int32_t*
     return rc;
 }
 
+int32_t prl_hand_rank_checksums(const int8_t* boards_1d, int32_t n_boards, int32_t chunk, uint64_t* out_checksums) {
+    if (n_boards <= 0 || chunk <= 0 || !boards_1d || !out_checksums) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    if (!prl_device_available()) { prl_set_error("no HIP device"); return PRL_ERR_NO_DEVICE; }
+    const uint16_t* lut = nullptr;
+    int e = prl_hole_lut_device(&lut);
+    if (e) return e;
+    const int n_chunks = (n_boards + chunk - 1) / chunk;
+    int8_t* d_b = nullptr;
+    unsigned long long* d_o = nullptr;
+    PRL_HIP_TRY(hipMalloc((void**)&d_b, (size_t)n_boards * 5));
+    if (hipMalloc((void**)&d_o, (size_t)n_chunks * 8) != hipSuccess) { (void)hipFree(d_b); prl_set_error("hipMalloc failed"); return PRL_ERR_OOM; }
+    int rc = PRL_OK;
+    if (hipMemcpy(d_b, boards_1d, (size_t)n_boards * 5, hipMemcpyHostToDevice) != hipSuccess) rc = PRL_ERR_HIP;
+    if (!rc) {
+        prl_launch_hand_rank_checksums(d_b, n_boards, chunk, lut, d_o, nullptr);
+        if (hipMemcpy(out_checksums, d_o, (size_t)n_chunks * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = PRL_ERR_HIP;
+    }
+    (void)hipFree(d_b);
+    (void)hipFree(d_o);
+    if (rc) prl_set_error("hip error in prl_hand_rank_checksums");
+    return rc;
+}
+
 // CppHandeval.py:45-65 legacy form: row-pointer arrays; `out` rows are written in full (blocked hands = -1)
 void get_hand_rank_all_hands_on_given_boards_52_holdem(int32_t** out, int8_t** boards_1d, int32_t n_boards,
                                                        int8_t** /*lut_idx_2_hole_cards*/, int8_t** /*lut_1d_2_2d*/) {

@@ -4,3 +4,19 @@
 
 // prl_handeval_kernels.hip
 void prl_launch_hand_rank_boards(const int8_t* d_boards, int n_boards, const uint16_t* d_hole_lut, int32_t* d_out, void* stream);
+
+// prl_tree_kernels.hip / prl_plan_kernels.hip (engine G: level-synchronous kernels over node vectors in HBM)
+struct PrlDevTree;
+struct PrlDevState;
+void prl_launch_fill_uniform(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_col_node, void* stream);
+void prl_launch_reach(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, void* stream);
+void prl_launch_ev(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, const int32_t* d_term_nodes, int n_term,
+                   void* stream);
+void prl_launch_regret_strategy(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, int iter,
+                                void* stream);
+void prl_launch_average(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, int iter, int mode,
+                        double m_old, double m_new, void* stream);
+void prl_launch_plan_build(const PrlDevTree& T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
+                           int16_t* plan_cl, int32_t* plan_nlive, void* stream);
+void prl_launch_hand_rank_checksums(const int8_t* d_boards, int n_boards, int chunk, const uint16_t* d_hole_lut, unsigned long long* d_out,
+                                    void* stream);

@@ -1,0 +1,114 @@
+// Per-board "showdown plans" for 2-hole-card ranges, built once per tree on the GPU.
+//
+// A plan is everything about a board that the terminal-equity scans need and that never changes during a solve:
+//   sh[i]   hand at sorted position i (live hands only, ascending (hand rank, hand index))
+//   pos[h]  sorted position of hand h, -1 if a hole card is on the board
+//   gs/ge   tie group [gs, ge) of every sorted position (equal hand ranks)
+//   cl[c]   for every card c, the sorted positions of the live hands that contain c, ascending (46 entries on a 5-card board)
+// This is the generalisation of the reference's per-terminal `handranks` loop (ValueFiller.py:140-143) to 1326-hand
+// ranges: ranks come from the same evaluator as get_hand_rank_all_hands_on_given_boards (prl_handeval.h), computed here
+// in-kernel so that no rank table ever round-trips through the host. Plan index n_boards is the "no board" plan
+// (hand-index order, one tie group) used by pre-deal fold nodes.
+//
+// One workgroup (256 lanes) per plan; 2048-key bitonic sort in LDS (keys = rank << 11 | hand, unique -> deterministic).
+#include "prl_device.h"
+#include "prl_handeval.h"
+#include "prl_kernels.h"
+#include "prl_solver_types.h"
+
+PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
+                                 int16_t* plan_cl, int32_t* plan_nlive) {
+    uint32_t* keys = (uint32_t*)prl_smem();  // [2048]
+    int* n_live_s = (int*)(keys + 2048);
+    const int tid = (int)prl_tid(), nt = (int)prl_nthreads();
+    for (int b = (int)prl_bid(); b < n_plans; b += (int)prl_nblocks()) {
+        const bool has_board = b < T.n_boards;
+        uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        unsigned long long on_board = 0ull;
+        if (has_board) {
+            for (int i = 0; i < T.board_len; ++i) {
+                int c = T.boards[(size_t)b * T.board_len + i];
+                uint32_t bit = 1u << (c >> 2);
+                int su = c & 3;
+                s0 |= su == 0 ? bit : 0u;
+                s1 |= su == 1 ? bit : 0u;
+                s2 |= su == 2 ? bit : 0u;
+                s3 |= su == 3 ? bit : 0u;
+                on_board |= 1ull << c;
+            }
+        }
+        for (int h = tid; h < 2048; h += nt) {
+            uint32_t key = 0xFFFFFFFFu;
+            if (h < T.R) {
+                int c1 = T.hole[2 * h], c2 = T.hole[2 * h + 1];
+                if (!has_board) key = (uint32_t)h;
+                else if (!((on_board >> c1) & 1ull) && !((on_board >> c2) & 1ull)) {
+                    uint32_t b1 = 1u << (c1 >> 2), b2 = 1u << (c2 >> 2);
+                    int u1 = c1 & 3, u2 = c2 & 3;
+                    int32_t r = prl_rank7_masks(s0 | (u1 == 0 ? b1 : 0u) | (u2 == 0 ? b2 : 0u), s1 | (u1 == 1 ? b1 : 0u) | (u2 == 1 ? b2 : 0u),
+                                                s2 | (u1 == 2 ? b1 : 0u) | (u2 == 2 ? b2 : 0u), s3 | (u1 == 3 ? b1 : 0u) | (u2 == 3 ? b2 : 0u));
+                    key = ((uint32_t)r << 11) | (uint32_t)h;
+                }
+            }
+            keys[h] = key;
+        }
+        if (tid == 0) *n_live_s = 0;
+        prl_sync();
+        // bitonic sort, ascending
+        for (int k = 2; k <= 2048; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < 2048; i += nt) {
+                    int ixj = i ^ j;
+                    if (ixj > i) {
+                        uint32_t a = keys[i], c = keys[ixj];
+                        bool up = (i & k) == 0;
+                        if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
+                    }
+                }
+                prl_sync();
+            }
+        }
+        for (int i = tid; i < 2048; i += nt)
+            if (keys[i] != 0xFFFFFFFFu && (i == 2047 || keys[i + 1] == 0xFFFFFFFFu)) *n_live_s = i + 1;
+        prl_sync();
+        const int n = *n_live_s;
+        int16_t* sh = plan_sh + (size_t)b * T.plan_stride;
+        int16_t* pos = plan_pos + (size_t)b * T.plan_stride;
+        int16_t* gs = plan_gs + (size_t)b * T.plan_stride;
+        int16_t* ge = plan_ge + (size_t)b * T.plan_stride;
+        int16_t* cl = plan_cl + (size_t)b * T.cl_stride;
+        for (int h = tid; h < T.R; h += nt) { pos[h] = -1; sh[h] = -1; gs[h] = 0; ge[h] = 0; }
+        prl_sync();
+        for (int i = tid; i < n; i += nt) {
+            const uint32_t key = keys[i];
+            const int h = (int)(key & 0x7FFu);
+            sh[i] = (int16_t)h;
+            pos[h] = (int16_t)i;
+            const uint32_t r = has_board ? (key >> 11) : 0u;
+            int j = i;
+            while (j > 0 && (has_board ? (keys[j - 1] >> 11) : 0u) == r) j--;
+            gs[i] = (int16_t)j;
+            j = i + 1;
+            while (j < n && (has_board ? (keys[j] >> 11) : 0u) == r) j++;
+            ge[i] = (int16_t)j;
+        }
+        for (int c = tid; c < T.n_cards; c += nt) {
+            int16_t* row = cl + (size_t)c * (T.n_cards - 1);
+            int m = 0;
+            for (int i = 0; i < n; ++i) {
+                const int h = (int)(keys[i] & 0x7FFu);
+                if (T.hole[2 * h] == c || T.hole[2 * h + 1] == c) row[m++] = (int16_t)i;
+            }
+            for (; m < T.n_cards - 1; ++m) row[m] = -1;
+        }
+        if (tid == 0) plan_nlive[b] = n;
+        prl_sync();
+    }
+}
+
+void prl_launch_plan_build(const PrlDevTree& T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
+                           int16_t* plan_cl, int32_t* plan_nlive, void* stream) {
+    int grid = n_plans < 32768 ? n_plans : 32768;
+    PRL_LAUNCH(prl_k_plan_build, grid, 256, 2048 * sizeof(uint32_t) + 16, stream, T, n_plans, plan_sh, plan_pos, plan_gs, plan_ge, plan_cl,
+               plan_nlive);
+}

@@ -1,0 +1,59 @@
+// Device-resident public tree + solver state (struct-of-arrays in HBM), passed BY VALUE to the kernels.
+//
+// Layout (DESIGN.md "data layout"):
+//   per-node vectors   reach / ev / ev_br : float32 [n_nodes][2 seats][R]      hand index fastest -> coalesced
+//   per-action columns strategy (float64), regret (float32), avg (float64), avg_sum (float32) : [n_cols][R]
+//       column id = first_col[node] + a  (children order), i.e. the reference's strategy[:, a] (nodes.py:35) is one
+//       contiguous R-vector; a node's A columns are adjacent; a board subtree's columns are one contiguous block.
+//   strategy is kept in float64 storage with a per-node dtype flag because the reference mixes float64 strategies
+//   (uniform fill, average strategy) with float32 ones (after regret matching) and the arithmetic dtype follows the
+//   strategy's dtype (SURVEY.md 8a dtype ledger); when the flag is 0 the stored values are exactly float32.
+#pragma once
+#include "prl_defs.h"
+
+#define PRL_CHANCE_BLOCK 32   // canonical chance-sum order: blocks of 32 children, groups of 32 blocks
+
+struct PrlDevTree {
+    int32_t n_nodes, n_cols, R, n_hole, n_cards, n_suits, rank_rule, n_boards, board_len, n_levels;
+    const int32_t *kind, *actor, *parent, *child_idx, *acted_last, *board_id, *main_pot, *n_children, *first_col,
+        *child_start, *child_list, *level_nodes;
+    const int8_t* boards;   // [n_boards][board_len]
+    const int16_t* hole;    // [R][2] 1d cards of every hand (second = -1 for 1-card games)
+    float chance_prob;      // generalised StrategyFiller.py:166 constant
+    float eq_const;         // generalised ValueFiller.py:19 constant
+    // showdown plans of 2-card games, one per board + one "no board" plan at index n_boards (see prl_plan_kernels.hip)
+    int32_t plan_stride;         // = R
+    int32_t cl_stride;           // = n_cards * (n_cards - 1)
+    const int16_t* plan_sh;      // [n_plans][R]   hand at sorted position (only the first n_live entries are valid)
+    const int16_t* plan_pos;     // [n_plans][R]   sorted position of a hand, -1 if blocked by the board
+    const int16_t* plan_gs;      // [n_plans][R]   first position of the tie group
+    const int16_t* plan_ge;      // [n_plans][R]   one past the last position of the tie group
+    const int16_t* plan_cl;      // [n_plans][n_cards][n_cards-1] positions of the hands containing card c, ascending; -1 pad
+    const int32_t* plan_nlive;   // [n_plans]
+};
+
+struct PrlDevState {
+    double* strategy;    // [n_cols][R]
+    uint8_t* strat_f64;  // [n_nodes]
+    float* reach;        // [n_nodes][2][R]
+    float* ev;
+    float* ev_br;
+    int32_t* br_idx;     // [n_nodes][R] first arg-max child of the actor's best response (nodes.py:39)
+    float* regret;       // [n_cols][R]
+    float* avg_sum;      // [n_cols][R]  (Vanilla / Linear)
+    double* avg;         // [n_cols][R]
+    uint8_t* avg_f64;    // [n_nodes]
+    float* expl;         // [2] root exploitability of the last EV pass
+};
+
+PRL_HD PRL_INLINE size_t prl_vidx(const PrlDevTree& T, int node, int p) { return ((size_t)node * 2 + (size_t)p) * (size_t)T.R; }
+PRL_HD PRL_INLINE size_t prl_cidx(const PrlDevTree& T, int col) { return (size_t)col * (size_t)T.R; }
+
+PRL_HD PRL_INLINE bool prl_hand_blocked(const PrlDevTree& T, int h, int board_id) {
+    if (board_id < 0) return false;
+    const int8_t* b = T.boards + (size_t)board_id * T.board_len;
+    int c1 = T.hole[2 * h], c2 = T.hole[2 * h + 1];
+    bool blk = false;
+    for (int i = 0; i < T.board_len; ++i) blk = blk || (b[i] == c1) || (b[i] == c2);
+    return blk;
+}

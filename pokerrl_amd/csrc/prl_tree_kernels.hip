@@ -1,0 +1,494 @@
+// Level-synchronous public-tree kernels ("engine G"): every per-node vector of the reference lives in HBM
+// (reach / ev / ev_br : [node][seat][hand]) and one kernel handles one tree level (or all terminals / all nodes of one
+// seat). Works for every supported tree (Leduc family and Hold'em-sized ranges) and keeps the reference's node
+// attribute protocol observable (node.reach_probs, node.ev, node.ev_br, node.data["regret"] ...). It is the general
+// path and the on-GPU cross-check for the fused board-block kernels (prl_fhp_kernels.hip), which keep the per-node
+// vectors on chip instead.
+//
+// Reference semantics implemented here (all float32 unless the strategy is float64, see prl_solver_types.h):
+//   k_reach_*        StrategyFiller._update_reach_probs          StrategyFiller.py:118-146 (+ chance weights :148-169)
+//   k_terminal_*     ValueFiller terminal branch                  ValueFiller.py:34-62, :103-175
+//   k_ev_level       ValueFiller non-terminal branch              ValueFiller.py:64-93
+//   k_exploitability ValueFiller epilogue at the root             ValueFiller.py:96-101
+//   k_regret_strategy  _CFRBase._compute_regrets + variants       _CFRBase.py:146-185; VanillaCFR.py:26-52; CFRPlus.py:37-63;
+//                                                                 LinearCFR.py:27-51
+//   k_average        _add_strategy_to_average                     VanillaCFR.py:54-77; CFRPlus.py:65-87; LinearCFR.py:53-76
+// Summation orders are the reference's (NumPy pairwise for contiguous inner axes, running add for outer axes,
+// SURVEY.md Appendix A); for 2-hole-card ranges the canonical wave-64 scan order of DESIGN.md.
+#include "prl_device.h"
+#include "prl_handeval.h"
+#include "prl_kernels.h"
+#include "prl_solver_types.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// summation helpers
+// ---------------------------------------------------------------------------------------------------------------------
+// NumPy float32 pairwise sum for n <= 128 (one block of the pairwise scheme), elements produced by get(i)
+template <class F>
+PRL_DEV PRL_INLINE float prl_np_sum(F get, int n) {
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; ++i) res = res + get(i);
+        return res;
+    }
+    float r0 = get(0), r1 = get(1), r2 = get(2), r3 = get(3), r4 = get(4), r5 = get(5), r6 = get(6), r7 = get(7);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 = r0 + get(i);
+        r1 = r1 + get(i + 1);
+        r2 = r2 + get(i + 2);
+        r3 = r3 + get(i + 3);
+        r4 = r4 + get(i + 4);
+        r5 = r5 + get(i + 5);
+        r6 = r6 + get(i + 6);
+        r7 = r7 + get(i + 7);
+    }
+    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res = res + get(i);
+    return res;
+}
+
+// wave-64 Hillis-Steele inclusive scan (every lane of the wave must call it)
+PRL_DEV PRL_INLINE float prl_wave_scan(float v) {
+    const unsigned lane = prl_lane();
+    for (unsigned d = 1; d < 64; d <<= 1) {
+        float t = prl_shfl_up(v, d);
+        if (lane >= d) v = v + t;
+    }
+    return v;
+}
+
+// Canonical chunked exclusive prefix of y[0..n) (LDS) into P[0..n] (LDS): 64-wide scans, sequential chunk carries.
+// tot / carry: LDS scratch of >= n_chunks + 1 floats each. Must be called by all threads of the block.
+PRL_DEV PRL_INLINE void prl_block_prefix(const float* y, int n, float* P, float* tot, float* carry) {
+    const int n_chunks = (n + 63) >> 6;
+    const int wave = (int)(prl_tid() >> 6), n_waves = (int)(prl_nthreads() >> 6), lane = (int)prl_lane();
+    for (int k = wave; k < n_chunks; k += n_waves) {
+        int j = 64 * k + lane;
+        float v = j < n ? y[j] : 0.f;
+        v = prl_wave_scan(v);
+        if (j + 1 <= n) P[j + 1] = v;  // inclusive value of position j, carry added below
+        if (lane == 63) tot[k] = v;
+    }
+    prl_sync();
+    if (prl_tid() == 0) {
+        float c = 0.f;
+        for (int k = 0; k < n_chunks; ++k) {
+            carry[k] = c;
+            c = c + tot[k];
+        }
+        carry[n_chunks] = c;
+    }
+    prl_sync();
+    // P[j] = (j % 64 == 0) ? carry[j / 64] : carry[j / 64] + incl[j - 1]
+    for (int j = (int)prl_tid(); j <= n; j += (int)prl_nthreads()) {
+        int k = j >> 6;
+        float c = carry[k];
+        P[j] = (j & 63) == 0 ? c : c + P[j];  // P[j] currently holds incl[j-1] (same chunk as j because j % 64 != 0)
+    }
+    prl_sync();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// strategy fill, reach push-down
+// ---------------------------------------------------------------------------------------------------------------------
+PRL_GLOBAL void prl_k_fill_uniform(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ col_node) {
+    const size_t total = (size_t)T.n_cols * T.R;
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        int col = (int)(t / T.R);
+        int node = col_node[col];
+        S.strategy[t] = 1.0 / (double)T.n_children[node];  // np.full(..., 1.0 / float(n_actions)) -> float64
+        if (t % T.R == 0) S.strat_f64[node] = 1;
+    }
+}
+
+PRL_GLOBAL void prl_k_reach_root(PrlDevTree T, PrlDevState S) {
+    const float r0 = (float)(1.0 / (double)T.R);  // PublicTree.py:122-124
+    for (int t = (int)(prl_bid() * prl_nthreads() + prl_tid()); t < 2 * T.R; t += (int)(prl_nblocks() * prl_nthreads())) S.reach[t] = r0;
+}
+
+PRL_GLOBAL void prl_k_reach_level(PrlDevTree T, PrlDevState S, int level_begin, int level_count) {
+    const size_t total = (size_t)level_count * T.R;
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        const int node = T.level_nodes[level_begin + (int)(t / T.R)];
+        const int h = (int)(t % T.R);
+        const int par = T.parent[node];
+        const float* rp = S.reach + prl_vidx(T, par, 0);
+        float* rc = S.reach + prl_vidx(T, node, 0);
+        if (T.kind[par] == PRL_NODE_DECISION) {
+            const int a = T.actor[par];
+            const double s = S.strategy[prl_cidx(T, T.first_col[par] + T.child_idx[node]) + h];
+            const float ra = rp[(size_t)a * T.R + h];
+            const float v = S.strat_f64[par] ? (float)(s * (double)ra) : (float)s * ra;
+            rc[(size_t)a * T.R + h] = v;
+            rc[(size_t)(1 - a) * T.R + h] = rp[(size_t)(1 - a) * T.R + h];
+        } else {  // chance: both seats' reach is scaled by the board probability, 0 for blocked hands
+            const float w = prl_hand_blocked(T, h, T.board_id[node]) ? 0.f : T.chance_prob;
+            rc[h] = rp[h] * w;
+            rc[(size_t)T.R + h] = rp[(size_t)T.R + h] * w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// terminal values, 1-hole-card games (reference arithmetic order, R <= 128)
+// ---------------------------------------------------------------------------------------------------------------------
+PRL_DEV PRL_INLINE int prl_rank_1card(const PrlDevTree& T, int h, int board_card) {
+    return prl_rank_leduc(h, board_card, T.n_suits, T.rank_rule == 1 ? 10000 : 100);
+}
+
+// ValueFiller._get_call_eq_final_street (ValueFiller.py:145-155): running float32 sum over ascending h_opp
+PRL_DEV PRL_INLINE float prl_showdown_1card(const PrlDevTree& T, const float* x, int board_card, int h) {
+    float e = 0.f;
+    if (h == board_card) return e;
+    const int rh = prl_rank_1card(T, h, board_card);
+    for (int ho = 0; ho < T.R; ++ho) {
+        if (ho == h || ho == board_card) continue;
+        const int ro = prl_rank_1card(T, ho, board_card);
+        if (rh > ro) e = e + x[ho];
+        else if (rh < ro) e = e - x[ho];
+    }
+    return e;
+}
+
+PRL_GLOBAL void prl_k_terminal_1card(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ term_nodes, int n_term) {
+    const size_t total = (size_t)n_term * 2 * T.R;
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        const int node = term_nodes[t / (2 * (size_t)T.R)];
+        const int p = (int)((t / T.R) & 1);
+        const int h = (int)(t % T.R);
+        const float* x = S.reach + prl_vidx(T, node, 1 - p);
+        const int bid = T.board_id[node];
+        const int bc = bid >= 0 ? (int)T.boards[(size_t)bid * T.board_len] : -1;
+        const bool fold = T.kind[node] == PRL_NODE_TERM_FOLD;
+        float e;
+        if (fold) {  // ValueFiller.py:103-125
+            float total_x = prl_np_sum([&](int i) { return x[i]; }, T.R);
+            e = (total_x - x[h]) * T.eq_const;
+            if (T.acted_last[node] == p) e = -e;
+        } else if (bc >= 0) {
+            e = prl_showdown_1card(T, x, bc, h) * T.eq_const;
+        } else {  // all-in before the board card: mean over the N-2 boards (ValueFiller.py:160-175)
+            float acc = 0.f;
+            for (int c = 0; c < T.n_cards; ++c) acc = acc + prl_showdown_1card(T, x, c, h) * T.eq_const;
+            e = acc / (float)(T.n_cards - 2);
+        }
+        if (h == bc) e = 0.f;  // ValueFiller.py:57-59
+        const float v = (e * (float)T.main_pot[node]) / 2.f;
+        S.ev[prl_vidx(T, node, p) + h] = v;
+        S.ev_br[prl_vidx(T, node, p) + h] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// terminal values, 2-hole-card games: one workgroup per terminal node, canonical scan order
+// ---------------------------------------------------------------------------------------------------------------------
+#define PRL_T2_YPAD 1344  // >= R = 1326, multiple of 64
+
+PRL_DEV PRL_INLINE size_t prl_t2_smem_floats(int n_cards) { return (size_t)PRL_T2_YPAD + (PRL_T2_YPAD + 8) + 64 + 64 + (size_t)n_cards * 65; }
+
+// equity of every hand against the opponent vector x (global, hand domain) on plan `plan`; result -> eq_out (global)
+PRL_DEV PRL_INLINE void prl_terminal_equity_2card(const PrlDevTree& T, const float* x, int plan, bool showdown, float* smem,
+                                                  float sign, float pot, float* out_ev, float* out_ev_br) {
+    float* y = smem;
+    float* P = y + PRL_T2_YPAD;
+    float* tot = P + PRL_T2_YPAD + 8;
+    float* carry = tot + 64;
+    float* Q = carry + 64;  // [n_cards][65]
+    const int16_t* sh = T.plan_sh + (size_t)plan * T.plan_stride;
+    const int16_t* pos = T.plan_pos + (size_t)plan * T.plan_stride;
+    const int16_t* gs = T.plan_gs + (size_t)plan * T.plan_stride;
+    const int16_t* ge = T.plan_ge + (size_t)plan * T.plan_stride;
+    const int16_t* cl = T.plan_cl + (size_t)plan * T.cl_stride;
+    const int n = T.plan_nlive[plan];
+    const int n_t = T.n_cards - 1 - (plan < T.n_boards ? T.board_len : 0);
+    const int tid = (int)prl_tid(), nt = (int)prl_nthreads();
+    for (int i = tid; i < n; i += nt) y[i] = x[sh[i]];
+    prl_sync();
+    prl_block_prefix(y, n, P, tot, carry);
+    {   // per-card scans: wave w takes cards w, w + n_waves, ...
+        const int wave = tid >> 6, n_waves = nt >> 6, lane = tid & 63;
+        for (int c = wave; c < T.n_cards; c += n_waves) {
+            const int16_t* row = cl + (size_t)c * (T.n_cards - 1);
+            int q = lane < n_t ? (int)row[lane] : -1;
+            float v = q >= 0 ? y[q] : 0.f;
+            v = prl_wave_scan(v);
+            if (lane == 0) Q[c * 65] = 0.f;
+            Q[c * 65 + lane + 1] = v;
+        }
+    }
+    prl_sync();
+    const float Tsum = P[n];
+    for (int h = tid; h < T.R; h += nt) {
+        const int i = pos[h];
+        float e = 0.f;
+        if (i >= 0) {
+            const int c1 = T.hole[2 * h], c2 = T.hole[2 * h + 1];
+            if (!showdown) {
+                const float m = Q[c1 * 65 + n_t] + Q[c2 * 65 + n_t];
+                e = Tsum - (m - x[h]);
+            } else {
+                const int g0 = gs[i], g1 = ge[i];
+                const float G = P[g0] - (Tsum - P[g1]);
+                float K[2];
+                for (int k = 0; k < 2; ++k) {
+                    const int c = k == 0 ? c1 : c2;
+                    const int16_t* row = cl + (size_t)c * (T.n_cards - 1);
+                    int lo = 0;
+                    while (lo < n_t && row[lo] < g0) lo++;
+                    int hi = lo;
+                    while (hi < n_t && row[hi] < g1) hi++;
+                    K[k] = Q[c * 65 + lo] - (Q[c * 65 + n_t] - Q[c * 65 + hi]);
+                }
+                e = (G - K[0]) - K[1];
+            }
+            e = e * T.eq_const;
+            e = sign * e;  // exact (+-1)
+        }
+        const float v = (e * pot) / 2.f;
+        out_ev[h] = v;
+        out_ev_br[h] = v;
+    }
+    prl_sync();
+}
+
+PRL_GLOBAL void prl_k_terminal_2card(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ term_nodes, int n_term) {
+    float* smem = (float*)prl_smem();
+    for (int ti = (int)prl_bid(); ti < n_term; ti += (int)prl_nblocks()) {
+        const int node = term_nodes[ti];
+        const int bid = T.board_id[node];
+        const bool fold = T.kind[node] == PRL_NODE_TERM_FOLD;
+        const float pot = (float)T.main_pot[node];
+        for (int p = 0; p < 2; ++p) {
+            float* oe = S.ev + prl_vidx(T, node, p);
+            float* ob = S.ev_br + prl_vidx(T, node, p);
+            if (!fold && bid < 0) {  // all-in before the deal is not representable in a 2-round 1-chance-level tree with 5 cards
+                for (int h = (int)prl_tid(); h < T.R; h += (int)prl_nthreads()) { oe[h] = 0.f; ob[h] = 0.f; }
+                prl_sync();
+                continue;
+            }
+            const float sign = (fold && T.acted_last[node] == p) ? -1.f : 1.f;
+            prl_terminal_equity_2card(T, S.reach + prl_vidx(T, node, 1 - p), bid < 0 ? T.n_boards : bid, !fold, smem, sign, pot, oe, ob);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// EV / best-response pull-up
+// ---------------------------------------------------------------------------------------------------------------------
+// canonical chance sum: running adds nested as blocks of 32 children, groups of 32 blocks, then the groups
+PRL_DEV PRL_INLINE float prl_chance_sum(const PrlDevTree& T, const float* arr, int node, int p, int h) {
+    const int A = T.n_children[node];
+    const int32_t* ch = T.child_list + T.child_start[node];
+    float total = 0.f;
+    for (int g0 = 0, gi = 0; g0 < A; g0 += PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK, ++gi) {
+        float gsum = 0.f;
+        for (int b0 = g0, bi = 0; b0 < A && b0 < g0 + PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK; b0 += PRL_CHANCE_BLOCK, ++bi) {
+            float bsum = arr[prl_vidx(T, ch[b0], p) + h];
+            for (int i = b0 + 1; i < A && i < b0 + PRL_CHANCE_BLOCK; ++i) bsum = bsum + arr[prl_vidx(T, ch[i], p) + h];
+            gsum = bi == 0 ? bsum : gsum + bsum;
+        }
+        total = gi == 0 ? gsum : total + gsum;
+    }
+    return total;
+}
+
+PRL_GLOBAL void prl_k_ev_level(PrlDevTree T, PrlDevState S, int level_begin, int level_count) {
+    const size_t total = (size_t)level_count * T.R;
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        const int node = T.level_nodes[level_begin + (int)(t / T.R)];
+        const int h = (int)(t % T.R);
+        const int kind = T.kind[node];
+        if (kind >= PRL_NODE_TERM_FOLD) continue;
+        if (kind == PRL_NODE_CHANCE) {  // ValueFiller.py:76-78
+            for (int p = 0; p < 2; ++p) {
+                S.ev[prl_vidx(T, node, p) + h] = prl_chance_sum(T, S.ev, node, p, h);
+                S.ev_br[prl_vidx(T, node, p) + h] = prl_chance_sum(T, S.ev_br, node, p, h);
+            }
+            continue;
+        }
+        const int A = T.n_children[node];
+        const int32_t* ch = T.child_list + T.child_start[node];
+        const int pl = T.actor[node], op = 1 - pl;
+        const int col0 = T.first_col[node];
+        float ev_pl;
+        if (S.strat_f64[node]) {  // float64 strategy: float64 products and sum, rounded on store (ValueFiller.py:87)
+            double acc = 0.;
+            for (int i = 0; i < A; ++i) {
+                double prod = S.strategy[prl_cidx(T, col0 + i) + h] * (double)S.ev[prl_vidx(T, ch[i], pl) + h];
+                acc = i == 0 ? prod : acc + prod;
+            }
+            ev_pl = (float)acc;
+        } else {
+            float acc = 0.f;
+            for (int i = 0; i < A; ++i) {
+                float prod = (float)S.strategy[prl_cidx(T, col0 + i) + h] * S.ev[prl_vidx(T, ch[i], pl) + h];
+                acc = i == 0 ? prod : acc + prod;
+            }
+            ev_pl = acc;
+        }
+        float s = S.ev[prl_vidx(T, ch[0], op) + h], sb = S.ev_br[prl_vidx(T, ch[0], op) + h];
+        float mx = S.ev_br[prl_vidx(T, ch[0], pl) + h];
+        int arg = 0;
+        for (int i = 1; i < A; ++i) {
+            s = s + S.ev[prl_vidx(T, ch[i], op) + h];
+            sb = sb + S.ev_br[prl_vidx(T, ch[i], op) + h];
+            float v = S.ev_br[prl_vidx(T, ch[i], pl) + h];
+            if (v > mx) { mx = v; arg = i; }
+        }
+        S.ev[prl_vidx(T, node, pl) + h] = ev_pl;
+        S.ev[prl_vidx(T, node, op) + h] = s;
+        S.ev_br[prl_vidx(T, node, op) + h] = sb;
+        S.ev_br[prl_vidx(T, node, pl) + h] = mx;
+        if (S.br_idx) S.br_idx[(size_t)node * T.R + h] = arg;
+    }
+}
+
+// root exploitability: sum_h (ev_br - ev) * reach  (ValueFiller.py:96-101). One workgroup.
+PRL_GLOBAL void prl_k_exploitability(PrlDevTree T, PrlDevState S, float* out2) {
+    float* smem = (float*)prl_smem();
+    if (T.n_hole == 1) {
+        if (prl_tid() < 2) {
+            const int p = (int)prl_tid();
+            const float* ev = S.ev + prl_vidx(T, 0, p);
+            const float* eb = S.ev_br + prl_vidx(T, 0, p);
+            const float* rc = S.reach + prl_vidx(T, 0, p);
+            out2[p] = prl_np_sum([&](int h) { return eb[h] * rc[h] - ev[h] * rc[h]; }, T.R);
+        }
+        return;
+    }
+    float* y = smem;
+    float* P = y + PRL_T2_YPAD;
+    float* tot = P + PRL_T2_YPAD + 8;
+    float* carry = tot + 64;
+    for (int p = 0; p < 2; ++p) {
+        const float* ev = S.ev + prl_vidx(T, 0, p);
+        const float* eb = S.ev_br + prl_vidx(T, 0, p);
+        const float* rc = S.reach + prl_vidx(T, 0, p);
+        for (int h = (int)prl_tid(); h < T.R; h += (int)prl_nthreads()) y[h] = eb[h] * rc[h] - ev[h] * rc[h];
+        prl_sync();
+        prl_block_prefix(y, T.R, P, tot, carry);
+        if (prl_tid() == 0) out2[p] = P[T.R];
+        prl_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// CFR updates of one seat
+// ---------------------------------------------------------------------------------------------------------------------
+PRL_GLOBAL void prl_k_regret_strategy(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ nodes, int n_nodes_p, int p,
+                                      int variant, int iter) {
+    const size_t total = (size_t)n_nodes_p * T.R;
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        const int node = nodes[t / T.R];
+        const int h = (int)(t % T.R);
+        const int A = T.n_children[node];
+        const int32_t* ch = T.child_list + T.child_start[node];
+        const int col0 = T.first_col[node];
+        const float strat_ev = S.ev[prl_vidx(T, node, p) + h];
+        for (int i = 0; i < A; ++i) {
+            float* rg = S.regret + prl_cidx(T, col0 + i) + h;
+            const float d = S.ev[prl_vidx(T, ch[i], p) + h] - strat_ev;
+            float r;
+            if (iter == 0) r = d;                                                   // *_first_it
+            else if (variant == PRL_CFR_LINEAR) r = ((float)(iter + 1) * d) + *rg;  // LinearCFR.py:27-28
+            else r = d + *rg;                                                       // VanillaCFR.py:26-27, CFRPlus.py:37-38
+            if (variant == PRL_CFR_PLUS) r = r > 0.f ? r : 0.f;
+            *rg = r;
+        }
+        // regret matching (CFR+ regrets are already >= 0; Vanilla / Linear clamp first)
+        auto capped = [&](int i) {
+            float r = S.regret[prl_cidx(T, col0 + i) + h];
+            return variant == PRL_CFR_PLUS ? r : (r > 0.f ? r : 0.f);
+        };
+        const float s = prl_np_sum(capped, A);
+        const float unif = (float)(1.0 / (double)A);
+        for (int i = 0; i < A; ++i) S.strategy[prl_cidx(T, col0 + i) + h] = s > 0.f ? (double)(capped(i) / s) : (double)unif;
+        if (h == 0) S.strat_f64[node] = 0;
+    }
+}
+
+// mode (CFR+ only): 0 nothing yet (iter < delay), 1 copy (iter == delay), 2 blend with the float64 weights m_old / m_new
+PRL_GLOBAL void prl_k_average(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ nodes, int n_nodes_p, int p, int variant,
+                              int iter, int mode, double m_old, double m_new) {
+    const size_t total = (size_t)n_nodes_p * T.R;
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        const int node = nodes[t / T.R];
+        const int h = (int)(t % T.R);
+        const int A = T.n_children[node];
+        const int col0 = T.first_col[node];
+        if (variant == PRL_CFR_PLUS) {
+            if (mode == 0) continue;
+            for (int i = 0; i < A; ++i) {
+                const size_t k = prl_cidx(T, col0 + i) + h;
+                if (mode == 2) S.avg[k] = m_old * S.avg[k] + m_new * S.strategy[k];
+                else S.avg[k] = S.strategy[k];
+            }
+            if (h == 0) S.avg_f64[node] = mode == 2 ? 1 : S.strat_f64[node];
+            continue;
+        }
+        const float rp = S.reach[prl_vidx(T, node, p) + h];
+        for (int i = 0; i < A; ++i) {
+            const size_t k = prl_cidx(T, col0 + i) + h;
+            float contrib = (float)S.strategy[k] * rp;
+            if (variant == PRL_CFR_LINEAR) contrib = contrib * (float)(iter + 1);
+            S.avg_sum[k] = iter > 0 ? S.avg_sum[k] + contrib : contrib;
+        }
+        const float s = prl_np_sum([&](int i) { return S.avg_sum[prl_cidx(T, col0 + i) + h]; }, A);
+        for (int i = 0; i < A; ++i) {
+            const size_t k = prl_cidx(T, col0 + i) + h;
+            S.avg[k] = (s == 0.f) ? 1.0 / (double)A : (double)(S.avg_sum[k] / s);
+        }
+        if (h == 0) S.avg_f64[node] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------------------
+static inline int prl_grid_for(size_t work_items, int block) {
+    size_t g = (work_items + (size_t)block - 1) / (size_t)block;
+    if (g < 1) g = 1;
+    if (g > 8192) g = 8192;  // grid-stride beyond 32 workgroups per CU
+    return (int)g;
+}
+
+void prl_launch_fill_uniform(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_col_node, void* stream) {
+    PRL_LAUNCH(prl_k_fill_uniform, prl_grid_for((size_t)T.n_cols * T.R, 256), 256, 0, stream, T, S, d_col_node);
+}
+
+void prl_launch_reach(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, void* stream) {
+    PRL_LAUNCH(prl_k_reach_root, 1, 256, 0, stream, T, S);
+    for (int d = 1; d < T.n_levels; ++d) {
+        int cnt = h_level_start[d + 1] - h_level_start[d];
+        if (cnt > 0) PRL_LAUNCH(prl_k_reach_level, prl_grid_for((size_t)cnt * T.R, 256), 256, 0, stream, T, S, h_level_start[d], cnt);
+    }
+}
+
+void prl_launch_ev(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, const int32_t* d_term_nodes, int n_term,
+                   void* stream) {
+    if (n_term > 0) {
+        if (T.n_hole == 1) {
+            PRL_LAUNCH(prl_k_terminal_1card, prl_grid_for((size_t)n_term * 2 * T.R, 256), 256, 0, stream, T, S, d_term_nodes, n_term);
+        } else {
+            size_t smem = ((size_t)PRL_T2_YPAD + (PRL_T2_YPAD + 8) + 64 + 64 + (size_t)T.n_cards * 65) * sizeof(float);
+            PRL_LAUNCH(prl_k_terminal_2card, n_term < 65536 ? n_term : 65536, 256, smem, stream, T, S, d_term_nodes, n_term);
+        }
+    }
+    for (int d = T.n_levels - 2; d >= 0; --d) {
+        int cnt = h_level_start[d + 1] - h_level_start[d];
+        if (cnt > 0) PRL_LAUNCH(prl_k_ev_level, prl_grid_for((size_t)cnt * T.R, 256), 256, 0, stream, T, S, h_level_start[d], cnt);
+    }
+    size_t smem = T.n_hole == 1 ? 0 : ((size_t)PRL_T2_YPAD + (PRL_T2_YPAD + 8) + 64 + 64) * sizeof(float);
+    PRL_LAUNCH(prl_k_exploitability, 1, 256, smem, stream, T, S, S.expl);
+}
+
+void prl_launch_regret_strategy(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, int iter,
+                                void* stream) {
+    if (n > 0) PRL_LAUNCH(prl_k_regret_strategy, prl_grid_for((size_t)n * T.R, 256), 256, 0, stream, T, S, d_nodes, n, p, variant, iter);
+}
+
+void prl_launch_average(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, int iter, int mode,
+                        double m_old, double m_new, void* stream) {
+    if (n > 0) PRL_LAUNCH(prl_k_average, prl_grid_for((size_t)n * T.R, 256), 256, 0, stream, T, S, d_nodes, n, p, variant, iter, mode, m_old, m_new);
+}

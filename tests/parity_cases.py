@@ -1,0 +1,159 @@
+"""
+Parity checks shared by the GPU suite (product library, `-m gpu`) and the CPU emulator suite (same kernel SOURCES built
+with -DPRL_EMU, see tests/emu/prl_emu.h). Every check compares the library's results with the CPU oracle (oracle/) on the
+same inputs, bit for bit, and -- where fixtures exist -- with values captured from the reference itself (tests/golden).
+"""
+import ctypes
+
+import numpy as np
+
+import oracle
+from helpers import GAMES, all_single_card_boards, env_args, golden
+from pokerrl_amd import _native
+from pokerrl_amd.game import bet_sets
+from pokerrl_amd.game import games as G
+
+STATE_FIELDS = ("reach", "ev", "ev_br", "strategy", "strat_f64", "regret", "avg", "avg_f64", "br_idx")
+RANK_RULE = {"StandardLeduc": 0, "BigLeduc": 1, "DiscretizedNLLeduc_POT": 0, "DiscretizedNLLeduc_B3_short": 0}
+
+
+def make_pair(L, game_cls, stack, bets, boards, variant, delay=0):
+    """(NativeTree, NativeSolver, Oracle) on the same flat tree (the product's builder feeds the oracle)."""
+    args = env_args(game_cls, stack, bets)
+    t = _native.NativeTree(game_cls.native_game(args), game_cls.native_rules(), boards, _lib=L)
+    s = _native.NativeSolver(t, variant, delay, _lib=L)
+    r = game_cls.RULES
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS,
+                      r._RANK_RULE)
+    o.cfr_reset(_native.VARIANTS[variant], delay)
+    c = s.get("constants")
+    assert c[0] == o.chance_prob and c[1] == o.eq_const
+    return t, s, o
+
+
+def assert_state_equal(s, o, tag, fields=STATE_FIELDS):
+    for k in fields:
+        a, b = s.get(k), np.asarray(getattr(o, k))
+        assert np.array_equal(a, b), "%s: %s differs in %d entries, first %s" % (tag, k, int(np.sum(a != b)), np.argwhere(a != b)[:3].tolist())
+    assert np.array_equal(s.exploitability(), o.exploitability), (tag, s.exploitability(), o.exploitability)
+
+
+def check_cfr_vs_oracle(L, gkey, variant, n_iters, delay=0, check_every=1):
+    cls, stack, bets = GAMES[gkey]
+    t, s, o = make_pair(L, cls, stack, bets, all_single_card_boards(cls), variant, delay)
+    assert_state_equal(s, o, "%s/%s it0" % (gkey, variant))
+    for it in range(1, n_iters + 1):
+        s.iteration()
+        o.cfr_iteration()
+        if it % check_every == 0 or it == n_iters:
+            assert_state_equal(s, o, "%s/%s it%d" % (gkey, variant, it))
+        if variant != "plus" or it > delay:
+            assert np.array_equal(s.eval_avg(), o.eval_avg()), (gkey, variant, it)
+    hist = s.get("expl_history")
+    assert hist.shape == (n_iters + 1, 2)
+    assert np.array_equal(hist[-1], o.exploitability)
+
+
+def check_cfr_vs_reference_series(L, fixture, gkey, variant):
+    """Logged exploitability (mean of seats x EV_NORMALIZER, _CFRBase.py:198-216,257-262) vs the reference's own log."""
+    g = golden("cfr_%s.npz" % fixture)
+    cls, stack, bets = GAMES[gkey]
+    args = env_args(cls, stack, bets)
+    t = _native.NativeTree(cls.native_game(args), cls.native_rules(), all_single_card_boards(cls), _lib=L)
+    s = _native.NativeSolver(t, variant, 0, _lib=L)
+    evn = float(g["ev_normalizer"])
+
+    def logged(e):
+        return (float(e[0]) * evn + float(e[1]) * evn) / 2
+
+    curr, avg = g["curr_series"], g["avg_series"]
+    assert logged(s.exploitability()) == curr[0, 1]
+    for it in range(1, int(curr[-1, 0]) + 1):
+        s.iteration()
+        assert logged(s.exploitability()) == curr[it, 1], (fixture, it)
+        row = avg[avg[:, 0] == it]
+        assert len(row) == 1 and logged(s.eval_avg()) == row[0, 1], (fixture, it)
+    # per-node arrays of the last snapshot, straight from the reference's tree
+    it = int(curr[-1, 0])
+    for k in ("reach", "ev", "ev_br", "regret", "strategy", "avg"):
+        key = "it%d_%s" % (it, k)
+        if key in g:
+            assert np.array_equal(s.get(k), g[key]), (fixture, k)
+        elif key + "_sha256" in g:
+            from helpers import h32
+            assert h32(s.get(k)) == str(g[key + "_sha256"]), (fixture, k)
+
+
+def fhp_boards(n, seed=5, with_special=True):
+    rng = np.random.RandomState(seed)
+    seen, out = set(), []
+    if with_special and n >= 3:
+        for b in ([24, 25, 26, 27, 33], [32, 36, 40, 44, 48], [0, 5, 10, 15, 51]):  # quads, royal flush, dry board
+            out.append(b)
+            seen.add(tuple(b))
+    while len(out) < n:
+        b = tuple(sorted(int(x) for x in rng.choice(52, 5, replace=False)))
+        if b not in seen:
+            seen.add(b)
+            out.append(list(b))
+    return np.array(out[:n], dtype=np.int8)
+
+
+def check_fhp_vs_oracle(L, n_boards, variant, n_iters, check_fields=STATE_FIELDS):
+    boards = fhp_boards(n_boards)
+    t, s, o = make_pair(L, G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards, variant)
+    assert t.n_nodes == 5 + 15 * n_boards
+    assert_state_equal(s, o, "FHP/%s it0" % variant, check_fields)
+    for it in range(1, n_iters + 1):
+        s.iteration()
+        o.cfr_iteration()
+        assert_state_equal(s, o, "FHP/%s it%d" % (variant, it), check_fields)
+        assert np.array_equal(s.eval_avg(), o.eval_avg())
+    return s, o
+
+
+def check_br_of_given_strategy(L, gkey, seed, f64):
+    """LocalBRMaster semantics (LocalBRMaster.py:67-80): fill an arbitrary strategy, reach, EV + best response."""
+    cls, stack, bets = GAMES[gkey]
+    t, s, o = make_pair(L, cls, stack, bets, all_single_card_boards(cls), "vanilla")
+    rng = np.random.RandomState(seed)
+    strat = np.zeros((t.n_cols, t.range_size), np.float64 if f64 else np.float32)
+    first_col, n_ch, kind = t.field("first_col"), t.field("n_children"), t.field("kind")
+    for n in np.where(kind == 0)[0]:
+        a = n_ch[n]
+        x = rng.random_sample((a, t.range_size))  # fill_random_random (StrategyFiller.py:67-86)
+        x /= x.sum(axis=0, keepdims=True)
+        strat[first_col[n]:first_col[n] + a] = x
+    s.set_strategy(strat)
+    o.set_strategy(strat.astype(np.float64), f64)
+    s.compute_ev()
+    o.compute_ev()
+    assert_state_equal(s, o, "BR %s" % gkey, ("reach", "ev", "ev_br", "br_idx"))
+    e = s.exploitability()
+    assert np.all(e >= -1e-3)  # a best response never does worse than the strategy itself
+
+
+def check_hand_rank_golden(L):
+    g = golden("handrank.npz")
+    b = np.ascontiguousarray(g["boards"])
+    out = np.empty((b.shape[0], 1326), np.int32)
+    _native.check(L.prl_hand_rank_boards(b.ctypes.data_as(ctypes.c_void_p), b.shape[0], out.ctypes.data_as(ctypes.c_void_p)), L)
+    assert np.array_equal(out, g["ranks"])
+    assert np.array_equal(out, oracle.rank_boards(b))
+    assert int(np.sum(out[0] == -1)) == 245  # blocked hands per 5-card board
+
+
+def check_hand_rank_checksums(L, n_chunks=None):
+    import itertools
+    g = golden("handrank_exhaustive.npz")
+    chunk = int(g["chunk_boards"])
+    ref = g["checksums"]
+    n_boards = 2598960 if n_chunks is None else n_chunks * chunk
+    it = itertools.chain.from_iterable(itertools.islice(itertools.combinations(range(52), 5), n_boards))
+    boards = np.fromiter(it, dtype=np.int8, count=5 * n_boards).reshape(n_boards, 5)
+    L.prl_hand_rank_checksums.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    L.prl_hand_rank_checksums.restype = ctypes.c_int32
+    out = np.zeros((n_boards + chunk - 1) // chunk, np.uint64)
+    _native.check(L.prl_hand_rank_checksums(boards.ctypes.data_as(ctypes.c_void_p), n_boards, chunk, out.ctypes.data_as(ctypes.c_void_p)), L)
+    assert np.array_equal(out, ref[:out.shape[0]])
+    return out.shape[0]

@@ -1,0 +1,59 @@
+"""
+CPU suite: the HIP kernel SOURCES (pokerrl_amd/csrc/*.hip) compiled with -DPRL_EMU and executed by the fiber-based SIMT
+emulator of tests/emu/ -- compared bit for bit with the CPU oracle and the reference's golden vectors. This catches
+indexing / barrier / scan-order mistakes in the GPU-less container; the same cases run against the real hipcc build on an
+MI355X in test_gpu_parity.py. (The emulator is test infrastructure; the package never loads it.)
+"""
+import os
+import sys
+
+import pytest
+
+import parity_cases as pc
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
+
+
+@pytest.fixture(scope="module")
+def L():
+    import build_emu
+    from pokerrl_amd import _native
+    lib = _native.bind(build_emu.build())
+    assert lib.prl_build_flavor().startswith(b"emu")
+    return lib
+
+
+@pytest.mark.parametrize("variant", ["vanilla", "plus", "linear"])
+def test_emu_standard_leduc_vs_oracle(L, variant):
+    pc.check_cfr_vs_oracle(L, "StandardLeduc", variant, 4)
+
+
+def test_emu_cfrplus_delay(L):
+    pc.check_cfr_vs_oracle(L, "StandardLeduc", "plus", 4, delay=2)
+
+
+def test_emu_nl_leduc_all_in_preflop_terminals(L):
+    pc.check_cfr_vs_oracle(L, "DiscretizedNLLeduc_POT", "linear", 2)
+
+
+def test_emu_reference_series_standard_leduc(L):
+    pc.check_cfr_vs_reference_series(L, "StandardLeduc_CFRPlus", "StandardLeduc", "plus")
+
+
+@pytest.mark.slow
+def test_emu_big_leduc_pairwise_sums(L):
+    pc.check_cfr_vs_oracle(L, "BigLeduc", "plus", 1)
+
+
+def test_emu_fhp_three_boards(L):
+    pc.check_fhp_vs_oracle(L, 3, "plus", 1)
+
+
+def test_emu_br_of_random_strategy(L):
+    pc.check_br_of_given_strategy(L, "StandardLeduc", 0, f64=True)
+    pc.check_br_of_given_strategy(L, "StandardLeduc", 1, f64=False)
+
+
+def test_emu_hand_rank_kernel(L):
+    pc.check_hand_rank_golden(L)
+    assert pc.check_hand_rank_checksums(L, n_chunks=2) == 2

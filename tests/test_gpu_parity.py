@@ -1,0 +1,140 @@
+"""
+GPU suite (`pytest -m gpu`, real MI355X): the hipcc-built libpokerrl_hip.so, called through its C ABI, against the CPU
+oracle and the reference's golden vectors. Bit-exact for ranks / indices / every float32 array of the Leduc-family CFR
+runs; float tolerance appears nowhere in this file except for the size-independent properties at bench scale.
+"""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from helpers import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from pokerrl_amd import _native
+    _native.require_device()
+    lib = _native.lib()
+    assert lib.prl_build_flavor() == b"hip-gfx950"
+    return lib
+
+
+# ---- hand evaluator -----------------------------------------------------------------------------------------------------
+def test_gpu_hand_rank_64_boards_vs_reference_binary(L):
+    pc.check_hand_rank_golden(L)
+
+
+def test_gpu_hand_rank_20000_boards_sha256(L):
+    """SHA-256 of the 20000 x 1326 result for RandomState(0) boards starts 928d0aa3b1ae9432."""
+    import hashlib
+
+    from pokerrl_amd import _native
+    g = golden("handrank.npz")
+    rng = np.random.RandomState(0)
+    boards = np.array([rng.choice(52, 5, replace=False) for _ in range(20000)], dtype=np.int8)
+    ranks = _native.hand_rank_boards(boards)
+    sha = hashlib.sha256(ranks.tobytes()).hexdigest()
+    assert sha == str(g["sha256_rs0_20000"])
+    assert sha.startswith("928d0aa3b1ae9432")
+    # board-order invariance (SURVEY.md 2.2 pinned property)
+    perm = boards[:, ::-1].copy()
+    assert np.array_equal(_native.hand_rank_boards(perm), ranks)
+
+
+def test_gpu_hand_rank_exhaustive_checksums(L):
+    """All C(52,5) x 1326 evaluations against per-256-board checksums of the reference binary's output."""
+    assert pc.check_hand_rank_checksums(L) == 10153
+
+
+def test_gpu_legacy_batched_symbol_row_pointers(L):
+    """Drop-in signature of lib_hand_eval.so: CppHandeval.py:45-65 passes row-pointer vectors."""
+    import ctypes
+    g = golden("handrank.npz")
+    boards = np.ascontiguousarray(g["boards"][:7])
+    out = np.full((7, 1326), -1, np.int32)
+
+    def rows(a):
+        return (a.__array_interface__["data"][0] + np.arange(a.shape[0]) * a.strides[0]).astype(np.intp)
+
+    lut1 = np.zeros((1326, 2), np.int8)
+    lut2 = np.zeros((52, 2), np.int8)
+    L.get_hand_rank_all_hands_on_given_boards_52_holdem(
+        rows(out).ctypes.data_as(ctypes.c_void_p), rows(boards).ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(7),
+        rows(lut1).ctypes.data_as(ctypes.c_void_p), rows(lut2).ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(out, g["ranks"][:7])
+
+
+# ---- CFR on the Leduc family: oracle (all arrays, every iteration) and the reference's own logs ---------------------------
+@pytest.mark.parametrize("variant", ["vanilla", "plus", "linear"])
+def test_gpu_standard_leduc_vs_oracle(L, variant):
+    pc.check_cfr_vs_oracle(L, "StandardLeduc", variant, 12)
+
+
+def test_gpu_cfrplus_delay(L):
+    pc.check_cfr_vs_oracle(L, "StandardLeduc", "plus", 6, delay=3)
+
+
+@pytest.mark.parametrize("gkey,variant", [("DiscretizedNLLeduc_POT", "plus"), ("DiscretizedNLLeduc_POT", "linear"),
+                                          ("DiscretizedNLLeduc_B3_short", "vanilla")])
+def test_gpu_nl_leduc_vs_oracle(L, gkey, variant):
+    pc.check_cfr_vs_oracle(L, gkey, variant, 5)
+
+
+def test_gpu_big_leduc_vs_oracle(L):
+    pc.check_cfr_vs_oracle(L, "BigLeduc", "plus", 3)
+
+
+@pytest.mark.parametrize("fixture,gkey,variant", [
+    ("StandardLeduc_CFRPlus", "StandardLeduc", "plus"),
+    ("StandardLeduc_VanillaCFR", "StandardLeduc", "vanilla"),
+    ("StandardLeduc_LinearCFR", "StandardLeduc", "linear"),
+    ("DiscretizedNLLeduc_POT_CFRPlus", "DiscretizedNLLeduc_POT", "plus"),
+    ("DiscretizedNLLeduc_POT_LinearCFR", "DiscretizedNLLeduc_POT", "linear"),
+    ("DiscretizedNLLeduc_B3_short_VanillaCFR", "DiscretizedNLLeduc_B3_short", "vanilla"),
+    ("BigLeduc_CFRPlus", "BigLeduc", "plus"),
+])
+def test_gpu_reference_exploitability_series(L, fixture, gkey, variant):
+    pc.check_cfr_vs_reference_series(L, fixture, gkey, variant)
+
+
+def test_gpu_long_run_150_iterations_matches_oracle(L):
+    """examples/run_cfrp_example.py runs 150 iterations; arrays compared every 50."""
+    pc.check_cfr_vs_oracle(L, "StandardLeduc", "plus", 150, check_every=50)
+
+
+@pytest.mark.parametrize("gkey", ["StandardLeduc", "DiscretizedNLLeduc_POT"])
+def test_gpu_best_response_of_random_strategy(L, gkey):
+    pc.check_br_of_given_strategy(L, gkey, 0, f64=True)
+    pc.check_br_of_given_strategy(L, gkey, 1, f64=False)
+
+
+# ---- Flop5Holdem (1326-hand ranges): oracle on small board sets, properties at bench scale --------------------------------
+@pytest.mark.parametrize("variant", ["plus", "linear", "vanilla"])
+def test_gpu_fhp_40_boards_vs_oracle(L, variant):
+    pc.check_fhp_vs_oracle(L, 40, variant, 3)  # 40 boards > one canonical chance block of 32
+
+
+def test_gpu_fhp_properties_at_scale(L):
+    """1024 boards: zero-sum, BR >= EV, exploitability >= 0 and decreasing on average, strategies row-stochastic."""
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    from helpers import native_tree
+    boards = pc.fhp_boards(1024, seed=11)
+    t = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)
+    s = _native.NativeSolver(t, "plus", 0)
+    e0 = s.exploitability()
+    s.iterations(10)
+    e10 = s.exploitability()
+    assert np.all(e0 > 0) and np.all(e10 >= 0)
+    assert e10.mean() < e0.mean()
+    ev, ev_br, reach = s.get("ev"), s.get("ev_br"), s.get("reach")
+    zs = np.sum(ev.astype(np.float64) * reach.astype(np.float64), axis=(1, 2))  # ValueFiller.py:98 per node
+    assert np.max(np.abs(zs)) < 1e-3
+    assert np.all(ev_br[0] >= ev[0] - 1e-3)
+    strat = s.get("strategy")
+    fc, nc, kind = t.field("first_col"), t.field("n_children"), t.field("kind")
+    for n in np.where(kind == 0)[0][:200]:
+        assert np.allclose(strat[fc[n]:fc[n] + nc[n]].sum(axis=0), 1, atol=1e-5)

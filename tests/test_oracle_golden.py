@@ -1,0 +1,109 @@
+"""
+Pins the CPU oracle (oracle/prl_oracle.c) to the reference: per-node CFR dumps + exploitability logs captured from
+PokerRL itself (tests/golden/cfr_*.npz), the binary evaluator's ranks (handrank.npz), NumPy's summation order, and -- for
+the 2-card generalisation that the reference cannot run -- the O(R^2) definition of showdown equity.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import golden, golden_tree_as_flat, h32
+from parity_cases import fhp_boards
+
+CASES = [
+    ("StandardLeduc_CFRPlus", "StandardLeduc", 1, 6, 0),
+    ("StandardLeduc_VanillaCFR", "StandardLeduc", 0, 6, 0),
+    ("StandardLeduc_LinearCFR", "StandardLeduc", 2, 6, 0),
+    ("DiscretizedNLLeduc_POT_CFRPlus", "DiscretizedNLLeduc_POT", 1, 6, 0),
+    ("DiscretizedNLLeduc_POT_LinearCFR", "DiscretizedNLLeduc_POT", 2, 6, 0),
+    ("DiscretizedNLLeduc_B3_short_VanillaCFR", "DiscretizedNLLeduc_B3_short", 0, 6, 0),
+    ("BigLeduc_CFRPlus", "BigLeduc", 1, 24, 1),
+]
+
+
+@pytest.mark.parametrize("fixture,gkey,variant,n_cards,rank_rule", CASES)
+def test_oracle_matches_reference_dumps(fixture, gkey, variant, n_cards, rank_rule):
+    g = golden("cfr_%s.npz" % fixture)
+    t = golden_tree_as_flat(gkey)  # the REFERENCE's tree, not the product's
+    o = oracle.Oracle(t, np.arange(n_cards, dtype=np.int8).reshape(-1, 1), 1, n_cards, 2, rank_rule)
+    o.cfr_reset(variant, 0)
+    evn = float(g["ev_normalizer"])
+
+    def cmp(prefix):
+        for k in ("reach", "ev", "ev_br", "strategy", "regret", "avg", "strat_f64", "avg_f64", "exploitability"):
+            mine = np.asarray(getattr(o, k))
+            if prefix + k in g:
+                assert np.array_equal(mine, g[prefix + k]), (fixture, prefix, k)
+            elif prefix + k + "_sha256" in g:
+                assert h32(mine) == str(g[prefix + k + "_sha256"]), (fixture, prefix, k)
+
+    cmp("it0_")
+    curr, avg = g["curr_series"], g["avg_series"]
+    for it in range(1, int(curr[-1, 0]) + 1):
+        o.cfr_iteration()
+        e = o.exploitability
+        assert (float(e[0]) * evn + float(e[1]) * evn) / 2 == curr[it, 1]
+        ea = o.eval_avg()
+        row = avg[avg[:, 0] == it]
+        assert len(row) == 1 and (float(ea[0]) * evn + float(ea[1]) * evn) / 2 == row[0, 1]
+        if ("it%d_reach" % it in g) or ("it%d_reach_sha256" % it in g):
+            cmp("it%d_" % it)
+
+
+def test_oracle_series_tripwires_from_survey():
+    """SURVEY.md section 8a golden values (logged exploitability, mA/g)."""
+    g = golden("cfr_StandardLeduc_CFRPlus.npz")
+    assert g["curr_series"][0, 1] == 2373.611330986023
+    assert g["curr_series"][1, 1] == 2051.1115193367004
+    assert g["avg_series"][-1, 1] == 527.1249711513519
+
+
+def test_oracle_hand_ranks_match_reference_binary():
+    g = golden("handrank.npz")
+    assert np.array_equal(oracle.rank_boards(g["boards"]), g["ranks"])
+    for hand, board, rank in zip(g["known_hands"], g["known_boards"], g["known_ranks"]):
+        assert oracle.rank7(board, hand[0], hand[1]) == rank
+
+
+def test_oracle_np_sum_order_is_numpys():
+    rng = np.random.RandomState(0)
+    for n in (1, 3, 6, 7, 8, 9, 12, 24, 100, 128):
+        for _ in range(50):
+            a = (rng.randn(n) * 10 ** rng.uniform(-3, 3, n)).astype(np.float32)
+            assert oracle.np_sum_f32(a) == np.sum(a), n
+
+
+def test_oracle_two_card_equity_against_the_quadratic_definition():
+    boards = fhp_boards(6)
+    tree = dict(kind=[0], actor=[0], parent=[-1], child_idx=[0], action=[-1], acted_last=[-1], round=[0], board_id=[-1],
+                main_pot=[0], n_children=[0], first_col=[0], child_start=[0, 0], child_list=[])
+    o = oracle.Oracle({k: np.array(v, np.int32) for k, v in tree.items()}, boards, 2, 52, 4, 2)
+    rng = np.random.RandomState(3)
+    lut = np.array([(a, b) for a in range(52) for b in range(a + 1, 52)])
+    for b in range(len(boards)):
+        blocked = np.isin(lut, boards[b]).any(axis=1)
+        # (1) dyadic reach values: every float32 partial sum is exact, so the scan order cannot matter -> bit-exact
+        x = (rng.randint(0, 64, 1326) / 64.0).astype(np.float32)
+        x[blocked] = 0
+        eq = o.terminal_equity(x, b, showdown=True)
+        bf = o.showdown_bruteforce(x, b)
+        assert np.array_equal(eq.astype(np.float64), bf), b
+        assert np.all(eq[blocked] == 0)
+        # (2) generic reach values: agreement to float32 round-off of the prefix sums
+        x = rng.random_sample(1326).astype(np.float32)
+        x[blocked] = 0
+        eq = o.terminal_equity(x, b, showdown=True)
+        bf = o.showdown_bruteforce(x, b)
+        assert np.max(np.abs(eq - bf)) <= 2e-5 * np.sum(x)
+        # fold equity: total opponent mass compatible with my two cards
+        ef = o.terminal_equity(x, b, showdown=False)
+        live = ~blocked
+        for h in rng.choice(np.where(live)[0], 25, replace=False):
+            comp = live & ~np.isin(lut, lut[h]).any(axis=1)
+            assert abs(ef[h] - x[comp].astype(np.float64).sum()) <= 2e-5 * np.sum(x)
+    # "no board" plan (pre-deal fold nodes): all 1326 hands live
+    x = (rng.randint(0, 64, 1326) / 64.0).astype(np.float32)
+    ef = o.terminal_equity(x, -1, showdown=False)
+    for h in (0, 17, 700, 1325):
+        comp = ~np.isin(lut, lut[h]).any(axis=1)
+        assert ef[h] == np.float32(x[comp].astype(np.float64).sum())
