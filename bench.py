@@ -66,8 +66,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--boards", type=int, default=int(os.environ.get("PRL_BENCH_BOARDS", "8192")), help="boards per GPU")
-    ap.add_argument("--engine", default=os.environ.get("PRL_BENCH_ENGINE", "levels"))
+    ap.add_argument("--boards", type=int, default=int(os.environ.get("PRL_BENCH_BOARDS", "16384")), help="boards per GPU")
+    ap.add_argument("--engine", default=os.environ.get("PRL_BENCH_ENGINE", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-boards", type=int, default=192)
     ap.add_argument("--cpu-iters", type=int, default=16)
@@ -94,7 +94,7 @@ def main():
     # every rank owns its own shard of boards (weak scaling: fixed boards per GPU)
     boards = seeded_boards(args.boards, 0, offset=rank * args.boards)
     tree = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)
-    solver = _native.NativeSolver(tree, "plus", 0)
+    solver = _native.NativeSolver(tree, "plus", 0, engine=args.engine)
     solver.sync()
 
     def barrier():
@@ -129,7 +129,7 @@ def main():
             "workload": "CFR+ (delay 0) full-width iterations on the Flop5Holdem public tree (blinds 50/100, stacks 20000, "
                         "pot-size raises), %d seeded boards per GPU, 1326-hand ranges" % args.boards,
             "boards_per_gpu": args.boards, "nodes_per_gpu": tree.n_nodes, "action_columns_per_gpu": sum_a,
-            "engine": args.engine, "parallelism": "boards sharded over %d GPU(s)" % world,
+            "engine": solver.engine, "fhp_cfg": os.environ.get("PRL_FHP_CFG", "0"), "parallelism": "boards sharded over %d GPU(s)" % world,
             "iterations_done": solver.iter, "exploitability_mbb_per_g": float(np.mean(expl) * 10.0),
             "hbm_bytes_allocated": int(solver.get("bytes_allocated")[0]),
         },

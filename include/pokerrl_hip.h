@@ -203,6 +203,11 @@ enum { PRL_VARIANT_VANILLA = 0, PRL_VARIANT_PLUS = 1, PRL_VARIANT_LINEAR = 2 };
 
 /* create = upload tree + build showdown plans + CFRBase.reset(); `delay` is CFR+'s linear-averaging delay */
 int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay, prl_solver_t** out_solver);
+/* engine selection: AUTO = FUSED where applicable (Flop5Holdem-shaped tree + CFR+), else LEVELS.
+ *   LEVELS keeps every per-node vector in HBM (any supported tree; node.reach_probs / ev / ev_br readable);
+ *   FUSED walks each board subtree on chip and only keeps regrets / averages / per-board root values in HBM. */
+enum { PRL_ENGINE_AUTO = 0, PRL_ENGINE_LEVELS = 1, PRL_ENGINE_FUSED = 2 };
+int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out_solver);
 void prl_solver_destroy(prl_solver_t* solver);
 int32_t prl_solver_reset(prl_solver_t* solver);                        /* _CFRBase.reset            :110-120 */
 int32_t prl_solver_iteration(prl_solver_t* solver);                    /* _CFRBase.iteration        :122-134 (w/o avg eval) */
@@ -231,7 +236,8 @@ enum {
     PRL_SF_EXPL_HISTORY = 10, /* float32 [iter+1][2]     current-strategy exploitability after every iteration */
     PRL_SF_ITER = 11,        /* int32                    iteration counter                     */
     PRL_SF_CONSTANTS = 12,   /* float32 [2]              chance probability, equity constant   */
-    PRL_SF_BYTES_ALLOCATED = 13 /* int64                 HBM bytes held by the solver          */
+    PRL_SF_BYTES_ALLOCATED = 13, /* int64                HBM bytes held by the solver          */
+    PRL_SF_ENGINE = 14       /* int32                    PRL_ENGINE_LEVELS or PRL_ENGINE_FUSED  */
 };
 int32_t prl_solver_get(prl_solver_t* solver, int32_t field, void* out);
 

@@ -132,6 +132,8 @@ def _bind_solver(L):
         return
     vp, i32, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_double
     L.prl_solver_create.argtypes = [vp, i32, i32, ctypes.POINTER(vp)]
+    L.prl_solver_create_ex.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp)]
+    L.prl_solver_create_ex.restype = i32
     L.prl_solver_get.argtypes = [vp, i32, vp]
     L.prl_solver_get.restype = i32
     L.prl_solver_create.restype = i32
@@ -261,22 +263,27 @@ class NativeTree:
 
 # solver field ids (include/pokerrl_hip.h)
 SF = dict(reach=0, ev=1, ev_br=2, strategy=3, strat_f64=4, regret=5, avg=6, avg_f64=7, avg_sum=8, br_idx=9,
-          expl_history=10, iter=11, constants=12, bytes_allocated=13)
+          expl_history=10, iter=11, constants=12, bytes_allocated=13, engine=14)
 VARIANTS = {"vanilla": 0, "plus": 1, "linear": 2}
+ENGINES = {"auto": 0, "levels": 1, "fused": 2}
 
 
 class NativeSolver:
     """Owns a prl_solver_t* : the device-resident CFR / best-response solver of one public tree."""
 
-    def __init__(self, tree, variant, delay=0, _lib=None):
+    def __init__(self, tree, variant, delay=0, engine="auto", _lib=None):
         self._L = _lib or tree._L
         if _lib is None and self._L is lib():
             require_device()
         self.tree = tree
         self._h = ctypes.c_void_p()
         v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
-        check(self._L.prl_solver_create(tree.handle, v, int(delay), ctypes.byref(self._h)), self._L)
+        e = ENGINES[engine] if isinstance(engine, str) else int(engine)
+        check(self._L.prl_solver_create_ex(tree.handle, v, int(delay), e, ctypes.byref(self._h)), self._L)
         self.n_nodes, self.n_cols, self.R = tree.n_nodes, tree.n_cols, tree.range_size
+        eng = np.zeros(1, np.int32)
+        self._call("prl_solver_get", SF["engine"], _ptr(eng))
+        self.engine = {1: "levels", 2: "fused"}[int(eng[0])]
 
     def __del__(self):
         try:

@@ -1,0 +1,100 @@
+// Compile-time description of the Flop5Holdem board subtree + runtime parameters of the fused board kernels.
+//
+// Shape (local node ids in DFS pre-order; reference game: PokerRL/game/games.py:222-254, pot-size raises, at most two
+// raises per round, BB acts first post-flop -- captured from the reference env in tests/golden/tree_Flop5Holdem_1board.npz):
+//
+//   0 seat1 {check -> 1, bet -> 9}
+//   1   seat0 {check -> 2 SHOWDOWN, bet -> 3}
+//   3     seat1 {fold -> 4, call -> 5 SHOWDOWN, raise -> 6}
+//   6       seat0 {fold -> 7, call -> 8 SHOWDOWN}
+//   9   seat0 {fold -> 10, call -> 11 SHOWDOWN, raise -> 12}
+//   12    seat1 {fold -> 13, call -> 14 SHOWDOWN}
+//
+// Only the SHAPE is compiled in; pots are runtime data, and prl_fhp_shape_matches() checks the flat tree of the actual
+// game against it before the fused engine is selected (otherwise the general level-synchronous engine is used).
+#pragma once
+#include "prl_defs.h"
+#include "prl_solver_types.h"
+#include "prl_tree.h"
+
+enum { PRL_SRC_REGRET = 0, PRL_SRC_UNIFORM64 = 1, PRL_SRC_ARR64 = 2, PRL_SRC_ARR32 = 3 };
+enum { PRL_FHP_UPDATE0 = 0, PRL_FHP_UPDATE1 = 1, PRL_FHP_EVAL = 2 };
+
+struct PrlFhpShape {
+    static constexpr int N_NODES = 15;
+    static constexpr int N_COLS = 14;
+    static constexpr int N_DEC = 6;
+    static constexpr int N_DEC_PER_SEAT = 3;
+
+    static constexpr int kind(int n) {
+        constexpr int K[N_NODES] = {0, 0, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3};
+        return K[n];
+    }
+    static constexpr int actor(int n) {
+        constexpr int A[N_NODES] = {1, 0, -1, 1, -1, -1, 0, -1, -1, 0, -1, -1, 1, -1, -1};
+        return A[n];
+    }
+    static constexpr int nch(int n) {
+        constexpr int C[N_NODES] = {2, 2, 0, 3, 0, 0, 2, 0, 0, 3, 0, 0, 2, 0, 0};
+        return C[n];
+    }
+    static constexpr int child(int n, int i) {
+        constexpr int C[N_NODES][3] = {{1, 9, -1}, {2, 3, -1}, {-1, -1, -1}, {4, 5, 6},  {-1, -1, -1}, {-1, -1, -1}, {7, 8, -1}, {-1, -1, -1},
+                                       {-1, -1, -1}, {10, 11, 12}, {-1, -1, -1}, {-1, -1, -1}, {13, 14, -1}, {-1, -1, -1}, {-1, -1, -1}};
+        return C[n][i];
+    }
+    static constexpr int col0(int n) {
+        constexpr int C[N_NODES] = {0, 2, -1, 4, -1, -1, 7, -1, -1, 9, -1, -1, 12, -1, -1};
+        return C[n];
+    }
+    // seat that folded at a fold node (= the parent's actor)
+    static constexpr int folder(int n) {
+        constexpr int F[N_NODES] = {-1, -1, -1, -1, 1, -1, -1, 0, -1, -1, 0, -1, -1, 1, -1};
+        return F[n];
+    }
+    static constexpr int parent(int n) {
+        constexpr int P[N_NODES] = {-1, 0, 1, 1, 3, 3, 3, 6, 6, 0, 9, 9, 9, 12, 12};
+        return P[n];
+    }
+    static constexpr int col_actor(int col) {
+        constexpr int A[N_COLS] = {1, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1, 1};
+        return A[col];
+    }
+    static constexpr int dec_node(int j) {
+        constexpr int D[N_DEC] = {0, 1, 3, 6, 9, 12};
+        return D[j];
+    }
+    static constexpr int seat_node(int seat, int j) {
+        constexpr int D[2][N_DEC_PER_SEAT] = {{1, 6, 9}, {0, 3, 12}};
+        return D[seat][j];
+    }
+};
+
+struct PrlFhpParams {
+    int32_t n_boards, R;
+    int32_t col_base;           // global action column of board 0, local column 0
+    int32_t variant, iter;
+    int32_t max_grid;
+    int32_t cfg;                // launch configuration of the board-pass kernel (prl_fhp_kernels.hip)
+    float chance_prob, eq_const;
+    float pot[PrlFhpShape::N_NODES];   // main pot of the terminal nodes (by local node id)
+    const float* chance_reach;  // [2][R] reach at the chance node (trunk state)
+    float* regret;              // [n_cols][R] (global column ids)
+    const double* strat_arr;    // explicit strategy (average strategy / caller-provided), [n_cols][R]
+    float* board_ev;            // [n_boards][2][R] root values of every board subtree
+    float* board_br;            // [n_boards][2][R] best-response values (PRL_FHP_EVAL)
+    const uint16_t* hole_packed;// [R] c1 | c2 << 8
+    int32_t plan_stride, cl_stride;
+    const int16_t *plan_pos, *plan_hgs, *plan_hge, *plan_gs;
+    const uint16_t* plan_clw;
+    const int32_t* plan_nlive;
+};
+
+// host: does the flat tree consist of a trunk + ONE chance node whose board subtrees all have the compiled shape?
+// On success fills the chance node id, the first board node, the global column base and the terminal pots.
+bool prl_fhp_shape_matches(const PrlFlatTree& t, int* chance_node, int* first_board_node, int* col_base, float* pots /*[15]*/);
+
+int prl_launch_fhp_pass(const PrlFhpParams& prm, int mode, int src0, int src1, void* stream);
+void prl_launch_fhp_average_plus(const PrlFhpParams& prm, int p, int mode, double m_old, double m_new, double* avg, void* stream);
+void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_cols, void* stream);
+void prl_launch_fhp_chance_sum(const float* d_board_vals, int n_boards, int R, float* d_scratch, float* d_dest, void* stream);

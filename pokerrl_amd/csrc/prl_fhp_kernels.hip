@@ -1,0 +1,187 @@
+// Fused board-block kernels ("engine F") for the Flop5Holdem public tree: CFR+ on 1326-hand ranges with every per-node
+// vector of a board subtree kept ON CHIP.
+//
+// Why: the reference materialises reach / ev / ev_br for every node ([2][R] float32 each, nodes.py:33-36). On the FHP tree
+// that is ~3.75 MB of transient traffic per board and iteration against ~0.4 MB of persistent state. Below
+// each chance outcome the board subtree is independent (ValueFiller.py:76-78 is a plain sum over boards), its shape is the
+// same for every board (betting never looks at the cards) and per hand everything except terminal equity is hand-local.
+// So: one workgroup walks ONE board subtree depth-first with the subtree shape known at COMPILE time (prl_fhp_shape.h):
+//   * 512 lanes x 3 hand slots cover the 1326 hands; reach / ev / regrets of the current DFS path live in VGPRs;
+//   * HBM traffic per board and pass: 14 regret columns in, the updated seat's 7 columns out, the board's [2][R] root
+//     values out, ~20 KB of showdown plan in -- nothing else;
+//   * the only cross-hand step, terminal equity, goes through LDS in the rank-sorted domain: wave-64 scans over the
+//     sorted range (2 waves) and over the 47 per-card blocker lists (6 waves), the canonical order of DESIGN.md, so the
+//     result is bit-identical to engine G (prl_tree_kernels.hip) and to the CPU oracle;
+//   * the chance-node sum over boards is done afterwards in the canonical nested order (blocks of 32, groups of 32).
+// No MFMA anywhere: nothing here is a contraction; the kernel is bound by HBM (regret / average columns) and by LDS /
+// cross-lane throughput of the scans.
+#include "prl_device.h"
+#include "prl_fhp.h"
+#include "prl_kernels.h"
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launch configurations of the board-pass kernel: the same source instantiated with different (threads, hand slots,
+// occupancy) triples; selected at run time (PrlFhpParams::cfg) so that they can be A/B-measured on the GPU.
+//   cfg 0: 512 lanes x 3 slots, registers uncapped (1 workgroup = 8 waves per CU, no scratch)
+//   cfg 1: 512 lanes x 3 slots, 128 VGPRs (2 workgroups per CU, spills to scratch)
+//   cfg 2: 768 lanes x 2 slots (12 waves per CU)
+//   cfg 3: 1024 lanes x 2 slots, 128 VGPRs (16 waves per CU)
+// ---------------------------------------------------------------------------------------------------------------------
+#if defined(PRL_EMU)
+#define FHP_LB(t, w)
+#else
+#define FHP_LB(t, w) __launch_bounds__(t, w)
+#endif
+
+#define FHP_THREADS 512
+#define FHP_SLOTS 3
+#define FHP_LAUNCH_BOUNDS FHP_LB(512, 2)
+namespace fhp_cfg0 {
+#include "prl_fhp_pass.inc"
+}
+#undef FHP_THREADS
+#undef FHP_SLOTS
+#undef FHP_LAUNCH_BOUNDS
+#undef FHP_LDS_BYTES
+
+#define FHP_THREADS 512
+#define FHP_SLOTS 3
+#define FHP_LAUNCH_BOUNDS FHP_LB(512, 4)
+namespace fhp_cfg1 {
+#include "prl_fhp_pass.inc"
+}
+#undef FHP_THREADS
+#undef FHP_SLOTS
+#undef FHP_LAUNCH_BOUNDS
+#undef FHP_LDS_BYTES
+
+#define FHP_THREADS 768
+#define FHP_SLOTS 2
+#define FHP_LAUNCH_BOUNDS FHP_LB(768, 3)
+namespace fhp_cfg2 {
+#include "prl_fhp_pass.inc"
+}
+#undef FHP_THREADS
+#undef FHP_SLOTS
+#undef FHP_LAUNCH_BOUNDS
+#undef FHP_LDS_BYTES
+
+#define FHP_THREADS 1024
+#define FHP_SLOTS 2
+#define FHP_LAUNCH_BOUNDS FHP_LB(1024, 4)
+namespace fhp_cfg3 {
+#include "prl_fhp_pass.inc"
+}
+#undef FHP_THREADS
+#undef FHP_SLOTS
+#undef FHP_LAUNCH_BOUNDS
+
+int prl_launch_fhp_pass(const PrlFhpParams& prm, int mode, int src0, int src1, void* stream) {
+    switch (prm.cfg) {
+        case 1: return fhp_cfg1::launch_pass(prm, mode, src0, src1, stream);
+        case 2: return fhp_cfg2::launch_pass(prm, mode, src0, src1, stream);
+        case 3: return fhp_cfg3::launch_pass(prm, mode, src0, src1, stream);
+        default: return fhp_cfg0::launch_pass(prm, mode, src0, src1, stream);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// CFR+ average strategy of the updated seat (CFRPlus.py:65-87), streaming: new strategy = regret matching of the new regrets
+// mode 1: avg = strategy (iteration == delay); mode 2: avg = m_old * avg + m_new * strategy in float64
+// ---------------------------------------------------------------------------------------------------------------------
+PRL_GLOBAL void prl_k_fhp_average_plus(PrlFhpParams prm, int p, int mode, double m_old, double m_new, double* avg) {
+    const size_t per_board = (size_t)PrlFhpShape::N_DEC_PER_SEAT * prm.R;
+    const size_t total = (size_t)prm.n_boards * per_board;
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        const size_t b = t / per_board;
+        const int j = (int)((t % per_board) / prm.R);
+        const size_t h = t % prm.R;
+        const int node = PrlFhpShape::seat_node(p, j);
+        const int A = PrlFhpShape::nch(node), col0 = PrlFhpShape::col0(node);
+        const size_t base = ((size_t)prm.col_base + b * PrlFhpShape::N_COLS + col0) * (size_t)prm.R + h;
+        float tt[3];
+        float sum = 0.f;
+        for (int i = 0; i < A; ++i) { tt[i] = prm.regret[base + (size_t)i * prm.R]; sum = sum + tt[i]; }
+        const float unif = (float)(1.0 / (double)A);
+        for (int i = 0; i < A; ++i) {
+            const float s = sum > 0.f ? tt[i] / sum : unif;
+            double* a = avg + base + (size_t)i * prm.R;
+            *a = mode == 2 ? m_old * *a + m_new * (double)s : (double)s;
+        }
+    }
+}
+
+// materialise the strategy implied by the regrets (tests / prl_solver_get): [n_board_cols][R] float64
+PRL_GLOBAL void prl_k_fhp_strategy_from_regret(PrlFhpParams prm, double* out_cols) {
+    const size_t per_board = (size_t)PrlFhpShape::N_DEC * prm.R;
+    const size_t total = (size_t)prm.n_boards * per_board;
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        const size_t b = t / per_board;
+        const int j = (int)((t % per_board) / prm.R);
+        const size_t h = t % prm.R;
+        const int node = PrlFhpShape::dec_node(j);
+        const int A = PrlFhpShape::nch(node), col0 = PrlFhpShape::col0(node);
+        const size_t base = ((size_t)prm.col_base + b * PrlFhpShape::N_COLS + col0) * (size_t)prm.R + h;
+        float tt[3];
+        float sum = 0.f;
+        for (int i = 0; i < A; ++i) {
+            float r = prm.regret[base + (size_t)i * prm.R];
+            tt[i] = prm.variant == PRL_CFR_PLUS ? r : (r > 0.f ? r : 0.f);
+            sum = sum + tt[i];
+        }
+        const float unif = (float)(1.0 / (double)A);
+        for (int i = 0; i < A; ++i) out_cols[base + (size_t)i * prm.R] = (double)(sum > 0.f ? tt[i] / sum : unif);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// canonical chance sum over the per-board root values: blocks of 32 boards, groups of 32 blocks, then the groups
+// level 0: in = per-board [n][2][R] -> out = per-block; level 1: per-block -> per-group; level 2: per-group -> dest [2][R]
+// ---------------------------------------------------------------------------------------------------------------------
+PRL_GLOBAL void prl_k_fhp_sum_level(const float* __restrict__ in, int n_in, int fan, int R2, float* __restrict__ out) {
+    const int n_out = (n_in + fan - 1) / fan;
+    const size_t total = (size_t)n_out * R2;
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        const int o = (int)(t / R2);
+        const int x = (int)(t % R2);
+        const int lo = o * fan, hi = lo + fan < n_in ? lo + fan : n_in;
+        float s = in[(size_t)lo * R2 + x];
+        for (int i = lo + 1; i < hi; ++i) s = s + in[(size_t)i * R2 + x];
+        out[(size_t)o * R2 + x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------------------
+static inline int fhp_grid_for(size_t items, int block) {
+    size_t g = (items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 16384) g = 16384;
+    return (int)g;
+}
+
+void prl_launch_fhp_average_plus(const PrlFhpParams& prm, int p, int mode, double m_old, double m_new, double* avg, void* stream) {
+    if (mode == 0 || prm.n_boards <= 0) return;
+    size_t items = (size_t)prm.n_boards * PrlFhpShape::N_DEC_PER_SEAT * prm.R;
+    PRL_LAUNCH(prl_k_fhp_average_plus, fhp_grid_for(items, 256), 256, 0, stream, prm, p, mode, m_old, m_new, avg);
+}
+
+void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_cols, void* stream) {
+    if (prm.n_boards <= 0) return;
+    size_t items = (size_t)prm.n_boards * PrlFhpShape::N_DEC * prm.R;
+    PRL_LAUNCH(prl_k_fhp_strategy_from_regret, fhp_grid_for(items, 256), 256, 0, stream, prm, out_cols);
+}
+
+// per-board [n_boards][2][R] -> dest [2][R] in the canonical nested order; scratch >= (ceil(n/32) + ceil(n/1024)) * 2R floats
+void prl_launch_fhp_chance_sum(const float* d_board_vals, int n_boards, int R, float* d_scratch, float* d_dest, void* stream) {
+    const int R2 = 2 * R;
+    const int n_blk = (n_boards + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
+    const int n_grp = (n_blk + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
+    float* blk = d_scratch;
+    float* grp = d_scratch + (size_t)n_blk * R2;
+    PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)n_blk * R2, 256), 256, 0, stream, d_board_vals, n_boards, PRL_CHANCE_BLOCK, R2, blk);
+    PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)n_grp * R2, 256), 256, 0, stream, (const float*)blk, n_blk, PRL_CHANCE_BLOCK, R2, grp);
+    PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)R2, 256), 256, 0, stream, (const float*)grp, n_grp, n_grp > 0 ? n_grp : 1, R2, d_dest);
+}

@@ -17,6 +17,6 @@ void prl_launch_regret_strategy(const PrlDevTree& T, const PrlDevState& S, const
 void prl_launch_average(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, int iter, int mode,
                         double m_old, double m_new, void* stream);
 void prl_launch_plan_build(const PrlDevTree& T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
-                           int16_t* plan_cl, int32_t* plan_nlive, void* stream);
+                           int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint16_t* plan_clw, void* stream);
 void prl_launch_hand_rank_checksums(const int8_t* d_boards, int n_boards, int chunk, const uint16_t* d_hole_lut, unsigned long long* d_out,
                                     void* stream);

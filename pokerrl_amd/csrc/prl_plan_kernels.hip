@@ -17,7 +17,7 @@
 #include "prl_solver_types.h"
 
 PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
-                                 int16_t* plan_cl, int32_t* plan_nlive) {
+                                 int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint16_t* plan_clw) {
     uint32_t* keys = (uint32_t*)prl_smem();  // [2048]
     int* n_live_s = (int*)(keys + 2048);
     const int tid = (int)prl_tid(), nt = (int)prl_nthreads();
@@ -77,7 +77,10 @@ PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, in
         int16_t* gs = plan_gs + (size_t)b * T.plan_stride;
         int16_t* ge = plan_ge + (size_t)b * T.plan_stride;
         int16_t* cl = plan_cl + (size_t)b * T.cl_stride;
-        for (int h = tid; h < T.R; h += nt) { pos[h] = -1; sh[h] = -1; gs[h] = 0; ge[h] = 0; }
+        int16_t* hgs = plan_hgs + (size_t)b * T.plan_stride;
+        int16_t* hge = plan_hge + (size_t)b * T.plan_stride;
+        uint16_t* clw = plan_clw + (size_t)b * T.cl_stride;
+        for (int h = tid; h < T.R; h += nt) { pos[h] = -1; sh[h] = -1; gs[h] = 0; ge[h] = 0; hgs[h] = 0; hge[h] = 0; }
         prl_sync();
         for (int i = tid; i < n; i += nt) {
             const uint32_t key = keys[i];
@@ -91,15 +94,21 @@ PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, in
             j = i + 1;
             while (j < n && (has_board ? (keys[j] >> 11) : 0u) == r) j++;
             ge[i] = (int16_t)j;
+            hgs[h] = gs[i];
+            hge[h] = (int16_t)j;
         }
         for (int c = tid; c < T.n_cards; c += nt) {
             int16_t* row = cl + (size_t)c * (T.n_cards - 1);
+            uint16_t* roww = clw + (size_t)c * (T.n_cards - 1);
             int m = 0;
             for (int i = 0; i < n; ++i) {
                 const int h = (int)(keys[i] & 0x7FFu);
-                if (T.hole[2 * h] == c || T.hole[2 * h + 1] == c) row[m++] = (int16_t)i;
+                if (T.hole[2 * h] == c || T.hole[2 * h + 1] == c) {
+                    roww[m] = (uint16_t)(i | (T.hole[2 * h] == c ? 0x8000 : 0));
+                    row[m++] = (int16_t)i;
+                }
             }
-            for (; m < T.n_cards - 1; ++m) row[m] = -1;
+            for (; m < T.n_cards - 1; ++m) { row[m] = -1; roww[m] = 0xFFFFu; }
         }
         if (tid == 0) plan_nlive[b] = n;
         prl_sync();
@@ -107,8 +116,8 @@ PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, in
 }
 
 void prl_launch_plan_build(const PrlDevTree& T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
-                           int16_t* plan_cl, int32_t* plan_nlive, void* stream) {
+                           int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint16_t* plan_clw, void* stream) {
     int grid = n_plans < 32768 ? n_plans : 32768;
     PRL_LAUNCH(prl_k_plan_build, grid, 256, 2048 * sizeof(uint32_t) + 16, stream, T, n_plans, plan_sh, plan_pos, plan_gs, plan_ge, plan_cl,
-               plan_nlive);
+               plan_nlive, plan_hgs, plan_hge, plan_clw);
 }

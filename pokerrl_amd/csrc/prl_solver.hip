@@ -1,7 +1,15 @@
 // prl_solver_*: device-resident tabular CFR / best-response solver behind the C ABI (include/pokerrl_hip.h section 5).
 // Host orchestration only: uploads the flat tree, owns the HIP stream and the HBM arrays, issues the kernels in the
 // reference's order (_CFRBase.py:110-134). Nothing here computes on the CPU.
+//
+// Two engines share this front end:
+//   LEVELS  every per-node vector in HBM, one kernel per tree level (prl_tree_kernels.hip). Any supported tree; exposes
+//           node.reach_probs / node.ev / node.ev_br / best-response indices.
+//   FUSED   Flop5Holdem-shaped trees with CFR+: the pre-deal trunk (a handful of nodes) runs on the LEVELS kernels with
+//           the chance node as a leaf; each board subtree is walked on chip by one workgroup (prl_fhp_kernels.hip); the
+//           boards' root values are summed in the canonical nested order into the chance node.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -9,13 +17,16 @@
 
 #include "prl_cards.h"
 #include "prl_device.h"
+#include "prl_fhp.h"
 #include "prl_host.h"
 #include "prl_kernels.h"
 #include "prl_rt.h"
 #include "prl_solver_types.h"
 
+#define PRL_NODE_LEAF 4  // trunk view of the chance node in the FUSED engine: values are written by the chance sum
+
 struct prl_solver {
-    PrlFlatTree ft;  // host copy (levels, lists)
+    PrlFlatTree ft;           // host copy of the tree the device kernels walk (the trunk only, for the FUSED engine)
     PrlDevTree T{};
     PrlDevState S{};
     PrlDevState Seval{};      // scratch per-node vectors for the average-strategy evaluation (allocated lazily)
@@ -29,10 +40,24 @@ struct prl_solver {
     int32_t* d_col_node = nullptr;
     int variant = PRL_CFR_PLUS, delay = 0, iter = 0;
     bool ev_valid = false;    // S.ev / S.ev_br / S.expl correspond to the current strategy + reach
-    bool keep_br_idx = false;
     float* d_expl_hist = nullptr;  // [cap][2] current-strategy exploitability after every iteration
     int hist_cap = 0;
     size_t bytes_allocated = 0;
+    // full-tree sizes (what the caller sees)
+    int full_nodes = 0, full_cols = 0, R = 0;
+    // ---- FUSED engine ----
+    bool fused = false;
+    PrlFhpParams fp{};
+    int chance_trunk = -1;    // trunk id of the chance node
+    float* d_board_ev = nullptr;
+    float* d_board_br = nullptr;
+    float* d_sum_scratch = nullptr;
+    double* d_user_strategy = nullptr;  // [full_cols][R], explicit strategy (prl_solver_set_strategy), lazily allocated
+    int user_strategy_f64 = -1;         // -1: strategy comes from regrets / uniform
+    int src[2] = {PRL_SRC_UNIFORM64, PRL_SRC_UNIFORM64};
+    bool board_avg_f64 = false;
+    float* d_regret = nullptr;  // [full_cols][R]
+    double* d_avg = nullptr;    // [full_cols][R]
 };
 
 namespace {
@@ -96,7 +121,34 @@ int do_update_reach(prl_solver* s, const PrlDevState& st) {
     return PRL_OK;
 }
 
-int do_compute_ev(prl_solver* s, const PrlDevState& st) {
+// FUSED: board pass + canonical chance sum into the trunk's chance node (st = trunk state to read reach from / write to)
+int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, int src1, const double* strat_arr) {
+    PrlFhpParams p = s->fp;
+    p.iter = s->iter;
+    p.variant = s->variant;
+    p.chance_reach = st.reach + prl_vidx(s->T, s->chance_trunk, 0);
+    p.strat_arr = strat_arr;
+    int e = prl_launch_fhp_pass(p, mode, src0, src1, s->stream);
+    if (e) { prl_set_error("fused engine: unsupported strategy-source combination"); return e; }
+    float* dst_ev = st.ev + prl_vidx(s->T, s->chance_trunk, 0);
+    float* dst_br = st.ev_br + prl_vidx(s->T, s->chance_trunk, 0);
+    prl_launch_fhp_chance_sum(s->d_board_ev, p.n_boards, p.R, s->d_sum_scratch, dst_ev, s->stream);
+    if (mode == PRL_FHP_EVAL) prl_launch_fhp_chance_sum(s->d_board_br, p.n_boards, p.R, s->d_sum_scratch, dst_br, s->stream);
+    else PRL_HIP_TRY(hipMemcpyAsync(dst_br, dst_ev, (size_t)2 * p.R * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    PRL_HIP_TRY(hipGetLastError());
+    return PRL_OK;
+}
+
+int do_compute_ev(prl_solver* s, const PrlDevState& st, int fused_mode = PRL_FHP_EVAL) {
+    if (s->fused) {
+        const double* arr = nullptr;
+        int s0 = s->src[0], s1 = s->src[1];
+        if (s->user_strategy_f64 >= 0) {
+            arr = s->d_user_strategy;
+            s0 = s1 = s->user_strategy_f64 ? PRL_SRC_ARR64 : PRL_SRC_ARR32;
+        }
+        TRY(fused_board_pass(s, st, fused_mode, s0, s1, arr));
+    }
     prl_launch_ev(s->T, st, s->ft.level_start.data(), s->d_term_nodes, s->n_term, s->stream);
     PRL_HIP_TRY(hipGetLastError());
     return PRL_OK;
@@ -127,27 +179,125 @@ int record_expl(prl_solver* s) {
     return PRL_OK;
 }
 
+// trunk view of a Flop5Holdem-shaped tree: nodes dealt before the board, the chance node as a leaf
+void make_trunk(const PrlFlatTree& t, int chance_node, int first_board_node, int board_nodes_total, PrlFlatTree* out, int* chance_trunk) {
+    PrlFlatTree& u = *out;
+    u = PrlFlatTree();
+    u.rules = t.rules;
+    u.game = t.game;
+    std::vector<int> map(t.n_nodes, -1);
+    for (int i = 0; i < t.n_nodes; ++i) {
+        if (i >= first_board_node && i < first_board_node + board_nodes_total) continue;
+        map[i] = u.n_nodes++;
+        const bool is_ch = i == chance_node;
+        u.kind.push_back(is_ch ? PRL_NODE_LEAF : t.kind[i]);
+        u.actor.push_back(t.actor[i]);
+        u.parent.push_back(t.parent[i] < 0 ? -1 : map[t.parent[i]]);
+        u.child_idx.push_back(t.child_idx[i]);
+        u.action.push_back(t.action[i]);
+        u.acted_last.push_back(t.acted_last[i]);
+        u.round.push_back(t.round[i]);
+        u.board_id.push_back(-1);
+        u.main_pot.push_back(t.main_pot[i]);
+        u.depth.push_back(t.depth[i]);
+        u.n_children.push_back(is_ch ? 0 : t.n_children[i]);
+        u.first_col.push_back(t.first_col[i]);
+        u.subtree_size.push_back(1);
+    }
+    *chance_trunk = map[chance_node];
+    u.n_cols = 0;
+    for (int i = 0; i < u.n_nodes; ++i)
+        if (u.kind[i] == PRL_NODE_DECISION) u.n_cols += u.n_children[i];
+    for (int c = 0; c < u.n_cols; ++c) { u.col_action.push_back(t.col_action[c]); u.col_node.push_back(map[t.col_node[c]]); }
+    u.n_boards = 0;
+    u.board_len = t.board_len;
+    u.child_start.assign(u.n_nodes + 1, 0);
+    for (int i = 0; i < u.n_nodes; ++i) u.child_start[i + 1] = u.child_start[i] + u.n_children[i];
+    u.child_list.assign(u.child_start[u.n_nodes], -1);
+    int max_depth = 0;
+    for (int i = 1; i < u.n_nodes; ++i) {
+        u.child_list[u.child_start[u.parent[i]] + u.child_idx[i]] = i;
+        max_depth = max_depth > u.depth[i] ? max_depth : u.depth[i];
+    }
+    u.n_levels = max_depth + 1;
+    u.level_start.assign(u.n_levels + 1, 0);
+    for (int i = 0; i < u.n_nodes; ++i) u.level_start[u.depth[i] + 1]++;
+    for (int d = 0; d < u.n_levels; ++d) u.level_start[d + 1] += u.level_start[d];
+    u.level_nodes.assign(u.n_nodes, 0);
+    std::vector<int32_t> fill(u.level_start.begin(), u.level_start.end() - 1);
+    for (int i = 0; i < u.n_nodes; ++i) u.level_nodes[fill[u.depth[i]]++] = i;
+}
+
 }  // namespace
+
+bool prl_fhp_shape_matches(const PrlFlatTree& t, int* chance_node, int* first_board_node, int* col_base, float* pots) {
+    if (t.rules.n_hole_cards != 2 || t.rules.n_cards != 52 || t.board_len != 5) return false;
+    int ch = -1;
+    for (int i = 0; i < t.n_nodes; ++i)
+        if (t.kind[i] == PRL_NODE_CHANCE) {
+            if (ch >= 0) return false;  // exactly one chance node
+            ch = i;
+        }
+    if (ch < 0 || t.n_children[ch] != t.n_boards) return false;
+    const int N = PrlFhpShape::N_NODES;
+    const int first = ch + 1;
+    if (first + (long long)t.n_boards * N != t.n_nodes) return false;  // the board subtrees are the tail of the DFS order
+    for (int b = 0; b < t.n_boards; ++b) {
+        const int base = first + b * N;
+        if (t.board_id[base] != b) return false;
+        if (b > 0 && b < t.n_boards - 1) continue;  // subtrees are replicas by construction; check the first and the last
+        for (int n = 0; n < N; ++n) {
+            const int g = base + n;
+            if (t.kind[g] != PrlFhpShape::kind(n) || t.n_children[g] != PrlFhpShape::nch(n)) return false;
+            if (t.kind[g] == PRL_NODE_DECISION && t.actor[g] != PrlFhpShape::actor(n)) return false;
+            if (n > 0 && t.parent[g] != base + PrlFhpShape::parent(n)) return false;
+            if (t.kind[g] == PRL_NODE_TERM_FOLD && t.acted_last[g] != PrlFhpShape::folder(n)) return false;
+            if (t.kind[g] == PRL_NODE_DECISION && t.first_col[g] != t.first_col[base] + PrlFhpShape::col0(n)) return false;
+        }
+    }
+    for (int i = 0; i < first; ++i)
+        if (t.kind[i] == PRL_NODE_DECISION && t.first_col[i] >= t.first_col[first]) return false;  // trunk columns precede
+    *chance_node = ch;
+    *first_board_node = first;
+    *col_base = t.first_col[first];
+    for (int n = 0; n < N; ++n) pots[n] = (float)t.main_pot[first + n];
+    return true;
+}
 
 extern "C" {
 
-int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay, prl_solver_t** out) {
+int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out) {
     if (!tree || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
-    if (variant < 0 || variant > 2 || delay < 0) { prl_set_error("bad variant / delay"); return PRL_ERR_ARG; }
+    if (variant < 0 || variant > 2 || delay < 0 || engine < 0 || engine > 2) { prl_set_error("bad variant / delay / engine"); return PRL_ERR_ARG; }
     if (!prl_device_available()) { prl_set_error("no HIP device: the solver has no CPU fallback"); return PRL_ERR_NO_DEVICE; }
-    const PrlFlatTree& ft = *prl_tree_flat(tree);
-    const PrlRules& r = ft.rules;
-    if (r.n_hole_cards == 1 && (r.range_size > 128 || ft.board_len != 1)) { prl_set_error("1-card games: R <= 128, 1 board card"); return PRL_ERR_UNSUPPORTED; }
-    if (r.n_hole_cards == 2 && (r.n_cards != 52 || r.n_suits != 4 || ft.board_len != 5 || r.rank_rule != 2)) {
+    const PrlFlatTree& full = *prl_tree_flat(tree);
+    const PrlRules& r = full.rules;
+    if (r.n_hole_cards == 1 && (r.range_size > 128 || full.board_len != 1)) { prl_set_error("1-card games: R <= 128, 1 board card"); return PRL_ERR_UNSUPPORTED; }
+    if (r.n_hole_cards == 2 && (r.n_cards != 52 || r.n_suits != 4 || full.board_len != 5 || r.rank_rule != 2)) {
         prl_set_error("2-card games: 52-card deck with 5-card boards (Flop5Holdem) only");
         return PRL_ERR_UNSUPPORTED;
     }
-    for (int i = 0; i < ft.n_nodes; ++i)
-        if (ft.kind[i] == PRL_NODE_DECISION && ft.n_children[i] > 96) { prl_set_error("more than 96 actions at a node"); return PRL_ERR_UNSUPPORTED; }
+    for (int i = 0; i < full.n_nodes; ++i)
+        if (full.kind[i] == PRL_NODE_DECISION && full.n_children[i] > 96) { prl_set_error("more than 96 actions at a node"); return PRL_ERR_UNSUPPORTED; }
+    int ch_node = -1, first_board = -1, col_base = -1;
+    float pots[PrlFhpShape::N_NODES];
+    const bool shape_ok = prl_fhp_shape_matches(full, &ch_node, &first_board, &col_base, pots);
+    bool fused = false;
+    if (engine == PRL_ENGINE_FUSED) {
+        if (!shape_ok || variant != PRL_CFR_PLUS) { prl_set_error("fused engine needs a Flop5Holdem-shaped tree and CFR+"); return PRL_ERR_UNSUPPORTED; }
+        fused = true;
+    } else if (engine == PRL_ENGINE_AUTO) fused = shape_ok && variant == PRL_CFR_PLUS;
+
     prl_solver* s = new prl_solver();
-    s->ft = ft;
     s->variant = variant;
     s->delay = delay;
+    s->fused = fused;
+    s->full_nodes = full.n_nodes;
+    s->full_cols = full.n_cols;
+    s->R = r.range_size;
+    if (fused) make_trunk(full, ch_node, first_board, full.n_boards * PrlFhpShape::N_NODES, &s->ft, &s->chance_trunk);
+    else s->ft = full;
+    const PrlFlatTree& ft = s->ft;
 #define FAIL_IF(x) do { int e_ = (x); if (e_) { prl_solver_destroy(s); return e_; } } while (0)
     if (hipStreamCreate(&s->stream) != hipSuccess) { prl_set_error("hipStreamCreate failed"); delete s; return PRL_ERR_HIP; }
     PrlDevTree& T = s->T;
@@ -165,24 +315,26 @@ int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay
     FAIL_IF(dev_upload(s, &T.child_start, ft.child_start));
     FAIL_IF(dev_upload(s, &T.child_list, ft.child_list));
     FAIL_IF(dev_upload(s, &T.level_nodes, ft.level_nodes));
-    FAIL_IF(dev_upload(s, &T.boards, ft.boards));
+    FAIL_IF(dev_upload(s, &T.boards, full.boards));
     std::vector<int16_t> hole((size_t)T.R * 2);
+    std::vector<uint16_t> hole_packed((size_t)T.R);
     for (int h = 0; h < T.R; ++h) {
         int c1, c2;
         prl_hand_cards(r, h, &c1, &c2);
         hole[2 * h] = (int16_t)c1;
         hole[2 * h + 1] = (int16_t)c2;
+        hole_packed[h] = (uint16_t)((c1 & 0xFF) | ((c2 & 0xFF) << 8));
     }
     FAIL_IF(dev_upload(s, &T.hole, hole));
-    int n_chance_children = ft.n_boards;
-    for (int i = 0; i < ft.n_nodes; ++i)
-        if (ft.kind[i] == PRL_NODE_CHANCE) { n_chance_children = ft.n_children[i]; break; }
-    T.chance_prob = chance_prob_f32(n_chance_children, r.n_cards, r.n_hole_cards, ft.board_len);
+    int n_chance_children = full.n_boards;
+    for (int i = 0; i < full.n_nodes; ++i)
+        if (full.kind[i] == PRL_NODE_CHANCE) { n_chance_children = full.n_children[i]; break; }
+    T.chance_prob = chance_prob_f32(n_chance_children, r.n_cards, r.n_hole_cards, full.board_len);
     T.eq_const = eq_const_f32(r.n_cards, r.n_hole_cards);
 
     std::vector<int32_t> term, np[2];
     for (int i = 0; i < ft.n_nodes; ++i) {
-        if (ft.kind[i] >= PRL_NODE_TERM_FOLD) term.push_back(i);
+        if (ft.kind[i] == PRL_NODE_TERM_FOLD || ft.kind[i] == PRL_NODE_TERM_SHOWDOWN) term.push_back(i);
         if (ft.kind[i] == PRL_NODE_DECISION) np[ft.actor[i]].push_back(i);
     }
     s->n_term = (int)term.size();
@@ -193,11 +345,12 @@ int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay
     }
     FAIL_IF(dev_upload(s, (const int32_t**)&s->d_col_node, ft.col_node));
 
-    if (T.n_hole == 2) {  // showdown plans, built on the device
-        const int n_plans = T.n_boards + 1;
+    if (T.n_hole == 2) {  // showdown plans of every board + the "no board" plan, built on the device
+        const int n_plans = full.n_boards + 1;
         T.plan_stride = T.R;
         T.cl_stride = T.n_cards * (T.n_cards - 1);
-        int16_t *sh, *pos, *gs, *ge, *cl;
+        int16_t *sh, *pos, *gs, *ge, *cl, *hgs, *hge;
+        uint16_t* clw;
         int32_t* nl;
         FAIL_IF(dev_alloc(s, &sh, (size_t)n_plans * T.plan_stride));
         FAIL_IF(dev_alloc(s, &pos, (size_t)n_plans * T.plan_stride));
@@ -205,18 +358,56 @@ int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay
         FAIL_IF(dev_alloc(s, &ge, (size_t)n_plans * T.plan_stride));
         FAIL_IF(dev_alloc(s, &cl, (size_t)n_plans * T.cl_stride));
         FAIL_IF(dev_alloc(s, &nl, (size_t)n_plans));
-        prl_launch_plan_build(T, n_plans, sh, pos, gs, ge, cl, nl, s->stream);
-        T.plan_sh = sh; T.plan_pos = pos; T.plan_gs = gs; T.plan_ge = ge; T.plan_cl = cl; T.plan_nlive = nl;
+        FAIL_IF(dev_alloc(s, &hgs, (size_t)n_plans * T.plan_stride));
+        FAIL_IF(dev_alloc(s, &hge, (size_t)n_plans * T.plan_stride));
+        FAIL_IF(dev_alloc(s, &clw, (size_t)n_plans * T.cl_stride));
+        PrlDevTree Tb = T;
+        Tb.n_boards = full.n_boards;
+        prl_launch_plan_build(Tb, n_plans, sh, pos, gs, ge, cl, nl, hgs, hge, clw, s->stream);
+        // the LEVELS kernels address plan `board_id`, or plan index T.n_boards for "no board"; in the FUSED engine the
+        // trunk tree has n_boards == 0, so its plan pointers are based at the last (no-board) plan
+        const size_t off = fused ? (size_t)full.n_boards : 0;
+        T.plan_sh = sh + off * T.plan_stride; T.plan_pos = pos + off * T.plan_stride; T.plan_gs = gs + off * T.plan_stride;
+        T.plan_ge = ge + off * T.plan_stride; T.plan_cl = cl + off * T.cl_stride; T.plan_nlive = nl + off;
+        T.plan_hgs = hgs + off * T.plan_stride; T.plan_hge = hge + off * T.plan_stride; T.plan_clw = clw + off * T.cl_stride;
+        if (fused) {
+            PrlFhpParams& fp = s->fp;
+            fp.n_boards = full.n_boards; fp.R = T.R; fp.col_base = col_base; fp.max_grid = 4096;
+            {
+                const char* e = getenv("PRL_FHP_CFG");  // tuning knob: launch configuration of the board-pass kernel
+                fp.cfg = e ? atoi(e) : 0;
+                const char* g = getenv("PRL_FHP_GRID");
+                if (g && atoi(g) > 0) fp.max_grid = atoi(g);
+            }
+            fp.chance_prob = T.chance_prob; fp.eq_const = T.eq_const;
+            for (int n = 0; n < PrlFhpShape::N_NODES; ++n) fp.pot[n] = pots[n];
+            fp.plan_stride = T.plan_stride; fp.cl_stride = T.cl_stride;
+            fp.plan_pos = pos; fp.plan_hgs = hgs; fp.plan_hge = hge; fp.plan_gs = gs; fp.plan_clw = clw; fp.plan_nlive = nl;
+            FAIL_IF(dev_upload(s, &fp.hole_packed, hole_packed));
+        }
     }
 
-    const size_t nc = (size_t)T.n_cols * T.R;
-    FAIL_IF(dev_alloc(s, &s->S.strategy, nc));
+    const size_t nc_full = (size_t)full.n_cols * T.R;
+    FAIL_IF(dev_alloc(s, &s->d_regret, nc_full));
+    FAIL_IF(dev_alloc(s, &s->d_avg, nc_full));
+    s->S.regret = s->d_regret;
+    s->S.avg = s->d_avg;
+    FAIL_IF(dev_alloc(s, &s->S.strategy, (size_t)T.n_cols * T.R));  // FUSED: trunk columns only
     FAIL_IF(dev_alloc(s, &s->S.strat_f64, (size_t)T.n_nodes));
-    FAIL_IF(dev_alloc(s, &s->S.regret, nc));
-    FAIL_IF(dev_alloc(s, &s->S.avg, nc));
     FAIL_IF(dev_alloc(s, &s->S.avg_f64, (size_t)T.n_nodes));
-    if (variant != PRL_CFR_PLUS) FAIL_IF(dev_alloc(s, &s->S.avg_sum, nc));
+    if (variant != PRL_CFR_PLUS) FAIL_IF(dev_alloc(s, &s->S.avg_sum, nc_full));
     FAIL_IF(alloc_node_vectors(s, &s->S, true));
+    if (fused) {
+        const size_t bv = (size_t)full.n_boards * 2 * T.R;
+        FAIL_IF(dev_alloc(s, &s->d_board_ev, bv));
+        FAIL_IF(dev_alloc(s, &s->d_board_br, bv));
+        const size_t n_blk = (full.n_boards + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
+        const size_t n_grp = (n_blk + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
+        FAIL_IF(dev_alloc(s, &s->d_sum_scratch, (n_blk + n_grp + 1) * 2 * T.R));
+        s->fp.regret = s->d_regret;
+        s->fp.board_ev = s->d_board_ev;
+        s->fp.board_br = s->d_board_br;
+    }
     if (hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
         prl_set_error("device error while building the showdown plans");
         prl_solver_destroy(s);
@@ -225,6 +416,10 @@ int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay
 #undef FAIL_IF
     *out = s;
     return prl_solver_reset(s);
+}
+
+int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay, prl_solver_t** out) {
+    return prl_solver_create_ex(tree, variant, delay, PRL_ENGINE_AUTO, out);
 }
 
 void prl_solver_destroy(prl_solver_t* s) {
@@ -238,12 +433,13 @@ void prl_solver_destroy(prl_solver_t* s) {
 // CFRBase.reset (_CFRBase.py:110-120): clear regrets / averages, uniform strategy, reach, EV (+ exploitability)
 int32_t prl_solver_reset(prl_solver_t* s) {
     if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }
-    const size_t nc = (size_t)s->T.n_cols * s->T.R;
+    const size_t nc = (size_t)s->full_cols * s->R;
     s->iter = 0;
-    PRL_HIP_TRY(hipMemsetAsync(s->S.regret, 0, nc * sizeof(float), s->stream));
-    PRL_HIP_TRY(hipMemsetAsync(s->S.avg, 0, nc * sizeof(double), s->stream));
+    PRL_HIP_TRY(hipMemsetAsync(s->d_regret, 0, nc * sizeof(float), s->stream));
+    PRL_HIP_TRY(hipMemsetAsync(s->d_avg, 0, nc * sizeof(double), s->stream));
     PRL_HIP_TRY(hipMemsetAsync(s->S.avg_f64, 0, (size_t)s->T.n_nodes, s->stream));
     if (s->S.avg_sum) PRL_HIP_TRY(hipMemsetAsync(s->S.avg_sum, 0, nc * sizeof(float), s->stream));
+    s->board_avg_f64 = false;
     TRY(prl_solver_fill_uniform(s));
     TRY(ensure_ev(s));
     return record_expl(s);
@@ -253,6 +449,8 @@ int32_t prl_solver_fill_uniform(prl_solver_t* s) {  // PublicTree.fill_uniform_r
     if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }
     PRL_HIP_TRY(hipMemsetAsync(s->S.strat_f64, 0, (size_t)s->T.n_nodes, s->stream));
     prl_launch_fill_uniform(s->T, s->S, s->d_col_node, s->stream);
+    s->src[0] = s->src[1] = PRL_SRC_UNIFORM64;
+    s->user_strategy_f64 = -1;
     s->ev_valid = false;
     return do_update_reach(s, s->S);
 }
@@ -261,7 +459,7 @@ int32_t prl_solver_fill_uniform(prl_solver_t* s) {  // PublicTree.fill_uniform_r
 // Equivalent of fill_with_agent_policy / fill_random_random + update_reach_probs (StrategyFiller.py:26-43).
 int32_t prl_solver_set_strategy(prl_solver_t* s, const void* strat, int32_t is_f64) {
     if (!s || !strat) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
-    const size_t nc = (size_t)s->T.n_cols * s->T.R;
+    const size_t nc = (size_t)s->full_cols * s->R;
     std::vector<double> tmp;
     const double* src = (const double*)strat;
     if (!is_f64) {
@@ -270,7 +468,13 @@ int32_t prl_solver_set_strategy(prl_solver_t* s, const void* strat, int32_t is_f
         for (size_t i = 0; i < nc; ++i) tmp[i] = (double)f[i];  // exact widening: storage only, arithmetic stays float32
         src = tmp.data();
     }
-    PRL_HIP_TRY(hipMemcpyAsync(s->S.strategy, src, nc * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    if (s->fused) {
+        if (!s->d_user_strategy) TRY(dev_alloc(s, &s->d_user_strategy, nc));
+        PRL_HIP_TRY(hipMemcpyAsync(s->d_user_strategy, src, nc * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        s->user_strategy_f64 = is_f64 ? 1 : 0;
+    }
+    // LEVELS: the whole array; FUSED: the trunk columns (they precede the board columns)
+    PRL_HIP_TRY(hipMemcpyAsync(s->S.strategy, src, (size_t)s->T.n_cols * s->R * sizeof(double), hipMemcpyHostToDevice, s->stream));
     PRL_HIP_TRY(hipStreamSynchronize(s->stream));  // tmp goes out of scope
     PRL_HIP_TRY(hipMemsetAsync(s->S.strat_f64, is_f64 ? 1 : 0, (size_t)s->T.n_nodes, s->stream));
     s->ev_valid = false;
@@ -290,13 +494,18 @@ int32_t prl_solver_compute_ev(prl_solver_t* s) {  // PublicTree.compute_ev (Publ
 }
 
 // One CFRBase.iteration() (_CFRBase.py:122-134) without _evaluate_avg_strats (see prl_solver_eval_avg). Asynchronous.
-// The reference recomputes the EVs at the top of the p = 0 half although nothing changed since the pass that closed the
-// previous iteration; that pass is reused here (identical values), so an iteration costs two EV passes, not three.
+// LEVELS: the reference recomputes the EVs at the top of the p = 0 half although nothing changed since the pass that
+// closed the previous iteration; that pass is reused (identical values), so an iteration costs two EV passes, not three.
+// FUSED: every half-iteration is one board pass that computes the EVs and updates that seat's regrets in place, then the
+// trunk is updated with the summed chance-node values; a third (best-response) pass yields the exploitability.
 int32_t prl_solver_iteration(prl_solver_t* s) {
     if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }
+    if (s->fused && s->user_strategy_f64 >= 0) { prl_set_error("call reset() / fill_uniform() before iterating after set_strategy()"); return PRL_ERR_STATE; }
     for (int p = 0; p < 2; ++p) {
-        TRY(ensure_ev(s));
+        if (s->fused) TRY(do_compute_ev(s, s->S, p == 0 ? PRL_FHP_UPDATE0 : PRL_FHP_UPDATE1));
+        else TRY(ensure_ev(s));
         prl_launch_regret_strategy(s->T, s->S, s->d_nodes_p[p], s->n_nodes_p[p], p, s->variant, s->iter, s->stream);
+        s->src[p] = PRL_SRC_REGRET;
         s->ev_valid = false;
         TRY(do_update_reach(s, s->S));
         int mode = 0;
@@ -312,6 +521,12 @@ int32_t prl_solver_iteration(prl_solver_t* s) {
             } else if (s->iter == s->delay) mode = 1;
         }
         prl_launch_average(s->T, s->S, s->d_nodes_p[p], s->n_nodes_p[p], p, s->variant, s->iter, mode, m_old, m_new, s->stream);
+        if (s->fused) {
+            PrlFhpParams fp = s->fp;
+            fp.variant = s->variant;
+            prl_launch_fhp_average_plus(fp, p, mode, m_old, m_new, s->d_avg, s->stream);
+            if (mode) s->board_avg_f64 = mode == 2;
+        }
     }
     s->iter += 1;
     TRY(ensure_ev(s));
@@ -366,28 +581,54 @@ int32_t prl_solver_eval_avg(prl_solver_t* s, float* out2) {
         s->eval_ready = true;
     }
     PrlDevState E = s->Seval;
-    E.strategy = s->S.avg;
+    E.strategy = s->d_avg;  // trunk columns precede the board columns, so the trunk view indexes the same array
     E.strat_f64 = s->S.avg_f64;
     E.regret = nullptr; E.avg = nullptr; E.avg_sum = nullptr; E.avg_f64 = nullptr;
     TRY(do_update_reach(s, E));
-    TRY(do_compute_ev(s, E));
+    if (s->fused) {
+        const int src = s->board_avg_f64 ? PRL_SRC_ARR64 : PRL_SRC_ARR32;
+        TRY(fused_board_pass(s, E, PRL_FHP_EVAL, src, src, s->d_avg));
+    }
+    prl_launch_ev(s->T, E, s->ft.level_start.data(), s->d_term_nodes, s->n_term, s->stream);
+    PRL_HIP_TRY(hipGetLastError());
     PRL_HIP_TRY(hipMemcpyAsync(out2, E.expl, 2 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     return prl_solver_sync(s);
 }
 
 int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
     if (!s || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
-    const size_t nv = (size_t)s->T.n_nodes * 2 * s->T.R, nc = (size_t)s->T.n_cols * s->T.R;
+    const size_t nv = (size_t)s->T.n_nodes * 2 * s->T.R, nc = (size_t)s->full_cols * s->R;
     const void* src = nullptr;
     size_t bytes = 0;
+    const bool node_vectors = field == PRL_SF_REACH || field == PRL_SF_EV || field == PRL_SF_EV_BR || field == PRL_SF_BR_IDX ||
+                              field == PRL_SF_STRAT_F64 || field == PRL_SF_AVG_F64;
+    if (s->fused && node_vectors) {
+        prl_set_error("the fused engine keeps per-node vectors on chip; create the solver with PRL_ENGINE_LEVELS to read them");
+        return PRL_ERR_UNSUPPORTED;
+    }
     switch (field) {
         case PRL_SF_REACH: src = s->S.reach; bytes = nv * 4; break;
         case PRL_SF_EV: TRY(ensure_ev(s)); src = s->S.ev; bytes = nv * 4; break;
         case PRL_SF_EV_BR: TRY(ensure_ev(s)); src = s->S.ev_br; bytes = nv * 4; break;
-        case PRL_SF_STRATEGY: src = s->S.strategy; bytes = nc * 8; break;
+        case PRL_SF_STRATEGY:
+            if (s->fused) {
+                if (s->user_strategy_f64 >= 0) { src = s->d_user_strategy; bytes = nc * 8; break; }
+                if (s->src[0] != PRL_SRC_REGRET || s->src[1] != PRL_SRC_REGRET) {  // uniform float64 fill
+                    prl_set_error("fused engine: strategy is the implicit uniform fill until both seats have been updated");
+                    return PRL_ERR_STATE;
+                }
+                if (!s->d_user_strategy) TRY(dev_alloc(s, &s->d_user_strategy, nc));
+                PRL_HIP_TRY(hipMemcpyAsync(s->d_user_strategy, s->S.strategy, (size_t)s->T.n_cols * s->R * 8, hipMemcpyDeviceToDevice, s->stream));
+                PrlFhpParams fp = s->fp;
+                fp.variant = s->variant;
+                prl_launch_fhp_strategy_from_regret(fp, s->d_user_strategy, s->stream);
+                src = s->d_user_strategy; bytes = nc * 8;
+                break;
+            }
+            src = s->S.strategy; bytes = nc * 8; break;
         case PRL_SF_STRAT_F64: src = s->S.strat_f64; bytes = (size_t)s->T.n_nodes; break;
-        case PRL_SF_REGRET: src = s->S.regret; bytes = nc * 4; break;
-        case PRL_SF_AVG: src = s->S.avg; bytes = nc * 8; break;
+        case PRL_SF_REGRET: src = s->d_regret; bytes = nc * 4; break;
+        case PRL_SF_AVG: src = s->d_avg; bytes = nc * 8; break;
         case PRL_SF_AVG_F64: src = s->S.avg_f64; bytes = (size_t)s->T.n_nodes; break;
         case PRL_SF_AVG_SUM: src = s->S.avg_sum; bytes = nc * 4; break;
         case PRL_SF_BR_IDX: TRY(ensure_ev(s)); src = s->S.br_idx; bytes = (size_t)s->T.n_nodes * s->T.R * 4; break;
@@ -395,6 +636,7 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
         case PRL_SF_ITER: *(int32_t*)out = s->iter; return PRL_OK;
         case PRL_SF_CONSTANTS: ((float*)out)[0] = s->T.chance_prob; ((float*)out)[1] = s->T.eq_const; return PRL_OK;
         case PRL_SF_BYTES_ALLOCATED: *(int64_t*)out = (int64_t)s->bytes_allocated; return PRL_OK;
+        case PRL_SF_ENGINE: *(int32_t*)out = s->fused ? PRL_ENGINE_FUSED : PRL_ENGINE_LEVELS; return PRL_OK;
         default: prl_set_error("unknown solver field"); return PRL_ERR_ARG;
     }
     if (!src) { prl_set_error("field not available for this variant"); return PRL_ERR_STATE; }

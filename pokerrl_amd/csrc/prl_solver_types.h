@@ -30,6 +30,10 @@ struct PrlDevTree {
     const int16_t* plan_ge;      // [n_plans][R]   one past the last position of the tie group
     const int16_t* plan_cl;      // [n_plans][n_cards][n_cards-1] positions of the hands containing card c, ascending; -1 pad
     const int32_t* plan_nlive;   // [n_plans]
+    // hand-domain / flagged copies used by the fused board kernels (prl_fhp_kernels.hip)
+    const int16_t* plan_hgs;     // [n_plans][R]   gs[pos[h]] (0 for blocked hands)
+    const int16_t* plan_hge;     // [n_plans][R]   ge[pos[h]]
+    const uint16_t* plan_clw;    // [n_plans][n_cards][n_cards-1]  position | (c is the LOWER card of that hand) << 15; 0xFFFF pad
 };
 
 struct PrlDevState {

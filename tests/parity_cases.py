@@ -157,3 +157,57 @@ def check_hand_rank_checksums(L, n_chunks=None):
     _native.check(L.prl_hand_rank_checksums(boards.ctypes.data_as(ctypes.c_void_p), n_boards, chunk, out.ctypes.data_as(ctypes.c_void_p)), L)
     assert np.array_equal(out, ref[:out.shape[0]])
     return out.shape[0]
+
+
+FUSED_FIELDS = ("regret", "avg")
+
+
+def check_fused_vs_oracle(L, n_boards, n_iters, delay=0):
+    """Fused board-block engine (per-node vectors on chip) against the oracle: every regret / average column of every
+    board, the strategy implied by the regrets, current- and average-strategy exploitability, after every iteration."""
+    boards = fhp_boards(n_boards)
+    args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
+    t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
+    s = _native.NativeSolver(t, "plus", delay, engine="fused", _lib=L)
+    assert s.engine == "fused"
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, 2, 52, 4, 2)
+    o.cfr_reset(1, delay)
+    assert np.array_equal(s.exploitability(), o.exploitability)
+    for it in range(1, n_iters + 1):
+        s.iteration()
+        o.cfr_iteration()
+        for k in FUSED_FIELDS + ("strategy",):
+            a, b = s.get(k), np.asarray(getattr(o, k))
+            assert np.array_equal(a, b), "fused it%d: %s differs in %d entries" % (it, k, int(np.sum(a != b)))
+        assert np.array_equal(s.exploitability(), o.exploitability), it
+        if it > delay:
+            assert np.array_equal(s.eval_avg(), o.eval_avg()), it
+    return s, o
+
+
+def check_fused_vs_levels(L, n_boards, n_iters, seed=11):
+    """Same tree solved by both engines of the library: bit-identical regrets, averages and exploitability history."""
+    boards = fhp_boards(n_boards, seed=seed)
+    args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
+    t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
+    a = _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
+    b = _native.NativeSolver(t, "plus", 0, engine="levels", _lib=L)
+    assert (a.engine, b.engine) == ("fused", "levels")
+    a.iterations(n_iters)
+    b.iterations(n_iters)
+    assert np.array_equal(a.get("expl_history"), b.get("expl_history"))
+    for k in FUSED_FIELDS:
+        assert np.array_equal(a.get(k), b.get(k)), k
+    assert np.array_equal(a.eval_avg(), b.eval_avg())
+    # exact best response of an explicit strategy (LocalBRMaster semantics) through both engines
+    rng = np.random.RandomState(seed)
+    strat = np.zeros((t.n_cols, t.range_size), np.float32)
+    first_col, n_ch, kind = t.field("first_col"), t.field("n_children"), t.field("kind")
+    for n in np.where(kind == 0)[0]:
+        x = rng.random_sample((n_ch[n], t.range_size)).astype(np.float32)
+        strat[first_col[n]:first_col[n] + n_ch[n]] = x / x.sum(axis=0, keepdims=True)
+    for sol in (a, b):
+        sol.set_strategy(strat)
+        sol.compute_ev()
+    assert np.array_equal(a.exploitability(), b.exploitability())
+    return a, b

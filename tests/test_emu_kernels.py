@@ -49,6 +49,14 @@ def test_emu_fhp_three_boards(L):
     pc.check_fhp_vs_oracle(L, 3, "plus", 1)
 
 
+def test_emu_fused_engine_three_boards(L):
+    pc.check_fused_vs_oracle(L, 3, 2)
+
+
+def test_emu_fused_engine_cfrplus_delay(L):
+    pc.check_fused_vs_oracle(L, 3, 3, delay=1)
+
+
 def test_emu_br_of_random_strategy(L):
     pc.check_br_of_given_strategy(L, "StandardLeduc", 0, f64=True)
     pc.check_br_of_given_strategy(L, "StandardLeduc", 1, f64=False)

@@ -116,6 +116,20 @@ def test_gpu_fhp_40_boards_vs_oracle(L, variant):
     pc.check_fhp_vs_oracle(L, 40, variant, 3)  # 40 boards > one canonical chance block of 32
 
 
+# ---- fused board-block engine (the benchmark path) -------------------------------------------------------------------------
+def test_gpu_fused_40_boards_vs_oracle(L):
+    pc.check_fused_vs_oracle(L, 40, 4)
+
+
+def test_gpu_fused_cfrplus_delay_vs_oracle(L):
+    pc.check_fused_vs_oracle(L, 33, 4, delay=2)
+
+
+def test_gpu_fused_vs_levels_2048_boards(L):
+    """2048 boards = 64 canonical chance blocks = 2 groups: both engines of the library must agree bit for bit."""
+    pc.check_fused_vs_levels(L, 2048, 6)
+
+
 def test_gpu_fhp_properties_at_scale(L):
     """1024 boards: zero-sum, BR >= EV, exploitability >= 0 and decreasing on average, strategies row-stochastic."""
     from pokerrl_amd import _native
@@ -124,7 +138,7 @@ def test_gpu_fhp_properties_at_scale(L):
     from helpers import native_tree
     boards = pc.fhp_boards(1024, seed=11)
     t = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)
-    s = _native.NativeSolver(t, "plus", 0)
+    s = _native.NativeSolver(t, "plus", 0, engine="levels")
     e0 = s.exploitability()
     s.iterations(10)
     e10 = s.exploitability()
