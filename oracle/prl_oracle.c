@@ -161,14 +161,19 @@ static double np_sum_f64(const double* a, int n, int stride) {
     return np_sum_f64(a, n2, stride) + np_sum_f64(a + n2 * stride, n - n2, stride);
 }
 
-/* wave-64 Hillis-Steele inclusive scan: lane l adds the value of lane l-d for d = 1,2,4,8,16,32 (all lanes in lock-step) */
+/* canonical wave-64 inclusive scan (DESIGN.md "summation order"), all lanes in lock-step: Hillis-Steele inside each row of
+ * 16 lanes (d = 1, 2, 4, 8), then rows 1 and 3 add lane 15 of the row below, then lanes 32..63 add lane 31 -- the
+ * association of the six-DPP-op scan of GCN/CDNA hardware (csrc/prl_device.h: prl_wave_scan_canonical) */
 static void scan64(float v[64]) {
-    for (int d = 1; d < 64; d <<= 1) {
-        float t[64];
-        for (int l = 0; l < 64; ++l) t[l] = l >= d ? v[l - d] : 0.f;
-        for (int l = 0; l < 64; ++l)
-            if (l >= d) v[l] = v[l] + t[l];
+    float t[64];
+    for (int d = 1; d < 16; d <<= 1) {
+        for (int l = 0; l < 64; ++l) t[l] = (l & 15) >= d ? v[l - d] : 0.f;
+        for (int l = 0; l < 64; ++l) v[l] = v[l] + t[l];
     }
+    for (int l = 0; l < 64; ++l) t[l] = ((l >> 4) & 1) ? v[(l >> 4) * 16 - 1] : 0.f;
+    for (int l = 0; l < 64; ++l) v[l] = v[l] + t[l];
+    for (int l = 0; l < 64; ++l) t[l] = l >= 32 ? v[31] : 0.f;
+    for (int l = 0; l < 64; ++l) v[l] = v[l] + t[l];
 }
 
 /* exclusive prefix P[0..n] of y[0..n) in the canonical chunked order: 64-wide scans + sequential chunk carries */

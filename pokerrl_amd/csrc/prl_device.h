@@ -29,7 +29,38 @@ PRL_DEV PRL_INLINE float prl_shfl(float v, int src_lane) { return __shfl(v, src_
 PRL_DEV PRL_INLINE int prl_shfl_i(int v, int src_lane) { return __shfl(v, src_lane, 64); }
 PRL_DEV PRL_INLINE int prl_shfl_up_i(int v, unsigned delta) { return __shfl_up(v, delta, 64); }
 PRL_DEV PRL_INLINE unsigned long long prl_ballot(int pred) { return __ballot(pred); }
+// DPP cross-lane moves (gfx9 data-parallel primitives: VALU latency instead of an LDS-crossbar round trip).
+// Lanes without a valid source receive 0.
+template <int D>
+PRL_DEV PRL_INLINE float prl_dpp_row_shr(float v) {  // lane l <- lane l - D inside its row of 16 lanes
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xF, 0xF, false));
+}
+PRL_DEV PRL_INLINE float prl_dpp_row_bcast15(float v) {  // rows 1 and 3 <- lane 15 of the previous row
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+}
+PRL_DEV PRL_INLINE float prl_dpp_row_bcast31(float v) {  // lanes 32..63 <- lane 31
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
+}
+PRL_DEV PRL_INLINE int prl_dpp_wave_shr1_i(int v, int fill) {  // lane l <- lane l - 1, lane 0 <- fill
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xF, 0xF, false);
+}
+PRL_DEV PRL_INLINE float prl_readlane(float v, int lane) {  // wave-uniform lane
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 #endif
+
+// Canonical wave-64 inclusive scan (DESIGN.md "summation order"): Hillis-Steele inside each row of 16 lanes
+// (d = 1, 2, 4, 8), then rows 1 and 3 add lane 15 of the row below, then lanes 32..63 add lane 31.
+// Six DPP adds on gfx950; the oracle (oracle/prl_oracle.c: scan64) replays exactly this association.
+PRL_DEV PRL_INLINE float prl_wave_scan_canonical(float v) {
+    v = v + prl_dpp_row_shr<1>(v);
+    v = v + prl_dpp_row_shr<2>(v);
+    v = v + prl_dpp_row_shr<4>(v);
+    v = v + prl_dpp_row_shr<8>(v);
+    v = v + prl_dpp_row_bcast15(v);
+    v = v + prl_dpp_row_bcast31(v);
+    return v;
+}
 
 // lane-local helpers on 64-bit masks
 PRL_HD PRL_INLINE int prl_popc64(unsigned long long x) {

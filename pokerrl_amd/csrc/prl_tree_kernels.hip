@@ -48,15 +48,8 @@ PRL_DEV PRL_INLINE float prl_np_sum(F get, int n) {
     return res;
 }
 
-// wave-64 Hillis-Steele inclusive scan (every lane of the wave must call it)
-PRL_DEV PRL_INLINE float prl_wave_scan(float v) {
-    const unsigned lane = prl_lane();
-    for (unsigned d = 1; d < 64; d <<= 1) {
-        float t = prl_shfl_up(v, d);
-        if (lane >= d) v = v + t;
-    }
-    return v;
-}
+// canonical wave-64 inclusive scan (every lane of the wave must call it)
+PRL_DEV PRL_INLINE float prl_wave_scan(float v) { return prl_wave_scan_canonical(v); }
 
 // Canonical chunked exclusive prefix of y[0..n) (LDS) into P[0..n] (LDS): 64-wide scans, sequential chunk carries.
 // tot / carry: LDS scratch of >= n_chunks + 1 floats each. Must be called by all threads of the block.

@@ -57,6 +57,30 @@ inline int prl_shfl_up_i(int v, unsigned delta) {
     return src < 0 ? v : r;
 }
 inline unsigned long long prl_ballot(int pred) { return prl_emu::wave_ballot(pred); }
+// DPP moves (see prl_device.h): lanes without a valid source receive 0
+template <int D>
+inline float prl_dpp_row_shr(float v) {
+    int lane = (int)prl_lane();
+    float r = prl_shfl(v, (lane & 15) >= D ? lane - D : lane);
+    return (lane & 15) >= D ? r : 0.f;
+}
+inline float prl_dpp_row_bcast15(float v) {
+    int lane = (int)prl_lane();
+    int row = lane >> 4;
+    float r = prl_shfl(v, (row & 1) ? row * 16 - 1 : lane);
+    return (row & 1) ? r : 0.f;
+}
+inline float prl_dpp_row_bcast31(float v) {
+    int lane = (int)prl_lane();
+    float r = prl_shfl(v, lane >= 32 ? 31 : lane);
+    return lane >= 32 ? r : 0.f;
+}
+inline int prl_dpp_wave_shr1_i(int v, int fill) {
+    int lane = (int)prl_lane();
+    int r = prl_shfl_i(v, lane > 0 ? lane - 1 : 0);
+    return lane > 0 ? r : fill;
+}
+inline float prl_readlane(float v, int lane) { return prl_shfl(v, lane); }
 
 // ---- the sliver of the HIP runtime API the C-ABI layer uses, mapped onto the host heap ---------------------------------
 typedef int hipError_t;

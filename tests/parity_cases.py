@@ -21,7 +21,7 @@ def make_pair(L, game_cls, stack, bets, boards, variant, delay=0):
     """(NativeTree, NativeSolver, Oracle) on the same flat tree (the product's builder feeds the oracle)."""
     args = env_args(game_cls, stack, bets)
     t = _native.NativeTree(game_cls.native_game(args), game_cls.native_rules(), boards, _lib=L)
-    s = _native.NativeSolver(t, variant, delay, _lib=L)
+    s = _native.NativeSolver(t, variant, delay, engine="levels", _lib=L)  # every per-node vector is compared below
     r = game_cls.RULES
     o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS,
                       r._RANK_RULE)
