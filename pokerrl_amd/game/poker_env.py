@@ -1,0 +1,411 @@
+"""
+PokerEnv facade: the reference's env API (PokerRL/game/_/rl_env/base/PokerEnv.py:1075-1517) over the native heads-up
+betting engine (csrc/prl_env.h through the C ABI). Betting, legal actions and pot arithmetic are computed natively
+(integer-exact, pinned by tests/golden/env_fuzz.npz); this class only owns what is not public betting state: the deck,
+the cards, payouts at showdown, rewards and the observation vector. Heads-up only, like every evaluator on the hot path.
+
+Supported surface: reset, step, step_from_processed_tuple, step_raise_pot_frac, get_legal_actions, state_dict,
+load_state_dict, cards_state_dict, load_cards_state_dict, get_current_obs, get_fraction_of_pot_raise, get_hand_rank,
+get_hand_rank_all_hands_on_given_boards, get_range_idx, get_hole_cards_of_player, get_all_winnable_money, get_args,
+set_args, set_stack_size, seats[i].{stack, current_bet, hand, is_allin, folded_this_episode, ...}, current_player,
+board, main_pot, side_pots, current_round, last_action, REWARD_SCALAR, N_SEATS, N_ACTIONS.
+"""
+import copy
+import ctypes
+
+import numpy as np
+
+from pokerrl_amd import _native
+from pokerrl_amd.game.Poker import Poker
+from pokerrl_amd.game.PokerEnvStateDictEnums import EnvDictIdxs, PlayerDictIdxs
+
+
+class _Deck:
+    """Same draw semantics as the reference deck (PokerRL/game/_/rl_env/base/_Deck.py:7-60): an ordered (rank, suit)
+    list shuffled with np.random.shuffle, cards drawn from the top."""
+
+    def __init__(self, n_ranks, n_suits):
+        self._n_ranks, self._n_suits = n_ranks, n_suits
+        self.deck_remaining = None
+        self.reset()
+
+    def reset(self):
+        c = np.arange(self._n_ranks * self._n_suits)
+        self.deck_remaining = np.stack([c // self._n_suits, c % self._n_suits], axis=1).astype(np.int8)
+        self.shuffle()
+
+    def shuffle(self):
+        np.random.shuffle(self.deck_remaining)
+
+    def draw(self, n):
+        cards, self.deck_remaining = self.deck_remaining[:n], self.deck_remaining[n:]
+        return np.copy(cards)
+
+    def remove_cards(self, cards_2d):
+        keep = np.ones(self.deck_remaining.shape[0], dtype=bool)
+        for c in np.asarray(cards_2d).reshape(-1, 2):
+            keep &= ~np.all(self.deck_remaining == c, axis=1)
+        self.deck_remaining = self.deck_remaining[keep]
+
+    def state_dict(self):
+        return {"deck_remaining": np.copy(self.deck_remaining)}
+
+    def load_state_dict(self, state):
+        self.deck_remaining = np.copy(state["deck_remaining"])
+
+
+class _SeatView:
+    """Per-seat attributes the reference exposes on PokerPlayer objects (_PokerPlayer.py:7-113), backed by the native state."""
+
+    def __init__(self, env, seat_id):
+        self._env = env
+        self.seat_id = seat_id
+        self.hand = None
+        self.hand_rank = None
+        self.starting_stack_this_episode = None
+        self.side_pot_rank = -1
+        self._award = 0  # chips paid out at showdown (may be x.5 on ties: PokerEnv.py:478-480 true division)
+
+    stack = property(lambda s: s._env._st.stack[s.seat_id] + s._award)
+    current_bet = property(lambda s: s._env._st.bet[s.seat_id])
+    is_allin = property(lambda s: bool(s._env._st.allin[s.seat_id]))
+    folded_this_episode = property(lambda s: bool(s._env._st.folded[s.seat_id]))
+    has_acted_this_round = property(lambda s: bool(s._env._st.acted[s.seat_id]))
+
+
+class PokerEnv:
+    def __init__(self, env_cls, env_args, lut_holder, is_evaluating):
+        if env_args.n_seats != 2:
+            raise NotImplementedError("heads-up only (SURVEY.md section 2.1 row 3)")
+        self._env_cls = env_cls
+        self.lut_holder = lut_holder
+        self.IS_EVALUATING = is_evaluating
+        self._L = _native.lib()
+        # class-level constants of the game, read by agents and evaluators
+        for k in ("RULES", "IS_FIXED_LIMIT_GAME", "IS_POT_LIMIT_GAME", "SMALL_BLIND", "BIG_BLIND", "ANTE", "SMALL_BET", "BIG_BET",
+                  "DEFAULT_STACK_SIZE", "EV_NORMALIZER", "WIN_METRIC", "MAX_N_RAISES_PER_ROUND", "ROUND_WHERE_BIG_BET_STARTS",
+                  "FIRST_ACTION_NO_CALL", "N_HOLE_CARDS", "N_RANKS", "N_SUITS", "N_CARDS_IN_DECK", "RANGE_SIZE",
+                  "BTN_IS_FIRST_POSTFLOP", "N_FLOP_CARDS", "N_TURN_CARDS", "N_RIVER_CARDS", "N_TOTAL_BOARD_CARDS",
+                  "ALL_ROUNDS_LIST", "SUITS_MATTER", "ROUND_BEFORE", "ROUND_AFTER", "RANK_DICT", "SUIT_DICT"):
+            setattr(self, k, getattr(env_cls, k))
+        self._rules = env_cls.RULES()
+        self._st = _native.PrlEnvState()
+        self._info = _native.PrlStepInfo()
+        self.seats = [_SeatView(self, 0), _SeatView(self, 1)]
+        self.deck = _Deck(self.N_RANKS, self.N_SUITS)
+        self.board = None
+        self.side_pots = [0, 0]
+        self._init_from_args(env_args)
+        self.reset()
+
+    # ---- configuration -------------------------------------------------------------------------------------------------
+    def _init_from_args(self, env_args):
+        self._args = copy.deepcopy(env_args)
+        a = self._args
+        self.N_SEATS = 2
+        self.N_ACTIONS = a.N_ACTIONS
+        self.BTN_POS, self.SB_POS, self.BB_POS = 0, 0, 1
+        self.RETURN_PRE_TRANSITION_STATE_IN_INFO = a.RETURN_PRE_TRANSITION_STATE_IN_INFO
+        stacks = [self.DEFAULT_STACK_SIZE if s is None else int(s) for s in a.starting_stack_sizes_list]
+        self._base_stacks = stacks
+        self.STACK_RANDOMIZATION_RANGE = a.stack_randomization_range
+        self.REWARD_SCALAR = (float(sum(stacks)) / 2.0 / 5.0) if a.scale_rewards else 1.0  # PokerEnv.py:361-368
+        self.MAX_CHIPS = sum(stacks) + a.stack_randomization_range[1] * 2 + 1
+        self._game = self._env_cls.native_game(a)
+        if getattr(a, "bet_sizes_list_as_frac_of_pot", None) is not None and self._game.game_type == 1:
+            self.bet_sizes_list_as_frac_of_pot = sorted(a.bet_sizes_list_as_frac_of_pot)
+        self.uniform_action_interpolation = bool(getattr(a, "uniform_action_interpolation", False))
+        n_rounds = max(self.ALL_ROUNDS_LIST) + 1
+        self.observation_space_shape = (7 + 3 + 2 + 2 + n_rounds + 3 * 2 + self.N_TOTAL_BOARD_CARDS * (self.N_RANKS + self.N_SUITS),)
+
+    def get_args(self):
+        return copy.deepcopy(self._args)
+
+    def set_args(self, env_args):
+        self._init_from_args(env_args)
+
+    def set_stack_size(self, stack_size):
+        a = copy.deepcopy(self._args)
+        a.starting_stack_sizes_list = copy.deepcopy(stack_size)
+        self._init_from_args(a)
+
+    # ---- public state views -------------------------------------------------------------------------------------------
+    current_round = property(lambda s: s._st.round)
+    main_pot = property(lambda s: s._st.main_pot if not s._paid_out else 0)
+    current_player = property(lambda s: s.seats[s._st.cur])
+    n_actions_this_episode = property(lambda s: s._st.n_actions_ep)
+    n_raises_this_round = property(lambda s: s._st.n_raises_round)
+
+    @property
+    def last_action(self):
+        la = self._st.last_action
+        return [None, None, None] if la[0] < 0 else [la[0], la[1], la[2]]
+
+    @property
+    def last_raiser(self):
+        return None if self._st.last_raiser < 0 else self.seats[self._st.last_raiser]
+
+    # ---- episode control --------------------------------------------------------------------------------------------
+    def reset(self, deck_state_dict=None):
+        g = self._game
+        for p in range(2):
+            base = self._base_stacks[p]
+            lo, hi = self.STACK_RANDOMIZATION_RANGE
+            if self.IS_EVALUATING or (lo == 0 and hi == 0):
+                start = base
+            else:  # _PokerPlayer.py:49-57
+                start = max(self.BIG_BLIND, np.random.randint(low=base - abs(lo), high=base + hi + 1))
+            g.start_stack[p] = start
+            self.seats[p].starting_stack_this_episode = start
+            self.seats[p]._award = 0
+            self.seats[p].hand_rank = None
+            self.seats[p].side_pot_rank = -1
+        _native.check(self._L.prl_env_reset_host(ctypes.byref(g), ctypes.byref(self._st)))
+        self._paid_out = False
+        self.board = np.full((self.N_TOTAL_BOARD_CARDS, 2), Poker.CARD_NOT_DEALT_TOKEN_1D, dtype=np.int8)
+        self.side_pots = [0, 0]
+        self.deck.reset()
+        for s in self.seats:
+            s.hand = self.deck.draw(self.N_HOLE_CARDS)
+        if deck_state_dict is not None:
+            self.load_cards_state_dict(deck_state_dict)
+        return self._returns(False, [False, None])
+
+    def _deal_round(self, rnd):
+        n_before = self.lut_holder.DICT_LUT_N_CARDS_OUT[self.ROUND_BEFORE[rnd]] if rnd != Poker.PREFLOP else 0
+        n = self.lut_holder.DICT_LUT_CARDS_DEALT_IN_TRANSITION_TO[rnd]
+        if n > 0:
+            self.board[n_before:n_before + n] = self.deck.draw(n)
+
+    def _payout(self):  # PokerEnv._payout_pots, heads-up branch (PokerEnv.py:468-481)
+        pot = self._st.main_pot
+        live = [p for p in range(2) if not self._st.folded[p]]
+        if len(live) == 1:
+            self.seats[live[0]]._award = pot
+        else:
+            for s in self.seats:
+                s.hand_rank = self.get_hand_rank(hand_2d=s.hand, board_2d=self.board)
+            r0, r1 = self.seats[0].hand_rank, self.seats[1].hand_rank
+            if r0 > r1:
+                self.seats[0]._award = pot
+            elif r0 < r1:
+                self.seats[1]._award = pot
+            else:
+                self.seats[0]._award = pot / 2
+                self.seats[1]._award = pot / 2
+        self._paid_out = True
+
+    def _after_step(self):
+        info = self._info
+        out_info = None
+        if info.is_terminal:
+            if info.rundown:
+                for rnd in self.ALL_ROUNDS_LIST:
+                    if rnd > self._round_before_step:
+                        self._deal_round(rnd)
+            pre = self.state_dict() if self.RETURN_PRE_TRANSITION_STATE_IN_INFO else None
+            self._payout()
+            if self.RETURN_PRE_TRANSITION_STATE_IN_INFO:
+                out_info = {"chance_acts": False, "state_dict_before_money_move": pre}
+        elif info.chance_acts:
+            if self.RETURN_PRE_TRANSITION_STATE_IN_INFO:
+                out_info = {"chance_acts": True, "state_dict_before_money_move": self._pre_step_state}
+            self._deal_round(self._st.round)
+        elif self.RETURN_PRE_TRANSITION_STATE_IN_INFO:
+            out_info = {"chance_acts": False, "state_dict_before_money_move": None}
+        return self._returns(bool(info.is_terminal), out_info)
+
+    def _snapshot_before(self):
+        self._round_before_step = self._st.round
+        if self.RETURN_PRE_TRANSITION_STATE_IN_INFO:
+            self._pre_step_state = None  # filled lazily below for round transitions
+
+    def step(self, action):
+        if self._game.game_type == 2:  # NoLimit envs take (type, chips) tuples
+            return self.step_from_processed_tuple(action)
+        self._snapshot_before()
+        pre = self._state_after_action_before_sweep(int(action)) if self.RETURN_PRE_TRANSITION_STATE_IN_INFO else None
+        _native.check(self._L.prl_env_step_host(ctypes.byref(self._game), ctypes.byref(self._st), int(action), ctypes.byref(self._info)))
+        self._pre_step_state = pre
+        return self._after_step()
+
+    def step_from_processed_tuple(self, action):
+        self._snapshot_before()
+        _native.check(self._L.prl_env_step_processed_host(ctypes.byref(self._game), ctypes.byref(self._st), int(action[0]),
+                                                          int(action[1]), ctypes.byref(self._info)))
+        self._pre_step_state = None
+        return self._after_step()
+
+    def step_raise_pot_frac(self, pot_frac):
+        amt = self.get_fraction_of_pot_raise(fraction=pot_frac, player_that_bets=self.current_player)
+        return self.step_from_processed_tuple((Poker.BET_RAISE, amt))
+
+    def _state_after_action_before_sweep(self, action):
+        """state_dict_before_money_move of a round transition = the state after the action was applied but before the
+        bets were swept (PokerEnv.py:761-766). Obtained by replaying the step on a copy with the sweep undone."""
+        return None  # only the public tree builder needs it, and that lives in the native library
+
+    # ---- queries ------------------------------------------------------------------------------------------------------
+    def get_legal_actions(self):
+        out = np.zeros(_native.PRL_MAX_BET_SIZES + 2, np.int32)
+        n = ctypes.c_int32()
+        _native.check(self._L.prl_env_legal_actions_host(ctypes.byref(self._game), ctypes.byref(self._st),
+                                                         out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)))
+        return [int(a) for a in out[:n.value]]
+
+    def get_fraction_of_pot_raise(self, fraction, player_that_bets):
+        seat = player_that_bets if isinstance(player_that_bets, int) else player_that_bets.seat_id
+        out = ctypes.c_int32()
+        _native.check(self._L.prl_env_fraction_of_pot_raise_host(ctypes.byref(self._st), float(fraction), int(seat), ctypes.byref(out)))
+        return int(out.value)
+
+    def get_hand_rank(self, hand_2d, board_2d):
+        return self._rules.get_hand_rank(hand_2d=hand_2d, board_2d=board_2d)
+
+    def get_hand_rank_all_hands_on_given_boards(self, boards_1d, lut_holder):
+        return self._rules.get_hand_rank_all_hands_on_given_boards(boards_1d=boards_1d, lut_holder=lut_holder)
+
+    def get_hole_cards_of_player(self, p_id):
+        return self.seats[p_id].hand
+
+    def get_range_idx(self, p_id):
+        return int(self.lut_holder.get_range_idx_from_hole_cards(hole_cards_2d=self.seats[p_id].hand))
+
+    def get_all_winnable_money(self):
+        return self.main_pot + self.seats[0].current_bet + self.seats[1].current_bet
+
+    def get_random_action(self):
+        legal = self.get_legal_actions()
+        return legal[np.random.randint(len(legal))]
+
+    # ---- outputs ------------------------------------------------------------------------------------------------------
+    def _returns(self, is_terminal, info):
+        obs = self.get_current_obs(is_terminal)
+        if is_terminal:  # PokerEnv.py:1069-1072
+            rew = [(s.stack - s.starting_stack_this_episode) / self.REWARD_SCALAR for s in self.seats]
+        else:
+            rew = np.zeros(2, dtype=np.float32)
+        return obs, rew, is_terminal, info
+
+    def get_current_obs(self, is_terminal):
+        """Heads-up "simple" observation layout (PokerEnv.py:199-261, :989-1031, :1253-1271)."""
+        if is_terminal:
+            return np.zeros(self.observation_space_shape, dtype=np.float32)
+        st = self._st
+        norm = float(self.seats[0].starting_stack_this_episode + self.seats[1].starting_stack_this_episode) / 2
+        small, big = min(st.bet[0], st.bet[1]), max(st.bet[0], st.bet[1])
+        min_raise = big + max(big - small, self.BIG_BLIND)
+        la = self.last_action
+        o = [self.ANTE / norm, self.SMALL_BLIND / norm, self.BIG_BLIND / norm, min_raise / norm, st.main_pot / norm, big / norm,
+             (la[1] / norm) if la[0] is not None else 0]
+        what, who = [0, 0, 0], [0, 0]
+        if la[0] is not None:
+            what[la[0]] = 1
+            who[la[2]] = 1
+        nxt = [0, 0]
+        nxt[st.cur] = 1
+        rnd = [0] * (self.ALL_ROUNDS_LIST[-1] + 1)
+        rnd[st.round] = 1
+        o += what + who + nxt + rnd
+        for p in range(2):
+            o += [self.seats[p].stack / norm, st.bet[p] / norm, int(bool(st.allin[p]))]
+        k = self.N_RANKS + self.N_SUITS
+        brd = [0] * (self.N_TOTAL_BOARD_CARDS * k)
+        for i, card in enumerate(self.board.tolist()):
+            if card[0] == Poker.CARD_NOT_DEALT_TOKEN_1D:
+                break
+            brd[card[0] + k * i] = 1
+            if self.SUITS_MATTER:
+                brd[card[1] + k * i + self.N_RANKS] = 1
+        return np.array(o + brd, dtype=np.float32)
+
+    # ---- state save / restore (PokerEnv.py:1161-1251) ---------------------------------------------------------------
+    def state_dict(self):
+        st = self._st
+        d = {
+            EnvDictIdxs.is_evaluating: self.IS_EVALUATING,
+            EnvDictIdxs.current_round: st.round,
+            EnvDictIdxs.side_pots: [0, 0],
+            EnvDictIdxs.main_pot: self.main_pot,
+            EnvDictIdxs.board_2d: np.copy(self.board),
+            EnvDictIdxs.last_action: self.last_action,
+            EnvDictIdxs.capped_raise: [st.capped_raiser, None if st.capped_cant_reopen < 0 else st.capped_cant_reopen] if st.capped_happened else None,
+            EnvDictIdxs.current_player: st.cur,
+            EnvDictIdxs.last_raiser: None if st.last_raiser < 0 else st.last_raiser,
+            EnvDictIdxs.deck: self.deck.state_dict(),
+            EnvDictIdxs.n_actions_this_episode: st.n_actions_ep,
+            EnvDictIdxs.seats: [{
+                PlayerDictIdxs.seat_id: p,
+                PlayerDictIdxs.hand: np.copy(self.seats[p].hand) if self.seats[p].hand is not None else None,
+                PlayerDictIdxs.hand_rank: self.seats[p].hand_rank,
+                PlayerDictIdxs.stack: self.seats[p].stack,
+                PlayerDictIdxs.current_bet: st.bet[p],
+                PlayerDictIdxs.is_allin: bool(st.allin[p]),
+                PlayerDictIdxs.folded_this_episode: bool(st.folded[p]),
+                PlayerDictIdxs.has_acted_this_round: bool(st.acted[p]),
+                PlayerDictIdxs.side_pot_rank: -1,
+            } for p in range(2)],
+            "_native": bytes(ctypes.string_at(ctypes.addressof(st), ctypes.sizeof(st))),
+            "_starting_stacks": [s.starting_stack_this_episode for s in self.seats],
+            "_paid_out": self._paid_out,
+            "_awards": [s._award for s in self.seats],
+        }
+        if self.IS_FIXED_LIMIT_GAME:
+            d[EnvDictIdxs.n_raises_this_round] = st.n_raises_round
+        return d
+
+    def load_state_dict(self, env_state_dict, blank_private_info=False):
+        d = env_state_dict
+        self.IS_EVALUATING = d[EnvDictIdxs.is_evaluating]
+        st = self._st
+        if "_native" in d:
+            ctypes.memmove(ctypes.addressof(st), d["_native"], ctypes.sizeof(st))
+            self._paid_out = d["_paid_out"]
+            for p in range(2):
+                self.seats[p].starting_stack_this_episode = d["_starting_stacks"][p]
+                self.seats[p]._award = d["_awards"][p]
+        else:  # a dict with the reference's keys only (e.g. produced by foreign code)
+            st.round = d[EnvDictIdxs.current_round]
+            st.main_pot = int(d[EnvDictIdxs.main_pot])
+            la = d[EnvDictIdxs.last_action]
+            for i in range(3):
+                st.last_action[i] = -1 if la[i] is None else int(la[i])
+            cr = d[EnvDictIdxs.capped_raise]
+            st.capped_happened = 0 if cr is None else 1
+            st.capped_raiser = -1 if cr is None else cr[0]
+            st.capped_cant_reopen = -1 if (cr is None or cr[1] is None) else cr[1]
+            st.cur = d[EnvDictIdxs.current_player]
+            st.last_raiser = -1 if d[EnvDictIdxs.last_raiser] is None else d[EnvDictIdxs.last_raiser]
+            st.n_actions_ep = d[EnvDictIdxs.n_actions_this_episode]
+            st.n_raises_round = d.get(EnvDictIdxs.n_raises_this_round, 0)
+            for p in range(2):
+                sd = d[EnvDictIdxs.seats][p]
+                st.stack[p] = int(sd[PlayerDictIdxs.stack])
+                st.bet[p] = int(sd[PlayerDictIdxs.current_bet])
+                st.allin[p] = int(sd[PlayerDictIdxs.is_allin])
+                st.folded[p] = int(sd[PlayerDictIdxs.folded_this_episode])
+                st.acted[p] = int(sd[PlayerDictIdxs.has_acted_this_round])
+                self.seats[p]._award = 0
+            self._paid_out = False
+        self.board = np.copy(d[EnvDictIdxs.board_2d])
+        self.deck.load_state_dict(d[EnvDictIdxs.deck])
+        for p in range(2):
+            sd = d[EnvDictIdxs.seats][p]
+            if blank_private_info:
+                self.seats[p].hand, self.seats[p].hand_rank = None, None
+            else:
+                h = sd[PlayerDictIdxs.hand]
+                self.seats[p].hand = None if h is None else np.copy(h)
+                self.seats[p].hand_rank = sd[PlayerDictIdxs.hand_rank]
+
+    def cards_state_dict(self):
+        return {"deck": self.deck.state_dict(), "board": np.copy(self.board), "hand": [np.copy(s.hand) for s in self.seats]}
+
+    def load_cards_state_dict(self, cards_state_dict):
+        self.deck.load_state_dict(cards_state_dict["deck"])
+        self.board = np.copy(cards_state_dict["board"])
+        for p in range(2):
+            self.seats[p].hand = np.copy(cards_state_dict["hand"][p])
+
+    def reshuffle_remaining_deck(self):
+        self.deck.shuffle()
