@@ -1,0 +1,328 @@
+"""
+PublicTree facade over the device-resident solver.
+
+Same constructor, methods and node attribute protocol as the reference (PokerRL/game/_/tree/PublicTree.py:30-158,
+PokerRL/game/_/tree/_/nodes.py:17-41), but the tree is a flat struct-of-arrays built natively (csrc/prl_tree.cpp) and every
+pass -- strategy fill, reach push-down, EV / best-response pull-up -- is a HIP kernel. Node objects are thin views: reading
+`node.ev`, `node.reach_probs`, `node.strategy` ... copies the corresponding slice out of HBM on demand (lazy host
+mirrors); assigning `node.strategy` stages the value and uploads all staged strategies before the next pass.
+
+Differences: `export_to_file` / `get_tree_as_dict` (debug JSON for a JS visualiser, PublicTree.py:313-420) are not
+provided; `stop_at_street` other than None is not supported (the hot path always builds full trees, _CFRBase.py:64-69).
+For 2-hole-card games the chance outcomes must be given (`boards=`): the reference cannot enumerate them at all
+ and the full C(52,5) set does not fit one GPU.
+"""
+import numpy as np
+
+from pokerrl_amd import _native
+from pokerrl_amd.game.Poker import Poker
+
+KIND_DECISION, KIND_CHANCE, KIND_FOLD, KIND_SHOWDOWN = 0, 1, 2, 3
+
+
+class TreeNode:
+    """View of one node of the flat tree; attribute names as in the reference's NodeBase (nodes.py:8-41)."""
+
+    def __init__(self, tree, idx):
+        self.tree = tree
+        self._i = idx
+        self.data = None  # algorithms may hang a dict here (nodes.py:40-41); CFR state itself lives in the solver
+        self._children = None
+
+    # ---- structure ----------------------------------------------------------------------------------------------------
+    @property
+    def is_terminal(self):
+        return self.tree._kind[self._i] >= KIND_FOLD
+
+    @property
+    def p_id_acting_next(self):
+        k = self.tree._kind[self._i]
+        if k == KIND_DECISION:
+            return int(self.tree._actor[self._i])
+        return PublicTree.CHANCE_ID if k == KIND_CHANCE else None
+
+    @property
+    def p_id_acted_last(self):
+        a = int(self.tree._acted_last[self._i])
+        return None if a == -1 else (PublicTree.CHANCE_ID if a == -2 else a)
+
+    @property
+    def action(self):
+        a = int(self.tree._action[self._i])
+        return "CHANCE" if a == -1 else a
+
+    @property
+    def depth(self):
+        return int(self.tree._depth[self._i])
+
+    @property
+    def parent(self):
+        p = int(self.tree._parent[self._i])
+        return None if p < 0 else self.tree.node(p)
+
+    @property
+    def children(self):
+        if self._children is None:
+            t = self.tree
+            lo, hi = t._child_start[self._i], t._child_start[self._i + 1]
+            self._children = [t.node(int(c)) for c in t._child_list[lo:hi]]
+        return self._children
+
+    @property
+    def allowed_actions(self):
+        t = self.tree
+        if t._kind[self._i] != KIND_DECISION:
+            return []
+        c0 = t._first_col[self._i]
+        return [int(a) for a in t._col_action[c0:c0 + t._n_children[self._i]]]
+
+    @property
+    def env_state(self):
+        return self.tree._env_state_of(self._i)
+
+    # ---- per-node vectors (lazy host mirrors of the HBM arrays) -------------------------------------------------------
+    @property
+    def reach_probs(self):
+        return self.tree._vec("reach")[self._i]
+
+    @property
+    def ev(self):
+        return self.tree._vec("ev")[self._i]
+
+    @property
+    def ev_br(self):
+        return self.tree._vec("ev_br")[self._i]
+
+    @property
+    def ev_weighted(self):
+        return self.ev * self.reach_probs
+
+    @property
+    def ev_br_weighted(self):
+        return self.ev_br * self.reach_probs
+
+    @property
+    def epsilon(self):
+        return self.ev_br_weighted - self.ev_weighted
+
+    @property
+    def exploitability(self):
+        if self._i == 0:
+            return self.tree._solver.exploitability()  # computed on the GPU in the reference's summation order
+        return np.sum(self.epsilon, axis=1)
+
+    @property
+    def br_a_idx_in_child_arr_for_each_hand(self):
+        return self.tree._vec("br_idx")[self._i]
+
+    @property
+    def strategy(self):
+        t = self.tree
+        if t._kind[self._i] == KIND_CHANCE:
+            return t._chance_strategy(self._i)
+        if t._kind[self._i] != KIND_DECISION:
+            return None
+        c0, a = t._first_col[self._i], t._n_children[self._i]
+        cols = t._vec("strategy")[c0:c0 + a]
+        out = cols.T
+        return out if t._vec("strat_f64")[self._i] else out.astype(np.float32)
+
+    @strategy.setter
+    def strategy(self, value):
+        self.tree._stage_strategy(self._i, np.asarray(value))
+
+
+class PublicTree:
+    CHANCE_ID = "Ch"
+
+    def __init__(self, env_bldr, stack_size, stop_at_street, put_out_new_round_after_limit=False, is_debugging=False, boards=None,
+                 engine="levels"):
+        if stop_at_street is not None:
+            raise NotImplementedError("partial trees (stop_at_street) are not on the hot path; build full trees")
+        self._env_bldr = env_bldr
+        self._stack_size = stack_size
+        self._is_debugging = is_debugging
+        self._put_out_new_round_after_limit = put_out_new_round_after_limit
+        self._stop_at_street = max(env_bldr.rules.ALL_ROUNDS_LIST) + 1
+        self._boards = boards
+        self._engine = engine
+        self._n_seats = env_bldr.N_SEATS
+        self.dir_tree_vis_data = None
+        self.root = None
+        self._native_tree = None
+        self._solver = None
+        self._nodes = {}
+        self._cache = {}
+        self._staged = {}
+        self._env_states = {}
+
+    # ---- reference properties -----------------------------------------------------------------------------------------
+    stack_size = property(lambda s: s._stack_size)
+    is_debugging = property(lambda s: s._is_debugging)
+    n_seats = property(lambda s: s._n_seats)
+    stop_at_street = property(lambda s: s._stop_at_street)
+    put_out_new_round_after_limit = property(lambda s: s._put_out_new_round_after_limit)
+    env_bldr = property(lambda s: s._env_bldr)
+
+    @property
+    def n_nodes(self):  # the reference's counter excludes the root (PublicTree.py:60,163)
+        return self._native_tree.n_nodes - 1
+
+    @property
+    def n_nonterm(self):
+        return int(np.sum(self._kind[1:] < KIND_FOLD))
+
+    # ---- construction -------------------------------------------------------------------------------------------------
+    def build_tree(self, variant="vanilla", delay=0):
+        import copy
+        env_cls, rules = self._env_bldr.env_cls, self._env_bldr.rules
+        args = copy.deepcopy(self._env_bldr.env_args)
+        args.starting_stack_sizes_list = copy.deepcopy(self._stack_size)
+        boards = self._boards
+        if boards is None:
+            if rules.N_HOLE_CARDS != 1:
+                raise ValueError("2-hole-card public trees need an explicit list of boards (boards=[[c1..c5], ...])")
+            boards = np.arange(rules.N_CARDS_IN_DECK, dtype=np.int8).reshape(-1, 1)  # PublicTree.py:193-203: cards ascending
+        self._native_tree = _native.NativeTree(env_cls.native_game(args), env_cls.native_rules(), boards)
+        t = self._native_tree
+        for f in ("kind", "actor", "parent", "action", "acted_last", "depth", "n_children", "first_col", "child_start", "child_list",
+                  "col_action", "board_id", "main_pot", "round", "child_idx"):
+            setattr(self, "_" + f, t.field(f))
+        self._solver = _native.NativeSolver(t, variant, delay, engine=self._engine)
+        self.root = self.node(0)
+        self._invalidate()
+
+    def node(self, idx):
+        n = self._nodes.get(idx)
+        if n is None:
+            n = self._nodes[idx] = TreeNode(self, idx)
+        return n
+
+    def nodes(self):
+        return (self.node(i) for i in range(self._native_tree.n_nodes))
+
+    @property
+    def solver(self):
+        return self._solver
+
+    @property
+    def native_tree(self):
+        return self._native_tree
+
+    # ---- passes (PublicTree.py:128-141) -------------------------------------------------------------------------------
+    def compute_ev(self):
+        self._flush()
+        self._solver.compute_ev()
+        self._invalidate()
+
+    def fill_uniform_random(self):
+        self._staged.clear()
+        self._solver.fill_uniform()
+        self._invalidate()
+
+    def fill_random_random(self):
+        """row-normalised np.random.random per decision node (StrategyFiller.py:67-86), then reach"""
+        t = self._native_tree
+        strat = np.zeros((t.n_cols, t.range_size), np.float64)
+        for n in np.where(self._kind == KIND_DECISION)[0]:
+            a = self._n_children[n]
+            x = np.random.random(size=(t.range_size, a))
+            x /= np.expand_dims(np.sum(x, axis=1), axis=-1)
+            strat[self._first_col[n]:self._first_col[n] + a] = x.T
+        self._staged.clear()
+        self._solver.set_strategy(strat)
+        self._invalidate()
+
+    def fill_with_agent_policy(self, agent):
+        """one query per decision node (StrategyFiller.py:88-116): strategy = agent probs restricted to the legal actions"""
+        t = self._native_tree
+        strat, dtype = np.zeros((t.n_cols, t.range_size), np.float64), None
+        for n in np.where(self._kind == KIND_DECISION)[0]:
+            node = self.node(int(n))
+            agent.set_to_public_tree_node_state(node=node)
+            assert node.p_id_acting_next == agent._internal_env_wrapper.env.current_player.seat_id, node.p_id_acting_next
+            probs = np.asarray(agent.get_a_probs_for_each_hand())
+            dtype = probs.dtype if dtype is None else np.promote_types(dtype, probs.dtype)
+            sel = probs[:, node.allowed_actions]
+            strat[self._first_col[n]:self._first_col[n] + self._n_children[n]] = sel.T
+        self._staged.clear()
+        self._solver.set_strategy(strat if dtype == np.float64 else strat.astype(np.float32))
+        self._invalidate()
+
+    def update_reach_probs(self):
+        self._flush()
+        self._solver.update_reach()
+        self._invalidate()
+
+    def copy(self):
+        c = PublicTree(self._env_bldr, self._stack_size, None, self._put_out_new_round_after_limit, self._is_debugging, self._boards,
+                       self._engine)
+        c.build_tree()
+        c._solver.set_strategy(self._vec("strategy"))
+        return c
+
+    def export_to_file(self, name="data"):
+        return None  # PokerViz JSON export is out of scope
+
+    # ---- internals ----------------------------------------------------------------------------------------------------
+    def _invalidate(self):
+        self._cache = {}
+
+    def _vec(self, name):
+        if name not in self._cache:
+            self._flush()
+            self._cache[name] = self._solver.get(name)
+        return self._cache[name]
+
+    def _stage_strategy(self, idx, value):
+        assert self._kind[idx] == KIND_DECISION and value.shape == (self._native_tree.range_size, self._n_children[idx])
+        self._staged[idx] = value
+        self._cache.pop("strategy", None)
+
+    def _flush(self):
+        if not self._staged:
+            return
+        staged, self._staged = self._staged, {}
+        cur = self._solver.get("strategy")
+        f64 = bool(self._solver.get("strat_f64").any()) or any(v.dtype == np.float64 for v in staged.values())
+        for idx, v in staged.items():
+            cur[self._first_col[idx]:self._first_col[idx] + self._n_children[idx]] = v.T
+        self._solver.set_strategy(cur if f64 else cur.astype(np.float32))
+        self._invalidate()
+
+    def _chance_strategy(self, idx):
+        """[R, n_boards] float32: board probability for hands not blocked by the board (StrategyFiller.py:148-169)"""
+        t, lut = self._native_tree, self._env_bldr.lut_holder.LUT_IDX_2_HOLE_CARDS
+        p = self._solver.get("constants")[0]
+        out = np.zeros((t.range_size, t.n_boards), np.float32)
+        for b in range(t.n_boards):
+            blocked = np.isin(lut, t.boards[b]).any(axis=1)
+            out[~blocked, b] = p
+        return out
+
+    def _env_state_of(self, idx):
+        """public env state of a node (PokerEnv.state_dict layout), rebuilt by replaying the actions from the root"""
+        if idx in self._env_states:
+            return self._env_states[idx]
+        import copy
+        env = self._env_bldr.get_new_env(is_evaluating=True, stack_size=self._stack_size)
+        path, i = [], idx
+        while i > 0:
+            path.append(i)
+            i = int(self._parent[i])
+        a = env.get_args()
+        a.RETURN_PRE_TRANSITION_STATE_IN_INFO = False
+        env.set_args(a)
+        env.reset()
+        lh = self._env_bldr.lut_holder
+        for n in reversed(path):
+            act = int(self._action[n])
+            if act == -1:  # chance outcome: put this node's board on the table
+                board_1d = self._native_tree.boards[self._board_id[n]]
+                env.board[:len(board_1d)] = lh.get_2d_cards(np.asarray(board_1d))
+                env.deck.remove_cards(env.board[:len(board_1d)])
+            elif self._kind[n] < KIND_FOLD:
+                env.step(act)
+        st = copy.deepcopy(env.state_dict())
+        self._env_states[idx] = st
+        return st

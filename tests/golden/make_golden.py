@@ -496,10 +496,43 @@ def make_cfr(only=None):
         save("cfr_%s.npz" % fx, **out)
 
 
+def make_env_obs():
+    """Full env episodes (cards, observation vectors, rewards) for seeded decks: pins the PokerEnv facade's dealing
+    order (_Deck.py), observation layout (PokerEnv.py:199-261,1253-1271), payouts (:468-481) and rewards (:1069-1072)."""
+    out = {}
+    for name in ("StandardLeduc", "BigLeduc_short", "DiscretizedNLLeduc_B5_short", "LimitHoldem", "DiscretizedNLHoldem_B5",
+                 "DiscretizedNLHoldem_OT11_short", "Flop5Holdem"):
+        cls, stack, bets = ENV_FUZZ[name]
+        bldr, args = make_bldr(cls, stack, bets)
+        env = bldr.get_new_env(is_evaluating=True, stack_size=args.starting_stack_sizes_list)
+        rng = np.random.RandomState(sum(map(ord, name)) + 7)
+        obs_rows, meta_rows = [], []
+        for ep in range(40):
+            np.random.seed(1000 + ep)
+            o, r, done, _ = env.reset()
+            obs_rows.append(o)
+            meta_rows.append([ep, -1, 0, 0.0, 0.0])
+            while not done:
+                legal = env.get_legal_actions()
+                act = int(legal[rng.randint(len(legal))])
+                o, r, done, _ = env.step(act)
+                obs_rows.append(o)
+                meta_rows.append([ep, act, int(done), float(r[0]), float(r[1])])
+            cards = [int(c) for c in env.lut_holder.get_1d_cards(env.board)] + \
+                    [int(c) for p in range(2) for c in env.lut_holder.get_1d_cards(env.seats[p].hand)]
+            meta_rows[-1] = meta_rows[-1] + cards
+        width = max(len(m) for m in meta_rows)
+        meta = np.array([m + [-999] * (width - len(m)) for m in meta_rows], dtype=np.float64)
+        out[name + "_obs"] = np.array(obs_rows, dtype=np.float32)
+        out[name + "_meta"] = meta
+        print(name, out[name + "_obs"].shape)
+    save("env_obs.npz", **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["luts", "handrank", "tree", "env", "cfr"]
     fns = {"luts": make_luts, "handrank": make_handrank, "handrank_exhaustive": make_handrank_exhaustive,
-           "tree": make_tree, "env": make_env, "cfr": make_cfr}
+           "tree": make_tree, "env": make_env, "cfr": make_cfr, "env_obs": make_env_obs}
     i = 0
     while i < len(what):
         w = what[i]

@@ -1,0 +1,150 @@
+"""
+GPU suite: the reference's plugin surface (CFR classes, PublicTree node protocol, LocalBRMaster + EvalAgentBase +
+TrainingProfileBase + ChiefBase) driven the way the reference's own scripts and tests drive it
+(examples/run_cfrp_example.py:27-37, test/cfr/test_cfr.py:15-62, test/game/test_tree.py:78-131), with results compared to
+logs captured from the reference (tests/golden/cfr_*.npz, SURVEY.md section 8a BR values).
+"""
+import numpy as np
+import pytest
+
+from helpers import golden
+from pokerrl_amd.game import bet_sets
+from pokerrl_amd.game.games import DiscretizedNLLeduc, StandardLeduc
+from pokerrl_amd.rl.base_cls.workers.ChiefBase import ChiefBase
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("algo,fixture", [("CFRPlus", "StandardLeduc_CFRPlus"), ("VanillaCFR", "StandardLeduc_VanillaCFR"),
+                                          ("LinearCFR", "StandardLeduc_LinearCFR")])
+def test_cfr_classes_log_the_references_series(algo, fixture):
+    import importlib
+    cls = getattr(importlib.import_module("pokerrl_amd.cfr." + algo), algo)
+    g = golden("cfr_%s.npz" % fixture)
+    chief = ChiefBase(t_prof=None)
+    kw = dict(delay=0) if algo == "CFRPlus" else {}
+    cfr = cls(name="g", game_cls=StandardLeduc, agent_bet_set=bet_sets.POT_ONLY, chief_handle=chief, **kw)
+    n = int(g["curr_series"][-1, 0])
+    for _ in range(n):
+        cfr.iteration()
+    assert cfr.iter_counter == n
+    vals, names = chief.get_new_values()
+    curr = [k for k in vals if "_Curr_S13_" in k][0]
+    avg = [k for k in vals if "_Avg_total_S13_" in k][0]
+    assert curr == "g_Curr_S13_total_" + cfr.algo_name and avg == "g_Avg_total_S13_" + cfr.algo_name
+    assert np.array_equal(np.array(vals[curr]["Evaluation/MA_per_G"], dtype=np.float64), g["curr_series"])
+    assert np.array_equal(np.array(vals[avg]["Evaluation/MA_per_G"], dtype=np.float64), g["avg_series"])
+    assert len(names) == 4
+    # node attribute protocol: the reference's per-node arrays of the final iteration
+    tree = cfr._trees[0]
+    snap = "it%d_" % n
+    nodes = list(tree.nodes())
+    assert len(nodes) == g[snap + "reach"].shape[0] == tree.n_nodes + 1
+    for i in (0, 1, 7, 100, 464):
+        assert np.array_equal(nodes[i].reach_probs, g[snap + "reach"][i])
+        assert np.array_equal(nodes[i].ev, g[snap + "ev"][i])
+        assert np.array_equal(nodes[i].ev_br, g[snap + "ev_br"][i])
+    assert np.array_equal(cfr.regrets(), g[snap + "regret"])
+    assert np.array_equal(cfr.average_strategy(), g[snap + "avg"])
+    root = tree.root
+    assert root.p_id_acting_next == 0 and root.action == "CHANCE" and root.parent is None and not root.is_terminal
+    assert root.strategy.shape == (6, len(root.children)) and root.allowed_actions == [1, 2]
+
+
+def test_run_cfrp_example_configuration():
+    """examples/run_cfrp_example.py: DiscretizedNLLeduc + POT_ONLY, CFR+ delay 0 (first 10 of its 150 iterations)."""
+    from pokerrl_amd.cfr.CFRPlus import CFRPlus
+    g = golden("cfr_DiscretizedNLLeduc_POT_CFRPlus.npz")
+    chief = ChiefBase(t_prof=None)
+    cfr = CFRPlus(name="CFRp_EXAMPLE", game_cls=DiscretizedNLLeduc, delay=0, agent_bet_set=bet_sets.POT_ONLY, chief_handle=chief)
+    cfr.iterations(10)  # batched: one host round trip, exploitability history read back from the device
+    vals, _ = chief.get_new_values()
+    curr = [k for k in vals if "_Curr_S20000_" in k][0]
+    assert np.array_equal(np.array(vals[curr]["Evaluation/MBB_per_G"], dtype=np.float64), g["curr_series"])
+    avg = [k for k in vals if "_Avg_total_S20000_" in k][0]
+    assert vals[avg]["Evaluation/MBB_per_G"][-1] == [10, g["avg_series"][-1, 1]]
+
+
+def _uniform_agent_cls():
+    from pokerrl_amd.rl.base_cls.EvalAgentBase import EvalAgentBase
+
+    class UniformAgent(EvalAgentBase):
+        """fixture agent of SURVEY.md section 8c: uniform over the legal actions, float32 [R, N_ACTIONS]"""
+        ALL_MODES = ["UNIFORM"]
+
+        def can_compute_mode(self):
+            return True
+
+        def update_weights(self, w):
+            pass
+
+        def _state_dict(self):
+            return {}
+
+        def _load_state_dict(self, s):
+            pass
+
+        def get_a_probs_for_each_hand(self):
+            env = self._internal_env_wrapper.env
+            legal = env.get_legal_actions()
+            p = np.zeros((self.env_bldr.rules.RANGE_SIZE, self.env_bldr.N_ACTIONS), dtype=np.float32)
+            p[:, legal] = 1.0 / len(legal)
+            return p
+
+    return UniformAgent
+
+
+@pytest.mark.parametrize("game_cls,expected", [(StandardLeduc, 2373.6114501953125), (DiscretizedNLLeduc, 12864.71435546875)])
+def test_local_br_master_uniform_agent(tmp_path, game_cls, expected):
+    """BR of a uniform agent through LocalBRMaster.evaluate (reference values, float32 agent probs)."""
+    from pokerrl_amd.eval.br.LocalBRMaster import LocalBRMaster
+    from pokerrl_amd.game.wrappers import HistoryEnvBuilder
+    from pokerrl_amd.rl.base_cls.TrainingProfileBase import TrainingProfileBase
+
+    class Chief(ChiefBase):
+        def pull_current_eval_strategy(self, last):
+            return None, last
+
+    t_prof = TrainingProfileBase(
+        name="br", log_verbose=False, log_export_freq=1, checkpoint_freq=10 ** 9, eval_agent_export_freq=10 ** 9, game_cls=game_cls,
+        env_bldr_cls=HistoryEnvBuilder, start_chips=None, eval_modes_of_algo=("UNIFORM",), eval_stack_sizes=None,
+        module_args={"env": game_cls.ARGS_CLS(n_seats=2, bet_sizes_list_as_frac_of_pot=bet_sets.POT_ONLY)}, path_data=str(tmp_path))
+    chief = Chief(t_prof)
+    br = LocalBRMaster(t_prof=t_prof, chief_handle=chief, eval_agent_cls=_uniform_agent_cls())
+    br.update_weights()
+    br.evaluate(iter_nr=0)
+    vals, _ = chief.get_new_values()
+    (exp, graphs), = vals.items()
+    assert exp == "br UNIFORM_stack_%d: BR Total" % game_cls.DEFAULT_STACK_SIZE
+    (graph, series), = graphs.items()
+    assert graph == "Evaluation/" + game_cls.WIN_METRIC
+    assert series == [[0, expected]]
+
+
+def test_public_tree_api_like_test_tree():
+    """test/game/test_tree.py:78-131: build, fill uniform, compute EVs; plus random fill and strategy assignment."""
+    from pokerrl_amd.game.PublicTree import PublicTree
+    from pokerrl_amd.game.wrappers import HistoryEnvBuilder
+    args = StandardLeduc.ARGS_CLS(n_seats=2, starting_stack_sizes_list=[13, 13])
+    tree = PublicTree(env_bldr=HistoryEnvBuilder(env_cls=StandardLeduc, env_args=args), stack_size=[13, 13], stop_at_street=None)
+    tree.build_tree()
+    assert (tree.n_nodes, tree.n_nonterm) == (464, 190)
+    tree.fill_uniform_random()
+    tree.compute_ev()
+    e = tree.root.exploitability
+    assert (float(e[0]) * 1000 + float(e[1]) * 1000) / 2 == 2373.611330986023  # SURVEY.md 8a, float64 uniform fill
+    np.random.seed(0)
+    tree.fill_random_random()
+    tree.compute_ev()
+    for n in list(tree.nodes())[:50]:
+        assert abs(float(np.sum(n.ev_weighted))) < 1e-3  # zero-sum check of ValueFiller.py:98
+    # assigning node.strategy stages an upload; the next pass sees it
+    root = tree.root
+    s = np.zeros((6, 2), np.float32)
+    s[:, 0] = 1
+    root.strategy = s
+    tree.update_reach_probs()
+    c0, c1 = root.children
+    assert np.array_equal(c0.reach_probs[0], root.reach_probs[0]) and np.all(c1.reach_probs[0] == 0)
+    st = c0.env_state
+    assert st["current_player"] == 1 and st["main_pot"] == 2
