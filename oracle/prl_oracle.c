@@ -424,7 +424,7 @@ static void terminal_equity_2card(Orc* o, const float* x, int board_id, int mode
                 while (hi < p->n_t && row[hi] < ge) hi++;
                 K[k] = Q[cs[k]][lo] - (Q[cs[k]][p->n_t] - Q[cs[k]][hi]);
             }
-            eq[h] = (G - K[0]) - K[1];
+            eq[h] = G - (K[0] + K[1]); /* the two corrections are added first: a + b is commutative bit for bit, so the GPU may accumulate them in any order */
         }
     }
     free(Q); free(P); free(y);

@@ -52,6 +52,11 @@ struct PrlFhpShape {
         constexpr int F[N_NODES] = {-1, -1, -1, -1, 1, -1, -1, 0, -1, -1, 0, -1, -1, 1, -1};
         return F[n];
     }
+    // slot of a terminal node among the 9 terminal vectors of a seat: showdown nodes 0..4, fold nodes 5..8
+    static constexpr int term_slot(int n) {
+        constexpr int T[N_NODES] = {-1, -1, 0, -1, 5, 1, -1, 6, 2, -1, 7, 3, -1, 8, 4};
+        return T[n];
+    }
     static constexpr int parent(int n) {
         constexpr int P[N_NODES] = {-1, 0, 1, 1, 3, 3, 3, 6, 6, 0, 9, 9, 9, 12, 12};
         return P[n];

@@ -233,7 +233,7 @@ PRL_DEV PRL_INLINE void prl_terminal_equity_2card(const PrlDevTree& T, const flo
                     while (hi < n_t && row[hi] < g1) hi++;
                     K[k] = Q[c * 65 + lo] - (Q[c * 65 + n_t] - Q[c * 65 + hi]);
                 }
-                e = (G - K[0]) - K[1];
+                e = G - (K[0] + K[1]);
             }
             e = e * T.eq_const;
             e = sign * e;  // exact (+-1)
