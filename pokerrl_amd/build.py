@@ -27,7 +27,7 @@ def sources():
 
 
 def _newest_header():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "pokerrl_hip.h")]
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + [os.path.join(INCLUDE, "pokerrl_hip.h")]
     return max(os.path.getmtime(h) for h in hs)
 
 

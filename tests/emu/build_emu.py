@@ -15,7 +15,7 @@ LIB = os.path.join(OUT_DIR, "libpokerrl_emu.so")
 def build(force=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hip")))
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + \
         [os.path.join(HERE, "prl_emu.h"), os.path.join(HERE, "prl_emu.cpp"), os.path.join(ROOT, "include", "pokerrl_hip.h")]
     newest = max(os.path.getmtime(d) for d in deps)
     if not force and os.path.isfile(LIB) and os.path.getmtime(LIB) >= newest:
