@@ -65,5 +65,26 @@ def build_native(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defines):
+    """Instrumented / experimental copy of the library (never loaded by the package): lib/libpokerrl_hip_<name>.so"""
+    out = os.path.join(LIB_DIR, "libpokerrl_hip_%s.so" % name)
+    vdir = os.path.join(LIB_DIR, "obj_" + name)
+    os.makedirs(vdir, exist_ok=True)
+    procs, objs = [], []
+    for s in sources():
+        obj = os.path.join(vdir, s + ".o")
+        objs.append(obj)
+        cmd = [HIPCC] + COMMON + DEVICE + ["-D" + d for d in defines] + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", os.path.join(CSRC, s), "-o", obj]
+        procs.append(subprocess.Popen(cmd))
+    if any(p.wait() != 0 for p in procs):
+        raise RuntimeError("hipcc failed")
+    subprocess.check_call([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-o", out] + objs)
+    return out
+
+
 if __name__ == "__main__":
-    print(build_native(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    if "--variant" in sys.argv:  # python -m pokerrl_amd.build --variant timing PRL_FHP_TIMING
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        print(build_native(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -19,6 +19,31 @@ PRL_DEV PRL_INLINE unsigned prl_nthreads() { return blockDim.x; }
 PRL_DEV PRL_INLINE unsigned prl_nblocks() { return gridDim.x; }
 PRL_DEV PRL_INLINE unsigned prl_lane() { return threadIdx.x & 63u; }
 PRL_DEV PRL_INLINE void prl_sync() { __syncthreads(); }
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory counter (loads, stores
+// and LDS DMA share vmcnt on gfx9), which would serialise the asynchronous prefetch below with every phase boundary.
+PRL_DEV PRL_INLINE void prl_sync_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// Asynchronous global -> LDS copy (gfx950 LDS DMA, no VGPR round trip), 16 bytes or 4 bytes per lane:
+// LDS[lds_wave_base + SIZE * lane ...] <- *(gbase + byte_off). gbase and lds_wave_base are wave-uniform; the 16-byte form
+// needs 16-byte aligned addresses on both sides. Not tracked by the compiler's wait-count insertion: the consumer calls
+// prl_dma_wait() (then a barrier) before reading the destination. The vector-memory address unit handles 64 lanes in
+// ~16 clocks per instruction whatever the width, so the 16-byte form moves 4x the data per issue slot.
+PRL_DEV PRL_INLINE void prl_lds_dma_x4(const void* gbase, uint32_t byte_off, void* lds_wave_base) {
+    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+    uint32_t saved_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved_m0) : "s"(la), "v"(byte_off), "s"(gbase) : "memory");
+}
+PRL_DEV PRL_INLINE void prl_lds_dma_dword(const void* gbase, uint32_t byte_off, void* lds_wave_base) {
+    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+    uint32_t saved_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved_m0) : "s"(la), "v"(byte_off), "s"(gbase) : "memory");
+}
+PRL_DEV PRL_INLINE void prl_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 PRL_DEV PRL_INLINE char* prl_smem() {
     extern __shared__ __attribute__((aligned(16))) char prl_dyn_smem[];
     return prl_dyn_smem;
@@ -57,8 +82,18 @@ PRL_DEV PRL_INLINE float prl_wave_scan_canonical(float v) {
     v = v + prl_dpp_row_shr<2>(v);
     v = v + prl_dpp_row_shr<4>(v);
     v = v + prl_dpp_row_shr<8>(v);
+#if defined(PRL_EMU)
     v = v + prl_dpp_row_bcast15(v);
     v = v + prl_dpp_row_bcast31(v);
+#else
+    // The two masked steps as ONE instruction each: the add itself carries the DPP modifier and leaves the rows outside
+    // row_mask untouched (v instead of v + 0.0: the same bits for every value but -0.0, which a sum of reach
+    // probabilities never is). The compiler only fuses a mov_dpp into a float add when all rows are enabled and would
+    // emit mov 0 / mov_dpp / add here. "s_nop 1": a DPP operand written by the preceding VALU instruction needs two wait
+    // states, which the hazard recogniser does not insert inside inline assembly.
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+#endif
     return v;
 }
 

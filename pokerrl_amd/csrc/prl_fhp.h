@@ -18,7 +18,10 @@
 #include "prl_tree.h"
 
 enum { PRL_SRC_REGRET = 0, PRL_SRC_UNIFORM64 = 1, PRL_SRC_ARR64 = 2, PRL_SRC_ARR32 = 3 };
-enum { PRL_FHP_UPDATE0 = 0, PRL_FHP_UPDATE1 = 1, PRL_FHP_EVAL = 2 };
+// UPDATE0 / UPDATE1: that seat's values + regret / average update. EVAL: both seats + best response.
+// UPDATE0_EVAL: EVAL and UPDATE0 of the same strategy in one pass (the evaluation that closes iteration t and the first
+// half of iteration t + 1 read the same regrets).
+enum { PRL_FHP_UPDATE0 = 0, PRL_FHP_UPDATE1 = 1, PRL_FHP_EVAL = 2, PRL_FHP_UPDATE0_EVAL = 3 };
 
 struct PrlFhpShape {
     static constexpr int N_NODES = 15;
@@ -85,6 +88,9 @@ struct PrlFhpParams {
     float pot[PrlFhpShape::N_NODES];   // main pot of the terminal nodes (by local node id)
     const float* chance_reach;  // [2][R] reach at the chance node (trunk state)
     float* regret;              // [n_cols][R] (global column ids)
+    double* avg;                // [n_cols][R] average strategy, updated by the update passes when avg_mode != 0
+    int32_t avg_mode;           // 0: no update (before the delay), 1: avg = strategy, 2: avg = m_old * avg + m_new * strategy
+    double m_old, m_new;        // CFRPlus.py:65-87 weights (float64)
     const double* strat_arr;    // explicit strategy (average strategy / caller-provided), [n_cols][R]
     float* board_ev;            // [n_boards][2][R] root values of every board subtree
     float* board_br;            // [n_boards][2][R] best-response values (PRL_FHP_EVAL)
@@ -93,6 +99,7 @@ struct PrlFhpParams {
     const int16_t *plan_pos, *plan_hgs, *plan_hge, *plan_gs;
     const uint16_t* plan_clw;
     const int32_t* plan_nlive;
+    unsigned long long* timing; // PRL_FHP_TIMING builds: [8] shader-clock accumulators per phase (prologue, B, C, D, E, epilogue)
 };
 
 // host: does the flat tree consist of a trunk + ONE chance node whose board subtrees all have the compiled shape?
@@ -100,6 +107,5 @@ struct PrlFhpParams {
 bool prl_fhp_shape_matches(const PrlFlatTree& t, int* chance_node, int* first_board_node, int* col_base, float* pots /*[15]*/);
 
 int prl_launch_fhp_pass(const PrlFhpParams& prm, int mode, int src0, int src1, void* stream);
-void prl_launch_fhp_average_plus(const PrlFhpParams& prm, int p, int mode, double m_old, double m_new, double* avg, void* stream);
 void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_cols, void* stream);
 void prl_launch_fhp_chance_sum(const float* d_board_vals, int n_boards, int R, float* d_scratch, float* d_dest, void* stream);

@@ -23,10 +23,10 @@
 // ---------------------------------------------------------------------------------------------------------------------
 // launch configurations of the board-pass kernel: the same source instantiated with different (threads, hand slots,
 // occupancy) triples; selected at run time (PrlFhpParams::cfg) so that they can be A/B-measured on the GPU.
-//   cfg 0: 512 lanes x 3 slots, registers uncapped (1 workgroup = 8 waves per CU, no scratch)
-//   cfg 1: 512 lanes x 3 slots, 128 VGPRs (2 workgroups per CU, spills to scratch)
-//   cfg 2: 768 lanes x 2 slots (12 waves per CU)
-//   cfg 3: 1024 lanes x 2 slots, 128 VGPRs (16 waves per CU)
+//   cfg 0: 704 lanes x 2 slots (11 waves per CU): a lane owns two ADJACENT hands, so every global access of the hand
+//          domain is one 8- or 16-byte vector instruction (the address unit takes ~16 clocks per wave instruction
+//          whatever its width)
+//   cfg 1: 448 lanes x 3 slots (7 waves per CU), scalar accesses
 // ---------------------------------------------------------------------------------------------------------------------
 #if defined(PRL_EMU)
 #define FHP_LB(t, w)
@@ -34,9 +34,9 @@
 #define FHP_LB(t, w) __launch_bounds__(t, w)
 #endif
 
-#define FHP_THREADS 512
-#define FHP_SLOTS 3
-#define FHP_LAUNCH_BOUNDS FHP_LB(512, 2)
+#define FHP_THREADS 704
+#define FHP_SLOTS 2
+#define FHP_LAUNCH_BOUNDS FHP_LB(704, 3)
 namespace fhp_cfg0 {
 #include "prl_fhp_pass.inc"
 }
@@ -45,32 +45,10 @@ namespace fhp_cfg0 {
 #undef FHP_LAUNCH_BOUNDS
 #undef FHP_LDS_BYTES
 
-#define FHP_THREADS 512
+#define FHP_THREADS 448
 #define FHP_SLOTS 3
-#define FHP_LAUNCH_BOUNDS FHP_LB(512, 4)
+#define FHP_LAUNCH_BOUNDS FHP_LB(448, 2)
 namespace fhp_cfg1 {
-#include "prl_fhp_pass.inc"
-}
-#undef FHP_THREADS
-#undef FHP_SLOTS
-#undef FHP_LAUNCH_BOUNDS
-#undef FHP_LDS_BYTES
-
-#define FHP_THREADS 768
-#define FHP_SLOTS 2
-#define FHP_LAUNCH_BOUNDS FHP_LB(768, 3)
-namespace fhp_cfg2 {
-#include "prl_fhp_pass.inc"
-}
-#undef FHP_THREADS
-#undef FHP_SLOTS
-#undef FHP_LAUNCH_BOUNDS
-#undef FHP_LDS_BYTES
-
-#define FHP_THREADS 1024
-#define FHP_SLOTS 2
-#define FHP_LAUNCH_BOUNDS FHP_LB(1024, 4)
-namespace fhp_cfg3 {
 #include "prl_fhp_pass.inc"
 }
 #undef FHP_THREADS
@@ -80,35 +58,7 @@ namespace fhp_cfg3 {
 int prl_launch_fhp_pass(const PrlFhpParams& prm, int mode, int src0, int src1, void* stream) {
     switch (prm.cfg) {
         case 1: return fhp_cfg1::launch_pass(prm, mode, src0, src1, stream);
-        case 2: return fhp_cfg2::launch_pass(prm, mode, src0, src1, stream);
-        case 3: return fhp_cfg3::launch_pass(prm, mode, src0, src1, stream);
         default: return fhp_cfg0::launch_pass(prm, mode, src0, src1, stream);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// CFR+ average strategy of the updated seat (CFRPlus.py:65-87), streaming: new strategy = regret matching of the new regrets
-// mode 1: avg = strategy (iteration == delay); mode 2: avg = m_old * avg + m_new * strategy in float64
-// ---------------------------------------------------------------------------------------------------------------------
-PRL_GLOBAL void prl_k_fhp_average_plus(PrlFhpParams prm, int p, int mode, double m_old, double m_new, double* avg) {
-    const size_t per_board = (size_t)PrlFhpShape::N_DEC_PER_SEAT * prm.R;
-    const size_t total = (size_t)prm.n_boards * per_board;
-    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
-        const size_t b = t / per_board;
-        const int j = (int)((t % per_board) / prm.R);
-        const size_t h = t % prm.R;
-        const int node = PrlFhpShape::seat_node(p, j);
-        const int A = PrlFhpShape::nch(node), col0 = PrlFhpShape::col0(node);
-        const size_t base = ((size_t)prm.col_base + b * PrlFhpShape::N_COLS + col0) * (size_t)prm.R + h;
-        float tt[3];
-        float sum = 0.f;
-        for (int i = 0; i < A; ++i) { tt[i] = prm.regret[base + (size_t)i * prm.R]; sum = sum + tt[i]; }
-        const float unif = (float)(1.0 / (double)A);
-        for (int i = 0; i < A; ++i) {
-            const float s = sum > 0.f ? tt[i] / sum : unif;
-            double* a = avg + base + (size_t)i * prm.R;
-            *a = mode == 2 ? m_old * *a + m_new * (double)s : (double)s;
-        }
     }
 }
 
@@ -160,12 +110,6 @@ static inline int fhp_grid_for(size_t items, int block) {
     if (g < 1) g = 1;
     if (g > 16384) g = 16384;
     return (int)g;
-}
-
-void prl_launch_fhp_average_plus(const PrlFhpParams& prm, int p, int mode, double m_old, double m_new, double* avg, void* stream) {
-    if (mode == 0 || prm.n_boards <= 0) return;
-    size_t items = (size_t)prm.n_boards * PrlFhpShape::N_DEC_PER_SEAT * prm.R;
-    PRL_LAUNCH(prl_k_fhp_average_plus, fhp_grid_for(items, 256), 256, 0, stream, prm, p, mode, m_old, m_new, avg);
 }
 
 void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_cols, void* stream) {

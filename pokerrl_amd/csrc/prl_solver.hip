@@ -47,6 +47,7 @@ struct prl_solver {
     int full_nodes = 0, full_cols = 0, R = 0;
     // ---- FUSED engine ----
     bool fused = false;
+    bool expl_pending = false;  // FUSED, inside prl_solver_iterations: exploitability of the current iterate not evaluated yet
     PrlFhpParams fp{};
     int chance_trunk = -1;    // trunk id of the chance node
     float* d_board_ev = nullptr;
@@ -66,7 +67,8 @@ template <class T>
 int dev_alloc(prl_solver* s, T** p, size_t count) {
     void* q = nullptr;
     size_t bytes = (count ? count : 1) * sizeof(T);
-    hipError_t e = hipMalloc(&q, bytes);
+    // 16 spare bytes: the fused engine's 16-byte LDS-DMA prefetch rounds the end of a board's block up to a whole chunk
+    hipError_t e = hipMalloc(&q, bytes + 16);
     if (e != hipSuccess) {
         prl_set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
         return PRL_ERR_OOM;
@@ -133,7 +135,7 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
     float* dst_ev = st.ev + prl_vidx(s->T, s->chance_trunk, 0);
     float* dst_br = st.ev_br + prl_vidx(s->T, s->chance_trunk, 0);
     prl_launch_fhp_chance_sum(s->d_board_ev, p.n_boards, p.R, s->d_sum_scratch, dst_ev, s->stream);
-    if (mode == PRL_FHP_EVAL) prl_launch_fhp_chance_sum(s->d_board_br, p.n_boards, p.R, s->d_sum_scratch, dst_br, s->stream);
+    if (mode == PRL_FHP_EVAL || mode == PRL_FHP_UPDATE0_EVAL) prl_launch_fhp_chance_sum(s->d_board_br, p.n_boards, p.R, s->d_sum_scratch, dst_br, s->stream);
     else PRL_HIP_TRY(hipMemcpyAsync(dst_br, dst_ev, (size_t)2 * p.R * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
     PRL_HIP_TRY(hipGetLastError());
     return PRL_OK;
@@ -372,7 +374,12 @@ int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t de
         T.plan_hgs = hgs + off * T.plan_stride; T.plan_hge = hge + off * T.plan_stride; T.plan_clw = clw + off * T.cl_stride;
         if (fused) {
             PrlFhpParams& fp = s->fp;
-            fp.n_boards = full.n_boards; fp.R = T.R; fp.col_base = col_base; fp.max_grid = 4096;
+            fp.n_boards = full.n_boards; fp.R = T.R; fp.col_base = col_base;
+            {   // persistent workgroups, one per CU (LDS-bound occupancy): each walks its boards with the next one prefetching
+                int dev = 0, cus = 256;
+                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                fp.max_grid = cus > 0 ? cus : 256;
+            }
             {
                 const char* e = getenv("PRL_FHP_CFG");  // tuning knob: launch configuration of the board-pass kernel
                 fp.cfg = e ? atoi(e) : 0;
@@ -407,6 +414,10 @@ int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t de
         s->fp.regret = s->d_regret;
         s->fp.board_ev = s->d_board_ev;
         s->fp.board_br = s->d_board_br;
+#ifdef PRL_FHP_TIMING
+        FAIL_IF(dev_alloc(s, &s->fp.timing, (size_t)8));
+        PRL_HIP_TRY(hipMemsetAsync(s->fp.timing, 0, 8 * sizeof(unsigned long long), s->stream));
+#endif
     }
     if (hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
         prl_set_error("device error while building the showdown plans");
@@ -435,6 +446,7 @@ int32_t prl_solver_reset(prl_solver_t* s) {
     if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }
     const size_t nc = (size_t)s->full_cols * s->R;
     s->iter = 0;
+    s->expl_pending = false;
     PRL_HIP_TRY(hipMemsetAsync(s->d_regret, 0, nc * sizeof(float), s->stream));
     PRL_HIP_TRY(hipMemsetAsync(s->d_avg, 0, nc * sizeof(double), s->stream));
     PRL_HIP_TRY(hipMemsetAsync(s->S.avg_f64, 0, (size_t)s->T.n_nodes, s->stream));
@@ -498,44 +510,62 @@ int32_t prl_solver_compute_ev(prl_solver_t* s) {  // PublicTree.compute_ev (Publ
 // closed the previous iteration; that pass is reused (identical values), so an iteration costs two EV passes, not three.
 // FUSED: every half-iteration is one board pass that computes the EVs and updates that seat's regrets in place, then the
 // trunk is updated with the summed chance-node values; a third (best-response) pass yields the exploitability.
-int32_t prl_solver_iteration(prl_solver_t* s) {
-    if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }
+static int iteration_core(prl_solver* s, bool closing_eval) {
     if (s->fused && s->user_strategy_f64 >= 0) { prl_set_error("call reset() / fill_uniform() before iterating after set_strategy()"); return PRL_ERR_STATE; }
+    int mode = 0;
+    double m_old = 0., m_new = 0.;
+    if (s->variant == PRL_CFR_PLUS) {  // CFRPlus.py:65-87: float64 weights from integer sums
+        if (s->iter > s->delay) {
+            long long cw = 0;
+            for (int k = s->delay + 1; k <= s->iter; ++k) cw += k;
+            long long nw = s->iter - s->delay + 1;
+            m_old = (double)cw / (double)(cw + nw);
+            m_new = (double)nw / (double)(cw + nw);
+            mode = 2;
+        } else if (s->iter == s->delay) mode = 1;
+    }
+    s->fp.avg = s->d_avg;
+    s->fp.avg_mode = mode;
+    s->fp.m_old = m_old;
+    s->fp.m_new = m_new;
     for (int p = 0; p < 2; ++p) {
-        if (s->fused) TRY(do_compute_ev(s, s->S, p == 0 ? PRL_FHP_UPDATE0 : PRL_FHP_UPDATE1));
-        else TRY(ensure_ev(s));
+        if (s->fused) {
+            if (p == 0 && s->expl_pending) {  // the evaluation that closes the previous iteration rides on this pass
+                TRY(do_compute_ev(s, s->S, PRL_FHP_UPDATE0_EVAL));
+                TRY(record_expl(s));
+                s->expl_pending = false;
+            } else TRY(do_compute_ev(s, s->S, p == 0 ? PRL_FHP_UPDATE0 : PRL_FHP_UPDATE1));
+        } else TRY(ensure_ev(s));
         prl_launch_regret_strategy(s->T, s->S, s->d_nodes_p[p], s->n_nodes_p[p], p, s->variant, s->iter, s->stream);
         s->src[p] = PRL_SRC_REGRET;
         s->ev_valid = false;
         TRY(do_update_reach(s, s->S));
-        int mode = 0;
-        double m_old = 0., m_new = 0.;
-        if (s->variant == PRL_CFR_PLUS) {  // CFRPlus.py:65-87: float64 weights from integer sums
-            if (s->iter > s->delay) {
-                long long cw = 0;
-                for (int k = s->delay + 1; k <= s->iter; ++k) cw += k;
-                long long nw = s->iter - s->delay + 1;
-                m_old = (double)cw / (double)(cw + nw);
-                m_new = (double)nw / (double)(cw + nw);
-                mode = 2;
-            } else if (s->iter == s->delay) mode = 1;
-        }
         prl_launch_average(s->T, s->S, s->d_nodes_p[p], s->n_nodes_p[p], p, s->variant, s->iter, mode, m_old, m_new, s->stream);
-        if (s->fused) {
-            PrlFhpParams fp = s->fp;
-            fp.variant = s->variant;
-            prl_launch_fhp_average_plus(fp, p, mode, m_old, m_new, s->d_avg, s->stream);
-            if (mode) s->board_avg_f64 = mode == 2;
-        }
+        if (s->fused && mode) s->board_avg_f64 = mode == 2;  // the board columns were averaged inside the board pass
     }
+    s->fp.avg_mode = 0;
     s->iter += 1;
+    if (s->fused && !closing_eval) {
+        s->expl_pending = true;
+        PRL_HIP_TRY(hipGetLastError());
+        return PRL_OK;
+    }
     TRY(ensure_ev(s));
     PRL_HIP_TRY(hipGetLastError());
     return record_expl(s);
 }
 
+int32_t prl_solver_iteration(prl_solver_t* s) {
+    if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }
+    return iteration_core(s, true);
+}
+
+// n iterations. FUSED: the evaluation (both seats + best response) of the strategy after iteration t is folded into the
+// first board pass of iteration t + 1, which reads the same regrets; only the last iteration runs a separate evaluation
+// pass. The exploitability history is the same as n single calls produce.
 int32_t prl_solver_iterations(prl_solver_t* s, int32_t n) {
-    for (int i = 0; i < n; ++i) TRY(prl_solver_iteration(s));
+    if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }
+    for (int i = 0; i < n; ++i) TRY(iteration_core(s, i == n - 1));
     return PRL_OK;
 }
 
@@ -557,6 +587,17 @@ int32_t prl_solver_time_iterations(prl_solver_t* s, int32_t n, float* out_ms) {
     (void)hipEventDestroy(e1);
     return rc;
 }
+
+#ifdef PRL_FHP_TIMING
+// instrumented builds only (scripts/gpu_phases.sh): shader clocks wave 0 spent per phase, summed over boards and passes
+extern "C" int32_t prl_debug_fhp_timing(prl_solver_t* s, unsigned long long* out8, int32_t reset) {
+    if (!s || !s->fp.timing) return PRL_ERR_ARG;
+    PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+    PRL_HIP_TRY(hipMemcpy(out8, s->fp.timing, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) PRL_HIP_TRY(hipMemset(s->fp.timing, 0, 8 * sizeof(unsigned long long)));
+    return PRL_OK;
+}
+#endif
 
 int32_t prl_solver_sync(prl_solver_t* s) {
     if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }

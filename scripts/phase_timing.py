@@ -1,0 +1,37 @@
+"""Per-phase shader-clock breakdown of the fused board pass (instrumented library: python -m pokerrl_amd.build --variant
+timing PRL_FHP_TIMING). Usage: python scripts/phase_timing.py [boards] [iters]"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import bench  # noqa: E402
+from pokerrl_amd import _native  # noqa: E402
+from pokerrl_amd.game import bet_sets  # noqa: E402
+from pokerrl_amd.game import games as G  # noqa: E402
+
+here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L = _native.bind(os.path.join(here, "pokerrl_amd", "lib", "libpokerrl_hip_timing.so"))
+n_boards = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+boards = bench.seeded_boards(n_boards, 0)
+from helpers import env_args  # noqa: E402  (tests/helpers.py, on sys.path through bench)
+
+t = _native.NativeTree(G.Flop5Holdem.native_game(env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)), G.Flop5Holdem.native_rules(), boards, _lib=L)
+s = _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
+s.iterations(2)
+s.sync()
+out = (ctypes.c_ulonglong * 8)()
+L.prl_debug_fhp_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int32]
+L.prl_debug_fhp_timing(s._h, out, 1)
+ms = s.time_iterations(iters)
+L.prl_debug_fhp_timing(s._h, out, 1)
+v = np.array(list(out), np.float64)
+names = ["prologue(stage+loads)", "B down/scatter", "C card scans", "D range prefix", "E up/regrets", "epilogue(store)"]
+# per iteration: UPDATE0_EVAL (2 seats) + UPDATE1 (1 seat), last iteration UPDATE0+UPDATE1+EVAL
+tot = v[:6].sum()
+print("ms/iter %.3f   clocks summed over wave-0 of every board pass: %.3e" % (ms / iters, tot))
+for n, x in zip(names, v[:6]):
+    print("%-24s %6.2f %%   %10.0f clk per board-iteration" % (n, 100 * x / tot, x / n_boards / iters))

@@ -33,6 +33,15 @@ inline unsigned prl_nthreads() { return prl_emu::g_ctx->bdim; }
 inline unsigned prl_nblocks() { return prl_emu::g_ctx->gdim; }
 inline unsigned prl_lane() { return prl_emu::g_ctx->tid & 63u; }
 inline void prl_sync() { prl_emu::block_barrier(); }
+inline void prl_sync_lds() { prl_emu::block_barrier(); }
+// the emulator's "DMA" is an immediate copy (lane l writes dword l of the wave's destination row)
+inline void prl_lds_dma_dword(const void* gbase, uint32_t byte_off, void* lds_wave_base) {
+    memcpy((char*)lds_wave_base + 4 * (prl_emu::g_ctx->tid & 63u), (const char*)gbase + byte_off, 4);
+}
+inline void prl_lds_dma_x4(const void* gbase, uint32_t byte_off, void* lds_wave_base) {
+    memcpy((char*)lds_wave_base + 16 * (prl_emu::g_ctx->tid & 63u), (const char*)gbase + byte_off, 16);
+}
+inline void prl_dma_wait() {}
 inline char* prl_smem() { return prl_emu::g_ctx->smem; }
 
 inline float prl_shfl(float v, int src_lane) {
@@ -93,6 +102,8 @@ typedef struct prl_emu_event* hipEvent_t;
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+enum { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 2; return 0; }  // two "CUs": persistent kernels walk several items per workgroup
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 inline hipError_t hipFree(void* p) { free(p); return 0; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }

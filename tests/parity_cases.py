@@ -185,6 +185,27 @@ def check_fused_vs_oracle(L, n_boards, n_iters, delay=0):
     return s, o
 
 
+def check_fused_batched_vs_oracle(L, n_boards, n_iters, delay=0):
+    """prl_solver_iterations(n) on the fused engine folds every closing evaluation into the next iteration's first board
+    pass; the exploitability history and the final state must equal the oracle's (= n single iteration() calls)."""
+    boards = fhp_boards(n_boards)
+    args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
+    t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
+    s = _native.NativeSolver(t, "plus", delay, engine="fused", _lib=L)
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, 2, 52, 4, 2)
+    o.cfr_reset(1, delay)
+    want = [np.array(o.exploitability, np.float32)]
+    for _ in range(n_iters):
+        o.cfr_iteration()
+        want.append(np.array(o.exploitability, np.float32))
+    s.iterations(n_iters - 1)
+    s.iterations(1)  # a batch of one closes with its own evaluation pass
+    assert np.array_equal(s.get("expl_history"), np.stack(want))
+    for k in FUSED_FIELDS + ("strategy",):
+        assert np.array_equal(s.get(k), np.asarray(getattr(o, k))), k
+    assert np.array_equal(s.eval_avg(), o.eval_avg())
+
+
 def check_fused_vs_levels(L, n_boards, n_iters, seed=11):
     """Same tree solved by both engines of the library: bit-identical regrets, averages and exploitability history."""
     boards = fhp_boards(n_boards, seed=seed)

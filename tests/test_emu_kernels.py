@@ -57,6 +57,10 @@ def test_emu_fused_engine_cfrplus_delay(L):
     pc.check_fused_vs_oracle(L, 3, 3, delay=1)
 
 
+def test_emu_fused_engine_batched_iterations(L):
+    pc.check_fused_batched_vs_oracle(L, 3, 4, delay=1)
+
+
 def test_emu_br_of_random_strategy(L):
     pc.check_br_of_given_strategy(L, "StandardLeduc", 0, f64=True)
     pc.check_br_of_given_strategy(L, "StandardLeduc", 1, f64=False)

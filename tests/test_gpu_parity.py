@@ -125,6 +125,10 @@ def test_gpu_fused_cfrplus_delay_vs_oracle(L):
     pc.check_fused_vs_oracle(L, 33, 4, delay=2)
 
 
+def test_gpu_fused_batched_iterations_vs_oracle(L):
+    pc.check_fused_batched_vs_oracle(L, 40, 5, delay=1)
+
+
 def test_gpu_fused_vs_levels_2048_boards(L):
     """2048 boards = 64 canonical chance blocks = 2 groups: both engines of the library must agree bit for bit."""
     pc.check_fused_vs_levels(L, 2048, 6)
