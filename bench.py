@@ -10,7 +10,12 @@ stacks 20000, pot-size raises; PokerRL/game/games.py:222-254) x B seeded boards 
 with the reference's float64 average strategy. Inputs are resident in HBM before the timed region. Prints ONE JSON line.
 
 node-updates/s = (tree nodes incl. root) x iterations / s  (SURVEY.md section 8d).
-roofline: algorithmic bytes per iteration = 20*R*sum(A) + 8*R*N_boards / measured device time.
+roofline: the dominant kernel is the fused engine's board pass (prl_k_fhp_pass, >90% of the device time). Algorithmic bytes
+per iteration = 20*R*sum(A) + 8*R*N_boards, all of them moved by that kernel; "achieved" = those
+bytes over the summed duration of its launches, each bracketed by HIP events on the solver's stream inside the timed
+region (prl_solver_time_iterations_ex). "traffic" = HBM bytes per iteration from the rocprofv3 PMC pass in profiles/.
+N > 1: boards sharded over the ranks (one process per GPU), the trunk replicated, one all-gather of the chance node's
+partial sums per EV pass over RCCL (pokerrl_amd/dist.py); weak scaling, value = nodes of the whole tree x iterations / s.
 cpu_baseline: the CPU oracle (plain-C restatement of the reference, 1 thread) on a bounded sample of the same workload --
 the reference itself cannot run 2-hole-card public trees.
 """
@@ -27,6 +32,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# HBM bytes per CFR+ iteration of the board-pass kernels, from the PMC pass (FETCH_SIZE / WRITE_SIZE, corrected as
+# MI355X_MICROARCH.md prescribes), keyed by boards per GPU; see the file named below. None until measured for a size.
+PMC_TRAFFIC_BYTES_PER_ITERATION = {16384: 9.40e9}  # pass<3>: 2*1.32 GB read + 2.12 GB written; pass<1>: 2*1.32 + 1.95
+PMC_TRAFFIC_SOURCE = "profiles/r01e_fused_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
 
 
 def seeded_boards(n, seed, offset=0):
@@ -69,8 +78,8 @@ def main():
     ap.add_argument("--boards", type=int, default=int(os.environ.get("PRL_BENCH_BOARDS", "16384")), help="boards per GPU")
     ap.add_argument("--engine", default=os.environ.get("PRL_BENCH_ENGINE", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-boards", type=int, default=192)
-    ap.add_argument("--cpu-iters", type=int, default=16)
+    ap.add_argument("--cpu-boards", type=int, default=384)
+    ap.add_argument("--cpu-iters", type=int, default=24)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,10 +100,16 @@ def main():
     from pokerrl_amd.game import games as G
 
     _native.require_device()
-    # every rank owns its own shard of boards (weak scaling: fixed boards per GPU)
+    # every rank owns a contiguous block of the global board list (weak scaling: fixed boards per GPU)
     boards = seeded_boards(args.boards, 0, offset=rank * args.boards)
     tree = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)
-    solver = _native.NativeSolver(tree, "plus", 0, engine=args.engine)
+    exchange = None
+    if world > 1:
+        from pokerrl_amd.dist import TorchExchange
+        exchange = TorchExchange("cuda")
+        solver = _native.NativeSolver(tree, "plus", 0, shard=(world, rank, exchange))
+    else:
+        solver = _native.NativeSolver(tree, "plus", 0, engine=args.engine)
     solver.sync()
 
     def barrier():
@@ -106,7 +121,7 @@ def main():
     solver.iterations(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    dev_ms = solver.time_iterations(args.steps)  # HIP events on the solver's stream + the K iterations
+    dev_ms, pass_ms, n_pass = solver.time_iterations_ex(args.steps)  # the K iterations, HIP events on the solver's stream
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -114,11 +129,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    n_nodes_total = tree.n_nodes * world
+    n_board_nodes = args.boards * 15
+    n_nodes_total = (tree.n_nodes - n_board_nodes) + n_board_nodes * world  # one trunk + every rank's board subtrees
     value = n_nodes_total * args.steps / dt
     R, sum_a = tree.range_size, tree.n_cols
-    bytes_iter = 20.0 * R * sum_a + 8.0 * R * args.boards
-    achieved = bytes_iter * args.steps / (dev_ms * 1e-3) / 1e9
+    bytes_iter = 20.0 * R * sum_a + 8.0 * R * args.boards  # per GPU
+    kernel_ms = pass_ms if n_pass else dev_ms
+    achieved = bytes_iter * args.steps / (kernel_ms * 1e-3) / 1e9
     expl = solver.exploitability()
     out = {
         "metric": "CFR+ node-updates/sec on FHP public tree",
@@ -129,12 +146,20 @@ def main():
             "workload": "CFR+ (delay 0) full-width iterations on the Flop5Holdem public tree (blinds 50/100, stacks 20000, "
                         "pot-size raises), %d seeded boards per GPU, 1326-hand ranges" % args.boards,
             "boards_per_gpu": args.boards, "nodes_per_gpu": tree.n_nodes, "action_columns_per_gpu": sum_a,
-            "engine": solver.engine, "fhp_cfg": os.environ.get("PRL_FHP_CFG", "0"), "parallelism": "boards sharded over %d GPU(s)" % world,
+            "engine": solver.engine, "fhp_cfg": os.environ.get("PRL_FHP_CFG", "0"),
+            "parallelism": "boards sharded over %d GPU(s), trunk replicated, 1 all-gather of chance-node partial sums per EV pass" % world,
+            "nodes_whole_tree": n_nodes_total, "exchanges": exchange.calls if exchange else 0,
             "iterations_done": solver.iter, "exploitability_mbb_per_g": float(np.mean(expl) * 10.0),
             "hbm_bytes_allocated": int(solver.get("bytes_allocated")[0]),
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "bytes_per_iteration_algorithmic": bytes_iter, "device_ms_per_iteration": dev_ms / args.steps},
+                     "traffic": PMC_TRAFFIC_BYTES_PER_ITERATION.get(args.boards) if solver.engine == "fused" else None,
+                     "traffic_source": PMC_TRAFFIC_SOURCE,
+                     "kernel": "prl_k_fhp_pass" if n_pass else "all kernels of the iteration",
+                     "launches_per_iteration": n_pass / float(args.steps) if n_pass else None,
+                     "kernel_ms_per_iteration": kernel_ms / args.steps, "device_ms_per_iteration": dev_ms / args.steps,
+                     "bytes_per_iteration_algorithmic": bytes_iter,
+                     "achieved_whole_iteration": bytes_iter * args.steps / (dev_ms * 1e-3) / 1e9},
     }
     if rank == 0:
         if not args.no_cpu_baseline:

@@ -208,6 +208,23 @@ int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay
  *   FUSED walks each board subtree on chip and only keeps regrets / averages / per-board root values in HBM. */
 enum { PRL_ENGINE_AUTO = 0, PRL_ENGINE_LEVELS = 1, PRL_ENGINE_FUSED = 2 };
 int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out_solver);
+/* Sharded solve over `world_size` GPUs, one process per GPU: the tree handed to rank r holds the
+ * r-th contiguous block of the global board list (every rank the same number of boards); the pre-chance trunk is
+ * replicated; regrets / averages of a board live on its owner only. The one exchange per EV pass is the pull-up of the
+ * chance node's values (ValueFiller.py:76-78 is a plain sum over the chance children): every rank reduces its boards to
+ * whole canonical summation units, `exchange` all-gathers them (rank-major), and every rank finishes the sum over all
+ * units in global order -- so the result is bit-identical to the single-GPU solve of the whole board list, for any
+ * world size. `exchange(user, local_dev, gathered_dev, bytes_per_rank)` must fill gathered_dev[rank * bytes_per_rank ...]
+ * with rank's local_dev for every rank (e.g. ncclAllGather / torch.distributed.all_gather_into_tensor) and return 0
+ * once gathered_dev is complete and visible to work submitted afterwards; the solver's own stream is idle while it
+ * runs. FUSED engine only. Every solver call that evaluates the tree is collective (all ranks must make it). */
+typedef int32_t (*prl_exchange_fn)(void* user, const void* local_dev, void* gathered_dev, uint64_t bytes_per_rank);
+int32_t prl_solver_create_sharded(const prl_tree_t* local_tree, int32_t variant, int32_t delay, int32_t world_size, int32_t rank,
+                                  prl_exchange_fn exchange, void* user, prl_solver_t** out_solver);
+/* The canonical chance-node sum on its own (host buffers in / out, device kernels inside): values [n_boards][2][R] ->
+ * out [2][R]. world_size > 1 replays the sharded path on one device (every rank's partial units at the level the shard
+ * size allows, rank-major gather, finish); the result must not depend on world_size. n_boards % world_size == 0. */
+int32_t prl_chance_sum_host(const float* board_values, int32_t n_boards, int32_t R, int32_t world_size, float* out);
 void prl_solver_destroy(prl_solver_t* solver);
 int32_t prl_solver_reset(prl_solver_t* solver);                        /* _CFRBase.reset            :110-120 */
 int32_t prl_solver_iteration(prl_solver_t* solver);                    /* _CFRBase.iteration        :122-134 (w/o avg eval) */
@@ -221,6 +238,9 @@ int32_t prl_solver_exploitability(prl_solver_t* solver, float* out_expl2); /* ro
 int32_t prl_solver_sync(prl_solver_t* solver);
 /* runs n iterations between two HIP events recorded on the solver's stream; elapsed device time in milliseconds */
 int32_t prl_solver_time_iterations(prl_solver_t* solver, int32_t n, float* out_ms);
+/* same, and every launch of the FUSED engine's board-pass kernel is bracketed by its own pair of events: their summed
+ * duration and count (the per-kernel figure bench.py's roofline is computed from; out_pass_* may be NULL) */
+int32_t prl_solver_time_iterations_ex(prl_solver_t* solver, int32_t n, float* out_ms, float* out_pass_ms, int32_t* out_n_pass);
 
 enum {
     PRL_SF_REACH = 0,        /* float32 [n_nodes][2][R]  node.reach_probs                      */

@@ -11,6 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# prl_exchange_fn (include/pokerrl_hip.h): int32 (*)(void* user, const void* local_dev, void* gathered_dev, uint64 bytes_per_rank)
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
 LIB_PATH = os.environ.get("POKERRL_AMD_LIB", os.path.join(_HERE, "lib", "libpokerrl_hip.so"))
 
 PRL_MAX_BET_SIZES = 96
@@ -134,6 +136,12 @@ def _bind_solver(L):
     L.prl_solver_create.argtypes = [vp, i32, i32, ctypes.POINTER(vp)]
     L.prl_solver_create_ex.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp)]
     L.prl_solver_create_ex.restype = i32
+    L.prl_solver_create_sharded.argtypes = [vp, i32, i32, i32, i32, EXCHANGE_FN, vp, ctypes.POINTER(vp)]
+    L.prl_solver_create_sharded.restype = i32
+    L.prl_solver_time_iterations_ex.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i32)]
+    L.prl_solver_time_iterations_ex.restype = i32
+    L.prl_chance_sum_host.argtypes = [vp, i32, i32, i32, vp]
+    L.prl_chance_sum_host.restype = i32
     L.prl_solver_get.argtypes = [vp, i32, vp]
     L.prl_solver_get.restype = i32
     L.prl_solver_create.restype = i32
@@ -269,9 +277,13 @@ ENGINES = {"auto": 0, "levels": 1, "fused": 2}
 
 
 class NativeSolver:
-    """Owns a prl_solver_t* : the device-resident CFR / best-response solver of one public tree."""
+    """Owns a prl_solver_t* : the device-resident CFR / best-response solver of one public tree.
 
-    def __init__(self, tree, variant, delay=0, engine="auto", _lib=None):
+    shard=(world_size, rank, exchange): sharded solve, `tree` holds this rank's contiguous block of the global board list
+    and `exchange(local_ptr, gathered_ptr, bytes_per_rank)` all-gathers device buffers (pokerrl_amd.dist.TorchExchange);
+    every call that evaluates the tree is then collective. Results are bit-identical to the unsharded solve."""
+
+    def __init__(self, tree, variant, delay=0, engine="auto", _lib=None, shard=None):
         self._L = _lib or tree._L
         if _lib is None and self._L is lib():
             require_device()
@@ -279,7 +291,24 @@ class NativeSolver:
         self._h = ctypes.c_void_p()
         v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
         e = ENGINES[engine] if isinstance(engine, str) else int(engine)
-        check(self._L.prl_solver_create_ex(tree.handle, v, int(delay), e, ctypes.byref(self._h)), self._L)
+        self._exchange_cb = None
+        if shard is not None and int(shard[0]) > 1:
+            world, rank, exchange = shard
+
+            def _cb(_user, local_ptr, gathered_ptr, nbytes):
+                try:
+                    exchange(int(local_ptr or 0), int(gathered_ptr or 0), int(nbytes))
+                    return 0
+                except Exception:  # an exception must not unwind through the C frame
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+
+            self._exchange_cb = EXCHANGE_FN(_cb)  # kept alive with the solver
+            check(self._L.prl_solver_create_sharded(tree.handle, v, int(delay), int(world), int(rank), self._exchange_cb, None,
+                                                    ctypes.byref(self._h)), self._L)
+        else:
+            check(self._L.prl_solver_create_ex(tree.handle, v, int(delay), e, ctypes.byref(self._h)), self._L)
         self.n_nodes, self.n_cols, self.R = tree.n_nodes, tree.n_cols, tree.range_size
         eng = np.zeros(1, np.int32)
         self._call("prl_solver_get", SF["engine"], _ptr(eng))
@@ -329,6 +358,12 @@ class NativeSolver:
         ms = ctypes.c_float()
         self._call("prl_solver_time_iterations", int(n), ctypes.byref(ms))
         return float(ms.value)
+
+    def time_iterations_ex(self, n):
+        """-> (total device ms, summed ms of the board-pass kernel launches, number of those launches)."""
+        ms, pms, cnt = ctypes.c_float(), ctypes.c_float(), ctypes.c_int32()
+        self._call("prl_solver_time_iterations_ex", int(n), ctypes.byref(ms), ctypes.byref(pms), ctypes.byref(cnt))
+        return float(ms.value), float(pms.value), int(cnt.value)
 
     def exploitability(self):
         out = np.zeros(2, np.float32)

@@ -120,12 +120,60 @@ void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_co
 
 // per-board [n_boards][2][R] -> dest [2][R] in the canonical nested order; scratch >= (ceil(n/32) + ceil(n/1024)) * 2R floats
 void prl_launch_fhp_chance_sum(const float* d_board_vals, int n_boards, int R, float* d_scratch, float* d_dest, void* stream) {
+    prl_launch_fhp_chance_finish(d_board_vals, n_boards, 0, R, d_scratch, d_dest, stream);
+}
+
+// Sharded solve: a rank reduces its own boards up to `level` (0: nothing, the per-board values themselves; 1: blocks of
+// 32 boards; 2: groups of 32 blocks) -- the units are whole canonical units because the shard size is a multiple of the
+// unit size -- and after the all-gather every rank finishes the remaining levels over ALL units in global order.
+int prl_fhp_units_at_level(int n_boards, int level) {
+    int n = n_boards;
+    for (int l = 0; l < level; ++l) n = (n + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
+    return n;
+}
+
+void prl_launch_fhp_chance_partial(const float* d_board_vals, int n_boards, int level, int R, float* d_scratch, float* d_units, void* stream) {
     const int R2 = 2 * R;
+    if (level == 0) {
+        PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)n_boards * R2, 256), 256, 0, stream, d_board_vals, n_boards, 1, R2, d_units);
+        return;
+    }
     const int n_blk = (n_boards + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
-    const int n_grp = (n_blk + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
-    float* blk = d_scratch;
-    float* grp = d_scratch + (size_t)n_blk * R2;
+    float* blk = level == 1 ? d_units : d_scratch;
     PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)n_blk * R2, 256), 256, 0, stream, d_board_vals, n_boards, PRL_CHANCE_BLOCK, R2, blk);
-    PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)n_grp * R2, 256), 256, 0, stream, (const float*)blk, n_blk, PRL_CHANCE_BLOCK, R2, grp);
-    PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)R2, 256), 256, 0, stream, (const float*)grp, n_grp, n_grp > 0 ? n_grp : 1, R2, d_dest);
+    if (level == 1) return;
+    const int n_grp = (n_blk + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
+    PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)n_grp * R2, 256), 256, 0, stream, (const float*)blk, n_blk, PRL_CHANCE_BLOCK, R2, d_units);
+}
+
+// units of `level` (contiguous [n_units][2][R]) -> dest [2][R]; scratch >= (ceil(n/32) + ceil(n/1024) + 1) * 2R floats
+void prl_launch_fhp_chance_finish(const float* d_units, int n_units, int level, int R, float* d_scratch, float* d_dest, void* stream) {
+    const int R2 = 2 * R;
+    const float* cur = d_units;
+    int n = n_units;
+    float* next = d_scratch;
+    for (int l = level; l < 2; ++l) {
+        const int n_out = (n + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
+        PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)n_out * R2, 256), 256, 0, stream, cur, n, PRL_CHANCE_BLOCK, R2, next);
+        cur = next;
+        next += (size_t)n_out * R2;
+        n = n_out;
+    }
+    PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)R2, 256), 256, 0, stream, cur, n, n > 0 ? n : 1, R2, d_dest);
+}
+
+// all-gather layout [world][n_which][n_units][2R] -> [n_which][world * n_units][2R] (global unit order)
+PRL_GLOBAL void prl_k_fhp_compact_gathered(const float* __restrict__ in, int world, int n_which, int n_units, int R2, float* __restrict__ out) {
+    const size_t total = (size_t)world * n_which * n_units * R2;
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        const int x = (int)(t % R2);
+        size_t q = t / R2;
+        const int u = (int)(q % n_units); q /= n_units;
+        const int w = (int)(q % n_which);
+        const int r = (int)(q / n_which);
+        out[(((size_t)w * world + r) * n_units + u) * R2 + x] = in[t];
+    }
+}
+void prl_launch_fhp_compact_gathered(const float* d_in, int world, int n_which, int n_units, int R, float* d_out, void* stream) {
+    PRL_LAUNCH(prl_k_fhp_compact_gathered, fhp_grid_for((size_t)world * n_which * n_units * 2 * R, 256), 256, 0, stream, d_in, world, n_which, n_units, 2 * R, d_out);
 }

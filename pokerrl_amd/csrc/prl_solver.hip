@@ -47,6 +47,13 @@ struct prl_solver {
     int full_nodes = 0, full_cols = 0, R = 0;
     // ---- FUSED engine ----
     bool fused = false;
+    // sharded solve (prl_solver_create_sharded)
+    int world = 1, rank = 0, xlevel = 0, n_units = 0;  // summation level exchanged, units per rank
+    prl_exchange_fn exchange = nullptr;
+    void* exchange_user = nullptr;
+    float *d_xlocal = nullptr, *d_xgather = nullptr, *d_xcompact = nullptr;
+    bool time_passes = false;   // prl_solver_time_iterations: bracket every board-pass launch with events
+    std::vector<hipEvent_t> pass_events;
     bool expl_pending = false;  // FUSED, inside prl_solver_iterations: exploitability of the current iterate not evaluated yet
     PrlFhpParams fp{};
     int chance_trunk = -1;    // trunk id of the chance node
@@ -130,13 +137,42 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
     p.variant = s->variant;
     p.chance_reach = st.reach + prl_vidx(s->T, s->chance_trunk, 0);
     p.strat_arr = strat_arr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (s->time_passes) {
+        PRL_HIP_TRY(hipEventCreate(&ev0));
+        PRL_HIP_TRY(hipEventCreate(&ev1));
+        PRL_HIP_TRY(hipEventRecord(ev0, s->stream));
+    }
     int e = prl_launch_fhp_pass(p, mode, src0, src1, s->stream);
     if (e) { prl_set_error("fused engine: unsupported strategy-source combination"); return e; }
+    if (s->time_passes) {
+        PRL_HIP_TRY(hipEventRecord(ev1, s->stream));
+        s->pass_events.push_back(ev0);
+        s->pass_events.push_back(ev1);
+    }
     float* dst_ev = st.ev + prl_vidx(s->T, s->chance_trunk, 0);
     float* dst_br = st.ev_br + prl_vidx(s->T, s->chance_trunk, 0);
-    prl_launch_fhp_chance_sum(s->d_board_ev, p.n_boards, p.R, s->d_sum_scratch, dst_ev, s->stream);
-    if (mode == PRL_FHP_EVAL || mode == PRL_FHP_UPDATE0_EVAL) prl_launch_fhp_chance_sum(s->d_board_br, p.n_boards, p.R, s->d_sum_scratch, dst_br, s->stream);
-    else PRL_HIP_TRY(hipMemcpyAsync(dst_br, dst_ev, (size_t)2 * p.R * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    const bool with_br = mode == PRL_FHP_EVAL || mode == PRL_FHP_UPDATE0_EVAL;
+    if (s->world == 1) {
+        prl_launch_fhp_chance_sum(s->d_board_ev, p.n_boards, p.R, s->d_sum_scratch, dst_ev, s->stream);
+        if (with_br) prl_launch_fhp_chance_sum(s->d_board_br, p.n_boards, p.R, s->d_sum_scratch, dst_br, s->stream);
+    } else {
+        // local units -> all-gather -> remaining levels over all units in global order (header: prl_solver_create_sharded)
+        const int n_which = with_br ? 2 : 1;
+        const size_t unit_floats = (size_t)s->n_units * 2 * p.R;
+        prl_launch_fhp_chance_partial(s->d_board_ev, p.n_boards, s->xlevel, p.R, s->d_sum_scratch, s->d_xlocal, s->stream);
+        if (with_br) prl_launch_fhp_chance_partial(s->d_board_br, p.n_boards, s->xlevel, p.R, s->d_sum_scratch, s->d_xlocal + unit_floats, s->stream);
+        PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+        if (s->exchange(s->exchange_user, s->d_xlocal, s->d_xgather, (uint64_t)(n_which * unit_floats * sizeof(float))) != 0) {
+            prl_set_error("sharded solve: the exchange callback failed");
+            return PRL_ERR_STATE;
+        }
+        prl_launch_fhp_compact_gathered(s->d_xgather, s->world, n_which, s->n_units, p.R, s->d_xcompact, s->stream);
+        const int n_all = s->world * s->n_units;
+        prl_launch_fhp_chance_finish(s->d_xcompact, n_all, s->xlevel, p.R, s->d_sum_scratch, dst_ev, s->stream);
+        if (with_br) prl_launch_fhp_chance_finish(s->d_xcompact + (size_t)n_all * 2 * p.R, n_all, s->xlevel, p.R, s->d_sum_scratch, dst_br, s->stream);
+    }
+    if (!with_br) PRL_HIP_TRY(hipMemcpyAsync(dst_br, dst_ev, (size_t)2 * p.R * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
     PRL_HIP_TRY(hipGetLastError());
     return PRL_OK;
 }
@@ -268,7 +304,8 @@ bool prl_fhp_shape_matches(const PrlFlatTree& t, int* chance_node, int* first_bo
 
 extern "C" {
 
-int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out) {
+static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t world, int32_t rank,
+                                  prl_exchange_fn exchange, void* exchange_user, prl_solver_t** out) {
     if (!tree || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
     if (variant < 0 || variant > 2 || delay < 0 || engine < 0 || engine > 2) { prl_set_error("bad variant / delay / engine"); return PRL_ERR_ARG; }
     if (!prl_device_available()) { prl_set_error("no HIP device: the solver has no CPU fallback"); return PRL_ERR_NO_DEVICE; }
@@ -289,8 +326,13 @@ int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t de
         if (!shape_ok || variant != PRL_CFR_PLUS) { prl_set_error("fused engine needs a Flop5Holdem-shaped tree and CFR+"); return PRL_ERR_UNSUPPORTED; }
         fused = true;
     } else if (engine == PRL_ENGINE_AUTO) fused = shape_ok && variant == PRL_CFR_PLUS;
+    if (world > 1 && !fused) { prl_set_error("sharded solve: FUSED engine only (Flop5Holdem-shaped tree + CFR+)"); return PRL_ERR_UNSUPPORTED; }
 
     prl_solver* s = new prl_solver();
+    s->world = world;
+    s->rank = rank;
+    s->exchange = exchange;
+    s->exchange_user = exchange_user;
     s->variant = variant;
     s->delay = delay;
     s->fused = fused;
@@ -331,7 +373,7 @@ int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t de
     int n_chance_children = full.n_boards;
     for (int i = 0; i < full.n_nodes; ++i)
         if (full.kind[i] == PRL_NODE_CHANCE) { n_chance_children = full.n_children[i]; break; }
-    T.chance_prob = chance_prob_f32(n_chance_children, r.n_cards, r.n_hole_cards, full.board_len);
+    T.chance_prob = chance_prob_f32(n_chance_children * world, r.n_cards, r.n_hole_cards, full.board_len);  // global number of boards
     T.eq_const = eq_const_f32(r.n_cards, r.n_hole_cards);
 
     std::vector<int32_t> term, np[2];
@@ -408,9 +450,18 @@ int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t de
         const size_t bv = (size_t)full.n_boards * 2 * T.R;
         FAIL_IF(dev_alloc(s, &s->d_board_ev, bv));
         FAIL_IF(dev_alloc(s, &s->d_board_br, bv));
-        const size_t n_blk = (full.n_boards + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
+        const size_t n_blk = ((size_t)full.n_boards * world + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;  // sized for the global board list
         const size_t n_grp = (n_blk + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
         FAIL_IF(dev_alloc(s, &s->d_sum_scratch, (n_blk + n_grp + 1) * 2 * T.R));
+        if (world > 1) {
+            // exchange whole canonical units: the highest summation level the shard size is a multiple of
+            s->xlevel = full.n_boards % (PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK) == 0 ? 2 : full.n_boards % PRL_CHANCE_BLOCK == 0 ? 1 : 0;
+            s->n_units = prl_fhp_units_at_level(full.n_boards, s->xlevel);
+            const size_t per_rank = (size_t)2 * s->n_units * 2 * T.R;  // [ev, br][units][2][R]
+            FAIL_IF(dev_alloc(s, &s->d_xlocal, per_rank));
+            FAIL_IF(dev_alloc(s, &s->d_xgather, per_rank * world));
+            FAIL_IF(dev_alloc(s, &s->d_xcompact, per_rank * world));
+        }
         s->fp.regret = s->d_regret;
         s->fp.board_ev = s->d_board_ev;
         s->fp.board_br = s->d_board_br;
@@ -427,6 +478,48 @@ int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t de
 #undef FAIL_IF
     *out = s;
     return prl_solver_reset(s);
+}
+
+int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out) {
+    return solver_create_impl(tree, variant, delay, engine, 1, 0, nullptr, nullptr, out);
+}
+
+int32_t prl_solver_create_sharded(const prl_tree_t* local_tree, int32_t variant, int32_t delay, int32_t world_size, int32_t rank,
+                                  prl_exchange_fn exchange, void* user, prl_solver_t** out) {
+    if (world_size < 1 || rank < 0 || rank >= world_size) { prl_set_error("bad world_size / rank"); return PRL_ERR_ARG; }
+    if (world_size > 1 && !exchange) { prl_set_error("sharded solve needs an exchange callback"); return PRL_ERR_ARG; }
+    return solver_create_impl(local_tree, variant, delay, world_size > 1 ? PRL_ENGINE_FUSED : PRL_ENGINE_AUTO, world_size, rank, exchange, user, out);
+}
+
+int32_t prl_chance_sum_host(const float* board_values, int32_t n_boards, int32_t R, int32_t world, float* out) {
+    if (!board_values || !out || n_boards <= 0 || R <= 0 || world < 1 || n_boards % world) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    if (!prl_device_available()) { prl_set_error("no HIP device"); return PRL_ERR_NO_DEVICE; }
+    const size_t R2 = (size_t)2 * R, nv = (size_t)n_boards * R2;
+    const int n_local = n_boards / world;
+    const int level = world == 1 ? 0 : n_local % (PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK) == 0 ? 2 : n_local % PRL_CHANCE_BLOCK == 0 ? 1 : 0;
+    const int n_units = prl_fhp_units_at_level(n_local, level);
+    float *d_vals = nullptr, *d_scratch = nullptr, *d_gather = nullptr, *d_compact = nullptr, *d_out = nullptr;
+    int rc = PRL_OK;
+#define CS_TRY(x) do { if ((x) != hipSuccess) { prl_set_error("HIP error in prl_chance_sum_host"); rc = PRL_ERR_HIP; goto done; } } while (0)
+    CS_TRY(hipMalloc((void**)&d_vals, nv * sizeof(float)));
+    CS_TRY(hipMalloc((void**)&d_scratch, ((size_t)n_boards / PRL_CHANCE_BLOCK + n_boards / (PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK) + 4) * R2 * sizeof(float)));
+    CS_TRY(hipMalloc((void**)&d_gather, (size_t)world * n_units * R2 * sizeof(float)));
+    CS_TRY(hipMalloc((void**)&d_compact, (size_t)world * n_units * R2 * sizeof(float)));
+    CS_TRY(hipMalloc((void**)&d_out, R2 * sizeof(float)));
+    CS_TRY(hipMemcpy(d_vals, board_values, nv * sizeof(float), hipMemcpyHostToDevice));
+    if (world == 1) prl_launch_fhp_chance_sum(d_vals, n_boards, R, d_scratch, d_out, nullptr);
+    else {
+        for (int r = 0; r < world; ++r)  // rank r's units land where the all-gather would put them
+            prl_launch_fhp_chance_partial(d_vals + (size_t)r * n_local * R2, n_local, level, R, d_scratch, d_gather + (size_t)r * n_units * R2, nullptr);
+        prl_launch_fhp_compact_gathered(d_gather, world, 1, n_units, R, d_compact, nullptr);
+        prl_launch_fhp_chance_finish(d_compact, world * n_units, level, R, d_scratch, d_out, nullptr);
+    }
+    CS_TRY(hipDeviceSynchronize());
+    CS_TRY(hipMemcpy(out, d_out, R2 * sizeof(float), hipMemcpyDeviceToHost));
+#undef CS_TRY
+done:
+    (void)hipFree(d_vals); (void)hipFree(d_scratch); (void)hipFree(d_gather); (void)hipFree(d_compact); (void)hipFree(d_out);
+    return rc;
 }
 
 int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay, prl_solver_t** out) {
@@ -570,22 +663,38 @@ int32_t prl_solver_iterations(prl_solver_t* s, int32_t n) {
 }
 
 // n iterations bracketed by HIP events on the solver's own stream (what bench.py's roofline figure is derived from)
-int32_t prl_solver_time_iterations(prl_solver_t* s, int32_t n, float* out_ms) {
+int32_t prl_solver_time_iterations_ex(prl_solver_t* s, int32_t n, float* out_ms, float* out_pass_ms, int32_t* out_n_pass) {
     if (!s || !out_ms || n < 0) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
     hipEvent_t e0, e1;
     PRL_HIP_TRY(hipEventCreate(&e0));
     PRL_HIP_TRY(hipEventCreate(&e1));
     TRY(ensure_hist(s, s->iter + n + 1));
+    s->time_passes = s->fused && out_pass_ms != nullptr;
     PRL_HIP_TRY(hipEventRecord(e0, s->stream));
     int rc = prl_solver_iterations(s, n);
+    s->time_passes = false;
     if (rc == PRL_OK) {
         PRL_HIP_TRY(hipEventRecord(e1, s->stream));
         PRL_HIP_TRY(hipEventSynchronize(e1));
         PRL_HIP_TRY(hipEventElapsedTime(out_ms, e0, e1));
+        float pass_ms = 0.f;
+        for (size_t i = 0; i + 1 < s->pass_events.size(); i += 2) {
+            float t = 0.f;
+            PRL_HIP_TRY(hipEventElapsedTime(&t, s->pass_events[i], s->pass_events[i + 1]));
+            pass_ms += t;
+        }
+        if (out_pass_ms) *out_pass_ms = pass_ms;
+        if (out_n_pass) *out_n_pass = (int32_t)(s->pass_events.size() / 2);
     }
+    for (hipEvent_t e : s->pass_events) (void)hipEventDestroy(e);
+    s->pass_events.clear();
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;
+}
+
+int32_t prl_solver_time_iterations(prl_solver_t* s, int32_t n, float* out_ms) {
+    return prl_solver_time_iterations_ex(s, n, out_ms, nullptr, nullptr);
 }
 
 #ifdef PRL_FHP_TIMING

@@ -1,0 +1,53 @@
+"""
+torch.distributed plumbing of the sharded solve (one process per GPU; backend "nccl" is RCCL over xGMI on ROCm).
+
+The solver's C-ABI takes an exchange callback (include/pokerrl_hip.h: prl_exchange_fn) that all-gathers one device buffer
+per EV pass: the chance node's partial sums of every rank's boards. TorchExchange wraps the raw
+pointers as tensors without copying and runs `all_gather_into_tensor` on them. PyTorch is used for the collective only.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class _DevBuf:
+    """Zero-copy view of a raw device pointer for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class TorchExchange:
+    """exchange(local_ptr, gathered_ptr, bytes_per_rank) for NativeSolver(shard=...).
+
+    device="cuda": the pointers are HBM addresses; with the nccl backend the collective runs on them directly, with any
+                   other backend (gloo: tests on a single GPU) it is staged through host memory.
+    device="cpu":  the pointers are host addresses (the CPU test-suite's emulator build of the library)."""
+
+    def __init__(self, device, group=None):
+        self.device = device
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.calls = 0
+        self.bytes = 0
+
+    def _view(self, ptr, nbytes):
+        if self.device == "cpu":
+            return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(ptr)))
+        return torch.as_tensor(_DevBuf(ptr, nbytes), device="cuda")
+
+    def __call__(self, local_ptr, gathered_ptr, nbytes):
+        local = self._view(local_ptr, nbytes)
+        gathered = self._view(gathered_ptr, nbytes * self.world)
+        if self.device == "cuda" and dist.get_backend(self.group) != "nccl":
+            host = torch.empty(nbytes * self.world, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, local.cpu(), group=self.group)
+            gathered.copy_(host)
+        else:
+            dist.all_gather_into_tensor(gathered, local, group=self.group)
+        if self.device == "cuda":
+            torch.cuda.synchronize()  # the solver's own stream continues only after the gathered buffer is complete
+        self.calls += 1
+        self.bytes += nbytes * self.world

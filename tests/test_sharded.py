@@ -1,0 +1,129 @@
+"""Sharded solve: boards partitioned over ranks, one all-gather of canonical partial sums per EV pass.
+The result must be bit-identical to the unsharded solve of the whole board list, for any world size.
+
+CPU: world_size 2 over gloo, every rank drives the emulator build of the library (same kernel sources, same host code).
+GPU: the product library, two processes sharing the one GPU of the test box (gloo + host staging instead of RCCL)."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import parity_cases as pc  # noqa: E402
+from helpers import env_args  # noqa: E402
+from pokerrl_amd import _native  # noqa: E402
+from pokerrl_amd.game import bet_sets  # noqa: E402
+from pokerrl_amd.game import games as G  # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_sharded(lib_path, device, world, n_local, n_iters, delay, seed, timeout):
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), lib_path, device, d,
+                                           str(n_local), str(n_iters), str(delay), str(seed)], env=env))
+        try:
+            for p in procs:
+                assert p.wait(timeout=timeout) == 0
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(world)]
+
+
+def check_against_union(L, ranks, world, n_local, n_iters, delay, seed):
+    boards = pc.fhp_boards(world * n_local, seed=seed, with_special=False)
+    args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
+    t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
+    s = _native.NativeSolver(t, "plus", delay, engine="fused", _lib=L)
+    s.iterations(n_iters)
+    hist, regret, avg, ev_avg = s.get("expl_history"), s.get("regret"), s.get("avg"), s.eval_avg()
+    per = n_local * 14
+    for r, out in enumerate(ranks):
+        nt = int(out["n_trunk_cols"])
+        assert np.array_equal(out["expl_history"], hist), "rank %d: exploitability history" % r
+        assert np.array_equal(out["eval_avg"], ev_avg), "rank %d: average-strategy exploitability" % r
+        for name, full in (("regret", regret), ("avg", avg)):
+            assert np.array_equal(out[name][:nt], full[:nt]), "rank %d: trunk %s" % (r, name)
+            assert np.array_equal(out[name][nt:], full[nt + r * per: nt + (r + 1) * per]), "rank %d: board %s" % (r, name)
+        # one exchange per EV pass: reset (1), iteration() = 3, every further batched iteration 2, the batch's closing
+        # evaluation 1, eval_avg 1
+        assert int(out["exchanges"]) == 1 + 3 + (2 * (n_iters - 1) + 1 if n_iters > 1 else 0) + 1
+
+
+def chance_sum_reference(vals):
+    """DESIGN.md canonical order in NumPy float32: blocks of 32 boards, groups of 32 blocks, then the groups, all sequential."""
+    def level(x, fan):
+        out = []
+        for lo in range(0, len(x), fan):
+            acc = x[lo].copy()
+            for i in range(lo + 1, min(lo + fan, len(x))):
+                acc = acc + x[i]
+            out.append(acc)
+        return out
+    x = [v.astype(np.float32) for v in vals]
+    x = level(level(x, 32), 32)
+    return level(x, len(x))[0]
+
+
+def check_chance_sum(L, n_boards, worlds):
+    import ctypes
+    rng = np.random.RandomState(n_boards)
+    R = 6
+    vals = (rng.random_sample((n_boards, 2, R)) * np.exp(rng.uniform(-8, 8, (n_boards, 2, R)))).astype(np.float32)
+    want = chance_sum_reference(vals.reshape(n_boards, 2 * R)).reshape(2, R)
+    for w in worlds:
+        out = np.zeros((2, R), np.float32)
+        rc = L.prl_chance_sum_host(vals.ctypes.data_as(ctypes.c_void_p), n_boards, R, w, out.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
+        assert np.array_equal(out, want), "world %d" % w
+
+
+@pytest.fixture(scope="module")
+def EMU():
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    import build_emu
+    return build_emu.build()
+
+
+def test_chance_sum_levels_do_not_depend_on_world_size_emu(EMU):
+    L = _native.bind(EMU)
+    check_chance_sum(L, 2048, (1, 2))       # shards of 1024 boards: whole groups are exchanged
+    check_chance_sum(L, 2048 + 64, (1, 2, 3, 11))  # 1056 / 704 / 192 boards per rank: blocks
+    check_chance_sum(L, 70, (1, 2, 5, 7))   # ragged: per-board values are exchanged
+
+
+def test_sharded_world2_gloo_emu(EMU):
+    ranks = run_sharded(EMU, "cpu", 2, 2, 3, 1, 21, timeout=900)
+    check_against_union(_native.bind(EMU), ranks, 2, 2, 3, 1, 21)
+
+
+@pytest.mark.gpu
+def test_gpu_chance_sum_levels_do_not_depend_on_world_size():
+    L = _native.lib()
+    check_chance_sum(L, 8192, (1, 2, 4, 8))
+    check_chance_sum(L, 2048 + 64, (1, 2, 3, 11))
+    check_chance_sum(L, 70, (1, 2, 5, 7))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_local", [3, 32, 1024])  # boards / blocks / groups are exchanged
+def test_gpu_sharded_world2_matches_unsharded(n_local):
+    ranks = run_sharded(_native.LIB_PATH, "cuda", 2, n_local, 4, 0, 33, timeout=600)
+    check_against_union(_native.lib(), ranks, 2, n_local, 4, 0, 33)
