@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--boards", type=int, default=int(os.environ.get("PRL_BENCH_BOARDS", "16384")), help="boards per GPU")
     ap.add_argument("--engine", default=os.environ.get("PRL_BENCH_ENGINE", "auto"))
+    ap.add_argument("--variant", default="plus", choices=["plus", "linear", "vanilla"],
+                    help="CFR variant (the metric is quoted on CFR+; BASELINE config 3 also names LinearCFR)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-boards", type=int, default=384)
     ap.add_argument("--cpu-iters", type=int, default=24)
@@ -104,12 +106,17 @@ def main():
     boards = seeded_boards(args.boards, 0, offset=rank * args.boards)
     tree = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)
     exchange = None
-    if world > 1:
+    if world > 1 or os.environ.get("PRL_BENCH_FORCE_EXCHANGE"):  # the env knob runs the all-gather path on one GPU (tests)
+        if dist is None:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         from pokerrl_amd.dist import TorchExchange
         exchange = TorchExchange("cuda")
-        solver = _native.NativeSolver(tree, "plus", 0, shard=(world, rank, exchange))
+        solver = _native.NativeSolver(tree, args.variant, 0, shard=(world, rank, exchange))
     else:
-        solver = _native.NativeSolver(tree, "plus", 0, engine=args.engine)
+        solver = _native.NativeSolver(tree, args.variant, 0, engine=args.engine)
     solver.sync()
 
     def barrier():
@@ -138,17 +145,19 @@ def main():
     achieved = bytes_iter * args.steps / (kernel_ms * 1e-3) / 1e9
     expl = solver.exploitability()
     out = {
-        "metric": "CFR+ node-updates/sec on FHP public tree",
+        "metric": "CFR+ node-updates/sec on FHP public tree" if args.variant == "plus" else "%s CFR node-updates/sec on FHP public tree" % args.variant,
         "value": value, "unit": "node-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": "CFR+ (delay 0) full-width iterations on the Flop5Holdem public tree (blinds 50/100, stacks 20000, "
+            "workload": {"plus": "CFR+ (delay 0)", "linear": "Linear CFR", "vanilla": "vanilla CFR"}[args.variant] +
+                        " full-width iterations on the Flop5Holdem public tree (blinds 50/100, stacks 20000, "
                         "pot-size raises), %d seeded boards per GPU, 1326-hand ranges" % args.boards,
             "boards_per_gpu": args.boards, "nodes_per_gpu": tree.n_nodes, "action_columns_per_gpu": sum_a,
             "engine": solver.engine, "fhp_cfg": os.environ.get("PRL_FHP_CFG", "0"),
             "parallelism": "boards sharded over %d GPU(s), trunk replicated, 1 all-gather of chance-node partial sums per EV pass" % world,
             "nodes_whole_tree": n_nodes_total, "exchanges": exchange.calls if exchange else 0,
+            "exchange_ms_mean": (exchange.seconds * 1e3 / max(exchange.calls, 1)) if exchange else None,
             "iterations_done": solver.iter, "exploitability_mbb_per_g": float(np.mean(expl) * 10.0),
             "hbm_bytes_allocated": int(solver.get("bytes_allocated")[0]),
         },
@@ -164,7 +173,9 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_boards, args.cpu_iters)
-        print(json.dumps(out))
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # RCCL's start-up banner sits in the C stdio buffer: push it out before the JSON line
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

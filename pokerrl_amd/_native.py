@@ -292,7 +292,7 @@ class NativeSolver:
         v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
         e = ENGINES[engine] if isinstance(engine, str) else int(engine)
         self._exchange_cb = None
-        if shard is not None and int(shard[0]) > 1:
+        if shard is not None:
             world, rank, exchange = shard
 
             def _cb(_user, local_ptr, gathered_ptr, nbytes):

@@ -91,6 +91,10 @@ struct PrlFhpParams {
     double* avg;                // [n_cols][R] average strategy, updated by the update passes when avg_mode != 0
     int32_t avg_mode;           // 0: no update (before the delay), 1: avg = strategy, 2: avg = m_old * avg + m_new * strategy
     double m_old, m_new;        // CFRPlus.py:65-87 weights (float64)
+    // Vanilla / Linear CFR: the reach-weighted average of seat q needs q's NEW reach, known only after the trunk update that
+    // follows q's pass -- so it rides on the next pass that walks q's reach (phase B for seat q): bit q of avgsum_mask
+    float* avg_sum;             // [n_cols][R] node.data["avg_strat_sum"] (VanillaCFR.py:40-55, LinearCFR.py:41-57)
+    int32_t avgsum_mask, avgsum_iter[2];
     const double* strat_arr;    // explicit strategy (average strategy / caller-provided), [n_cols][R]
     float* board_ev;            // [n_boards][2][R] root values of every board subtree
     float* board_br;            // [n_boards][2][R] best-response values (PRL_FHP_EVAL)

@@ -52,6 +52,7 @@ struct prl_solver {
     prl_exchange_fn exchange = nullptr;
     void* exchange_user = nullptr;
     float *d_xlocal = nullptr, *d_xgather = nullptr, *d_xcompact = nullptr;
+    int avg_pending[2] = {-1, -1};  // FUSED Vanilla / Linear: iteration whose average update of that seat still has to run
     bool time_passes = false;   // prl_solver_time_iterations: bracket every board-pass launch with events
     std::vector<hipEvent_t> pass_events;
     bool expl_pending = false;  // FUSED, inside prl_solver_iterations: exploitability of the current iterate not evaluated yet
@@ -137,6 +138,20 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
     p.variant = s->variant;
     p.chance_reach = st.reach + prl_vidx(s->T, s->chance_trunk, 0);
     p.strat_arr = strat_arr;
+    // pending Vanilla / Linear average updates ride on the phase-B walk of that seat (the training state only)
+    p.avg_sum = s->S.avg_sum;
+    p.avg = s->d_avg;
+    p.avgsum_mask = 0;
+    if (&st == &s->S && strat_arr == nullptr) {
+        const bool walks[2] = {mode != PRL_FHP_UPDATE0, mode != PRL_FHP_UPDATE1};  // seat q is the opponent of a batch of 1 - q
+        for (int q = 0; q < 2; ++q)
+            if (walks[q] && s->avg_pending[q] >= 0) {
+                p.avgsum_mask |= 1 << q;
+                p.avgsum_iter[q] = s->avg_pending[q];
+                s->avg_pending[q] = -1;
+                s->board_avg_f64 = true;
+            }
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (s->time_passes) {
         PRL_HIP_TRY(hipEventCreate(&ev0));
@@ -153,7 +168,7 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
     float* dst_ev = st.ev + prl_vidx(s->T, s->chance_trunk, 0);
     float* dst_br = st.ev_br + prl_vidx(s->T, s->chance_trunk, 0);
     const bool with_br = mode == PRL_FHP_EVAL || mode == PRL_FHP_UPDATE0_EVAL;
-    if (s->world == 1) {
+    if (!s->exchange) {
         prl_launch_fhp_chance_sum(s->d_board_ev, p.n_boards, p.R, s->d_sum_scratch, dst_ev, s->stream);
         if (with_br) prl_launch_fhp_chance_sum(s->d_board_br, p.n_boards, p.R, s->d_sum_scratch, dst_br, s->stream);
     } else {
@@ -323,10 +338,10 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     const bool shape_ok = prl_fhp_shape_matches(full, &ch_node, &first_board, &col_base, pots);
     bool fused = false;
     if (engine == PRL_ENGINE_FUSED) {
-        if (!shape_ok || variant != PRL_CFR_PLUS) { prl_set_error("fused engine needs a Flop5Holdem-shaped tree and CFR+"); return PRL_ERR_UNSUPPORTED; }
+        if (!shape_ok) { prl_set_error("fused engine needs a Flop5Holdem-shaped tree"); return PRL_ERR_UNSUPPORTED; }
         fused = true;
-    } else if (engine == PRL_ENGINE_AUTO) fused = shape_ok && variant == PRL_CFR_PLUS;
-    if (world > 1 && !fused) { prl_set_error("sharded solve: FUSED engine only (Flop5Holdem-shaped tree + CFR+)"); return PRL_ERR_UNSUPPORTED; }
+    } else if (engine == PRL_ENGINE_AUTO) fused = shape_ok;
+    if (exchange && !fused) { prl_set_error("sharded solve: FUSED engine only (Flop5Holdem-shaped tree)"); return PRL_ERR_UNSUPPORTED; }
 
     prl_solver* s = new prl_solver();
     s->world = world;
@@ -453,7 +468,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         const size_t n_blk = ((size_t)full.n_boards * world + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;  // sized for the global board list
         const size_t n_grp = (n_blk + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
         FAIL_IF(dev_alloc(s, &s->d_sum_scratch, (n_blk + n_grp + 1) * 2 * T.R));
-        if (world > 1) {
+        if (exchange) {
             // exchange whole canonical units: the highest summation level the shard size is a multiple of
             s->xlevel = full.n_boards % (PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK) == 0 ? 2 : full.n_boards % PRL_CHANCE_BLOCK == 0 ? 1 : 0;
             s->n_units = prl_fhp_units_at_level(full.n_boards, s->xlevel);
@@ -488,7 +503,8 @@ int32_t prl_solver_create_sharded(const prl_tree_t* local_tree, int32_t variant,
                                   prl_exchange_fn exchange, void* user, prl_solver_t** out) {
     if (world_size < 1 || rank < 0 || rank >= world_size) { prl_set_error("bad world_size / rank"); return PRL_ERR_ARG; }
     if (world_size > 1 && !exchange) { prl_set_error("sharded solve needs an exchange callback"); return PRL_ERR_ARG; }
-    return solver_create_impl(local_tree, variant, delay, world_size > 1 ? PRL_ENGINE_FUSED : PRL_ENGINE_AUTO, world_size, rank, exchange, user, out);
+    // with a callback the exchange path is taken even for world_size 1 (a one-rank all-gather): same code on any world size
+    return solver_create_impl(local_tree, variant, delay, exchange ? PRL_ENGINE_FUSED : PRL_ENGINE_AUTO, world_size, rank, exchange, user, out);
 }
 
 int32_t prl_chance_sum_host(const float* board_values, int32_t n_boards, int32_t R, int32_t world, float* out) {
@@ -540,6 +556,7 @@ int32_t prl_solver_reset(prl_solver_t* s) {
     const size_t nc = (size_t)s->full_cols * s->R;
     s->iter = 0;
     s->expl_pending = false;
+    s->avg_pending[0] = s->avg_pending[1] = -1;
     PRL_HIP_TRY(hipMemsetAsync(s->d_regret, 0, nc * sizeof(float), s->stream));
     PRL_HIP_TRY(hipMemsetAsync(s->d_avg, 0, nc * sizeof(double), s->stream));
     PRL_HIP_TRY(hipMemsetAsync(s->S.avg_f64, 0, (size_t)s->T.n_nodes, s->stream));
@@ -635,6 +652,7 @@ static int iteration_core(prl_solver* s, bool closing_eval) {
         TRY(do_update_reach(s, s->S));
         prl_launch_average(s->T, s->S, s->d_nodes_p[p], s->n_nodes_p[p], p, s->variant, s->iter, mode, m_old, m_new, s->stream);
         if (s->fused && mode) s->board_avg_f64 = mode == 2;  // the board columns were averaged inside the board pass
+        if (s->fused && s->variant != PRL_CFR_PLUS) s->avg_pending[p] = s->iter;  // applied by the next pass that walks seat p
     }
     s->fp.avg_mode = 0;
     s->iter += 1;

@@ -6,6 +6,7 @@ per EV pass: the chance node's partial sums of every rank's boards (SURVEY.md se
 pointers as tensors without copying and runs `all_gather_into_tensor` on them. PyTorch is used for the collective only.
 """
 import ctypes
+import time
 
 import numpy as np
 import torch
@@ -32,13 +33,23 @@ class TorchExchange:
         self.world = dist.get_world_size(group)
         self.calls = 0
         self.bytes = 0
+        self.seconds = 0.0
+        self._views = {}  # the solver's exchange buffers never move: wrap each (pointer, size) once
 
     def _view(self, ptr, nbytes):
+        key = (ptr, nbytes)
+        v = self._views.get(key)
+        if v is None:
+            v = self._views[key] = self._make_view(ptr, nbytes)
+        return v
+
+    def _make_view(self, ptr, nbytes):
         if self.device == "cpu":
             return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(ptr)))
         return torch.as_tensor(_DevBuf(ptr, nbytes), device="cuda")
 
     def __call__(self, local_ptr, gathered_ptr, nbytes):
+        t0 = time.perf_counter()
         local = self._view(local_ptr, nbytes)
         gathered = self._view(gathered_ptr, nbytes * self.world)
         if self.device == "cuda" and dist.get_backend(self.group) != "nccl":
@@ -51,3 +62,4 @@ class TorchExchange:
             torch.cuda.synchronize()  # the solver's own stream continues only after the gathered buffer is complete
         self.calls += 1
         self.bytes += nbytes * self.world
+        self.seconds += time.perf_counter() - t0

@@ -162,21 +162,25 @@ def check_hand_rank_checksums(L, n_chunks=None):
 FUSED_FIELDS = ("regret", "avg")
 
 
-def check_fused_vs_oracle(L, n_boards, n_iters, delay=0):
+VARIANT_ID = {"vanilla": 0, "plus": 1, "linear": 2}
+
+
+def check_fused_vs_oracle(L, n_boards, n_iters, delay=0, variant="plus"):
     """Fused board-block engine (per-node vectors on chip) against the oracle: every regret / average column of every
     board, the strategy implied by the regrets, current- and average-strategy exploitability, after every iteration."""
     boards = fhp_boards(n_boards)
     args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
     t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
-    s = _native.NativeSolver(t, "plus", delay, engine="fused", _lib=L)
+    s = _native.NativeSolver(t, variant, delay, engine="fused", _lib=L)
     assert s.engine == "fused"
     o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, 2, 52, 4, 2)
-    o.cfr_reset(1, delay)
+    o.cfr_reset(VARIANT_ID[variant], delay)
     assert np.array_equal(s.exploitability(), o.exploitability)
+    fields = FUSED_FIELDS + ("strategy",) + (() if variant == "plus" else ("avg_sum",))
     for it in range(1, n_iters + 1):
         s.iteration()
         o.cfr_iteration()
-        for k in FUSED_FIELDS + ("strategy",):
+        for k in fields:
             a, b = s.get(k), np.asarray(getattr(o, k))
             assert np.array_equal(a, b), "fused it%d: %s differs in %d entries" % (it, k, int(np.sum(a != b)))
         assert np.array_equal(s.exploitability(), o.exploitability), it
@@ -185,15 +189,15 @@ def check_fused_vs_oracle(L, n_boards, n_iters, delay=0):
     return s, o
 
 
-def check_fused_batched_vs_oracle(L, n_boards, n_iters, delay=0):
+def check_fused_batched_vs_oracle(L, n_boards, n_iters, delay=0, variant="plus"):
     """prl_solver_iterations(n) on the fused engine folds every closing evaluation into the next iteration's first board
     pass; the exploitability history and the final state must equal the oracle's (= n single iteration() calls)."""
     boards = fhp_boards(n_boards)
     args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
     t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
-    s = _native.NativeSolver(t, "plus", delay, engine="fused", _lib=L)
+    s = _native.NativeSolver(t, variant, delay, engine="fused", _lib=L)
     o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, 2, 52, 4, 2)
-    o.cfr_reset(1, delay)
+    o.cfr_reset(VARIANT_ID[variant], delay)
     want = [np.array(o.exploitability, np.float32)]
     for _ in range(n_iters):
         o.cfr_iteration()
@@ -201,23 +205,23 @@ def check_fused_batched_vs_oracle(L, n_boards, n_iters, delay=0):
     s.iterations(n_iters - 1)
     s.iterations(1)  # a batch of one closes with its own evaluation pass
     assert np.array_equal(s.get("expl_history"), np.stack(want))
-    for k in FUSED_FIELDS + ("strategy",):
+    for k in FUSED_FIELDS + ("strategy",) + (() if variant == "plus" else ("avg_sum",)):
         assert np.array_equal(s.get(k), np.asarray(getattr(o, k))), k
     assert np.array_equal(s.eval_avg(), o.eval_avg())
 
 
-def check_fused_vs_levels(L, n_boards, n_iters, seed=11):
+def check_fused_vs_levels(L, n_boards, n_iters, seed=11, variant="plus"):
     """Same tree solved by both engines of the library: bit-identical regrets, averages and exploitability history."""
     boards = fhp_boards(n_boards, seed=seed)
     args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
     t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
-    a = _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
-    b = _native.NativeSolver(t, "plus", 0, engine="levels", _lib=L)
+    a = _native.NativeSolver(t, variant, 0, engine="fused", _lib=L)
+    b = _native.NativeSolver(t, variant, 0, engine="levels", _lib=L)
     assert (a.engine, b.engine) == ("fused", "levels")
     a.iterations(n_iters)
     b.iterations(n_iters)
     assert np.array_equal(a.get("expl_history"), b.get("expl_history"))
-    for k in FUSED_FIELDS:
+    for k in FUSED_FIELDS + (() if variant == "plus" else ("avg_sum",)):
         assert np.array_equal(a.get(k), b.get(k)), k
     assert np.array_equal(a.eval_avg(), b.eval_avg())
     # exact best response of an explicit strategy (LocalBRMaster semantics) through both engines

@@ -57,6 +57,15 @@ def test_emu_fused_engine_cfrplus_delay(L):
     pc.check_fused_vs_oracle(L, 3, 3, delay=1)
 
 
+@pytest.mark.parametrize("variant", ["vanilla", "linear"])
+def test_emu_fused_engine_vanilla_linear(L, variant):
+    pc.check_fused_vs_oracle(L, 3, 3, variant=variant)
+
+
+def test_emu_fused_engine_linear_batched_iterations(L):
+    pc.check_fused_batched_vs_oracle(L, 3, 3, variant="linear")
+
+
 def test_emu_fused_engine_batched_iterations(L):
     pc.check_fused_batched_vs_oracle(L, 3, 4, delay=1)
 

@@ -125,6 +125,16 @@ def test_gpu_fused_cfrplus_delay_vs_oracle(L):
     pc.check_fused_vs_oracle(L, 33, 4, delay=2)
 
 
+@pytest.mark.parametrize("variant", ["vanilla", "linear"])
+def test_gpu_fused_vanilla_linear_vs_oracle(L, variant):
+    pc.check_fused_vs_oracle(L, 40, 4, variant=variant)
+
+
+def test_gpu_fused_linear_batched_vs_oracle_and_levels(L):
+    pc.check_fused_batched_vs_oracle(L, 35, 5, variant="linear")
+    pc.check_fused_vs_levels(L, 2048, 5, variant="linear")
+
+
 def test_gpu_fused_batched_iterations_vs_oracle(L):
     pc.check_fused_batched_vs_oracle(L, 40, 5, delay=1)
 

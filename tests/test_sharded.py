@@ -127,3 +127,19 @@ def test_gpu_chance_sum_levels_do_not_depend_on_world_size():
 def test_gpu_sharded_world2_matches_unsharded(n_local):
     ranks = run_sharded(_native.LIB_PATH, "cuda", 2, n_local, 4, 0, 33, timeout=600)
     check_against_union(_native.lib(), ranks, 2, n_local, 4, 0, 33)
+
+
+@pytest.mark.gpu
+def test_gpu_bench_exchange_path_over_rccl_one_rank():
+    """bench.py with the all-gather path forced on: torch.distributed nccl (= RCCL) on zero-copy views of the solver's device
+    buffers, world_size 1 -- the same code the multi-GPU launch runs; its exploitability must equal the plain run's."""
+    import json
+    root = os.path.dirname(HERE)
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--boards", "2048", "--no-cpu-baseline"]
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    a = json.loads(subprocess.run(base, env=env, capture_output=True, text=True, timeout=600, check=True).stdout.strip().splitlines()[-1])
+    b = json.loads(subprocess.run(base, env=dict(env, PRL_BENCH_FORCE_EXCHANGE="1"), capture_output=True, text=True, timeout=600,
+                                  check=True).stdout.strip().splitlines()[-1])
+    assert b["config"]["exchanges"] > 0 and a["config"]["exchanges"] == 0
+    assert a["config"]["exploitability_mbb_per_g"] == b["config"]["exploitability_mbb_per_g"]
+    assert a["config"]["iterations_done"] == b["config"]["iterations_done"] == 4
