@@ -261,6 +261,18 @@ enum {
 };
 int32_t prl_solver_get(prl_solver_t* solver, int32_t field, void* out);
 
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* 6. Local best response (LBR): the check-down equity of LBR's hand against agent ranges.                           */
+/*    replaces  PokerRL/eval/lbr/LocalLBRWorker.py:379-512 (_LBRRolloutManager.__init__/_build_eq_vecs,               */
+/*              get_lbr_checkdown_equity, _calc_eq) incl. PokerRange.get_card_probs / set_cards_to_zero_prob /         */
+/*              normalize (PokerRange.py:26-84) as they are used there. float32, NumPy's summation order: bit-exact.   */
+/*    board_dealt: the n_dealt board cards on the table (1d cards, deal order); lbr_hand: n_hole_cards 1d cards;       */
+/*    ranges: [n_q][R] candidate agent ranges (the current one, and the one after "agent does not fold" per raise);    */
+/*    out_wp[n_q]: P(LBR wins the check-down) per range. At most 2 board cards to come (lbr_check_to_round).            */
+/* ---------------------------------------------------------------------------------------------------------------- */
+int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t* board_dealt, int32_t n_dealt, const int8_t* lbr_hand,
+                                 const float* ranges, int32_t n_q, float* out_wp);
+
 #ifdef __cplusplus
 }
 #endif

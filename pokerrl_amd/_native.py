@@ -140,6 +140,8 @@ def _bind_solver(L):
     L.prl_solver_create_sharded.restype = i32
     L.prl_solver_time_iterations_ex.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i32)]
     L.prl_solver_time_iterations_ex.restype = i32
+    L.prl_lbr_checkdown_equity.argtypes = [ctypes.POINTER(PrlRules), vp, i32, vp, vp, i32, vp]
+    L.prl_lbr_checkdown_equity.restype = i32
     L.prl_chance_sum_host.argtypes = [vp, i32, i32, i32, vp]
     L.prl_chance_sum_host.restype = i32
     L.prl_solver_get.argtypes = [vp, i32, vp]

@@ -96,7 +96,11 @@ class PokerEnv:
         self.board = None
         self.side_pots = [0, 0]
         self._init_from_args(env_args)
+        # The reference constructor leaves the episode state to the first reset() and draws from np.random exactly once (the
+        # deck's initial shuffle, PokerEnv.py:143): give the views a valid state without consuming any further randomness.
+        rng_state = np.random.get_state()
         self.reset()
+        np.random.set_state(rng_state)
 
     # ---- configuration -------------------------------------------------------------------------------------------------
     def _init_from_args(self, env_args):
