@@ -59,6 +59,91 @@ def check_case(tag, tmp_path, max_hands=None):
     return w
 
 
+def _rank_fn(tag):
+    from oracle import rank_boards
+    if tag == "StandardLeduc":
+        return lambda board: np.array([100 + c // 2 if c // 2 == board[0] // 2 else c // 2 for c in range(6)], dtype=np.int32)
+    return lambda board: rank_boards(np.array([board], dtype=np.int8))[0]
+
+
+def _game_dims(tag):
+    return (1, 6, 1, StandardLeduc) if tag == "StandardLeduc" else (2, 52, 5, DiscretizedNLHoldem)
+
+
+def check_equity_oracle_vs_golden(tag, max_to_deal=2):
+    """the NumPy restatement (oracle/lbr.py) reproduces the reference's rollout manager bit for bit"""
+    from oracle.lbr import checkdown_equity
+    g = np.load(os.path.join(HERE, "golden", "lbr_equity.npz"))
+    n_hole, n_cards, n_board, _ = _game_dims(tag)
+    n = 0
+    for board, nd, hand, rng, wp in zip(g[tag + "_board"], g[tag + "_n_dealt"], g[tag + "_hand"], g[tag + "_range"], g[tag + "_wp"]):
+        if n_board - int(nd) > max_to_deal:
+            continue
+        got = checkdown_equity(_rank_fn(tag), n_hole, n_cards, n_board, board[:nd], hand[:n_hole], rng)
+        assert got == wp or (np.isnan(got) and np.isnan(wp)), (tag, board, nd, got, wp)
+        n += 1
+    assert n > 10
+
+
+def check_equity_kernel(L, tag, extra_random=0, max_to_deal=2):
+    """prl_lbr_checkdown_equity against the reference's outputs (golden) and, on fresh seeded ranges, against the oracle"""
+    import ctypes
+    from oracle.lbr import checkdown_equity
+    g = np.load(os.path.join(HERE, "golden", "lbr_equity.npz"))
+    n_hole, n_cards, n_board, game_cls = _game_dims(tag)
+    rules = game_cls.native_rules()
+
+    def native(board_dealt, hand, ranges):
+        b = np.ascontiguousarray(board_dealt, dtype=np.int8)
+        h = np.ascontiguousarray(hand, dtype=np.int8)
+        r = np.ascontiguousarray(ranges, dtype=np.float32)
+        out = np.zeros(r.shape[0], np.float32)
+        assert L.prl_lbr_checkdown_equity(ctypes.byref(rules), b.ctypes.data_as(ctypes.c_void_p), int(b.shape[0]), h.ctypes.data_as(ctypes.c_void_p),
+                                          r.ctypes.data_as(ctypes.c_void_p), int(r.shape[0]), out.ctypes.data_as(ctypes.c_void_p)) == 0
+        return out
+
+    n = 0
+    for board, nd, hand, rng, wp in zip(g[tag + "_board"], g[tag + "_n_dealt"], g[tag + "_hand"], g[tag + "_range"], g[tag + "_wp"]):
+        if n_board - int(nd) > max_to_deal:
+            continue
+        got = native(board[:nd], hand[:n_hole], rng[None, :])[0]
+        assert got == wp or (np.isnan(got) and np.isnan(wp)), (tag, board, nd, got, wp)
+        n += 1
+    assert n > 5
+    rs = np.random.RandomState(3)
+    for _ in range(extra_random):  # several candidate ranges per call, incl. an all-zero one (-> uniform)
+        cards = rs.choice(n_cards, n_hole + n_board, replace=False)
+        nd = int(rs.randint(max(0, n_board - max_to_deal), n_board + 1))
+        hand, board = np.sort(cards[:n_hole]), cards[n_hole:n_hole + nd]
+        R = 6 if n_hole == 1 else 1326
+        ranges = (rs.random_sample((4, R)) ** 4).astype(np.float32)
+        ranges[3] = 0
+        got = native(board, hand, ranges)
+        for q in range(4):
+            want = checkdown_equity(_rank_fn(tag), n_hole, n_cards, n_board, board, hand, ranges[q])
+            assert got[q] == want or (np.isnan(got[q]) and np.isnan(want)), (tag, q, got[q], want)
+
+
+def test_lbr_equity_oracle_vs_reference_golden():
+    check_equity_oracle_vs_golden("StandardLeduc")
+    check_equity_oracle_vs_golden("DiscretizedNLHoldem", max_to_deal=1)  # the flop cases (990 boards) run in the GPU suite
+
+
+def test_lbr_equity_kernel_emu():
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    import build_emu
+    L = _native.bind(build_emu.build())
+    check_equity_kernel(L, "StandardLeduc", extra_random=20)
+    check_equity_kernel(L, "DiscretizedNLHoldem", extra_random=2, max_to_deal=1)
+
+
+@pytest.mark.gpu
+def test_gpu_lbr_equity_kernel_vs_reference_and_oracle():
+    check_equity_oracle_vs_golden("DiscretizedNLHoldem")
+    check_equity_kernel(_native.lib(), "StandardLeduc", extra_random=40)
+    check_equity_kernel(_native.lib(), "DiscretizedNLHoldem", extra_random=6)
+
+
 @pytest.fixture()
 def emu_lib(monkeypatch):
     sys.path.insert(0, os.path.join(HERE, "emu"))
