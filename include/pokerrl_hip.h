@@ -273,6 +273,20 @@ int32_t prl_solver_get(prl_solver_t* solver, int32_t field, void* out);
 int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t* board_dealt, int32_t n_dealt, const int8_t* lbr_hand,
                                  const float* ranges, int32_t n_q, float* out_wp);
 
+/* Device-resident batched LBR (BASELINE config 5): n_envs hands of LocalLBRWorker.run (LocalLBRWorker.py:61-308) against a
+ * synthetic tabular agent, each played start to finish by one workgroup: betting engine (PokerEnv._step), dealing, the
+ * agent's PokerRange, LBR's look-ahead with check-down equities, payout. Same float32 arithmetic as the host worker.
+ *   lbr_game / agent_game: the same game with LBR's and the agent's bet sizes; cards: [n_envs][2*n_hole + n_board] 1d cards
+ *   (seat 0's hole cards, seat 1's, then the board in deal order = the top of the reference's shuffled deck);
+ *   check_to_round: -1 = None; agent_kind 0 uniform, 1 seeded hash policy (csrc/prl_lbr_batch.hip); episode_base: hand e
+ *   draws the agent's actions as episode episode_base + e + 1; reward_scalar / ev_normalizer: env.REWARD_SCALAR, EV_NORMALIZER.
+ *   out_winnings[n_envs] float32 = reward[lbr_seat] * REWARD_SCALAR * EV_NORMALIZER; out_stats4: env steps, LBR look-ahead
+ *   decisions, (range, board) equities, agent actions; out_device_ms: kernel time (HIP events). LBR may only decide with at
+ *   most one board card to come (hold'em: lbr_check_to_round >= TURN). */
+int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* agent_game, const PrlRules* rules, int32_t n_envs, int32_t agent_seat,
+                          int32_t check_to_round, int32_t agent_kind, uint32_t agent_seed, uint32_t episode_base, double reward_scalar,
+                          double ev_normalizer, const int8_t* cards, float* out_winnings, uint64_t* out_stats4, float* out_device_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,6 +142,9 @@ def _bind_solver(L):
     L.prl_solver_time_iterations_ex.restype = i32
     L.prl_lbr_checkdown_equity.argtypes = [ctypes.POINTER(PrlRules), vp, i32, vp, vp, i32, vp]
     L.prl_lbr_checkdown_equity.restype = i32
+    L.prl_lbr_batch_run.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), i32, i32, i32, i32,
+                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.prl_lbr_batch_run.restype = i32
     L.prl_chance_sum_host.argtypes = [vp, i32, i32, i32, vp]
     L.prl_chance_sum_host.restype = i32
     L.prl_solver_get.argtypes = [vp, i32, vp]

@@ -7,12 +7,16 @@
 
 #if defined(PRL_EMU)
 #include "prl_emu.h"
+#define PRL_LAUNCH_BOUNDS(n)
+inline void prl_atomic_add_u64(unsigned long long* p, unsigned long long v) { *p += v; }  // the emulator runs one fiber at a time
 #else
 #include <hip/hip_runtime.h>
 
 #define PRL_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(smem), (hipStream_t)(stream), __VA_ARGS__)
 
+#define PRL_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+PRL_DEV PRL_INLINE void prl_atomic_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 PRL_DEV PRL_INLINE unsigned prl_tid() { return threadIdx.x; }
 PRL_DEV PRL_INLINE unsigned prl_bid() { return blockIdx.x; }
 PRL_DEV PRL_INLINE unsigned prl_nthreads() { return blockDim.x; }

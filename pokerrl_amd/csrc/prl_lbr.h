@@ -63,3 +63,118 @@ PRL_HD PRL_INLINE int32_t prl_lbr_rank(const PrlLbrGame& g, int h, const int8_t*
         if (full_board[i] == c1 || full_board[i] == c2) return -1;
     return prl_rank7_cards_52(full_board, c1, c2);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// per-(range, board) and per-range pieces of the check-down equity (LocalLBRWorker.py:427-512); used by the stand-alone
+// equity kernels (one call per LBR decision of the host worker) and by the device-resident batched LBR engine
+// ---------------------------------------------------------------------------------------------------------------------
+PRL_HD PRL_INLINE bool prl_lbr_blocked(const PrlLbrGame& g, int h, const int8_t* full_board) {
+    for (int i = 0; i < g.n_board_total; ++i)
+        if (prl_lbr_hand_has(g, h, full_board[i])) return true;
+    return false;
+}
+
+// cls[h]: 1 where LBR's hand beats hand h on `full_board`, 2 where it ties (np.argwhere(handranks < / == lbr_rank), :424-425)
+PRL_HD PRL_INLINE uint8_t prl_lbr_classify_hand(const PrlLbrGame& g, int lbr_idx, int h, const int8_t* full_board) {
+    const int32_t rl = prl_lbr_rank(g, lbr_idx, full_board);
+    const int32_t rh = prl_lbr_rank(g, h, full_board);
+    return rh < rl ? 1 : (rh == rl ? 2 : 0);
+}
+
+// PokerRange.set_cards_to_zero_prob(board) -> normalize (PokerRange.py:45-50, :67-84; an all-zero range becomes uniform),
+// then the sums over the hands LBR beats (+ half the ties) (:509-510). `cl` is the classification of the FIRST board.
+PRL_HD PRL_INLINE float prl_lbr_board_equity(const PrlLbrGame& g, const int8_t* full_board, const uint8_t* cl, const float* rg) {
+    int h0 = 0;
+    auto nx = [&]() { const int h = h0++; return prl_lbr_blocked(g, h, full_board) ? 0.f : rg[h]; };
+    const float norm = prl_np_sum_stream<4>(g.R, nx);
+    const float unif = (float)(1.0 / (double)g.R);
+    auto value = [&](int h) { return norm == 0.f ? unif : (prl_lbr_blocked(g, h, full_board) ? 0.f : rg[h]) / norm; };
+    int n_big = 0, n_eq = 0;
+    for (int h = 0; h < g.R; ++h) { n_big += cl[h] == 1; n_eq += cl[h] == 2; }
+    int hb = 0, he = 0;
+    auto next_big = [&]() { while (cl[hb] != 1) ++hb; return value(hb++); };
+    auto next_eq = [&]() { while (cl[he] != 2) ++he; return value(he++); };
+    const float s_big = prl_np_sum_stream<4>(n_big, next_big);
+    const float s_eq = prl_np_sum_stream<4>(n_eq, next_eq);
+    return s_big + s_eq / 2.0f;
+}
+
+// the cards that can still come, ascending (LocalLBRWorker.py:392-396)
+PRL_HD PRL_INLINE int prl_lbr_possible_cards(const PrlLbrGame& g, int8_t* pc) {
+    int n = 0;
+    for (int c = 0; c < g.n_cards; ++c) {
+        bool used = false;
+        for (int i = 0; i < g.n_hole; ++i) used |= g.lbr_hand[i] == c;
+        for (int i = 0; i < g.n_dealt; ++i) used |= g.board[i] == c;
+        if (!used) pc[n++] = (int8_t)c;
+    }
+    return n;
+}
+PRL_HD PRL_INLINE int prl_lbr_n_boards(const PrlLbrGame& g) {
+    const int n = g.n_cards - g.n_hole - g.n_dealt;
+    return g.n_to_deal == 0 ? 1 : (g.n_to_deal == 1 ? n : n * (n - 1) / 2);
+}
+// b-th complete board in the reference's enumeration order (:408-417)
+PRL_HD PRL_INLINE void prl_lbr_board_at(const PrlLbrGame& g, const int8_t* pc, int n_pc, int b, int8_t* fb) {
+    for (int i = 0; i < 5; ++i) fb[i] = i < g.n_dealt ? g.board[i] : (int8_t)0;
+    if (g.n_to_deal == 1) fb[g.n_dealt] = pc[b];
+    else if (g.n_to_deal == 2) {
+        int i = 0, left = b;
+        while (left >= n_pc - 1 - i) { left -= n_pc - 1 - i; ++i; }
+        fb[g.n_dealt] = pc[i];
+        fb[g.n_dealt + 1] = pc[i + 1 + left];
+    }
+}
+
+// card-removal-aware board probabilities and the running float32 sum over the boards (:432-468, :470-497)
+PRL_HD PRL_INLINE float prl_lbr_reduce_range(const PrlLbrGame& g, const float* rg, const float* e /* [n_boards] */) {
+    float cp[PRL_LBR_MAX_CARDS];
+    for (int c = 0; c < g.n_cards; ++c) {
+        float p;
+        if (g.n_hole == 1) p = rg[c];
+        else {
+            int k = 0;  // the 51 hands holding c, ascending range index (= LUT_CARD_IN_WHAT_RANGE_IDXS[c])
+            auto nx = [&]() {
+                const int o = k < c ? k : k + 1;
+                ++k;
+                return rg[o < c ? prl_range_idx_2(o, c, g.n_cards) : prl_range_idx_2(c, o, g.n_cards)];
+            };
+            p = prl_np_sum_stream<0>(g.n_cards - 1, nx);
+        }
+        cp[c] = 1.f - p;
+    }
+    for (int i = 0; i < g.n_hole; ++i) cp[g.lbr_hand[i]] = 0.f;
+    for (int i = 0; i < g.n_dealt; ++i) cp[g.board[i]] = 0.f;
+    {
+        int k = 0;
+        auto nx = [&]() { return cp[k++]; };
+        const float s = prl_np_sum_stream<0>(g.n_cards, nx);
+        if (s > 0.f)
+            for (int c = 0; c < g.n_cards; ++c) cp[c] = cp[c] / s;
+    }
+    int8_t pc[PRL_LBR_MAX_CARDS];
+    const int n_pc = prl_lbr_possible_cards(g, pc);
+    float win = 0.f;
+    bool first = true;
+    auto add = [&](float x) { win = first ? x : win + x; first = false; };  // 0.0 (Python float) + float32 -> float32
+    int b = 0;
+    if (g.n_to_deal == 0) add(e[b++] * 1.0f);
+    else if (g.n_to_deal == 1) {
+        for (int i = 0; i < n_pc; ++i) add(e[b++] * cp[pc[i]]);
+    } else {
+        for (int i = 0; i + 1 < n_pc; ++i) {
+            float cp2[PRL_LBR_MAX_CARDS];
+            for (int c = 0; c < g.n_cards; ++c) cp2[c] = cp[c];
+            cp2[pc[i]] = 0.f;
+            int k = 0;
+            auto nx = [&]() { return cp2[k++]; };
+            const float s = prl_np_sum_stream<0>(g.n_cards, nx);
+            for (int c = 0; c < g.n_cards; ++c) cp2[c] = cp2[c] / s;
+            const float r1 = cp[pc[i]];  // 1.0 * card_probs[c]
+            for (int j = i + 1; j < n_pc; ++j) add(e[b++] * (r1 * cp2[pc[j]]));
+        }
+    }
+    float fact = 1.f;
+    for (int m = 2; m <= g.n_to_deal; ++m) fact = fact * (float)m;
+    return win * fact;  // :463-468
+}

@@ -1,0 +1,419 @@
+// Device-resident batched LBR (BASELINE.json config 5: "2^20 batched PokerEnv rollouts + 7-card eval"): every episode of
+// LocalLBRWorker._run_limit / _run_no_limit (LocalLBRWorker.py:61-308) runs start to finish inside one workgroup -- betting
+// engine (prl_env.h), card dealing, the agent's range (PokerRange.py), the synthetic tabular agent, LBR's look-ahead with the
+// check-down equity (prl_lbr.h) and the payout. State lives in LDS while the hand is played; HBM holds only the decks in and
+// the winnings out. The arithmetic is the host worker's (= the reference's) operation for operation: float32, NumPy
+// summation order; tests/test_lbr.py compares the two paths hand by hand.
+//
+// Synthetic agents (no neural network in the timed region):
+//   kind 0  uniform over the legal actions
+//   kind 1  seeded hash policy: weight ((mix32(key + h * 0x9E3779B1 + a * 0x85EBCA6B) >> 8) & 0xFFFF) + 1 per (hand, legal
+//           action), key = hash chain over the public betting state and the board, normalised per hand in float32;
+//           tests/lbr_fixture_agent.py is the same policy as a host EvalAgent (the reference plays against that one)
+// The agent's action is drawn with a counter-based hash of (seed, episode, step): no RNG state.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "prl_device.h"
+#include "prl_env.h"
+#include "prl_host.h"
+#include "prl_lbr.h"
+#include "prl_rt.h"
+
+extern "C" int32_t prl_device_available(void);
+
+#define LBRB_THREADS 256
+#define LBRB_MAX_Q 13      // check/call + up to 12 raise sizes considered by LBR
+#define LBRB_MAX_BOARDS 64  // boards per equity: at most one card to come (52-card turn: 46)
+
+struct PrlLbrBatchParams {
+    PrlGame g_lbr, g_agent;
+    PrlRules rules;
+    int32_t n_envs, agent_seat, check_to_round, agent_kind, n_deal, limit;
+    uint32_t seed, episode_base;
+    double reward_scalar, ev_normalizer;
+    const int8_t* cards;          // [n_envs][n_deal]: seat 0's hole cards, seat 1's, then the board in deal order
+    float* winnings;              // [n_envs]
+    unsigned long long* stats;    // [4] env steps, LBR look-ahead decisions, (range, board) equities, agent actions
+};
+
+PRL_HD PRL_INLINE uint32_t lbrb_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+// hash chain over the public state (tests/lbr_fixture_agent.py: state_key)
+PRL_HD PRL_INLINE uint32_t lbrb_state_key(uint32_t seed, const PrlEnvState& s, const int8_t* board, int n_dealt, int n_board_total, int n_suits) {
+    uint32_t k = seed;
+    const int vals[7] = {s.round, s.main_pot, s.bet[0], s.bet[1], s.stack[0], s.stack[1], (int)s.cur};
+    for (int i = 0; i < 7; ++i) k = lbrb_mix32(k * 31u + (uint32_t)vals[i]);
+    for (int i = 0; i < n_board_total; ++i) {  // 2-D cards (rank, suit); the not-dealt token is -127 in both fields
+        const int r = i < n_dealt ? board[i] / n_suits : -127, su = i < n_dealt ? board[i] % n_suits : -127;
+        k = lbrb_mix32(k * 31u + (uint32_t)(r & 0xFF));
+        k = lbrb_mix32(k * 31u + (uint32_t)(su & 0xFF));
+    }
+    return k;
+}
+
+// P(action `a` | hand h) of the synthetic agent; legal[0..n_legal) ascending. 0 for an illegal action.
+PRL_HD PRL_INLINE float lbrb_agent_prob(int kind, uint32_t key, int h, const int32_t* legal, int n_legal, int a) {
+    bool is_legal = false;
+    for (int j = 0; j < n_legal; ++j) is_legal |= legal[j] == a;
+    if (!is_legal) return 0.f;
+    if (kind == 0) return (float)(1.0 / (double)n_legal);
+    float sum = 0.f, wa = 0.f;
+    for (int j = 0; j < n_legal; ++j) {
+        const uint32_t x = lbrb_mix32(key + (uint32_t)h * 0x9E3779B1u + (uint32_t)legal[j] * 0x85EBCA6Bu);
+        const float w = (float)(((x >> 8) & 0xFFFFu) + 1u);
+        sum = sum + w;
+        if (legal[j] == a) wa = w;
+    }
+    return wa / sum;
+}
+
+PRL_HD PRL_INLINE int lbrb_hand_idx(const PrlRules& r, const int8_t* hc) {
+    if (r.n_hole_cards == 1) return hc[0];
+    const int a = hc[0] < hc[1] ? hc[0] : hc[1], b = hc[0] < hc[1] ? hc[1] : hc[0];
+    return prl_range_idx_2(a, b, r.n_cards);
+}
+
+struct LbrbShared {
+    PrlEnvState st;
+    PrlStepInfo info;
+    int32_t legal[PRL_MAX_BET_SIZES + 2];
+    int32_t n_legal, action, done, n_dealt, step_ctr, n_q, n_boards, lbr_idx;
+    uint32_t key;
+    float total;
+    int32_t raise_action[LBRB_MAX_Q], pot_after[LBRB_MAX_Q];
+    uint32_t raise_key[LBRB_MAX_Q];
+    int32_t raise_n_legal[LBRB_MAX_Q];
+    int32_t raise_legal[LBRB_MAX_Q][8];   // only FOLD's legality matters for the look-ahead; first entries kept for the hash
+    float fold_prob[LBRB_MAX_Q], notfold_total[LBRB_MAX_Q], wp[LBRB_MAX_Q];
+    int8_t board[5];
+    int8_t pc[PRL_LBR_MAX_CARDS];
+    int32_t n_pc;
+    PrlLbrGame lg;
+};
+
+PRL_DEV PRL_INLINE float lbrb_serial_sum(const float* a, int n) {
+    int k = 0;
+    auto nx = [&]() { return a[k++]; };
+    return prl_np_sum_stream<4>(n, nx);
+}
+
+// PokerRange.normalize (PokerRange.py:45-50), workgroup-wide: thread 0 sums in NumPy's order, everyone divides
+PRL_DEV PRL_INLINE void lbrb_normalize(float* rg, int R, LbrbShared& S) {
+    prl_sync();
+    if (prl_tid() == 0) S.total = lbrb_serial_sum(rg, R);
+    prl_sync();
+    const float t = S.total, unif = (float)(1.0 / (double)R);
+    for (int h = (int)prl_tid(); h < R; h += LBRB_THREADS) rg[h] = t == 0.f ? unif : rg[h] / t;
+    prl_sync();
+}
+
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParams P) {
+    char* lbrb_smem = prl_smem();
+    const int R = P.rules.range_size, tid = (int)prl_tid();
+    float* rg = (float*)lbrb_smem;                 // [R] the agent's range
+    float* cand = rg + R;                          // [LBRB_MAX_Q][R] candidate ranges of a look-ahead
+    float* eq = cand + (size_t)LBRB_MAX_Q * R;     // [LBRB_MAX_Q][LBRB_MAX_BOARDS]
+    uint8_t* cls = (uint8_t*)(eq + LBRB_MAX_Q * LBRB_MAX_BOARDS);  // [R]
+    LbrbShared& S = *(LbrbShared*)(((size_t)(cls + R) + 15) & ~(size_t)15);
+    const int nh = P.rules.n_hole_cards, lbr_seat = 1 - P.agent_seat, n_board_total = P.rules.n_board_cards;
+    unsigned long long n_steps = 0, n_look = 0, n_eq = 0, n_agent = 0;
+
+    for (int e = (int)prl_bid(); e < P.n_envs; e += (int)prl_nblocks()) {
+        const int8_t* cards = P.cards + (size_t)e * P.n_deal;
+        const int8_t* lbr_hand = cards + lbr_seat * nh;
+        const int8_t* agent_hand = cards + P.agent_seat * nh;
+        const int8_t* deck_board = cards + 2 * nh;
+        const uint32_t episode = P.episode_base + (uint32_t)e + 1u;
+        prl_sync();
+        if (tid == 0) {
+            prl_env_reset(P.g_lbr, S.st);
+            S.done = 0; S.n_dealt = 0; S.step_ctr = 0;
+            S.lbr_idx = lbrb_hand_idx(P.rules, lbr_hand);
+        }
+        // agent_range.reset(); set_cards_to_zero_prob(lbr_hand) (:73-74, :190-191)
+        const float unif = (float)(1.0 / (double)R);
+        PrlLbrGame hg;  // only the card geometry is needed for hand_has
+        hg.n_hole = nh; hg.n_cards = P.rules.n_cards; hg.n_suits = P.rules.n_suits; hg.rank_rule = P.rules.rank_rule; hg.R = R;
+        hg.n_board_total = n_board_total;
+        for (int h = tid; h < R; h += LBRB_THREADS) {
+            bool z = false;
+            for (int i = 0; i < nh; ++i) z |= prl_lbr_hand_has(hg, h, lbr_hand[i]);
+            rg[h] = z ? 0.f : unif;
+        }
+        lbrb_normalize(rg, R, S);
+
+        while (true) {
+            prl_sync();
+            if (S.done) break;
+            const int cur = S.st.cur;
+            if (cur == lbr_seat) {
+                int action = PRL_CHECK_CALL;
+                const bool look = !(P.check_to_round >= 0 && S.st.round < P.check_to_round);
+                if (look) {
+                    // ---------------- LBR's one-step look-ahead (:91-154, :205-270) ------------------------------------------
+                    if (tid == 0) {
+                        PrlLbrGame& g = S.lg;
+                        g = hg;
+                        g.n_dealt = S.n_dealt; g.n_to_deal = n_board_total - S.n_dealt;
+                        for (int i = 0; i < 5; ++i) g.board[i] = i < S.n_dealt ? S.board[i] : (int8_t)0;
+                        for (int i = 0; i < nh; ++i) g.lbr_hand[i] = lbr_hand[i];
+                        if (nh == 2 && g.lbr_hand[0] > g.lbr_hand[1]) { const int8_t t = g.lbr_hand[0]; g.lbr_hand[0] = g.lbr_hand[1]; g.lbr_hand[1] = t; }
+                        S.n_pc = prl_lbr_possible_cards(g, S.pc);
+                        S.n_boards = prl_lbr_n_boards(g);
+                        S.n_legal = prl_legal_actions(P.g_lbr, S.st, S.legal);
+                        int nq = 1;
+                        for (int j = 0; j < S.n_legal && nq < LBRB_MAX_Q; ++j) {
+                            const int a = S.legal[j];
+                            if (a == PRL_FOLD || a == PRL_CHECK_CALL) continue;
+                            // simulate LBR's raise; what the agent would answer in that state (its own bet set decides legality)
+                            PrlEnvState s2 = S.st;
+                            PrlStepInfo inf;
+                            prl_env_step(P.g_lbr, s2, a, &inf);
+                            S.raise_action[nq] = a;
+                            S.pot_after[nq] = s2.main_pot + s2.bet[0] + s2.bet[1];
+                            int32_t lg2[PRL_MAX_BET_SIZES + 2];
+                            const int nl2 = prl_legal_actions(P.g_agent, s2, lg2);
+                            S.raise_n_legal[nq] = nl2;
+                            for (int k = 0; k < 8; ++k) S.raise_legal[nq][k] = k < nl2 ? lg2[k] : -1;
+                            S.raise_key[nq] = lbrb_state_key(P.seed, s2, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
+                            if (P.limit) S.step_ctr += 1;  // the limit branch asks get_action(step_env=False): one draw is consumed (:120)
+                            ++nq;
+                        }
+                        S.n_q = nq;
+                    }
+                    prl_sync();
+                    const PrlLbrGame g = S.lg;
+                    const int n_q = S.n_q, n_boards = S.n_boards;
+                    if (g.n_to_deal > 1 || n_boards > LBRB_MAX_BOARDS) {  // create() rejects configurations that get here
+                        if (tid == 0) S.done = 1;
+                        continue;
+                    }
+                    // candidate 0: the range as it is; candidate q: after "agent does not fold to raise q" (:131-141, :241-251)
+                    for (int h = tid; h < R; h += LBRB_THREADS) cand[h] = rg[h];
+                    for (int q = 1; q < n_q; ++q) {
+                        int32_t lg2[PRL_MAX_BET_SIZES + 2];
+                        const int nl2 = S.raise_n_legal[q];
+                        // the hash needs the whole legal list: recompute it (cheap, scalar) when it is longer than the cache
+                        if (nl2 > 8) {
+                            PrlEnvState s2 = S.st;
+                            PrlStepInfo inf;
+                            prl_env_step(P.g_lbr, s2, S.raise_action[q], &inf);
+                            prl_legal_actions(P.g_agent, s2, lg2);
+                        } else for (int k = 0; k < nl2; ++k) lg2[k] = S.raise_legal[q][k];
+                        for (int h = tid; h < R; h += LBRB_THREADS)
+                            cand[(size_t)q * R + h] = lbrb_agent_prob(P.agent_kind, S.raise_key[q], h, lg2, nl2, PRL_FOLD);  // p(fold | hand)
+                    }
+                    // first complete board for the classification (see the quirk in prl_lbr_kernels.hip)
+                    {
+                        int8_t fb0[5];
+                        prl_lbr_board_at(g, S.pc, S.n_pc, 0, fb0);
+                        for (int h = tid; h < R; h += LBRB_THREADS) cls[h] = prl_lbr_classify_hand(g, S.lbr_idx, h, fb0);
+                    }
+                    prl_sync();
+                    // one lane per raise: fold probability and the not-fold mass, NumPy order
+                    if (tid >= 1 && tid < n_q) {
+                        const float* pf = cand + (size_t)tid * R;
+                        int k = 0;
+                        auto nx = [&]() { const float v = rg[k] * pf[k]; ++k; return v; };
+                        S.fold_prob[tid] = prl_np_sum_stream<4>(R, nx);              // np.sum(range * a_probs[:, FOLD])
+                        int k2 = 0;
+                        auto nx2 = [&]() { const float v = rg[k2] * (1.f - pf[k2]); ++k2; return v; };
+                        S.notfold_total[tid] = prl_np_sum_stream<4>(R, nx2);         // mul_and_norm(1 - p_fold): normalisation
+                    }
+                    prl_sync();
+                    for (int q = 1; q < n_q; ++q) {
+                        const float t = S.notfold_total[q];
+                        for (int h = tid; h < R; h += LBRB_THREADS) {
+                            const float v = rg[h] * (1.f - cand[(size_t)q * R + h]);
+                            cand[(size_t)q * R + h] = t == 0.f ? unif : v / t;
+                        }
+                    }
+                    prl_sync();
+                    for (int t = tid; t < n_q * n_boards; t += LBRB_THREADS) {
+                        const int q = t / n_boards, b = t % n_boards;
+                        int8_t fb[5];
+                        prl_lbr_board_at(g, S.pc, S.n_pc, b, fb);
+                        eq[q * LBRB_MAX_BOARDS + b] = prl_lbr_board_equity(g, fb, cls, cand + (size_t)q * R);
+                    }
+                    prl_sync();
+                    if (tid < n_q) S.wp[tid] = prl_lbr_reduce_range(g, cand + (size_t)tid * R, eq + tid * LBRB_MAX_BOARDS);
+                    prl_sync();
+                    if (tid == 0) {
+                        const int n_u = P.limit ? 3 : 2 + P.g_lbr.n_bet_sizes;
+                        float best = 0.f;  // utility[FOLD] = 0; illegal actions are -1 (:209-212)
+                        int best_a = PRL_FOLD;
+                        const int asked = S.st.bet[P.agent_seat] - S.st.bet[lbr_seat];
+                        const int pot_before = S.st.main_pot + S.st.bet[0] + S.st.bet[1];
+                        for (int a = 1; a < n_u; ++a) {
+                            float u = -1.f;
+                            if (a == PRL_CHECK_CALL) {
+                                const float wp = S.wp[0];
+                                u = wp * (float)pot_before - (1.f - wp) * (float)asked;
+                            } else {
+                                for (int q = 1; q < n_q; ++q)
+                                    if (S.raise_action[q] == a) {
+                                        const float wp = S.wp[q], fp = S.fold_prob[q];
+                                        const int chips_in = S.pot_after[q] - pot_before;
+                                        const float ev_nf = (wp * (float)S.pot_after[q]) - ((1.f - wp) * (float)chips_in);
+                                        u = fp * (float)pot_before + (1.f - fp) * ev_nf;
+                                    }
+                            }
+                            if (u > best) { best = u; best_a = a; }  // np.argmax: the first maximum
+                        }
+                        S.action = best_a;
+                        n_look += 1;
+                        n_eq += (unsigned long long)n_q * n_boards;
+                    }
+                    prl_sync();
+                    action = S.action;
+                }
+                if (tid == 0) {
+                    if (!P.limit && action >= 2) {  // step by pot fraction (:287-289)
+                        const int amt = prl_fraction_of_pot_raise(S.st, P.g_lbr.bet_fracs[action - 2], S.st.cur);
+                        prl_env_step_processed(P.g_lbr, S.st, PRL_BET_RAISE, amt, &S.info);
+                    } else prl_env_step(P.g_lbr, S.st, action, &S.info);
+                }
+            } else {
+                // ---------------- the agent acts: draw its action, Bayes-update its range (:156-160, :272-281) --------------
+                if (tid == 0) {
+                    S.n_legal = prl_legal_actions(P.g_agent, S.st, S.legal);
+                    S.key = lbrb_state_key(P.seed, S.st, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
+                    const int hi = lbrb_hand_idx(P.rules, agent_hand);
+                    const uint32_t x = lbrb_mix32(P.seed * 0x51ED27u + episode * 0x9E3779B1u + (uint32_t)S.step_ctr);
+                    const float u = (float)(x >> 8) / 16777216.0f;
+                    S.step_ctr += 1;
+                    int a = S.legal[S.n_legal - 1];
+                    float c = 0.f;
+                    for (int j = 0; j < S.n_legal; ++j) {
+                        c = c + lbrb_agent_prob(P.agent_kind, S.key, hi, S.legal, S.n_legal, S.legal[j]);
+                        if (u < c) { a = S.legal[j]; break; }
+                    }
+                    S.action = a;
+                    n_agent += 1;
+                }
+                prl_sync();
+                const int a = S.action;
+                for (int h = tid; h < R; h += LBRB_THREADS) rg[h] = rg[h] * lbrb_agent_prob(P.agent_kind, S.key, h, S.legal, S.n_legal, a);
+                lbrb_normalize(rg, R, S);
+                if (tid == 0) {
+                    if (!P.limit && a >= 2) {
+                        const int amt = prl_fraction_of_pot_raise(S.st, P.g_agent.bet_fracs[a - 2], S.st.cur);
+                        prl_env_step_processed(P.g_lbr, S.st, PRL_BET_RAISE, amt, &S.info);
+                    } else prl_env_step(P.g_lbr, S.st, a, &S.info);
+                }
+            }
+            prl_sync();
+            // ---------------- after the step: cards, range, payout (PokerEnv._step + the facade's _after_step) ---------------
+            n_steps += tid == 0;
+            const PrlStepInfo info = S.info;
+            if (info.is_terminal) {
+                if (tid == 0) {
+                    int n_dealt = S.n_dealt;
+                    if (info.rundown) {
+                        for (; n_dealt < n_board_total; ++n_dealt) S.board[n_dealt] = deck_board[n_dealt];
+                    }
+                    const int pot = S.st.main_pot;
+                    double award_lbr = 0.0;
+                    if (S.st.folded[0] || S.st.folded[1]) award_lbr = S.st.folded[lbr_seat] ? 0.0 : (double)pot;
+                    else {
+                        PrlLbrGame g = hg;
+                        int8_t fb[5] = {0, 0, 0, 0, 0};
+                        for (int i = 0; i < n_board_total; ++i) fb[i] = S.board[i];
+                        const int32_t rl = prl_lbr_rank(g, S.lbr_idx, fb), ra = prl_lbr_rank(g, lbrb_hand_idx(P.rules, agent_hand), fb);
+                        award_lbr = rl > ra ? (double)pot : (rl < ra ? 0.0 : (double)pot / 2.0);
+                    }
+                    const double stack_after = (double)S.st.stack[lbr_seat] + award_lbr;
+                    const double rew = (stack_after - (double)P.g_lbr.start_stack[lbr_seat]) / P.reward_scalar;  // PokerEnv.py:1069-1072
+                    P.winnings[e] = (float)(rew * P.reward_scalar * P.ev_normalizer);                            // :161, :304
+                    S.done = 1;
+                }
+            } else if (info.chance_acts) {
+                if (tid == 0) {
+                    const int n_new = P.rules.board_cards_in_round[S.st.round];
+                    for (int i = 0; i < n_new; ++i) { S.board[S.n_dealt] = deck_board[S.n_dealt]; S.n_dealt += 1; }
+                    S.n_legal = n_new;  // scratch: how many cards are new
+                }
+                prl_sync();
+                // agent_range.update_after_new_round (PokerRange.py:60-65): the new board cards leave the range
+                const int n_new = S.n_legal, nd = S.n_dealt;
+                for (int h = tid; h < R; h += LBRB_THREADS) {
+                    bool z = false;
+                    for (int i = nd - n_new; i < nd; ++i) z |= prl_lbr_hand_has(hg, h, S.board[i]);
+                    if (z) rg[h] = 0.f;
+                }
+                lbrb_normalize(rg, R, S);
+            }
+        }
+    }
+    if (tid == 0) {
+        prl_atomic_add_u64(P.stats + 0, n_steps);
+        prl_atomic_add_u64(P.stats + 1, n_look);
+        prl_atomic_add_u64(P.stats + 2, n_eq);
+        prl_atomic_add_u64(P.stats + 3, n_agent);
+    }
+}
+
+extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* agent_game, const PrlRules* rules, int32_t n_envs, int32_t agent_seat,
+                                     int32_t check_to_round, int32_t agent_kind, uint32_t agent_seed, uint32_t episode_base, double reward_scalar,
+                                     double ev_normalizer, const int8_t* cards, float* out_winnings, uint64_t* out_stats4, float* out_device_ms) {
+    if (!lbr_game || !agent_game || !rules || !cards || !out_winnings || n_envs <= 0 || agent_seat < 0 || agent_seat > 1) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    if (!prl_device_available()) { prl_set_error("no HIP device: batched LBR has no CPU fallback"); return PRL_ERR_NO_DEVICE; }
+    const int nh = rules->n_hole_cards, nb = rules->n_board_cards;
+    if (nh < 1 || nh > 2 || rules->n_cards > PRL_LBR_MAX_CARDS || nb > 5 || (nh == 2 && (rules->n_cards != 52 || nb != 5))) {
+        prl_set_error("batched LBR: 1-hole-card games or 52-card hold'em"); return PRL_ERR_UNSUPPORTED;
+    }
+    if (lbr_game->game_type == PRL_GAME_NOLIMIT || agent_game->game_type != lbr_game->game_type) { prl_set_error("batched LBR: fixed-limit or discretized games"); return PRL_ERR_UNSUPPORTED; }
+    if (lbr_game->game_type == PRL_GAME_DISCRETIZED && lbr_game->n_bet_sizes + 1 > LBRB_MAX_Q) { prl_set_error("batched LBR: at most 12 LBR bet sizes"); return PRL_ERR_UNSUPPORTED; }
+    // the look-ahead equity is sized for at most one board card to come where LBR decides
+    {
+        int dealt_before_first_decision = 0;
+        const int first_round = check_to_round >= 0 ? check_to_round : 0;
+        for (int r = 0; r <= first_round && r < 4; ++r) dealt_before_first_decision += rules->board_cards_in_round[r];
+        if (nb - dealt_before_first_decision > 1) { prl_set_error("batched LBR: LBR may only decide with at most one board card to come (lbr_check_to_round)"); return PRL_ERR_UNSUPPORTED; }
+    }
+    PrlLbrBatchParams P;
+    memset(&P, 0, sizeof(P));
+    P.g_lbr = *lbr_game; P.g_agent = *agent_game; P.rules = *rules;
+    P.n_envs = n_envs; P.agent_seat = agent_seat; P.check_to_round = check_to_round; P.agent_kind = agent_kind;
+    P.n_deal = 2 * nh + nb; P.limit = lbr_game->game_type == PRL_GAME_LIMIT;
+    P.seed = agent_seed; P.episode_base = episode_base; P.reward_scalar = reward_scalar; P.ev_normalizer = ev_normalizer;
+    const int R = rules->range_size;
+    const size_t smem = ((size_t)(1 + LBRB_MAX_Q) * R + LBRB_MAX_Q * LBRB_MAX_BOARDS) * sizeof(float) + R + 16 + sizeof(LbrbShared);
+    int8_t* d_cards = nullptr; float* d_win = nullptr; unsigned long long* d_stats = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = PRL_OK;
+#define LB_TRY(x) do { if ((x) != hipSuccess) { prl_set_error("HIP error in prl_lbr_batch_run"); rc = PRL_ERR_HIP; goto done; } } while (0)
+    LB_TRY(hipMalloc((void**)&d_cards, (size_t)n_envs * P.n_deal));
+    LB_TRY(hipMalloc((void**)&d_win, (size_t)n_envs * sizeof(float)));
+    LB_TRY(hipMalloc((void**)&d_stats, 4 * sizeof(unsigned long long)));
+    LB_TRY(hipMemcpy(d_cards, cards, (size_t)n_envs * P.n_deal, hipMemcpyHostToDevice));
+    LB_TRY(hipMemset(d_stats, 0, 4 * sizeof(unsigned long long)));
+    LB_TRY(hipMemset(d_win, 0, (size_t)n_envs * sizeof(float)));
+    P.cards = d_cards; P.winnings = d_win; P.stats = d_stats;
+    LB_TRY(hipEventCreate(&e0));
+    LB_TRY(hipEventCreate(&e1));
+    {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int grid = n_envs < cus * 8 ? n_envs : cus * 8;  // persistent workgroups; every one plays its hands start to finish
+        LB_TRY(hipEventRecord(e0, nullptr));
+        PRL_LAUNCH(prl_k_lbr_batch, grid, LBRB_THREADS, smem, nullptr, P);
+        LB_TRY(hipEventRecord(e1, nullptr));
+    }
+    LB_TRY(hipDeviceSynchronize());
+    if (out_device_ms) LB_TRY(hipEventElapsedTime(out_device_ms, e0, e1));
+    LB_TRY(hipMemcpy(out_winnings, d_win, (size_t)n_envs * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_stats4) LB_TRY(hipMemcpy(out_stats4, d_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+#undef LB_TRY
+done:
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_cards); (void)hipFree(d_win); (void)hipFree(d_stats);
+    return rc;
+}

@@ -1,0 +1,85 @@
+"""
+BatchedLBR: LBR with every hand played start to finish on the GPU (BASELINE.json config 5: "2^20 batched PokerEnv rollouts +
+7-card eval"). Same computation as LocalLBRWorker.run -- the per-hand winnings are bit-identical for the same decks and the
+same agent draws -- but the agent has to be one of the library's synthetic tabular agents, because a host EvalAgent cannot be
+queried from inside a kernel (batched querying of neural agents is the "next" row of SURVEY.md section 8f).
+
+    lbr = BatchedLBR(t_prof, agent_kind="hash", agent_seed=7)
+    winnings = lbr.run(agent_seat_id=0, n_hands=1 << 20, deck_seed=0)          # float32 [n_hands], mbb per hand
+"""
+import ctypes
+
+import numpy as np
+
+from pokerrl_amd import _native
+from pokerrl_amd.eval.lbr import _util
+
+AGENT_KINDS = {"uniform": 0, "hash": 1}
+
+
+def deal_decks(n_hands, n_cards_in_deck, n_deal, seed, first_hand=0):
+    """Counter-based decks: hand i's cards depend on (seed, i) only, so any split of the hands over GPUs deals the same cards.
+    A partial Fisher-Yates shuffle of 0..n_cards-1 driven by a SplitMix-style hash; returns int8 [n_hands, n_deal]."""
+    with np.errstate(over="ignore"):
+        idx = (np.arange(first_hand, first_hand + n_hands, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)
+    deck = np.tile(np.arange(n_cards_in_deck, dtype=np.int8), (n_hands, 1))
+    rows = np.arange(n_hands)
+    with np.errstate(over="ignore"):  # 64-bit wrap-around is the point of the hash
+        for i in range(n_deal):
+            x = idx + np.uint64(i + 1) * np.uint64(0xBF58476D1CE4E5B9)
+            x ^= x >> np.uint64(30)
+            x *= np.uint64(0xBF58476D1CE4E5B9)
+            x ^= x >> np.uint64(27)
+            x *= np.uint64(0x94D049BB133111EB)
+            x ^= x >> np.uint64(31)
+            j = i + (x % np.uint64(n_cards_in_deck - i)).astype(np.int64)
+            tmp = deck[rows, i].copy()
+            deck[rows, i] = deck[rows, j]
+            deck[rows, j] = tmp
+    return np.ascontiguousarray(deck[:, :n_deal])
+
+
+class BatchedLBR:
+    def __init__(self, t_prof, agent_kind="hash", agent_seed=7):
+        assert t_prof.n_seats == 2
+        self.t_prof = t_prof
+        self.lbr_args = t_prof.module_args["lbr"]
+        self._lbr_bldr = _util.get_env_builder_lbr(t_prof=t_prof)
+        env_cls = self._lbr_bldr.env_cls
+        self._env_cls = env_cls
+        self._g_lbr = env_cls.native_game(self._lbr_bldr.env_args)
+        self._g_agent = env_cls.native_game(t_prof.module_args["env"])
+        self._rules = env_cls.native_rules()
+        self.agent_kind = AGENT_KINDS[agent_kind]
+        self.agent_seed = int(agent_seed)
+        self.n_deal = 2 * self._rules.n_hole_cards + self._rules.n_board_cards
+        self.last_stats = None
+
+    def set_stack_size(self, stack_size):
+        for g in (self._g_lbr, self._g_agent):
+            g.start_stack[0], g.start_stack[1] = int(stack_size[0]), int(stack_size[1])
+
+    def run(self, agent_seat_id, n_hands, decks=None, deck_seed=0, episode_base=0, first_hand=0):
+        """decks: int8 [n_hands, 2 * N_HOLE_CARDS + N_BOARD_CARDS] 1d cards (seat 0, seat 1, board in deal order), or None for
+        counter-based decks from (deck_seed, first_hand + i). Returns float32 [n_hands]; self.last_stats has the counters."""
+        L = _native.lib()
+        _native.require_device()
+        if decks is None:
+            decks = deal_decks(n_hands, self._rules.n_cards, self.n_deal, deck_seed, first_hand)
+        decks = np.ascontiguousarray(decks, dtype=np.int8)
+        assert decks.shape == (n_hands, self.n_deal)
+        args = self._lbr_bldr.env_args
+        stacks = [self._g_lbr.start_stack[0], self._g_lbr.start_stack[1]]
+        reward_scalar = (float(sum(stacks)) / 2.0 / 5.0) if args.scale_rewards else 1.0
+        ctr = self.lbr_args.lbr_check_to_round
+        out = np.zeros(n_hands, np.float32)
+        stats = np.zeros(4, np.uint64)
+        ms = ctypes.c_float()
+        _native.check(L.prl_lbr_batch_run(ctypes.byref(self._g_lbr), ctypes.byref(self._g_agent), ctypes.byref(self._rules), int(n_hands),
+                                          int(agent_seat_id), -1 if ctr is None else int(ctr), self.agent_kind, self.agent_seed,
+                                          int(episode_base), reward_scalar, float(self._env_cls.EV_NORMALIZER),
+                                          decks.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
+                                          stats.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ms)), L)
+        self.last_stats = {"env_steps": int(stats[0]), "lbr_lookaheads": int(stats[1]), "range_board_equities": int(stats[2]),
+                           "agent_actions": int(stats[3]), "device_ms": float(ms.value)}
+        return out

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 import lbr_fixture_agent as fx  # noqa: E402
 from pokerrl_amd import _native  # noqa: E402
-from pokerrl_amd.eval.lbr import LBRArgs, LocalLBRMaster, LocalLBRWorker  # noqa: E402
+from pokerrl_amd.eval.lbr import BatchedLBR, LBRArgs, LocalLBRMaster, LocalLBRWorker  # noqa: E402
 from pokerrl_amd.game import bet_sets  # noqa: E402
 from pokerrl_amd.game.games import DiscretizedNLHoldem, DiscretizedNLLeduc, StandardLeduc  # noqa: E402
 from pokerrl_amd.game.Poker import Poker  # noqa: E402
@@ -142,6 +142,55 @@ def test_gpu_lbr_equity_kernel_vs_reference_and_oracle():
     check_equity_oracle_vs_golden("DiscretizedNLHoldem")
     check_equity_kernel(_native.lib(), "StandardLeduc", extra_random=40)
     check_equity_kernel(_native.lib(), "DiscretizedNLHoldem", extra_random=6)
+
+
+def decks_from_record(record, lut, n_board):
+    """cards of every recorded episode in the batched engine's layout: seat 0's hole cards, seat 1's, the board in deal order"""
+    out = []
+    for d in record:
+        hole = [lut.get_1d_cards(np.asarray(h)) for h in d["hand"]]
+        board = lut.get_1d_cards(np.asarray(d["deck"]["deck_remaining"])[:n_board])
+        out.append(np.concatenate([hole[0], hole[1], board]).astype(np.int8))
+    return np.stack(out)
+
+
+def check_batched_vs_golden(tag, tmp_path, max_hands=None):
+    """the device-resident engine plays the golden hands (same decks, same agent draws): per-hand winnings bit-identical to
+    the reference's LocalLBRWorker"""
+    game_cls, agent_bets, lbr_kwargs = CASES[tag]
+    g = np.load(os.path.join(HERE, "golden", "lbr_%s.npz" % tag))
+    n = int(g["n_hands"]) if max_hands is None else min(int(g["n_hands"]), max_hands)
+    t_prof = make_t_prof(game_cls, agent_bets, lbr_kwargs, n, tmp_path)
+    b = BatchedLBR(t_prof, agent_kind="hash", agent_seed=7)
+    lut = game_cls.get_lut_holder()
+    # the decks of the golden run: replay the reference's shuffles with the facade env (same np.random consumption)
+    record = []
+    w = LocalLBRWorker(t_prof=t_prof, chief_handle=None, eval_agent_cls=fx.make_agent_cls(EvalAgentBase, seed=7, record=record))
+    w._lbr_action = lambda **kw: 1  # decks only: LBR just calls, no equity work
+    for seat in (0, 1):
+        np.random.seed(int(g["np_seed"]) + seat)
+        n0 = len(record)
+        w.run(agent_seat_id=seat, n_iterations=n, mode="HASH", stack_size=[game_cls.DEFAULT_STACK_SIZE] * 2)
+        decks = decks_from_record(record[n0:], lut, game_cls.RULES.N_TOTAL_BOARD_CARDS if hasattr(game_cls.RULES, "N_TOTAL_BOARD_CARDS") else b.n_deal - 2 * b._rules.n_hole_cards)
+        got = b.run(agent_seat_id=seat, n_hands=n, decks=decks)
+        want = g["winnings_agent_seat%d" % seat][:n]
+        assert np.array_equal(got, want), "%s seat %d: %d of %d hands differ (first at %s)" % (
+            tag, seat, int(np.sum(got != want)), n, np.flatnonzero(got != want)[:5])
+        assert b.last_stats["env_steps"] > n and b.last_stats["agent_actions"] > 0
+
+
+def test_batched_lbr_standard_leduc_vs_reference_emu(emu_lib, tmp_path):
+    check_batched_vs_golden("StandardLeduc", tmp_path, max_hands=60)
+
+
+def test_batched_lbr_nl_leduc_vs_reference_emu(emu_lib, tmp_path):
+    check_batched_vs_golden("DiscretizedNLLeduc", tmp_path, max_hands=40)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["StandardLeduc", "DiscretizedNLLeduc", "DiscretizedNLHoldem"])
+def test_gpu_batched_lbr_vs_reference(tag, tmp_path):
+    check_batched_vs_golden(tag, tmp_path)
 
 
 @pytest.fixture()
