@@ -81,14 +81,27 @@ PRL_HD PRL_INLINE uint8_t prl_lbr_classify_hand(const PrlLbrGame& g, int lbr_idx
     return rh < rl ? 1 : (rh == rl ? 2 : 0);
 }
 
+// bit c set for every card c of the hand / of the board: "hand shares a card with the board" is one AND
+PRL_HD PRL_INLINE unsigned long long prl_lbr_hand_mask(const PrlLbrGame& g, int h, const uint16_t* hole_lut /* c1 | c2 << 8, or NULL */) {
+    if (g.n_hole == 1) return 1ull << h;
+    if (hole_lut) { const unsigned v = hole_lut[h]; return (1ull << (v & 0xFFu)) | (1ull << (v >> 8)); }
+    int c1, c2;
+    prl_hole_cards_2(h, g.n_cards, &c1, &c2);
+    return (1ull << c1) | (1ull << c2);
+}
+
 // PokerRange.set_cards_to_zero_prob(board) -> normalize (PokerRange.py:45-50, :67-84; an all-zero range becomes uniform),
 // then the sums over the hands LBR beats (+ half the ties) (:509-510). `cl` is the classification of the FIRST board.
-PRL_HD PRL_INLINE float prl_lbr_board_equity(const PrlLbrGame& g, const int8_t* full_board, const uint8_t* cl, const float* rg) {
+PRL_HD PRL_INLINE float prl_lbr_board_equity(const PrlLbrGame& g, const int8_t* full_board, const uint8_t* cl, const float* rg,
+                                             const uint16_t* hole_lut = nullptr) {
+    unsigned long long bmask = 0ull;
+    for (int i = 0; i < g.n_board_total; ++i) bmask |= 1ull << full_board[i];
+    auto blocked = [&](int h) { return (prl_lbr_hand_mask(g, h, hole_lut) & bmask) != 0ull; };
     int h0 = 0;
-    auto nx = [&]() { const int h = h0++; return prl_lbr_blocked(g, h, full_board) ? 0.f : rg[h]; };
+    auto nx = [&]() { const int h = h0++; return blocked(h) ? 0.f : rg[h]; };
     const float norm = prl_np_sum_stream<4>(g.R, nx);
     const float unif = (float)(1.0 / (double)g.R);
-    auto value = [&](int h) { return norm == 0.f ? unif : (prl_lbr_blocked(g, h, full_board) ? 0.f : rg[h]) / norm; };
+    auto value = [&](int h) { return norm == 0.f ? unif : (blocked(h) ? 0.f : rg[h]) / norm; };
     int n_big = 0, n_eq = 0;
     for (int h = 0; h < g.R; ++h) { n_big += cl[h] == 1; n_eq += cl[h] == 2; }
     int hb = 0, he = 0;

@@ -120,9 +120,15 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
     float* cand = rg + R;                          // [LBRB_MAX_Q][R] candidate ranges of a look-ahead
     float* eq = cand + (size_t)LBRB_MAX_Q * R;     // [LBRB_MAX_Q][LBRB_MAX_BOARDS]
     uint8_t* cls = (uint8_t*)(eq + LBRB_MAX_Q * LBRB_MAX_BOARDS);  // [R]
-    LbrbShared& S = *(LbrbShared*)(((size_t)(cls + R) + 15) & ~(size_t)15);
+    uint16_t* hole_lut = (uint16_t*)(((size_t)(cls + R) + 15) & ~(size_t)15);  // [R] c1 | c2 << 8
+    LbrbShared& S = *(LbrbShared*)(((size_t)(hole_lut + R) + 15) & ~(size_t)15);
     const int nh = P.rules.n_hole_cards, lbr_seat = 1 - P.agent_seat, n_board_total = P.rules.n_board_cards;
     unsigned long long n_steps = 0, n_look = 0, n_eq = 0, n_agent = 0;
+    for (int h = tid; h < R; h += LBRB_THREADS) {
+        int c1 = h, c2 = h;
+        if (nh == 2) prl_hole_cards_2(h, P.rules.n_cards, &c1, &c2);
+        hole_lut[h] = (uint16_t)(c1 | (c2 << 8));
+    }
 
     for (int e = (int)prl_bid(); e < P.n_envs; e += (int)prl_nblocks()) {
         const int8_t* cards = P.cards + (size_t)e * P.n_deal;
@@ -141,10 +147,10 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
         PrlLbrGame hg;  // only the card geometry is needed for hand_has
         hg.n_hole = nh; hg.n_cards = P.rules.n_cards; hg.n_suits = P.rules.n_suits; hg.rank_rule = P.rules.rank_rule; hg.R = R;
         hg.n_board_total = n_board_total;
-        for (int h = tid; h < R; h += LBRB_THREADS) {
-            bool z = false;
-            for (int i = 0; i < nh; ++i) z |= prl_lbr_hand_has(hg, h, lbr_hand[i]);
-            rg[h] = z ? 0.f : unif;
+        {
+            unsigned long long m = 0ull;
+            for (int i = 0; i < nh; ++i) m |= 1ull << lbr_hand[i];
+            for (int h = tid; h < R; h += LBRB_THREADS) rg[h] = (prl_lbr_hand_mask(hg, h, hole_lut) & m) ? 0.f : unif;
         }
         lbrb_normalize(rg, R, S);
 
@@ -239,7 +245,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                         const int q = t / n_boards, b = t % n_boards;
                         int8_t fb[5];
                         prl_lbr_board_at(g, S.pc, S.n_pc, b, fb);
-                        eq[q * LBRB_MAX_BOARDS + b] = prl_lbr_board_equity(g, fb, cls, cand + (size_t)q * R);
+                        eq[q * LBRB_MAX_BOARDS + b] = prl_lbr_board_equity(g, fb, cls, cand + (size_t)q * R, hole_lut);
                     }
                     prl_sync();
                     if (tid < n_q) S.wp[tid] = prl_lbr_reduce_range(g, cand + (size_t)tid * R, eq + tid * LBRB_MAX_BOARDS);
@@ -342,11 +348,10 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                 prl_sync();
                 // agent_range.update_after_new_round (PokerRange.py:60-65): the new board cards leave the range
                 const int n_new = S.n_legal, nd = S.n_dealt;
-                for (int h = tid; h < R; h += LBRB_THREADS) {
-                    bool z = false;
-                    for (int i = nd - n_new; i < nd; ++i) z |= prl_lbr_hand_has(hg, h, S.board[i]);
-                    if (z) rg[h] = 0.f;
-                }
+                unsigned long long m = 0ull;
+                for (int i = nd - n_new; i < nd; ++i) m |= 1ull << S.board[i];
+                for (int h = tid; h < R; h += LBRB_THREADS)
+                    if (prl_lbr_hand_mask(hg, h, hole_lut) & m) rg[h] = 0.f;
                 lbrb_normalize(rg, R, S);
             }
         }
@@ -384,7 +389,7 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
     P.n_deal = 2 * nh + nb; P.limit = lbr_game->game_type == PRL_GAME_LIMIT;
     P.seed = agent_seed; P.episode_base = episode_base; P.reward_scalar = reward_scalar; P.ev_normalizer = ev_normalizer;
     const int R = rules->range_size;
-    const size_t smem = ((size_t)(1 + LBRB_MAX_Q) * R + LBRB_MAX_Q * LBRB_MAX_BOARDS) * sizeof(float) + R + 16 + sizeof(LbrbShared);
+    const size_t smem = ((size_t)(1 + LBRB_MAX_Q) * R + LBRB_MAX_Q * LBRB_MAX_BOARDS) * sizeof(float) + R + 16 + (size_t)R * 2 + 16 + sizeof(LbrbShared);
     int8_t* d_cards = nullptr; float* d_win = nullptr; unsigned long long* d_stats = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = PRL_OK;

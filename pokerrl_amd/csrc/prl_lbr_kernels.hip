@@ -11,10 +11,12 @@
 
 #include "prl_device.h"
 #include "prl_host.h"
+#include "prl_kernels.h"
 #include "prl_lbr.h"
 #include "prl_rt.h"
 
 extern "C" int32_t prl_device_available(void);
+int prl_hole_lut_device(const uint16_t** out);  // prl_capi_device.hip: device-resident [1326] c1 | c2 << 8
 
 PRL_GLOBAL void prl_k_lbr_classify(PrlLbrGame g, const int8_t* __restrict__ boards, int n_boards, uint8_t* __restrict__ cls) {
     const size_t total = (size_t)n_boards * g.R;
@@ -27,11 +29,11 @@ PRL_GLOBAL void prl_k_lbr_classify(PrlLbrGame g, const int8_t* __restrict__ boar
 // the win / tie index lists of the FIRST enumerated board are applied to every board. Replicated: it defines the
 // reference's LBR numbers; cls holds that one board's classification.
 PRL_GLOBAL void prl_k_lbr_board_eq(PrlLbrGame g, const int8_t* __restrict__ boards, int n_boards, const uint8_t* __restrict__ cls,
-                                   const float* __restrict__ ranges, int n_q, float* __restrict__ eq) {
+                                   const float* __restrict__ ranges, int n_q, float* __restrict__ eq, const uint16_t* __restrict__ hole_lut) {
     const int total = n_q * n_boards;
     for (int t = (int)(prl_bid() * prl_nthreads() + prl_tid()); t < total; t += (int)(prl_nblocks() * prl_nthreads())) {
         const int q = t / n_boards, b = t % n_boards;
-        eq[t] = prl_lbr_board_equity(g, boards + (size_t)b * 5, cls, ranges + (size_t)q * g.R);
+        eq[t] = prl_lbr_board_equity(g, boards + (size_t)b * 5, cls, ranges + (size_t)q * g.R, hole_lut);
     }
 }
 
@@ -76,6 +78,8 @@ extern "C" int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t*
     else if (g.n_to_deal == 1) for (size_t i = 0; i < pc.size(); ++i) push(pc[i], -1);
     else for (size_t i = 0; i + 1 < pc.size(); ++i) for (size_t j = i + 1; j < pc.size(); ++j) push(pc[i], pc[j]);
     const int n_boards = (int)(boards.size() / 5);
+    const uint16_t* hole_lut = nullptr;  // hold'em: the process-wide (c1, c2) table of the hand evaluator
+    if (g.n_hole == 2 && prl_hole_lut_device(&hole_lut) != PRL_OK) return PRL_ERR_HIP;
     int8_t* d_boards = nullptr; uint8_t* d_cls = nullptr; float *d_rg = nullptr, *d_eq = nullptr, *d_out = nullptr;
     int rc = PRL_OK;
 #define LB_TRY(x) do { if ((x) != hipSuccess) { prl_set_error("HIP error in prl_lbr_checkdown_equity"); rc = PRL_ERR_HIP; goto done; } } while (0)
@@ -90,7 +94,7 @@ extern "C" int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t*
         const size_t items = (size_t)g.R;  // first board only
         PRL_LAUNCH(prl_k_lbr_classify, (int)((items + 255) / 256), 256, 0, nullptr, g, (const int8_t*)d_boards, 1, d_cls);
         PRL_LAUNCH(prl_k_lbr_board_eq, (n_q * n_boards + 63) / 64, 64, 0, nullptr, g, (const int8_t*)d_boards, n_boards, (const uint8_t*)d_cls,
-                   (const float*)d_rg, n_q, d_eq);
+                   (const float*)d_rg, n_q, d_eq, hole_lut);
         PRL_LAUNCH(prl_k_lbr_reduce, (n_q + 63) / 64, 64, 0, nullptr, g, n_boards, (const float*)d_rg, n_q, (const float*)d_eq, d_out);
     }
     LB_TRY(hipDeviceSynchronize());
