@@ -11,30 +11,55 @@
 #define PRL_LBR_MAX_DEAL 2   // cards still to come when LBR evaluates (flop: 2, turn: 1, river / Leduc flop: 0, Leduc pre-flop: 1)
 
 // NumPy's pairwise sum (numpy/_core/src/umath/loops_utils.h.src) over a stream: `next()` yields the elements in order. The
-// algorithm visits a[0], a[1], ... exactly once and in order, so no random access is needed. D bounds the halving depth
-// (n <= 128 * 2^D).
+// algorithm visits a[0], a[1], ... exactly once and in order, so no random access is needed. The recursion (halve until a
+// block has <= 128 elements, 8 accumulators per block) is walked with an explicit frame stack: one instance of the block
+// code, whatever n is. The template argument is kept for call-site compatibility (0 promises n <= 128).
 template <int D, class Next>
 PRL_HD PRL_INLINE float prl_np_sum_stream(int n, Next& next) {
-    if (n < 8) {
-        float res = 0.f;
-        for (int i = 0; i < n; ++i) res = res + next();
-        return res;
+    struct Frame { int n; int stage; float left; };
+    Frame fr[12];  // depth <= log2(n / 128) + 1
+    int sp = 0;
+    fr[0].n = n; fr[0].stage = 0; fr[0].left = 0.f;
+    float ret = 0.f;
+    while (sp >= 0) {
+        Frame& f = fr[sp];
+        if (f.stage == 0) {
+            if (f.n < 8) {
+                float res = 0.f;
+                for (int i = 0; i < f.n; ++i) res = res + next();
+                ret = res;
+                --sp;
+            } else if (f.n <= 128 || D == 0) {
+                float r0 = next(), r1 = next(), r2 = next(), r3 = next(), r4 = next(), r5 = next(), r6 = next(), r7 = next();
+                int i = 8;
+                for (; i < f.n - (f.n % 8); i += 8) {
+                    r0 = r0 + next(); r1 = r1 + next(); r2 = r2 + next(); r3 = r3 + next();
+                    r4 = r4 + next(); r5 = r5 + next(); r6 = r6 + next(); r7 = r7 + next();
+                }
+                float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+                for (; i < f.n; ++i) res = res + next();
+                ret = res;
+                --sp;
+            } else {
+                int n2 = f.n / 2;
+                n2 -= n2 % 8;
+                f.stage = 1;
+                fr[sp + 1].n = n2; fr[sp + 1].stage = 0; fr[sp + 1].left = 0.f;
+                ++sp;
+            }
+        } else if (f.stage == 1) {  // the left half returned
+            int n2 = f.n / 2;
+            n2 -= n2 % 8;
+            f.left = ret;
+            f.stage = 2;
+            fr[sp + 1].n = f.n - n2; fr[sp + 1].stage = 0; fr[sp + 1].left = 0.f;
+            ++sp;
+        } else {  // the right half returned
+            ret = f.left + ret;
+            --sp;
+        }
     }
-    if (n <= 128 || D == 0) {
-        float r[8];
-        for (int j = 0; j < 8; ++j) r[j] = next();
-        int i = 8;
-        for (; i < n - (n % 8); i += 8)
-            for (int j = 0; j < 8; ++j) r[j] = r[j] + next();
-        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; ++i) res = res + next();
-        return res;
-    }
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    const float a = prl_np_sum_stream<(D > 0 ? D - 1 : 0)>(n2, next);
-    const float b = prl_np_sum_stream<(D > 0 ? D - 1 : 0)>(n - n2, next);
-    return a + b;
+    return ret;
 }
 
 struct PrlLbrGame {
