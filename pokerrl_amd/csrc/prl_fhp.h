@@ -21,7 +21,24 @@ enum { PRL_SRC_REGRET = 0, PRL_SRC_UNIFORM64 = 1, PRL_SRC_ARR64 = 2, PRL_SRC_ARR
 // UPDATE0 / UPDATE1: that seat's values + regret / average update. EVAL: both seats + best response.
 // UPDATE0_EVAL: EVAL and UPDATE0 of the same strategy in one pass (the evaluation that closes iteration t and the first
 // half of iteration t + 1 read the same regrets).
-enum { PRL_FHP_UPDATE0 = 0, PRL_FHP_UPDATE1 = 1, PRL_FHP_EVAL = 2, PRL_FHP_UPDATE0_EVAL = 3 };
+// Steady state of prl_solver_iterations (two single-seat passes per iteration, PRL_FHP_* below):
+//   UPDATE1_EVAL1: seat 1's batch; after its regrets are updated the hand-local bottom-up phase runs a second time with
+//                  the NEW strategy: seat 1's value and best response against seat 0's (final) strategy of this iteration
+//                  -- seat 1's half of the exploitability, at the price of one phase E instead of a whole batch
+//   UPDATE0_BR:    seat 0's batch of the next iteration with best response: seat 0's half of the exploitability of the
+//                  previous iterate (its own strategy is still the old one) + the update
+//   EVAL0:         seat 0's batch with best response, no update (closes a run of iterations)
+enum { PRL_FHP_UPDATE0 = 0, PRL_FHP_UPDATE1 = 1, PRL_FHP_EVAL = 2, PRL_FHP_UPDATE0_EVAL = 3, PRL_FHP_UPDATE0_BR = 4, PRL_FHP_UPDATE1_EVAL1 = 5,
+       PRL_FHP_EVAL0 = 6 };
+constexpr bool prl_fhp_runs_seat(int mode, int p) {
+    return mode == PRL_FHP_EVAL || mode == PRL_FHP_UPDATE0_EVAL ? true
+         : (mode == PRL_FHP_UPDATE1 || mode == PRL_FHP_UPDATE1_EVAL1) ? p == 1 : p == 0;
+}
+constexpr bool prl_fhp_updates(int mode, int p) {
+    return p == 0 ? (mode == PRL_FHP_UPDATE0 || mode == PRL_FHP_UPDATE0_EVAL || mode == PRL_FHP_UPDATE0_BR)
+                  : (mode == PRL_FHP_UPDATE1 || mode == PRL_FHP_UPDATE1_EVAL1);
+}
+constexpr bool prl_fhp_with_br(int mode) { return mode >= PRL_FHP_EVAL; }
 
 struct PrlFhpShape {
     static constexpr int N_NODES = 15;
@@ -97,7 +114,8 @@ struct PrlFhpParams {
     int32_t avgsum_mask, avgsum_iter[2];
     const double* strat_arr;    // explicit strategy (average strategy / caller-provided), [n_cols][R]
     float* board_ev;            // [n_boards][2][R] root values of every board subtree
-    float* board_br;            // [n_boards][2][R] best-response values (PRL_FHP_EVAL)
+    float* board_br;            // [n_boards][2][R] best-response values (modes with best response); UPDATE1_EVAL1: slot 0 =
+                                // seat 1's value under its NEW strategy, slot 1 = seat 1's best response
     const uint16_t* hole_packed;// [R] c1 | c2 << 8
     int32_t plan_stride, cl_stride;
     const int16_t *plan_pos, *plan_hgs, *plan_hge, *plan_gs;

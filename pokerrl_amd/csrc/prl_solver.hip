@@ -52,6 +52,8 @@ struct prl_solver {
     prl_exchange_fn exchange = nullptr;
     void* exchange_user = nullptr;
     float *d_xlocal = nullptr, *d_xgather = nullptr, *d_xcompact = nullptr;
+    bool have_half = false;      // FUSED steady state: seat 1's half of the exploitability of the current iterate is in d_half
+    float* d_half = nullptr;     // [R] chance-summed seat-1 value under its new strategy, [R] its best response, then [2] the saved exploitability
     int avg_pending[2] = {-1, -1};  // FUSED Vanilla / Linear: iteration whose average update of that seat still has to run
     bool time_passes = false;   // prl_solver_time_iterations: bracket every board-pass launch with events
     std::vector<hipEvent_t> pass_events;
@@ -143,7 +145,7 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
     p.avg = s->d_avg;
     p.avgsum_mask = 0;
     if (&st == &s->S && strat_arr == nullptr) {
-        const bool walks[2] = {mode != PRL_FHP_UPDATE0, mode != PRL_FHP_UPDATE1};  // seat q is the opponent of a batch of 1 - q
+        const bool walks[2] = {prl_fhp_runs_seat(mode, 1), prl_fhp_runs_seat(mode, 0)};  // seat q is the opponent of a batch of 1 - q
         for (int q = 0; q < 2; ++q)
             if (walks[q] && s->avg_pending[q] >= 0) {
                 p.avgsum_mask |= 1 << q;
@@ -167,7 +169,8 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
     }
     float* dst_ev = st.ev + prl_vidx(s->T, s->chance_trunk, 0);
     float* dst_br = st.ev_br + prl_vidx(s->T, s->chance_trunk, 0);
-    const bool with_br = mode == PRL_FHP_EVAL || mode == PRL_FHP_UPDATE0_EVAL;
+    const bool with_br = prl_fhp_with_br(mode);
+    if (mode == PRL_FHP_UPDATE1_EVAL1) dst_br = s->d_half;  // (seat 1 value under the new strategy, its best response): applied after the trunk update
     if (!s->exchange) {
         prl_launch_fhp_chance_sum(s->d_board_ev, p.n_boards, p.R, s->d_sum_scratch, dst_ev, s->stream);
         if (with_br) prl_launch_fhp_chance_sum(s->d_board_br, p.n_boards, p.R, s->d_sum_scratch, dst_br, s->stream);
@@ -187,7 +190,8 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
         prl_launch_fhp_chance_finish(s->d_xcompact, n_all, s->xlevel, p.R, s->d_sum_scratch, dst_ev, s->stream);
         if (with_br) prl_launch_fhp_chance_finish(s->d_xcompact + (size_t)n_all * 2 * p.R, n_all, s->xlevel, p.R, s->d_sum_scratch, dst_br, s->stream);
     }
-    if (!with_br) PRL_HIP_TRY(hipMemcpyAsync(dst_br, dst_ev, (size_t)2 * p.R * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    if (!with_br || mode == PRL_FHP_UPDATE1_EVAL1)
+        PRL_HIP_TRY(hipMemcpyAsync(st.ev_br + prl_vidx(s->T, s->chance_trunk, 0), dst_ev, (size_t)2 * p.R * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
     PRL_HIP_TRY(hipGetLastError());
     return PRL_OK;
 }
@@ -477,6 +481,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             FAIL_IF(dev_alloc(s, &s->d_xgather, per_rank * world));
             FAIL_IF(dev_alloc(s, &s->d_xcompact, per_rank * world));
         }
+        FAIL_IF(dev_alloc(s, &s->d_half, (size_t)2 * T.R + 4));
         s->fp.regret = s->d_regret;
         s->fp.board_ev = s->d_board_ev;
         s->fp.board_br = s->d_board_br;
@@ -556,6 +561,7 @@ int32_t prl_solver_reset(prl_solver_t* s) {
     const size_t nc = (size_t)s->full_cols * s->R;
     s->iter = 0;
     s->expl_pending = false;
+    s->have_half = false;
     s->avg_pending[0] = s->avg_pending[1] = -1;
     PRL_HIP_TRY(hipMemsetAsync(s->d_regret, 0, nc * sizeof(float), s->stream));
     PRL_HIP_TRY(hipMemsetAsync(s->d_avg, 0, nc * sizeof(double), s->stream));
@@ -639,11 +645,24 @@ static int iteration_core(prl_solver* s, bool closing_eval) {
     s->fp.m_old = m_old;
     s->fp.m_new = m_new;
     for (int p = 0; p < 2; ++p) {
+        bool second_half = false;
         if (s->fused) {
-            if (p == 0 && s->expl_pending) {  // the evaluation that closes the previous iteration rides on this pass
+            const bool steady = s->src[0] == PRL_SRC_REGRET && s->src[1] == PRL_SRC_REGRET;
+            if (p == 0 && s->expl_pending && s->have_half) {
+                // seat 0's half of the previous iterate's exploitability rides on this pass; seat 1's half was computed
+                // by the pass that updated seat 1
+                TRY(do_compute_ev(s, s->S, PRL_FHP_UPDATE0_BR));
+                PRL_HIP_TRY(hipMemcpyAsync(s->S.expl + 1, s->d_half + 2 * s->R + 1, sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+                TRY(record_expl(s));
+                s->expl_pending = false;
+                s->have_half = false;
+            } else if (p == 0 && s->expl_pending) {  // the evaluation that closes the previous iteration rides on this pass
                 TRY(do_compute_ev(s, s->S, PRL_FHP_UPDATE0_EVAL));
                 TRY(record_expl(s));
                 s->expl_pending = false;
+            } else if (p == 1 && steady) {
+                TRY(do_compute_ev(s, s->S, PRL_FHP_UPDATE1_EVAL1));
+                second_half = true;
             } else TRY(do_compute_ev(s, s->S, p == 0 ? PRL_FHP_UPDATE0 : PRL_FHP_UPDATE1));
         } else TRY(ensure_ev(s));
         prl_launch_regret_strategy(s->T, s->S, s->d_nodes_p[p], s->n_nodes_p[p], p, s->variant, s->iter, s->stream);
@@ -653,6 +672,17 @@ static int iteration_core(prl_solver* s, bool closing_eval) {
         prl_launch_average(s->T, s->S, s->d_nodes_p[p], s->n_nodes_p[p], p, s->variant, s->iter, mode, m_old, m_new, s->stream);
         if (s->fused && mode) s->board_avg_f64 = mode == 2;  // the board columns were averaged inside the board pass
         if (s->fused && s->variant != PRL_CFR_PLUS) s->avg_pending[p] = s->iter;  // applied by the next pass that walks seat p
+        if (second_half) {
+            // trunk values of seat 1 under the updated strategies: the chance node takes (value, best response) of seat 1
+            // summed over the boards; seat 0's slots are stale and their results are not used
+            float* ch_ev = s->S.ev + prl_vidx(s->T, s->chance_trunk, 1);
+            float* ch_br = s->S.ev_br + prl_vidx(s->T, s->chance_trunk, 1);
+            PRL_HIP_TRY(hipMemcpyAsync(ch_ev, s->d_half, (size_t)s->R * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+            PRL_HIP_TRY(hipMemcpyAsync(ch_br, s->d_half + s->R, (size_t)s->R * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+            prl_launch_ev(s->T, s->S, s->ft.level_start.data(), s->d_term_nodes, s->n_term, s->stream);
+            PRL_HIP_TRY(hipMemcpyAsync(s->d_half + 2 * s->R + 1, s->S.expl + 1, sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+            s->have_half = true;
+        }
     }
     s->fp.avg_mode = 0;
     s->iter += 1;
@@ -661,7 +691,12 @@ static int iteration_core(prl_solver* s, bool closing_eval) {
         PRL_HIP_TRY(hipGetLastError());
         return PRL_OK;
     }
-    TRY(ensure_ev(s));
+    if (s->fused && s->have_half) {  // seat 1's half is known: seat 0's batch with best response closes the iteration
+        TRY(do_compute_ev(s, s->S, PRL_FHP_EVAL0));
+        PRL_HIP_TRY(hipMemcpyAsync(s->S.expl + 1, s->d_half + 2 * s->R + 1, sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+        s->have_half = false;
+        s->ev_valid = true;
+    } else TRY(ensure_ev(s));
     PRL_HIP_TRY(hipGetLastError());
     return record_expl(s);
 }
