@@ -130,9 +130,10 @@ bool prl_fhp_shape_matches(const PrlFlatTree& t, int* chance_node, int* first_bo
 
 int prl_launch_fhp_pass(const PrlFhpParams& prm, int mode, int src0, int src1, void* stream);
 void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_cols, void* stream);
-void prl_launch_fhp_chance_sum(const float* d_board_vals, int n_boards, int R, float* d_scratch, float* d_dest, void* stream);
+// W = floats per board / unit: 2R for both seats' vectors, R for one seat's
+void prl_launch_fhp_chance_sum(const float* d_board_vals, int n_boards, int W, float* d_scratch, float* d_dest, void* stream);
 // sharded solve (prl_solver_create_sharded): local reduction up to `level`, all-gather, then the remaining levels
 int prl_fhp_units_at_level(int n_boards, int level);
-void prl_launch_fhp_chance_partial(const float* d_board_vals, int n_boards, int level, int R, float* d_scratch, float* d_units, void* stream);
-void prl_launch_fhp_chance_finish(const float* d_units, int n_units, int level, int R, float* d_scratch, float* d_dest, void* stream);
-void prl_launch_fhp_compact_gathered(const float* d_in, int world, int n_which, int n_units, int R, float* d_out, void* stream);
+void prl_launch_fhp_chance_partial(const float* d_board_vals, int n_boards, int level, int W, float* d_scratch, float* d_units, void* stream);
+void prl_launch_fhp_chance_finish(const float* d_units, int n_units, int level, int W, float* d_scratch, float* d_dest, void* stream);
+void prl_launch_fhp_compact_gathered(const float* d_in, int world, int n_which, int n_units, int W, float* d_out, void* stream);

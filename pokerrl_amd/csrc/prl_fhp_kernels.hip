@@ -119,8 +119,8 @@ void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_co
 }
 
 // per-board [n_boards][2][R] -> dest [2][R] in the canonical nested order; scratch >= (ceil(n/32) + ceil(n/1024)) * 2R floats
-void prl_launch_fhp_chance_sum(const float* d_board_vals, int n_boards, int R, float* d_scratch, float* d_dest, void* stream) {
-    prl_launch_fhp_chance_finish(d_board_vals, n_boards, 0, R, d_scratch, d_dest, stream);
+void prl_launch_fhp_chance_sum(const float* d_board_vals, int n_boards, int W, float* d_scratch, float* d_dest, void* stream) {
+    prl_launch_fhp_chance_finish(d_board_vals, n_boards, 0, W, d_scratch, d_dest, stream);
 }
 
 // Sharded solve: a rank reduces its own boards up to `level` (0: nothing, the per-board values themselves; 1: blocks of
@@ -132,8 +132,8 @@ int prl_fhp_units_at_level(int n_boards, int level) {
     return n;
 }
 
-void prl_launch_fhp_chance_partial(const float* d_board_vals, int n_boards, int level, int R, float* d_scratch, float* d_units, void* stream) {
-    const int R2 = 2 * R;
+void prl_launch_fhp_chance_partial(const float* d_board_vals, int n_boards, int level, int W, float* d_scratch, float* d_units, void* stream) {
+    const int R2 = W;
     if (level == 0) {
         PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)n_boards * R2, 256), 256, 0, stream, d_board_vals, n_boards, 1, R2, d_units);
         return;
@@ -147,8 +147,8 @@ void prl_launch_fhp_chance_partial(const float* d_board_vals, int n_boards, int 
 }
 
 // units of `level` (contiguous [n_units][2][R]) -> dest [2][R]; scratch >= (ceil(n/32) + ceil(n/1024) + 1) * 2R floats
-void prl_launch_fhp_chance_finish(const float* d_units, int n_units, int level, int R, float* d_scratch, float* d_dest, void* stream) {
-    const int R2 = 2 * R;
+void prl_launch_fhp_chance_finish(const float* d_units, int n_units, int level, int W, float* d_scratch, float* d_dest, void* stream) {
+    const int R2 = W;
     const float* cur = d_units;
     int n = n_units;
     float* next = d_scratch;
@@ -162,7 +162,7 @@ void prl_launch_fhp_chance_finish(const float* d_units, int n_units, int level, 
     PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)R2, 256), 256, 0, stream, cur, n, n > 0 ? n : 1, R2, d_dest);
 }
 
-// all-gather layout [world][n_which][n_units][2R] -> [n_which][world * n_units][2R] (global unit order)
+// all-gather layout [world][n_which][n_units][W] -> [n_which][world * n_units][W] (global unit order)
 PRL_GLOBAL void prl_k_fhp_compact_gathered(const float* __restrict__ in, int world, int n_which, int n_units, int R2, float* __restrict__ out) {
     const size_t total = (size_t)world * n_which * n_units * R2;
     for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
@@ -174,6 +174,6 @@ PRL_GLOBAL void prl_k_fhp_compact_gathered(const float* __restrict__ in, int wor
         out[(((size_t)w * world + r) * n_units + u) * R2 + x] = in[t];
     }
 }
-void prl_launch_fhp_compact_gathered(const float* d_in, int world, int n_which, int n_units, int R, float* d_out, void* stream) {
-    PRL_LAUNCH(prl_k_fhp_compact_gathered, fhp_grid_for((size_t)world * n_which * n_units * 2 * R, 256), 256, 0, stream, d_in, world, n_which, n_units, 2 * R, d_out);
+void prl_launch_fhp_compact_gathered(const float* d_in, int world, int n_which, int n_units, int W, float* d_out, void* stream) {
+    PRL_LAUNCH(prl_k_fhp_compact_gathered, fhp_grid_for((size_t)world * n_which * n_units * W, 256), 256, 0, stream, d_in, world, n_which, n_units, W, d_out);
 }

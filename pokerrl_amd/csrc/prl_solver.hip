@@ -167,31 +167,44 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
         s->pass_events.push_back(ev0);
         s->pass_events.push_back(ev1);
     }
-    float* dst_ev = st.ev + prl_vidx(s->T, s->chance_trunk, 0);
-    float* dst_br = st.ev_br + prl_vidx(s->T, s->chance_trunk, 0);
+    // single-seat passes produce (and sum) that seat's vector only
+    const bool both = prl_fhp_runs_seat(mode, 0) && prl_fhp_runs_seat(mode, 1);
+    const int seat = prl_fhp_runs_seat(mode, 0) ? 0 : 1;
+    const int W_ev = both ? 2 * p.R : p.R;
+    const int W_br = (both || mode == PRL_FHP_UPDATE1_EVAL1) ? 2 * p.R : p.R;
+    float* dst_ev = st.ev + prl_vidx(s->T, s->chance_trunk, both ? 0 : seat);
+    float* dst_br = st.ev_br + prl_vidx(s->T, s->chance_trunk, both ? 0 : seat);
     const bool with_br = prl_fhp_with_br(mode);
     if (mode == PRL_FHP_UPDATE1_EVAL1) dst_br = s->d_half;  // (seat 1 value under the new strategy, its best response): applied after the trunk update
     if (!s->exchange) {
-        prl_launch_fhp_chance_sum(s->d_board_ev, p.n_boards, p.R, s->d_sum_scratch, dst_ev, s->stream);
-        if (with_br) prl_launch_fhp_chance_sum(s->d_board_br, p.n_boards, p.R, s->d_sum_scratch, dst_br, s->stream);
+        prl_launch_fhp_chance_sum(s->d_board_ev, p.n_boards, W_ev, s->d_sum_scratch, dst_ev, s->stream);
+        if (with_br) prl_launch_fhp_chance_sum(s->d_board_br, p.n_boards, W_br, s->d_sum_scratch, dst_br, s->stream);
     } else {
-        // local units -> all-gather -> remaining levels over all units in global order (header: prl_solver_create_sharded)
-        const int n_which = with_br ? 2 : 1;
-        const size_t unit_floats = (size_t)s->n_units * 2 * p.R;
-        prl_launch_fhp_chance_partial(s->d_board_ev, p.n_boards, s->xlevel, p.R, s->d_sum_scratch, s->d_xlocal, s->stream);
-        if (with_br) prl_launch_fhp_chance_partial(s->d_board_br, p.n_boards, s->xlevel, p.R, s->d_sum_scratch, s->d_xlocal + unit_floats, s->stream);
+        // local units -> all-gather -> remaining levels over all units in global order (header: prl_solver_create_sharded);
+        // one exchange carries the value units and, behind them, the best-response units
+        const size_t ev_floats = (size_t)s->n_units * W_ev, br_floats = with_br ? (size_t)s->n_units * W_br : 0;
+        prl_launch_fhp_chance_partial(s->d_board_ev, p.n_boards, s->xlevel, W_ev, s->d_sum_scratch, s->d_xlocal, s->stream);
+        if (with_br) prl_launch_fhp_chance_partial(s->d_board_br, p.n_boards, s->xlevel, W_br, s->d_sum_scratch, s->d_xlocal + ev_floats, s->stream);
         PRL_HIP_TRY(hipStreamSynchronize(s->stream));
-        if (s->exchange(s->exchange_user, s->d_xlocal, s->d_xgather, (uint64_t)(n_which * unit_floats * sizeof(float))) != 0) {
+        const size_t per_rank = ev_floats + br_floats;
+        if (s->exchange(s->exchange_user, s->d_xlocal, s->d_xgather, (uint64_t)(per_rank * sizeof(float))) != 0) {
             prl_set_error("sharded solve: the exchange callback failed");
             return PRL_ERR_STATE;
         }
-        prl_launch_fhp_compact_gathered(s->d_xgather, s->world, n_which, s->n_units, p.R, s->d_xcompact, s->stream);
+        // rank r's block = [ev units | br units]: compact each part into global unit order
         const int n_all = s->world * s->n_units;
-        prl_launch_fhp_chance_finish(s->d_xcompact, n_all, s->xlevel, p.R, s->d_sum_scratch, dst_ev, s->stream);
-        if (with_br) prl_launch_fhp_chance_finish(s->d_xcompact + (size_t)n_all * 2 * p.R, n_all, s->xlevel, p.R, s->d_sum_scratch, dst_br, s->stream);
+        float* c_ev = s->d_xcompact;
+        float* c_br = s->d_xcompact + (size_t)n_all * W_ev;
+        for (int r = 0; r < s->world; ++r) {
+            const float* src = s->d_xgather + (size_t)r * per_rank;
+            PRL_HIP_TRY(hipMemcpyAsync(c_ev + (size_t)r * ev_floats, src, ev_floats * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+            if (with_br) PRL_HIP_TRY(hipMemcpyAsync(c_br + (size_t)r * br_floats, src + ev_floats, br_floats * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+        }
+        prl_launch_fhp_chance_finish(c_ev, n_all, s->xlevel, W_ev, s->d_sum_scratch, dst_ev, s->stream);
+        if (with_br) prl_launch_fhp_chance_finish(c_br, n_all, s->xlevel, W_br, s->d_sum_scratch, dst_br, s->stream);
     }
     if (!with_br || mode == PRL_FHP_UPDATE1_EVAL1)
-        PRL_HIP_TRY(hipMemcpyAsync(st.ev_br + prl_vidx(s->T, s->chance_trunk, 0), dst_ev, (size_t)2 * p.R * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+        PRL_HIP_TRY(hipMemcpyAsync(st.ev_br + prl_vidx(s->T, s->chance_trunk, both ? 0 : seat), dst_ev, (size_t)W_ev * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
     PRL_HIP_TRY(hipGetLastError());
     return PRL_OK;
 }
@@ -528,12 +541,12 @@ int32_t prl_chance_sum_host(const float* board_values, int32_t n_boards, int32_t
     CS_TRY(hipMalloc((void**)&d_compact, (size_t)world * n_units * R2 * sizeof(float)));
     CS_TRY(hipMalloc((void**)&d_out, R2 * sizeof(float)));
     CS_TRY(hipMemcpy(d_vals, board_values, nv * sizeof(float), hipMemcpyHostToDevice));
-    if (world == 1) prl_launch_fhp_chance_sum(d_vals, n_boards, R, d_scratch, d_out, nullptr);
+    if (world == 1) prl_launch_fhp_chance_sum(d_vals, n_boards, 2 * R, d_scratch, d_out, nullptr);
     else {
         for (int r = 0; r < world; ++r)  // rank r's units land where the all-gather would put them
-            prl_launch_fhp_chance_partial(d_vals + (size_t)r * n_local * R2, n_local, level, R, d_scratch, d_gather + (size_t)r * n_units * R2, nullptr);
-        prl_launch_fhp_compact_gathered(d_gather, world, 1, n_units, R, d_compact, nullptr);
-        prl_launch_fhp_chance_finish(d_compact, world * n_units, level, R, d_scratch, d_out, nullptr);
+            prl_launch_fhp_chance_partial(d_vals + (size_t)r * n_local * R2, n_local, level, 2 * R, d_scratch, d_gather + (size_t)r * n_units * R2, nullptr);
+        prl_launch_fhp_compact_gathered(d_gather, world, 1, n_units, 2 * R, d_compact, nullptr);
+        prl_launch_fhp_chance_finish(d_compact, world * n_units, level, 2 * R, d_scratch, d_out, nullptr);
     }
     CS_TRY(hipDeviceSynchronize());
     CS_TRY(hipMemcpy(out, d_out, R2 * sizeof(float), hipMemcpyDeviceToHost));
