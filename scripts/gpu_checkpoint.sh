@@ -1,4 +1,4 @@
-# round-1 checkpoint: full GPU test-suite, smoke, bench (+cpu baseline), rocprofv3 kernel trace, PMC passes. args: tag
+# checkpoint run on the GPU box (gpurun -- bash scripts/gpu_checkpoint.sh TAG): full GPU test-suite, smoke, bench (+cpu baseline), rocprofv3 kernel trace, PMC passes. args: tag
 cd $GRAFT_REPO_ROOT; TAG=${1:-e}; mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_$TAG.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_$TAG.log
 tail -5 gpurun_out/pytest_$TAG.log
