@@ -221,6 +221,12 @@ int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t de
 typedef int32_t (*prl_exchange_fn)(void* user, const void* local_dev, void* gathered_dev, uint64_t bytes_per_rank);
 int32_t prl_solver_create_sharded(const prl_tree_t* local_tree, int32_t variant, int32_t delay, int32_t world_size, int32_t rank,
                                   prl_exchange_fn exchange, void* user, prl_solver_t** out_solver);
+/* Stream-ordered exchange: by default the solver drains its stream before it calls `exchange` and expects the gathered
+ * buffer to be complete when the callback returns. A callback that ENQUEUES the collective on the solver's own stream
+ * (prl_solver_get_stream; e.g. ncclAllGather(..., stream), or torch.distributed under torch.cuda.ExternalStream) needs
+ * neither: prl_solver_set_exchange_async(solver, 1) removes the host synchronisation on both sides. */
+int32_t prl_solver_get_stream(prl_solver_t* solver, void** out_hip_stream);
+int32_t prl_solver_set_exchange_async(prl_solver_t* solver, int32_t stream_ordered);
 /* The canonical chance-node sum on its own (host buffers in / out, device kernels inside): values [n_boards][2][R] ->
  * out [2][R]. world_size > 1 replays the sharded path on one device (every rank's partial units at the level the shard
  * size allows, rank-major gather, finish); the result must not depend on world_size. n_boards % world_size == 0. */

@@ -145,6 +145,10 @@ def _bind_solver(L):
     L.prl_lbr_batch_run.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), i32, i32, i32, i32,
                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.prl_lbr_batch_run.restype = i32
+    L.prl_solver_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    L.prl_solver_get_stream.restype = i32
+    L.prl_solver_set_exchange_async.argtypes = [vp, i32]
+    L.prl_solver_set_exchange_async.restype = i32
     L.prl_chance_sum_host.argtypes = [vp, i32, i32, i32, vp]
     L.prl_chance_sum_host.restype = i32
     L.prl_solver_get.argtypes = [vp, i32, vp]
@@ -314,6 +318,12 @@ class NativeSolver:
                                                     ctypes.byref(self._h)), self._L)
         else:
             check(self._L.prl_solver_create_ex(tree.handle, v, int(delay), e, ctypes.byref(self._h)), self._L)
+        if shard is not None and hasattr(shard[2], "bind_stream"):
+            # a stream-ordered exchange (RCCL under the solver's own stream): no host synchronisation per pass
+            sp = ctypes.c_void_p()
+            check(self._L.prl_solver_get_stream(self._h, ctypes.byref(sp)), self._L)
+            if shard[2].bind_stream(sp.value or 0):
+                check(self._L.prl_solver_set_exchange_async(self._h, 1), self._L)
         self.n_nodes, self.n_cols, self.R = tree.n_nodes, tree.n_cols, tree.range_size
         eng = np.zeros(1, np.int32)
         self._call("prl_solver_get", SF["engine"], _ptr(eng))

@@ -50,6 +50,7 @@ struct prl_solver {
     // sharded solve (prl_solver_create_sharded)
     int world = 1, rank = 0, xlevel = 0, n_units = 0;  // summation level exchanged, units per rank
     prl_exchange_fn exchange = nullptr;
+    bool exchange_async = false;  // the callback enqueues on s->stream: no host synchronisation around it
     void* exchange_user = nullptr;
     float *d_xlocal = nullptr, *d_xgather = nullptr, *d_xcompact = nullptr;
     bool have_half = false;      // FUSED steady state: seat 1's half of the exploitability of the current iterate is in d_half
@@ -185,7 +186,7 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
         const size_t ev_floats = (size_t)s->n_units * W_ev, br_floats = with_br ? (size_t)s->n_units * W_br : 0;
         prl_launch_fhp_chance_partial(s->d_board_ev, p.n_boards, s->xlevel, W_ev, s->d_sum_scratch, s->d_xlocal, s->stream);
         if (with_br) prl_launch_fhp_chance_partial(s->d_board_br, p.n_boards, s->xlevel, W_br, s->d_sum_scratch, s->d_xlocal + ev_floats, s->stream);
-        PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+        if (!s->exchange_async) PRL_HIP_TRY(hipStreamSynchronize(s->stream));
         const size_t per_rank = ev_floats + br_floats;
         if (s->exchange(s->exchange_user, s->d_xlocal, s->d_xgather, (uint64_t)(per_rank * sizeof(float))) != 0) {
             prl_set_error("sharded solve: the exchange callback failed");
@@ -523,6 +524,18 @@ int32_t prl_solver_create_sharded(const prl_tree_t* local_tree, int32_t variant,
     if (world_size > 1 && !exchange) { prl_set_error("sharded solve needs an exchange callback"); return PRL_ERR_ARG; }
     // with a callback the exchange path is taken even for world_size 1 (a one-rank all-gather): same code on any world size
     return solver_create_impl(local_tree, variant, delay, exchange ? PRL_ENGINE_FUSED : PRL_ENGINE_AUTO, world_size, rank, exchange, user, out);
+}
+
+int32_t prl_solver_get_stream(prl_solver_t* s, void** out) {
+    if (!s || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
+    *out = (void*)s->stream;
+    return PRL_OK;
+}
+
+int32_t prl_solver_set_exchange_async(prl_solver_t* s, int32_t on) {
+    if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }
+    s->exchange_async = on != 0;
+    return PRL_OK;
 }
 
 int32_t prl_chance_sum_host(const float* board_values, int32_t n_boards, int32_t R, int32_t world, float* out) {

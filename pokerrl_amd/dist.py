@@ -35,6 +35,17 @@ class TorchExchange:
         self.bytes = 0
         self.seconds = 0.0
         self._views = {}  # the solver's exchange buffers never move: wrap each (pointer, size) once
+        self._stream = None
+
+    def bind_stream(self, hip_stream_ptr):
+        """Called by NativeSolver with its HIP stream. With the nccl backend the collective is enqueued under that stream
+        (torch.cuda.ExternalStream): ProcessGroupNCCL orders it after the stream's pending kernels and makes the stream wait
+        for its completion, so neither side blocks the host. Returns True if the exchange is now stream-ordered. The reset
+        at solver creation already ran one exchange the synchronous way."""
+        if self.device != "cuda" or dist.get_backend(self.group) != "nccl" or not hip_stream_ptr:
+            return False
+        self._stream = torch.cuda.ExternalStream(hip_stream_ptr)
+        return True
 
     def _view(self, ptr, nbytes):
         key = (ptr, nbytes)
@@ -56,9 +67,12 @@ class TorchExchange:
             host = torch.empty(nbytes * self.world, dtype=torch.uint8)
             dist.all_gather_into_tensor(host, local.cpu(), group=self.group)
             gathered.copy_(host)
+        elif self._stream is not None:
+            with torch.cuda.stream(self._stream):
+                dist.all_gather_into_tensor(gathered, local, group=self.group)
         else:
             dist.all_gather_into_tensor(gathered, local, group=self.group)
-        if self.device == "cuda":
+        if self.device == "cuda" and self._stream is None:
             torch.cuda.synchronize()  # the solver's own stream continues only after the gathered buffer is complete
         self.calls += 1
         self.bytes += nbytes * self.world
