@@ -39,6 +39,11 @@ constexpr bool prl_fhp_updates(int mode, int p) {
                   : (mode == PRL_FHP_UPDATE1 || mode == PRL_FHP_UPDATE1_EVAL1);
 }
 constexpr bool prl_fhp_with_br(int mode) { return mode >= PRL_FHP_EVAL; }
+// root vectors a pass stores per board (row length of PrlFhpParams::board_out in units of R), see prl_k_fhp_pass
+constexpr int prl_fhp_out_width(int mode) {
+    return mode == PRL_FHP_UPDATE1_EVAL1 ? 3
+         : (prl_fhp_runs_seat(mode, 0) && prl_fhp_runs_seat(mode, 1) ? 2 : 1) * (prl_fhp_with_br(mode) ? 2 : 1);
+}
 
 struct PrlFhpShape {
     static constexpr int N_NODES = 15;
@@ -113,9 +118,7 @@ struct PrlFhpParams {
     float* avg_sum;             // [n_cols][R] node.data["avg_strat_sum"] (VanillaCFR.py:40-55, LinearCFR.py:41-57)
     int32_t avgsum_mask, avgsum_iter[2];
     const double* strat_arr;    // explicit strategy (average strategy / caller-provided), [n_cols][R]
-    float* board_ev;            // [n_boards][2][R] root values of every board subtree
-    float* board_br;            // [n_boards][2][R] best-response values (modes with best response); UPDATE1_EVAL1: slot 0 =
-                                // seat 1's value under its NEW strategy, slot 1 = seat 1's best response
+    float* board_out;           // [n_boards][prl_fhp_out_width(mode)][R] root vectors of every board subtree
     const uint16_t* hole_packed;// [R] c1 | c2 << 8
     int32_t plan_stride, cl_stride;
     const int16_t *plan_pos, *plan_hgs, *plan_hge, *plan_gs;

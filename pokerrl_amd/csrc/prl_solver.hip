@@ -52,8 +52,10 @@ struct prl_solver {
     prl_exchange_fn exchange = nullptr;
     bool exchange_async = false;  // the callback enqueues on s->stream: no host synchronisation around it
     void* exchange_user = nullptr;
-    float *d_xlocal = nullptr, *d_xgather = nullptr, *d_xcompact = nullptr;
+    float *d_xlocal = nullptr, *d_xgather = nullptr;
     bool have_half = false;      // FUSED steady state: seat 1's half of the exploitability of the current iterate is in d_half
+    float* d_board_out = nullptr;  // [n_boards][<= 4][R] root vectors of the last board pass
+    float* d_row_sum = nullptr;    // [<= 4][R] their canonical sum
     float* d_half = nullptr;     // [R] chance-summed seat-1 value under its new strategy, [R] its best response, then [2] the saved exploitability
     int avg_pending[2] = {-1, -1};  // FUSED Vanilla / Linear: iteration whose average update of that seat still has to run
     bool time_passes = false;   // prl_solver_time_iterations: bracket every board-pass launch with events
@@ -61,8 +63,6 @@ struct prl_solver {
     bool expl_pending = false;  // FUSED, inside prl_solver_iterations: exploitability of the current iterate not evaluated yet
     PrlFhpParams fp{};
     int chance_trunk = -1;    // trunk id of the chance node
-    float* d_board_ev = nullptr;
-    float* d_board_br = nullptr;
     float* d_sum_scratch = nullptr;
     double* d_user_strategy = nullptr;  // [full_cols][R], explicit strategy (prl_solver_set_strategy), lazily allocated
     int user_strategy_f64 = -1;         // -1: strategy comes from regrets / uniform
@@ -168,44 +168,42 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
         s->pass_events.push_back(ev0);
         s->pass_events.push_back(ev1);
     }
-    // single-seat passes produce (and sum) that seat's vector only
+    // one canonical sum over the boards' rows (every vector of the row at once), then the pieces go to their places in the
+    // trunk's chance node: value(s) -> ev, best response(s) -> ev_br (UPDATE1_EVAL1: kept in d_half until the trunk is updated)
     const bool both = prl_fhp_runs_seat(mode, 0) && prl_fhp_runs_seat(mode, 1);
     const int seat = prl_fhp_runs_seat(mode, 0) ? 0 : 1;
-    const int W_ev = both ? 2 * p.R : p.R;
-    const int W_br = (both || mode == PRL_FHP_UPDATE1_EVAL1) ? 2 * p.R : p.R;
-    float* dst_ev = st.ev + prl_vidx(s->T, s->chance_trunk, both ? 0 : seat);
-    float* dst_br = st.ev_br + prl_vidx(s->T, s->chance_trunk, both ? 0 : seat);
     const bool with_br = prl_fhp_with_br(mode);
-    if (mode == PRL_FHP_UPDATE1_EVAL1) dst_br = s->d_half;  // (seat 1 value under the new strategy, its best response): applied after the trunk update
+    const int W = prl_fhp_out_width(mode) * p.R;
+    float* summed = s->d_row_sum;
     if (!s->exchange) {
-        prl_launch_fhp_chance_sum(s->d_board_ev, p.n_boards, W_ev, s->d_sum_scratch, dst_ev, s->stream);
-        if (with_br) prl_launch_fhp_chance_sum(s->d_board_br, p.n_boards, W_br, s->d_sum_scratch, dst_br, s->stream);
+        prl_launch_fhp_chance_sum(s->d_board_out, p.n_boards, W, s->d_sum_scratch, summed, s->stream);
     } else {
-        // local units -> all-gather -> remaining levels over all units in global order (header: prl_solver_create_sharded);
-        // one exchange carries the value units and, behind them, the best-response units
-        const size_t ev_floats = (size_t)s->n_units * W_ev, br_floats = with_br ? (size_t)s->n_units * W_br : 0;
-        prl_launch_fhp_chance_partial(s->d_board_ev, p.n_boards, s->xlevel, W_ev, s->d_sum_scratch, s->d_xlocal, s->stream);
-        if (with_br) prl_launch_fhp_chance_partial(s->d_board_br, p.n_boards, s->xlevel, W_br, s->d_sum_scratch, s->d_xlocal + ev_floats, s->stream);
+        // local units -> all-gather -> remaining levels over all units in global order (header: prl_solver_create_sharded)
+        const size_t per_rank = (size_t)s->n_units * W;
+        prl_launch_fhp_chance_partial(s->d_board_out, p.n_boards, s->xlevel, W, s->d_sum_scratch, s->d_xlocal, s->stream);
         if (!s->exchange_async) PRL_HIP_TRY(hipStreamSynchronize(s->stream));
-        const size_t per_rank = ev_floats + br_floats;
         if (s->exchange(s->exchange_user, s->d_xlocal, s->d_xgather, (uint64_t)(per_rank * sizeof(float))) != 0) {
             prl_set_error("sharded solve: the exchange callback failed");
             return PRL_ERR_STATE;
         }
-        // rank r's block = [ev units | br units]: compact each part into global unit order
-        const int n_all = s->world * s->n_units;
-        float* c_ev = s->d_xcompact;
-        float* c_br = s->d_xcompact + (size_t)n_all * W_ev;
-        for (int r = 0; r < s->world; ++r) {
-            const float* src = s->d_xgather + (size_t)r * per_rank;
-            PRL_HIP_TRY(hipMemcpyAsync(c_ev + (size_t)r * ev_floats, src, ev_floats * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-            if (with_br) PRL_HIP_TRY(hipMemcpyAsync(c_br + (size_t)r * br_floats, src + ev_floats, br_floats * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-        }
-        prl_launch_fhp_chance_finish(c_ev, n_all, s->xlevel, W_ev, s->d_sum_scratch, dst_ev, s->stream);
-        if (with_br) prl_launch_fhp_chance_finish(c_br, n_all, s->xlevel, W_br, s->d_sum_scratch, dst_br, s->stream);
+        // rank-major blocks of whole units = global unit order already
+        prl_launch_fhp_chance_finish(s->d_xgather, s->world * s->n_units, s->xlevel, W, s->d_sum_scratch, summed, s->stream);
     }
-    if (!with_br || mode == PRL_FHP_UPDATE1_EVAL1)
-        PRL_HIP_TRY(hipMemcpyAsync(st.ev_br + prl_vidx(s->T, s->chance_trunk, both ? 0 : seat), dst_ev, (size_t)W_ev * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    const size_t vec = (size_t)p.R * sizeof(float);
+    float* ch_ev = st.ev + prl_vidx(s->T, s->chance_trunk, 0);
+    float* ch_br = st.ev_br + prl_vidx(s->T, s->chance_trunk, 0);
+    auto put = [&](float* dst, int k, int n_vec) { return hipMemcpyAsync(dst, summed + (size_t)k * p.R, n_vec * vec, hipMemcpyDeviceToDevice, s->stream); };
+    if (both) {
+        PRL_HIP_TRY(put(ch_ev, 0, 2));
+        PRL_HIP_TRY(put(ch_br, with_br ? 2 : 0, 2));
+    } else if (mode == PRL_FHP_UPDATE1_EVAL1) {
+        PRL_HIP_TRY(put(ch_ev + p.R, 0, 1));
+        PRL_HIP_TRY(put(ch_br + p.R, 0, 1));
+        PRL_HIP_TRY(put(s->d_half, 1, 2));  // (seat 1 value under the new strategy, its best response): applied after the trunk update
+    } else {
+        PRL_HIP_TRY(put(ch_ev + (size_t)seat * p.R, 0, 1));
+        PRL_HIP_TRY(put(ch_br + (size_t)seat * p.R, with_br ? 1 : 0, 1));
+    }
     PRL_HIP_TRY(hipGetLastError());
     return PRL_OK;
 }
@@ -481,24 +479,22 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     FAIL_IF(alloc_node_vectors(s, &s->S, true));
     if (fused) {
         const size_t bv = (size_t)full.n_boards * 2 * T.R;
-        FAIL_IF(dev_alloc(s, &s->d_board_ev, bv));
-        FAIL_IF(dev_alloc(s, &s->d_board_br, bv));
+        FAIL_IF(dev_alloc(s, &s->d_board_out, 2 * bv));
+        FAIL_IF(dev_alloc(s, &s->d_row_sum, (size_t)4 * T.R));
         const size_t n_blk = ((size_t)full.n_boards * world + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;  // sized for the global board list
         const size_t n_grp = (n_blk + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
-        FAIL_IF(dev_alloc(s, &s->d_sum_scratch, (n_blk + n_grp + 1) * 2 * T.R));
+        FAIL_IF(dev_alloc(s, &s->d_sum_scratch, (n_blk + n_grp + 1) * 4 * T.R));  // rows of up to 4 vectors
         if (exchange) {
             // exchange whole canonical units: the highest summation level the shard size is a multiple of
             s->xlevel = full.n_boards % (PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK) == 0 ? 2 : full.n_boards % PRL_CHANCE_BLOCK == 0 ? 1 : 0;
             s->n_units = prl_fhp_units_at_level(full.n_boards, s->xlevel);
-            const size_t per_rank = (size_t)2 * s->n_units * 2 * T.R;  // [ev, br][units][2][R]
+            const size_t per_rank = (size_t)s->n_units * 4 * T.R;  // [units][<= 4 vectors][R]
             FAIL_IF(dev_alloc(s, &s->d_xlocal, per_rank));
             FAIL_IF(dev_alloc(s, &s->d_xgather, per_rank * world));
-            FAIL_IF(dev_alloc(s, &s->d_xcompact, per_rank * world));
         }
         FAIL_IF(dev_alloc(s, &s->d_half, (size_t)2 * T.R + 4));
         s->fp.regret = s->d_regret;
-        s->fp.board_ev = s->d_board_ev;
-        s->fp.board_br = s->d_board_br;
+        s->fp.board_out = s->d_board_out;
 #ifdef PRL_FHP_TIMING
         FAIL_IF(dev_alloc(s, &s->fp.timing, (size_t)8));
         PRL_HIP_TRY(hipMemsetAsync(s->fp.timing, 0, 8 * sizeof(unsigned long long), s->stream));
