@@ -56,7 +56,7 @@ struct prl_solver {
     bool have_half = false;      // FUSED steady state: seat 1's half of the exploitability of the current iterate is in d_half
     float* d_board_out = nullptr;  // [n_boards][<= 4][R] root vectors of the last board pass
     float* d_row_sum = nullptr;    // [<= 4][R] their canonical sum
-    float* d_half = nullptr;     // [R] chance-summed seat-1 value under its new strategy, [R] its best response, then [2] the saved exploitability
+    float* d_half = nullptr;     // [R] chance-summed seat-1 value under its new strategy, [R] its best response
     int avg_pending[2] = {-1, -1};  // FUSED Vanilla / Linear: iteration whose average update of that seat still has to run
     bool time_passes = false;   // prl_solver_time_iterations: bracket every board-pass launch with events
     std::vector<hipEvent_t> pass_events;
@@ -203,6 +203,12 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
     } else {
         PRL_HIP_TRY(put(ch_ev + (size_t)seat * p.R, 0, 1));
         PRL_HIP_TRY(put(ch_br + (size_t)seat * p.R, with_br ? 1 : 0, 1));
+        if (seat == 0 && with_br && s->have_half && &st == &s->S) {
+            // seat 1's half of the same iterate (its value and best response under the current strategies, left by the pass
+            // that updated it) completes the chance node: the trunk evaluation that follows yields both exploitabilities
+            PRL_HIP_TRY(hipMemcpyAsync(ch_ev + p.R, s->d_half, vec, hipMemcpyDeviceToDevice, s->stream));
+            PRL_HIP_TRY(hipMemcpyAsync(ch_br + p.R, s->d_half + p.R, vec, hipMemcpyDeviceToDevice, s->stream));
+        }
     }
     PRL_HIP_TRY(hipGetLastError());
     return PRL_OK;
@@ -601,6 +607,7 @@ int32_t prl_solver_fill_uniform(prl_solver_t* s) {  // PublicTree.fill_uniform_r
     prl_launch_fill_uniform(s->T, s->S, s->d_col_node, s->stream);
     s->src[0] = s->src[1] = PRL_SRC_UNIFORM64;
     s->user_strategy_f64 = -1;
+    s->have_half = false;
     s->ev_valid = false;
     return do_update_reach(s, s->S);
 }
@@ -674,7 +681,6 @@ static int iteration_core(prl_solver* s, bool closing_eval) {
                 // seat 0's half of the previous iterate's exploitability rides on this pass; seat 1's half was computed
                 // by the pass that updated seat 1
                 TRY(do_compute_ev(s, s->S, PRL_FHP_UPDATE0_BR));
-                PRL_HIP_TRY(hipMemcpyAsync(s->S.expl + 1, s->d_half + 2 * s->R + 1, sizeof(float), hipMemcpyDeviceToDevice, s->stream));
                 TRY(record_expl(s));
                 s->expl_pending = false;
                 s->have_half = false;
@@ -694,17 +700,7 @@ static int iteration_core(prl_solver* s, bool closing_eval) {
         prl_launch_average(s->T, s->S, s->d_nodes_p[p], s->n_nodes_p[p], p, s->variant, s->iter, mode, m_old, m_new, s->stream);
         if (s->fused && mode) s->board_avg_f64 = mode == 2;  // the board columns were averaged inside the board pass
         if (s->fused && s->variant != PRL_CFR_PLUS) s->avg_pending[p] = s->iter;  // applied by the next pass that walks seat p
-        if (second_half) {
-            // trunk values of seat 1 under the updated strategies: the chance node takes (value, best response) of seat 1
-            // summed over the boards; seat 0's slots are stale and their results are not used
-            float* ch_ev = s->S.ev + prl_vidx(s->T, s->chance_trunk, 1);
-            float* ch_br = s->S.ev_br + prl_vidx(s->T, s->chance_trunk, 1);
-            PRL_HIP_TRY(hipMemcpyAsync(ch_ev, s->d_half, (size_t)s->R * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-            PRL_HIP_TRY(hipMemcpyAsync(ch_br, s->d_half + s->R, (size_t)s->R * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-            prl_launch_ev(s->T, s->S, s->ft.level_start.data(), s->d_term_nodes, s->n_term, s->stream);
-            PRL_HIP_TRY(hipMemcpyAsync(s->d_half + 2 * s->R + 1, s->S.expl + 1, sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-            s->have_half = true;
-        }
+        if (second_half) s->have_half = true;  // d_half: seat 1's value / best response under the updated strategies
     }
     s->fp.avg_mode = 0;
     s->iter += 1;
@@ -715,7 +711,6 @@ static int iteration_core(prl_solver* s, bool closing_eval) {
     }
     if (s->fused && s->have_half) {  // seat 1's half is known: seat 0's batch with best response closes the iteration
         TRY(do_compute_ev(s, s->S, PRL_FHP_EVAL0));
-        PRL_HIP_TRY(hipMemcpyAsync(s->S.expl + 1, s->d_half + 2 * s->R + 1, sizeof(float), hipMemcpyDeviceToDevice, s->stream));
         s->have_half = false;
         s->ev_valid = true;
     } else TRY(ensure_ev(s));
