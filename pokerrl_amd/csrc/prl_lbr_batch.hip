@@ -24,7 +24,7 @@
 
 extern "C" int32_t prl_device_available(void);
 
-#define LBRB_THREADS 256
+#define LBRB_THREADS 576
 #define LBRB_MAX_Q 13      // check/call + up to 12 raise sizes considered by LBR
 #define LBRB_MAX_BOARDS 64  // boards per equity: at most one card to come (52-card turn: 46)
 
