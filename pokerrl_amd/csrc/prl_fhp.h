@@ -17,7 +17,8 @@
 #include "prl_solver_types.h"
 #include "prl_tree.h"
 
-enum { PRL_SRC_REGRET = 0, PRL_SRC_UNIFORM64 = 1, PRL_SRC_ARR64 = 2, PRL_SRC_ARR32 = 3 };
+enum { PRL_SRC_REGRET = 0, PRL_SRC_UNIFORM64 = 1, PRL_SRC_ARR64 = 2, PRL_SRC_ARR32 = 3,
+       PRL_SRC_STRAT32 = 4 /* kernel-internal: the register file already holds float32 strategies */ };
 // UPDATE0 / UPDATE1: that seat's values + regret / average update. EVAL: both seats + best response.
 // UPDATE0_EVAL: EVAL and UPDATE0 of the same strategy in one pass (the evaluation that closes iteration t and the first
 // half of iteration t + 1 read the same regrets).
