@@ -1,0 +1,64 @@
+"""
+bench_handeval.py -- 7-card hand evaluations/s: all 1326 hole-card pairs on B seeded 5-card boards, device buffers in and out
+(prl_hand_rank_boards_device = get_hand_rank_all_hands_on_given_boards_52_holdem of the reference, CppHandeval.py:34-46).
+Algorithmic bytes: 5 B of board in + 4 B per (board, hand) out; the kernel is bound by integer ALU issue and the int32 store
+(SURVEY.md section 8d). The CPU figure beside it is the C oracle's evaluator on one core.
+
+    python bench_handeval.py [--boards B] [--reps K]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--boards", type=int, default=1 << 17)
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
+    import torch
+    import bench
+    import oracle
+    from pokerrl_amd import _native
+    _native.require_device()
+    L = _native.lib()
+    boards = bench.seeded_boards(args.boards, 0)
+    d_b = torch.from_numpy(boards.astype(np.int8)).cuda()
+    d_o = torch.empty((args.boards, 1326), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    import ctypes
+    L.prl_hand_rank_boards_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+
+    def run():
+        assert L.prl_hand_rank_boards_device(d_b.data_ptr(), args.boards, d_o.data_ptr(), None) == 0
+
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.reps
+    evals = args.boards * 1326
+    n_cpu = 2000
+    t0 = time.perf_counter()
+    ref = oracle.rank_boards(boards[:n_cpu])
+    cpu = n_cpu * 1326 / (time.perf_counter() - t0)
+    assert np.array_equal(d_o[:n_cpu].cpu().numpy(), ref)
+    print(json.dumps({"metric": "7-card hand evaluations/s (all 1326 hands on given boards)", "value": evals / (ms * 1e-3), "unit": "evals/s",
+                      "boards": args.boards, "ms_per_call": ms, "achieved_GBps_store": evals * 4 / (ms * 1e-3) / 1e9,
+                      "cpu_baseline": {"value": cpu, "unit": "evals/s", "cores": 1, "kind": "port", "sample": "%d boards, oracle/prl_oracle.c" % n_cpu},
+                      "data": "synthetic"}))
+
+
+if __name__ == "__main__":
+    main()
