@@ -1,4 +1,4 @@
-// Fused board-block kernels ("engine F") for the Flop5Holdem public tree: CFR+ on 1326-hand ranges with every per-node
+// Fused board-block kernels ("engine F") for the Flop5Holdem public tree: CFR / CFR+ / Linear CFR on 1326-hand ranges with every per-node
 // vector of a board subtree kept ON CHIP.
 //
 // Why: the reference materialises reach / ev / ev_br for every node ([2][R] float32 each, nodes.py:33-36). On the FHP tree
@@ -6,15 +6,15 @@
 // each chance outcome the board subtree is independent (ValueFiller.py:76-78 is a plain sum over boards), its shape is the
 // same for every board (betting never looks at the cards) and per hand everything except terminal equity is hand-local.
 // So: one workgroup walks ONE board subtree depth-first with the subtree shape known at COMPILE time (prl_fhp_shape.h):
-//   * 512 lanes x 3 hand slots cover the 1326 hands; reach / ev / regrets of the current DFS path live in VGPRs;
-//   * HBM traffic per board and pass: 14 regret columns in, the updated seat's 7 columns out, the board's [2][R] root
-//     values out, ~20 KB of showdown plan in -- nothing else;
-//   * the only cross-hand step, terminal equity, goes through LDS in the rank-sorted domain: wave-64 scans over the
-//     sorted range (2 waves) and over the 47 per-card blocker lists (6 waves), the canonical order of DESIGN.md, so the
-//     result is bit-identical to engine G (prl_tree_kernels.hip) and to the CPU oracle;
+//   * 704 lanes x 2 adjacent hands cover the 1326 hands; reach / ev / regrets of the current DFS path live in VGPRs;
+//   * HBM traffic per board and pass: 14 regret columns + ~15 KB of showdown plan in (prefetched into LDS by LDS-DMA while
+//     the previous board is walked), the updated seat's 7 regret columns and float64 average columns read-modify-written,
+//     one row of 1-4 root vectors out -- nothing else;
+//   * the only cross-hand step, terminal equity, goes through LDS in the rank-sorted domain: six-op DPP wave scans over
+//     the sorted range and over the 47 per-card blocker lists, the canonical order of DESIGN.md, so the result is
+//     bit-identical to engine G (prl_tree_kernels.hip) and to the CPU oracle;
 //   * the chance-node sum over boards is done afterwards in the canonical nested order (blocks of 32, groups of 32).
-// No MFMA anywhere: nothing here is a contraction; the kernel is bound by HBM (regret / average columns) and by LDS /
-// cross-lane throughput of the scans.
+// No MFMA anywhere: nothing here is a contraction; measured, the kernel is bound by VALU issue.
 #include "prl_device.h"
 #include "prl_fhp.h"
 #include "prl_kernels.h"
