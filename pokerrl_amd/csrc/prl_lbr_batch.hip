@@ -103,11 +103,79 @@ PRL_DEV PRL_INLINE float lbrb_serial_sum(const float* a, int n) {
     return prl_np_sum_stream<4>(n, nx);
 }
 
-// PokerRange.normalize (PokerRange.py:45-50), workgroup-wide: thread 0 sums in NumPy's order, everyone divides
-PRL_DEV PRL_INLINE void lbrb_normalize(float* rg, int R, LbrbShared& S) {
+// NumPy's pairwise sum of a[0..n) by the whole workgroup, same association as prl_np_sum_stream: the halving recursion ends
+// in blocks of 8..128 elements with 8 strided accumulators each -- 8 lanes per block run the accumulator chains, one lane
+// per block folds them and adds the tail, lane 0 adds the blocks in the recursion's order. Result in S.total.
+#define LBRB_MAX_LEAVES 32
+struct LbrbLeaves { int n_leaves; int lo[LBRB_MAX_LEAVES], n[LBRB_MAX_LEAVES]; float part[LBRB_MAX_LEAVES][8], sum[LBRB_MAX_LEAVES]; };
+
+PRL_DEV PRL_INLINE void lbrb_build_leaves(LbrbLeaves& Lf, int n) {  // one thread; the block boundaries depend on n only
+    int stack_lo[16], stack_n[16], sp = 0, nl = 0;
+    stack_lo[0] = 0; stack_n[0] = n;
+    while (sp >= 0) {
+        const int lo = stack_lo[sp], m = stack_n[sp];
+        --sp;
+        if (m <= 128) { Lf.lo[nl] = lo; Lf.n[nl] = m; ++nl; continue; }
+        int n2 = m / 2;
+        n2 -= n2 % 8;
+        ++sp; stack_lo[sp] = lo + n2; stack_n[sp] = m - n2;  // right half is visited after the left one
+        ++sp; stack_lo[sp] = lo; stack_n[sp] = n2;
+    }
+    Lf.n_leaves = nl;
+}
+
+// sum over the recursion tree of the per-block sums (blocks in order): same halving as above, post-order adds
+PRL_DEV PRL_INLINE float lbrb_combine(const LbrbLeaves& Lf, int n) {
+    struct Frame { int n; int stage; float left; };
+    Frame fr[12];
+    int sp = 0, leaf = 0;
+    fr[0].n = n; fr[0].stage = 0; fr[0].left = 0.f;
+    float ret = 0.f;
+    while (sp >= 0) {
+        Frame& f = fr[sp];
+        int n2 = f.n / 2;
+        n2 -= n2 % 8;
+        if (f.stage == 0) {
+            if (f.n <= 128) { ret = Lf.sum[leaf++]; --sp; }
+            else { f.stage = 1; fr[sp + 1].n = n2; fr[sp + 1].stage = 0; ++sp; }
+        } else if (f.stage == 1) {
+            f.left = ret; f.stage = 2;
+            fr[sp + 1].n = f.n - n2; fr[sp + 1].stage = 0; ++sp;
+        } else { ret = f.left + ret; --sp; }
+    }
+    return ret;
+}
+
+PRL_DEV PRL_INLINE void lbrb_wg_sum(const float* a, int n, LbrbLeaves& Lf, LbrbShared& S) {
+    const int tid = (int)prl_tid();
     prl_sync();
-    if (prl_tid() == 0) S.total = lbrb_serial_sum(rg, R);
+    if (n < 8 * 8 || Lf.n_leaves * 8 > LBRB_THREADS) {  // tiny ranges (Leduc): one lane
+        if (tid == 0) S.total = lbrb_serial_sum(a, n);
+        prl_sync();
+        return;
+    }
+    if (tid < Lf.n_leaves * 8) {
+        const int leaf = tid >> 3, j = tid & 7, lo = Lf.lo[leaf], m = Lf.n[leaf];
+        float acc = a[lo + j];  // every block of a range >= 64 has >= 8 elements
+        for (int i = 8 + j; i < m - (m % 8); i += 8) acc = acc + a[lo + i];
+        Lf.part[leaf][j] = acc;
+    }
     prl_sync();
+    if (tid < Lf.n_leaves) {
+        const float* r = Lf.part[tid];
+        const int lo = Lf.lo[tid], m = Lf.n[tid];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (int i = m - (m % 8); i < m; ++i) res = res + a[lo + i];
+        Lf.sum[tid] = res;
+    }
+    prl_sync();
+    if (tid == 0) S.total = lbrb_combine(Lf, n);
+    prl_sync();
+}
+
+// PokerRange.normalize (PokerRange.py:45-50), workgroup-wide
+PRL_DEV PRL_INLINE void lbrb_normalize(float* rg, int R, LbrbLeaves& Lf, LbrbShared& S) {
+    lbrb_wg_sum(rg, R, Lf, S);
     const float t = S.total, unif = (float)(1.0 / (double)R);
     for (int h = (int)prl_tid(); h < R; h += LBRB_THREADS) rg[h] = t == 0.f ? unif : rg[h] / t;
     prl_sync();
@@ -122,6 +190,8 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
     uint8_t* cls = (uint8_t*)(eq + LBRB_MAX_Q * LBRB_MAX_BOARDS);  // [R]
     uint16_t* hole_lut = (uint16_t*)(((size_t)(cls + R) + 15) & ~(size_t)15);  // [R] c1 | c2 << 8
     LbrbShared& S = *(LbrbShared*)(((size_t)(hole_lut + R) + 15) & ~(size_t)15);
+    LbrbLeaves& Lf = *(LbrbLeaves*)(((size_t)(&S + 1) + 15) & ~(size_t)15);
+    if (tid == 0) lbrb_build_leaves(Lf, R);
     const int nh = P.rules.n_hole_cards, lbr_seat = 1 - P.agent_seat, n_board_total = P.rules.n_board_cards;
     unsigned long long n_steps = 0, n_look = 0, n_eq = 0, n_agent = 0;
     for (int h = tid; h < R; h += LBRB_THREADS) {
@@ -152,7 +222,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
             for (int i = 0; i < nh; ++i) m |= 1ull << lbr_hand[i];
             for (int h = tid; h < R; h += LBRB_THREADS) rg[h] = (prl_lbr_hand_mask(hg, h, hole_lut) & m) ? 0.f : unif;
         }
-        lbrb_normalize(rg, R, S);
+        lbrb_normalize(rg, R, Lf, S);
 
         while (true) {
             prl_sync();
@@ -306,7 +376,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                 prl_sync();
                 const int a = S.action;
                 for (int h = tid; h < R; h += LBRB_THREADS) rg[h] = rg[h] * lbrb_agent_prob(P.agent_kind, S.key, h, S.legal, S.n_legal, a);
-                lbrb_normalize(rg, R, S);
+                lbrb_normalize(rg, R, Lf, S);
                 if (tid == 0) {
                     if (!P.limit && a >= 2) {
                         const int amt = prl_fraction_of_pot_raise(S.st, P.g_agent.bet_fracs[a - 2], S.st.cur);
@@ -352,7 +422,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                 for (int i = nd - n_new; i < nd; ++i) m |= 1ull << S.board[i];
                 for (int h = tid; h < R; h += LBRB_THREADS)
                     if (prl_lbr_hand_mask(hg, h, hole_lut) & m) rg[h] = 0.f;
-                lbrb_normalize(rg, R, S);
+                lbrb_normalize(rg, R, Lf, S);
             }
         }
     }
@@ -389,7 +459,7 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
     P.n_deal = 2 * nh + nb; P.limit = lbr_game->game_type == PRL_GAME_LIMIT;
     P.seed = agent_seed; P.episode_base = episode_base; P.reward_scalar = reward_scalar; P.ev_normalizer = ev_normalizer;
     const int R = rules->range_size;
-    const size_t smem = ((size_t)(1 + LBRB_MAX_Q) * R + LBRB_MAX_Q * LBRB_MAX_BOARDS) * sizeof(float) + R + 16 + (size_t)R * 2 + 16 + sizeof(LbrbShared);
+    const size_t smem = ((size_t)(1 + LBRB_MAX_Q) * R + LBRB_MAX_Q * LBRB_MAX_BOARDS) * sizeof(float) + R + 16 + (size_t)R * 2 + 16 + sizeof(LbrbShared) + 16 + sizeof(LbrbLeaves);
     int8_t* d_cards = nullptr; float* d_win = nullptr; unsigned long long* d_stats = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = PRL_OK;
