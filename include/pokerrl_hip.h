@@ -221,6 +221,13 @@ int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t de
 typedef int32_t (*prl_exchange_fn)(void* user, const void* local_dev, void* gathered_dev, uint64_t bytes_per_rank);
 int32_t prl_solver_create_sharded(const prl_tree_t* local_tree, int32_t variant, int32_t delay, int32_t world_size, int32_t rank,
                                   prl_exchange_fn exchange, void* user, prl_solver_t** out_solver);
+/* Checkpoint / resume (the reference's CFR has none): the solver's persistent state -- iteration
+ * counter, regrets, average strategy (+ sum), current trunk strategy with its dtype flags, exploitability history -- as one
+ * opaque host blob. load_state needs a solver created on the same tree with the same variant / delay / engine; a resumed
+ * run continues bit-identically. Sharded solves: every rank saves / loads its own blob. */
+int32_t prl_solver_state_size(prl_solver_t* solver, uint64_t* out_bytes);
+int32_t prl_solver_save_state(prl_solver_t* solver, void* out_blob, uint64_t bytes);
+int32_t prl_solver_load_state(prl_solver_t* solver, const void* blob, uint64_t bytes);
 /* Stream-ordered exchange: by default the solver drains its stream before it calls `exchange` and expects the gathered
  * buffer to be complete when the callback returns. A callback that ENQUEUES the collective on the solver's own stream
  * (prl_solver_get_stream; e.g. ncclAllGather(..., stream), or torch.distributed under torch.cuda.ExternalStream) needs

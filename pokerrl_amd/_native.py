@@ -145,6 +145,12 @@ def _bind_solver(L):
     L.prl_lbr_batch_run.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), i32, i32, i32, i32,
                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.prl_lbr_batch_run.restype = i32
+    L.prl_solver_state_size.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.prl_solver_state_size.restype = i32
+    L.prl_solver_save_state.argtypes = [vp, vp, ctypes.c_uint64]
+    L.prl_solver_save_state.restype = i32
+    L.prl_solver_load_state.argtypes = [vp, vp, ctypes.c_uint64]
+    L.prl_solver_load_state.restype = i32
     L.prl_solver_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
     L.prl_solver_get_stream.restype = i32
     L.prl_solver_set_exchange_async.argtypes = [vp, i32]
@@ -373,6 +379,19 @@ class NativeSolver:
         ms = ctypes.c_float()
         self._call("prl_solver_time_iterations", int(n), ctypes.byref(ms))
         return float(ms.value)
+
+    def save_state(self):
+        """The solver's persistent state as one uint8 array (checkpoint): np.save it, load_state() it into a solver built on
+        the same tree / variant / delay / engine and the run continues bit-identically."""
+        n = ctypes.c_uint64()
+        self._call("prl_solver_state_size", ctypes.byref(n))
+        blob = np.zeros(int(n.value), np.uint8)
+        self._call("prl_solver_save_state", _ptr(blob), int(n.value))
+        return blob
+
+    def load_state(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._call("prl_solver_load_state", _ptr(blob), int(blob.shape[0]))
 
     def time_iterations_ex(self, n):
         """-> (total device ms, summed ms of the board-pass kernel launches, number of those launches)."""

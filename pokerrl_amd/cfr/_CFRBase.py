@@ -104,6 +104,18 @@ class CFRBase:
         self._chief_handle.add_scalar(self._exp_all_averaged_avg_total, "Evaluation/" + metric, self._iter_counter,
                                       sum(totals) / float(len(totals)))
 
+    # ---- checkpoint / resume (the reference's CFR has none; prl_solver_save_state / load_state) ----------------------------
+    def state_dict(self):
+        return {"iter_counter": self._iter_counter, "solvers": [t.solver.save_state() for t in self._trees]}
+
+    def load_state_dict(self, state):
+        """Into an instance constructed with the same arguments: the run continues bit-identically."""
+        assert len(state["solvers"]) == len(self._trees)
+        for t, blob in zip(self._trees, state["solvers"]):
+            t.solver.load_state(blob)
+            t._invalidate()
+        self._iter_counter = state["iter_counter"]
+
     # ---- access to the tabular state (column-major [n_cols, R]; column first_col[node] + a == node.strategy[:, a]) ------
     def regrets(self, t_idx=0):
         return self._trees[t_idx].solver.get("regret")

@@ -528,6 +528,87 @@ int32_t prl_solver_create_sharded(const prl_tree_t* local_tree, int32_t variant,
     return solver_create_impl(local_tree, variant, delay, exchange ? PRL_ENGINE_FUSED : PRL_ENGINE_AUTO, world_size, rank, exchange, user, out);
 }
 
+namespace {
+struct PrlStateHeader {
+    uint32_t magic, version;
+    int32_t variant, delay, fused, iter, full_cols, R, trunk_cols, trunk_nodes, src0, src1, board_avg_f64, has_avg_sum;
+};
+const uint32_t PRL_STATE_MAGIC = 0x50524C53u;  // "PRLS"
+
+struct StateLayout { size_t regret, avg, avg_sum, strategy, strat_f64, avg_f64, hist, total; };
+StateLayout state_layout(const prl_solver* s, int iter) {
+    const size_t nc = (size_t)s->full_cols * s->R, tc = (size_t)s->T.n_cols * s->R;
+    StateLayout L;
+    size_t o = sizeof(PrlStateHeader);
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 15) & ~(size_t)15; return at; };
+    L.regret = take(nc * 4); L.avg = take(nc * 8); L.avg_sum = take(s->S.avg_sum ? nc * 4 : 0); L.strategy = take(tc * 8);
+    L.strat_f64 = take((size_t)s->T.n_nodes); L.avg_f64 = take((size_t)s->T.n_nodes); L.hist = take((size_t)(iter + 1) * 2 * 4);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+int32_t prl_solver_state_size(prl_solver_t* s, uint64_t* out) {
+    if (!s || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
+    *out = (uint64_t)state_layout(s, s->iter).total;
+    return PRL_OK;
+}
+
+int32_t prl_solver_save_state(prl_solver_t* s, void* out, uint64_t bytes) {
+    if (!s || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
+    if (s->user_strategy_f64 >= 0) { prl_set_error("save_state: an explicit strategy is loaded (set_strategy); reset or fill_uniform first"); return PRL_ERR_STATE; }
+    TRY(ensure_ev(s));  // closes a pending evaluation / pending average updates, so the blob is a clean iteration boundary
+    const StateLayout L = state_layout(s, s->iter);
+    if (bytes < L.total) { prl_set_error("save_state: buffer too small"); return PRL_ERR_ARG; }
+    if (s->avg_pending[0] >= 0 || s->avg_pending[1] >= 0 || s->expl_pending) { prl_set_error("save_state: iteration not closed"); return PRL_ERR_STATE; }
+    PrlStateHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = PRL_STATE_MAGIC; h.version = 1; h.variant = s->variant; h.delay = s->delay; h.fused = s->fused; h.iter = s->iter;
+    h.full_cols = s->full_cols; h.R = s->R; h.trunk_cols = s->T.n_cols; h.trunk_nodes = s->T.n_nodes; h.src0 = s->src[0]; h.src1 = s->src[1];
+    h.board_avg_f64 = s->board_avg_f64; h.has_avg_sum = s->S.avg_sum != nullptr;
+    char* b = (char*)out;
+    memcpy(b, &h, sizeof(h));
+    const size_t nc = (size_t)s->full_cols * s->R, tc = (size_t)s->T.n_cols * s->R;
+    PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+    PRL_HIP_TRY(hipMemcpy(b + L.regret, s->d_regret, nc * 4, hipMemcpyDeviceToHost));
+    PRL_HIP_TRY(hipMemcpy(b + L.avg, s->d_avg, nc * 8, hipMemcpyDeviceToHost));
+    if (s->S.avg_sum) PRL_HIP_TRY(hipMemcpy(b + L.avg_sum, s->S.avg_sum, nc * 4, hipMemcpyDeviceToHost));
+    PRL_HIP_TRY(hipMemcpy(b + L.strategy, s->S.strategy, tc * 8, hipMemcpyDeviceToHost));
+    PRL_HIP_TRY(hipMemcpy(b + L.strat_f64, s->S.strat_f64, (size_t)s->T.n_nodes, hipMemcpyDeviceToHost));
+    PRL_HIP_TRY(hipMemcpy(b + L.avg_f64, s->S.avg_f64, (size_t)s->T.n_nodes, hipMemcpyDeviceToHost));
+    PRL_HIP_TRY(hipMemcpy(b + L.hist, s->d_expl_hist, (size_t)(s->iter + 1) * 2 * 4, hipMemcpyDeviceToHost));
+    return PRL_OK;
+}
+
+int32_t prl_solver_load_state(prl_solver_t* s, const void* in, uint64_t bytes) {
+    if (!s || !in || bytes < sizeof(PrlStateHeader)) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    PrlStateHeader h;
+    memcpy(&h, in, sizeof(h));
+    if (h.magic != PRL_STATE_MAGIC || h.version != 1) { prl_set_error("load_state: not a solver state blob"); return PRL_ERR_ARG; }
+    if (h.variant != s->variant || h.delay != s->delay || h.fused != (int32_t)s->fused || h.full_cols != s->full_cols || h.R != s->R ||
+        h.trunk_cols != s->T.n_cols || h.trunk_nodes != s->T.n_nodes || h.has_avg_sum != (int32_t)(s->S.avg_sum != nullptr) || h.iter < 0) {
+        prl_set_error("load_state: the blob was saved by a solver with a different tree / variant / delay / engine");
+        return PRL_ERR_STATE;
+    }
+    const StateLayout L = state_layout(s, h.iter);
+    if (bytes < L.total) { prl_set_error("load_state: truncated blob"); return PRL_ERR_ARG; }
+    const char* b = (const char*)in;
+    const size_t nc = (size_t)s->full_cols * s->R, tc = (size_t)s->T.n_cols * s->R;
+    TRY(ensure_hist(s, h.iter + 1));
+    PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+    PRL_HIP_TRY(hipMemcpy(s->d_regret, b + L.regret, nc * 4, hipMemcpyHostToDevice));
+    PRL_HIP_TRY(hipMemcpy(s->d_avg, b + L.avg, nc * 8, hipMemcpyHostToDevice));
+    if (s->S.avg_sum) PRL_HIP_TRY(hipMemcpy(s->S.avg_sum, b + L.avg_sum, nc * 4, hipMemcpyHostToDevice));
+    PRL_HIP_TRY(hipMemcpy(s->S.strategy, b + L.strategy, tc * 8, hipMemcpyHostToDevice));
+    PRL_HIP_TRY(hipMemcpy(s->S.strat_f64, b + L.strat_f64, (size_t)s->T.n_nodes, hipMemcpyHostToDevice));
+    PRL_HIP_TRY(hipMemcpy(s->S.avg_f64, b + L.avg_f64, (size_t)s->T.n_nodes, hipMemcpyHostToDevice));
+    PRL_HIP_TRY(hipMemcpy(s->d_expl_hist, b + L.hist, (size_t)(h.iter + 1) * 2 * 4, hipMemcpyHostToDevice));
+    s->iter = h.iter; s->src[0] = h.src0; s->src[1] = h.src1; s->board_avg_f64 = h.board_avg_f64 != 0;
+    s->user_strategy_f64 = -1; s->expl_pending = false; s->have_half = false; s->avg_pending[0] = s->avg_pending[1] = -1;
+    s->ev_valid = false;
+    return do_update_reach(s, s->S);
+}
+
 int32_t prl_solver_get_stream(prl_solver_t* s, void** out) {
     if (!s || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
     *out = (void*)s->stream;

@@ -6,6 +6,7 @@ same inputs, bit for bit, and -- where fixtures exist -- with values captured fr
 import ctypes
 
 import numpy as np
+import pytest
 
 import oracle
 from helpers import GAMES, all_single_card_boards, env_args, golden
@@ -236,3 +237,33 @@ def check_fused_vs_levels(L, n_boards, n_iters, seed=11, variant="plus"):
         sol.compute_ev()
     assert np.array_equal(a.exploitability(), b.exploitability())
     return a, b
+
+
+def check_checkpoint_resume(L, fused, variant="plus", n_before=3, n_after=2):
+    """save_state after n_before iterations, load into a fresh solver, run n_after more: identical to n_before + n_after
+    straight (regrets, averages, exploitability history, average-strategy exploitability)."""
+    if fused:
+        boards = fhp_boards(3)
+        args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
+        t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
+        mk = lambda: _native.NativeSolver(t, variant, 1, engine="fused", _lib=L)  # noqa: E731
+    else:
+        cls, stack, bets = GAMES["StandardLeduc"]
+        t = _native.NativeTree(cls.native_game(env_args(cls, stack, bets)), cls.native_rules(), all_single_card_boards(cls), _lib=L)
+        mk = lambda: _native.NativeSolver(t, variant, 1, engine="levels", _lib=L)  # noqa: E731
+    a = mk()
+    a.iterations(n_before + n_after)
+    b = mk()
+    b.iterations(n_before)
+    blob = b.save_state()
+    c = mk()
+    c.iterations(1)  # some other state that the load must overwrite
+    c.load_state(blob)
+    assert c.iter == n_before
+    c.iterations(n_after)
+    for k in ("regret", "avg", "expl_history") + (() if variant == "plus" else ("avg_sum",)):
+        assert np.array_equal(a.get(k), c.get(k)), k
+    assert np.array_equal(a.eval_avg(), c.eval_avg())
+    with pytest.raises(Exception):
+        mk2 = _native.NativeSolver(t, variant, 0, engine="fused" if fused else "levels", _lib=L)  # different delay
+        mk2.load_state(blob)

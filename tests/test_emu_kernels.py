@@ -70,6 +70,11 @@ def test_emu_fused_engine_batched_iterations(L):
     pc.check_fused_batched_vs_oracle(L, 3, 4, delay=1)
 
 
+@pytest.mark.parametrize("fused,variant", [(False, "plus"), (False, "linear"), (True, "plus"), (True, "vanilla")])
+def test_emu_checkpoint_resume(L, fused, variant):
+    pc.check_checkpoint_resume(L, fused, variant)
+
+
 def test_emu_br_of_random_strategy(L):
     pc.check_br_of_given_strategy(L, "StandardLeduc", 0, f64=True)
     pc.check_br_of_given_strategy(L, "StandardLeduc", 1, f64=False)

@@ -135,6 +135,11 @@ def test_gpu_fused_linear_batched_vs_oracle_and_levels(L):
     pc.check_fused_vs_levels(L, 2048, 5, variant="linear")
 
 
+@pytest.mark.parametrize("fused,variant", [(False, "vanilla"), (True, "plus"), (True, "linear")])
+def test_gpu_checkpoint_resume(L, fused, variant):
+    pc.check_checkpoint_resume(L, fused, variant, n_before=4, n_after=3)
+
+
 def test_gpu_fused_batched_iterations_vs_oracle(L):
     pc.check_fused_batched_vs_oracle(L, 40, 5, delay=1)
 
