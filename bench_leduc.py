@@ -62,7 +62,7 @@ def main():
     out = {"metric": "%s CFR node-updates/s on the %s public tree (replicas)" % (args.variant, args.game),
            "value": tree.n_nodes * args.steps * world / dt, "unit": "node-updates/s", "n_gpus": world, "steps": args.steps,
            "ms_per_step": dt * 1e3 / args.steps, "device_ms_per_step": dev_ms / args.steps, "nodes": tree.n_nodes, "range_size": tree.range_size,
-           "exploitability_mA_or_mbb_per_g": float(np.mean(s.exploitability()) * game_cls.EV_NORMALIZER), "engine": s.engine,
+           "exploitability_mA_or_mbb_per_g": float(np.mean(s.exploitability()) * game_cls.EV_NORMALIZER), "engine": s.engine, "graph_replay": s.graph_replay,
            "note": "tree state fits in L2: launch / latency bound, no roofline claim (SURVEY.md 8d)", "data": "synthetic"}
     if rank == 0:
         r = game_cls.native_rules()

@@ -270,7 +270,8 @@ enum {
     PRL_SF_ITER = 11,        /* int32                    iteration counter                     */
     PRL_SF_CONSTANTS = 12,   /* float32 [2]              chance probability, equity constant   */
     PRL_SF_BYTES_ALLOCATED = 13, /* int64                HBM bytes held by the solver          */
-    PRL_SF_ENGINE = 14       /* int32                    PRL_ENGINE_LEVELS or PRL_ENGINE_FUSED  */
+    PRL_SF_ENGINE = 14,      /* int32                    PRL_ENGINE_LEVELS or PRL_ENGINE_FUSED  */
+    PRL_SF_GRAPH_REPLAY = 15 /* int32                    1 if iterations are replays of a captured hipGraph (LEVELS engine) */
 };
 int32_t prl_solver_get(prl_solver_t* solver, int32_t field, void* out);
 

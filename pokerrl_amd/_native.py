@@ -286,7 +286,7 @@ class NativeTree:
 
 # solver field ids (include/pokerrl_hip.h)
 SF = dict(reach=0, ev=1, ev_br=2, strategy=3, strat_f64=4, regret=5, avg=6, avg_f64=7, avg_sum=8, br_idx=9,
-          expl_history=10, iter=11, constants=12, bytes_allocated=13, engine=14)
+          expl_history=10, iter=11, constants=12, bytes_allocated=13, engine=14, graph_replay=15)
 VARIANTS = {"vanilla": 0, "plus": 1, "linear": 2}
 ENGINES = {"auto": 0, "levels": 1, "fused": 2}
 
@@ -392,6 +392,13 @@ class NativeSolver:
     def load_state(self, blob):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self._call("prl_solver_load_state", _ptr(blob), int(blob.shape[0]))
+
+    @property
+    def graph_replay(self):
+        """True once the LEVELS engine replays a captured hipGraph per iteration (launch-bound small trees)."""
+        v = np.zeros(1, np.int32)
+        self._call("prl_solver_get", SF["graph_replay"], _ptr(v))
+        return bool(v[0])
 
     def time_iterations_ex(self, n):
         """-> (total device ms, summed ms of the board-pass kernel launches, number of those launches)."""

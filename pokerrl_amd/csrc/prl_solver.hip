@@ -57,6 +57,10 @@ struct prl_solver {
     float* d_board_out = nullptr;  // [n_boards][<= 4][R] root vectors of the last board pass
     float* d_row_sum = nullptr;    // [<= 4][R] their canonical sum
     float* d_half = nullptr;     // [R] chance-summed seat-1 value under its new strategy, [R] its best response
+    // LEVELS engine: one captured hipGraph of a whole iteration, replayed per iteration (launch-bound small trees)
+    PrlIterDev* d_ip = nullptr;
+    void* levels_graph_exec = nullptr;  // hipGraphExec_t
+    bool graphs_off = false;
     int avg_pending[2] = {-1, -1};  // FUSED Vanilla / Linear: iteration whose average update of that seat still has to run
     bool time_passes = false;   // prl_solver_time_iterations: bracket every board-pass launch with events
     std::vector<hipEvent_t> pass_events;
@@ -659,6 +663,9 @@ int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay
 void prl_solver_destroy(prl_solver_t* s) {
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+#if !defined(PRL_EMU)
+    if (s->levels_graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)s->levels_graph_exec);
+#endif
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -799,9 +806,54 @@ static int iteration_core(prl_solver* s, bool closing_eval) {
     return record_expl(s);
 }
 
+#if !defined(PRL_EMU)
+// LEVELS engine: n iterations as n replays of one captured graph. The iteration counter, the CFR+ averaging weights and the
+// exploitability-history slot are read from device memory (PrlIterDev), so the captured launches never change.
+static int levels_graph_iterations(prl_solver* s, int n) {
+    TRY(ensure_ev(s));  // an iteration starts from the evaluation that closed the previous one
+    TRY(ensure_hist(s, s->iter + n + 1));
+    if (!s->d_ip) TRY(dev_alloc(s, &s->d_ip, (size_t)1));
+    PrlIterDev ip;
+    memset(&ip, 0, sizeof(ip));
+    ip.iter = s->iter;
+    ip.hist = s->d_expl_hist;
+    PRL_HIP_TRY(hipMemcpyAsync(s->d_ip, &ip, sizeof(ip), hipMemcpyHostToDevice, s->stream));
+    PRL_HIP_TRY(hipStreamSynchronize(s->stream));  // `ip` is a stack variable
+    if (!s->levels_graph_exec) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        PRL_HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+        prl_launch_iter_begin(s->d_ip, s->variant, s->delay, s->stream);
+        for (int p = 0; p < 2; ++p) {
+            if (p == 1) prl_launch_ev(s->T, s->S, s->ft.level_start.data(), s->d_term_nodes, s->n_term, s->stream);
+            prl_launch_regret_strategy_dev(s->T, s->S, s->d_nodes_p[p], s->n_nodes_p[p], p, s->variant, s->d_ip, s->stream);
+            prl_launch_reach(s->T, s->S, s->ft.level_start.data(), s->stream);
+            prl_launch_average_dev(s->T, s->S, s->d_nodes_p[p], s->n_nodes_p[p], p, s->variant, s->d_ip, s->stream);
+        }
+        prl_launch_ev(s->T, s->S, s->ft.level_start.data(), s->d_term_nodes, s->n_term, s->stream);
+        prl_launch_iter_end(s->d_ip, s->S.expl, s->stream);
+        hipError_t e = hipStreamEndCapture(s->stream, &graph);
+        if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) {  // no graph support here: plain launches from now on
+            (void)hipGetLastError();
+            s->graphs_off = true;
+            return PRL_ERR_UNSUPPORTED;
+        }
+        s->levels_graph_exec = (void*)exec;
+    }
+    for (int i = 0; i < n; ++i) PRL_HIP_TRY(hipGraphLaunch((hipGraphExec_t)s->levels_graph_exec, s->stream));
+    s->iter += n;
+    s->src[0] = s->src[1] = PRL_SRC_REGRET;
+    s->ev_valid = true;
+    PRL_HIP_TRY(hipGetLastError());
+    return PRL_OK;
+}
+#endif
+
 int32_t prl_solver_iteration(prl_solver_t* s) {
     if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }
-    return iteration_core(s, true);
+    return prl_solver_iterations(s, 1);
 }
 
 // n iterations. FUSED: the evaluation (both seats + best response) of the strategy after iteration t is folded into the
@@ -809,6 +861,12 @@ int32_t prl_solver_iteration(prl_solver_t* s) {
 // pass. The exploitability history is the same as n single calls produce.
 int32_t prl_solver_iterations(prl_solver_t* s, int32_t n) {
     if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }
+#if !defined(PRL_EMU)
+    if (!s->fused && !s->graphs_off && n > 0) {
+        const int rc = levels_graph_iterations(s, n);
+        if (rc != PRL_ERR_UNSUPPORTED) return rc;
+    }
+#endif
     for (int i = 0; i < n; ++i) TRY(iteration_core(s, i == n - 1));
     return PRL_OK;
 }
@@ -938,6 +996,7 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
         case PRL_SF_CONSTANTS: ((float*)out)[0] = s->T.chance_prob; ((float*)out)[1] = s->T.eq_const; return PRL_OK;
         case PRL_SF_BYTES_ALLOCATED: *(int64_t*)out = (int64_t)s->bytes_allocated; return PRL_OK;
         case PRL_SF_ENGINE: *(int32_t*)out = s->fused ? PRL_ENGINE_FUSED : PRL_ENGINE_LEVELS; return PRL_OK;
+        case PRL_SF_GRAPH_REPLAY: *(int32_t*)out = s->levels_graph_exec != nullptr; return PRL_OK;
         default: prl_set_error("unknown solver field"); return PRL_ERR_ARG;
     }
     if (!src) { prl_set_error("field not available for this variant"); return PRL_ERR_STATE; }

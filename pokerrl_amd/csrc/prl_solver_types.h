@@ -11,6 +11,9 @@
 #pragma once
 #include "prl_defs.h"
 
+// iteration state of a graph-replayed iteration (prl_tree_kernels.hip: *_dev kernels)
+struct PrlIterDev { int32_t iter, mode; double m_old, m_new; float* hist; };
+
 #define PRL_CHANCE_BLOCK 32   // canonical chance-sum order: blocks of 32 children, groups of 32 blocks
 
 struct PrlDevTree {

@@ -369,8 +369,8 @@ PRL_GLOBAL void prl_k_exploitability(PrlDevTree T, PrlDevState S, float* out2) {
 // ---------------------------------------------------------------------------------------------------------------------
 // CFR updates of one seat
 // ---------------------------------------------------------------------------------------------------------------------
-PRL_GLOBAL void prl_k_regret_strategy(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ nodes, int n_nodes_p, int p,
-                                      int variant, int iter) {
+PRL_DEV PRL_INLINE void prl_regret_strategy_body(const PrlDevTree& T, const PrlDevState& S, const int32_t* __restrict__ nodes, int n_nodes_p, int p,
+                                                 int variant, int iter) {
     const size_t total = (size_t)n_nodes_p * T.R;
     for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
         const int node = nodes[t / T.R];
@@ -402,8 +402,8 @@ PRL_GLOBAL void prl_k_regret_strategy(PrlDevTree T, PrlDevState S, const int32_t
 }
 
 // mode (CFR+ only): 0 nothing yet (iter < delay), 1 copy (iter == delay), 2 blend with the float64 weights m_old / m_new
-PRL_GLOBAL void prl_k_average(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ nodes, int n_nodes_p, int p, int variant,
-                              int iter, int mode, double m_old, double m_new) {
+PRL_DEV PRL_INLINE void prl_average_body(const PrlDevTree& T, const PrlDevState& S, const int32_t* __restrict__ nodes, int n_nodes_p, int p, int variant,
+                                        int iter, int mode, double m_old, double m_new) {
     const size_t total = (size_t)n_nodes_p * T.R;
     for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
         const int node = nodes[t / T.R];
@@ -434,6 +434,48 @@ PRL_GLOBAL void prl_k_average(PrlDevTree T, PrlDevState S, const int32_t* __rest
         }
         if (h == 0) S.avg_f64[node] = 1;
     }
+}
+
+PRL_GLOBAL void prl_k_regret_strategy(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ nodes, int n_nodes_p, int p, int variant, int iter) {
+    prl_regret_strategy_body(T, S, nodes, n_nodes_p, p, variant, iter);
+}
+PRL_GLOBAL void prl_k_average(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ nodes, int n_nodes_p, int p, int variant, int iter, int mode,
+                              double m_old, double m_new) {
+    prl_average_body(T, S, nodes, n_nodes_p, p, variant, iter, mode, m_old, m_new);
+}
+
+// ---- graph-replayable flavours: the iteration counter and the CFR+ averaging weights live in device memory, so that one
+// captured hipGraph of a whole iteration can be replayed for every iteration (launch-bound Leduc-sized trees) -------------
+PRL_GLOBAL void prl_k_iter_begin(PrlIterDev* ip, int variant, int delay) {
+    if (prl_bid() != 0 || prl_tid() != 0) return;
+    const int it = ip->iter;
+    int mode = 0;
+    double m_old = 0., m_new = 0.;
+    if (variant == PRL_CFR_PLUS) {  // CFRPlus.py:65-87: float64 weights from integer sums
+        if (it > delay) {
+            const long long cw = ((long long)it * (it + 1) - (long long)delay * (delay + 1)) / 2;  // sum of delay + 1 .. it
+            const long long nw = it - delay + 1;
+            m_old = (double)cw / (double)(cw + nw);
+            m_new = (double)nw / (double)(cw + nw);
+            mode = 2;
+        } else if (it == delay) mode = 1;
+    }
+    ip->mode = mode; ip->m_old = m_old; ip->m_new = m_new;
+}
+PRL_GLOBAL void prl_k_iter_end(PrlIterDev* ip, const float* __restrict__ expl) {
+    if (prl_bid() != 0 || prl_tid() != 0) return;
+    const int it = ip->iter + 1;
+    ip->iter = it;
+    ip->hist[2 * (size_t)it] = expl[0];
+    ip->hist[2 * (size_t)it + 1] = expl[1];
+}
+PRL_GLOBAL void prl_k_regret_strategy_dev(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ nodes, int n_nodes_p, int p, int variant,
+                                          const PrlIterDev* __restrict__ ip) {
+    prl_regret_strategy_body(T, S, nodes, n_nodes_p, p, variant, ip->iter);
+}
+PRL_GLOBAL void prl_k_average_dev(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ nodes, int n_nodes_p, int p, int variant,
+                                  const PrlIterDev* __restrict__ ip) {
+    prl_average_body(T, S, nodes, n_nodes_p, p, variant, ip->iter, ip->mode, ip->m_old, ip->m_new);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -484,4 +526,14 @@ void prl_launch_regret_strategy(const PrlDevTree& T, const PrlDevState& S, const
 void prl_launch_average(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, int iter, int mode,
                         double m_old, double m_new, void* stream) {
     if (n > 0) PRL_LAUNCH(prl_k_average, prl_grid_for((size_t)n * T.R, 256), 256, 0, stream, T, S, d_nodes, n, p, variant, iter, mode, m_old, m_new);
+}
+
+void prl_launch_iter_begin(PrlIterDev* d_ip, int variant, int delay, void* stream) { PRL_LAUNCH(prl_k_iter_begin, 1, 64, 0, stream, d_ip, variant, delay); }
+void prl_launch_iter_end(PrlIterDev* d_ip, const float* d_expl, void* stream) { PRL_LAUNCH(prl_k_iter_end, 1, 64, 0, stream, d_ip, d_expl); }
+void prl_launch_regret_strategy_dev(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, const PrlIterDev* d_ip,
+                                    void* stream) {
+    if (n > 0) PRL_LAUNCH(prl_k_regret_strategy_dev, prl_grid_for((size_t)n * T.R, 256), 256, 0, stream, T, S, d_nodes, n, p, variant, d_ip);
+}
+void prl_launch_average_dev(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, const PrlIterDev* d_ip, void* stream) {
+    if (n > 0) PRL_LAUNCH(prl_k_average_dev, prl_grid_for((size_t)n * T.R, 256), 256, 0, stream, T, S, d_nodes, n, p, variant, d_ip);
 }
