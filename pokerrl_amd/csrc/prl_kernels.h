@@ -17,6 +17,9 @@ void prl_launch_regret_strategy(const PrlDevTree& T, const PrlDevState& S, const
 void prl_launch_average(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, int iter, int mode,
                         double m_old, double m_new, void* stream);
 struct PrlIterDev;
+void prl_launch_small_iterations(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_level_start, const int32_t* d_term_nodes, int n_term,
+                                 const int32_t* d_nodes_p0, int n0, const int32_t* d_nodes_p1, int n1, int variant, int delay, int n_iters,
+                                 PrlIterDev* d_ip, void* stream);
 void prl_launch_iter_begin(PrlIterDev* d_ip, int variant, int delay, void* stream);
 void prl_launch_iter_end(PrlIterDev* d_ip, const float* d_expl, void* stream);
 void prl_launch_regret_strategy_dev(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, const PrlIterDev* d_ip,

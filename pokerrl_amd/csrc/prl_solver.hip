@@ -59,6 +59,8 @@ struct prl_solver {
     float* d_half = nullptr;     // [R] chance-summed seat-1 value under its new strategy, [R] its best response
     // LEVELS engine: one captured hipGraph of a whole iteration, replayed per iteration (launch-bound small trees)
     PrlIterDev* d_ip = nullptr;
+    const int32_t* d_level_start = nullptr;  // small-tree path: BFS level offsets on the device
+    bool small_tree = false;                 // 1-hole-card tree small enough for the single-workgroup iteration kernel
     void* levels_graph_exec = nullptr;  // hipGraphExec_t
     bool graphs_off = false;
     int avg_pending[2] = {-1, -1};  // FUSED Vanilla / Linear: iteration whose average update of that seat still has to run
@@ -377,6 +379,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     s->variant = variant;
     s->delay = delay;
     s->fused = fused;
+    s->small_tree = !fused && r.n_hole_cards == 1 && (long long)full.n_nodes * r.range_size <= 32768 && !getenv("PRL_NO_SMALL_TREE");
     s->full_nodes = full.n_nodes;
     s->full_cols = full.n_cols;
     s->R = r.range_size;
@@ -806,6 +809,31 @@ static int iteration_core(prl_solver* s, bool closing_eval) {
     return record_expl(s);
 }
 
+// LEVELS engine, small 1-hole-card trees: whole iterations inside one single-workgroup kernel (prl_k_small_iterations)
+static int small_tree_iterations(prl_solver* s, int n) {
+    TRY(ensure_ev(s));  // an iteration starts from the evaluation that closed the previous one
+    TRY(ensure_hist(s, s->iter + n + 1));
+    if (!s->d_ip) TRY(dev_alloc(s, &s->d_ip, (size_t)1));
+    if (!s->d_level_start) TRY(dev_upload(s, &s->d_level_start, s->ft.level_start));
+    PrlIterDev ip;
+    memset(&ip, 0, sizeof(ip));
+    ip.iter = s->iter;
+    ip.hist = s->d_expl_hist;
+    PRL_HIP_TRY(hipMemcpyAsync(s->d_ip, &ip, sizeof(ip), hipMemcpyHostToDevice, s->stream));
+    PRL_HIP_TRY(hipStreamSynchronize(s->stream));  // `ip` is a stack variable
+    for (int done = 0; done < n;) {
+        const int k = n - done < 256 ? n - done : 256;  // bounded kernel run time
+        prl_launch_small_iterations(s->T, s->S, s->d_level_start, s->d_term_nodes, s->n_term, s->d_nodes_p[0], s->n_nodes_p[0], s->d_nodes_p[1],
+                                    s->n_nodes_p[1], s->variant, s->delay, k, s->d_ip, s->stream);
+        done += k;
+    }
+    s->iter += n;
+    s->src[0] = s->src[1] = PRL_SRC_REGRET;
+    s->ev_valid = true;
+    PRL_HIP_TRY(hipGetLastError());
+    return PRL_OK;
+}
+
 #if !defined(PRL_EMU)
 // LEVELS engine: n iterations as n replays of one captured graph. The iteration counter, the CFR+ averaging weights and the
 // exploitability-history slot are read from device memory (PrlIterDev), so the captured launches never change.
@@ -861,6 +889,7 @@ int32_t prl_solver_iteration(prl_solver_t* s) {
 // pass. The exploitability history is the same as n single calls produce.
 int32_t prl_solver_iterations(prl_solver_t* s, int32_t n) {
     if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }
+    if (!s->fused && s->small_tree && n > 0) return small_tree_iterations(s, n);
 #if !defined(PRL_EMU)
     if (!s->fused && !s->graphs_off && n > 0) {
         const int rc = levels_graph_iterations(s, n);

@@ -95,12 +95,12 @@ PRL_GLOBAL void prl_k_fill_uniform(PrlDevTree T, PrlDevState S, const int32_t* _
     }
 }
 
-PRL_GLOBAL void prl_k_reach_root(PrlDevTree T, PrlDevState S) {
+PRL_DEV PRL_INLINE void prl_reach_root_body(const PrlDevTree& T, const PrlDevState& S) {
     const float r0 = (float)(1.0 / (double)T.R);  // PublicTree.py:122-124
     for (int t = (int)(prl_bid() * prl_nthreads() + prl_tid()); t < 2 * T.R; t += (int)(prl_nblocks() * prl_nthreads())) S.reach[t] = r0;
 }
 
-PRL_GLOBAL void prl_k_reach_level(PrlDevTree T, PrlDevState S, int level_begin, int level_count) {
+PRL_DEV PRL_INLINE void prl_reach_level_body(const PrlDevTree& T, const PrlDevState& S, int level_begin, int level_count) {
     const size_t total = (size_t)level_count * T.R;
     for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
         const int node = T.level_nodes[level_begin + (int)(t / T.R)];
@@ -144,7 +144,7 @@ PRL_DEV PRL_INLINE float prl_showdown_1card(const PrlDevTree& T, const float* x,
     return e;
 }
 
-PRL_GLOBAL void prl_k_terminal_1card(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ term_nodes, int n_term) {
+PRL_DEV PRL_INLINE void prl_terminal_1card_body(const PrlDevTree& T, const PrlDevState& S, const int32_t* __restrict__ term_nodes, int n_term) {
     const size_t total = (size_t)n_term * 2 * T.R;
     for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
         const int node = term_nodes[t / (2 * (size_t)T.R)];
@@ -286,7 +286,7 @@ PRL_DEV PRL_INLINE float prl_chance_sum(const PrlDevTree& T, const float* arr, i
     return total;
 }
 
-PRL_GLOBAL void prl_k_ev_level(PrlDevTree T, PrlDevState S, int level_begin, int level_count) {
+PRL_DEV PRL_INLINE void prl_ev_level_body(const PrlDevTree& T, const PrlDevState& S, int level_begin, int level_count) {
     const size_t total = (size_t)level_count * T.R;
     for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
         const int node = T.level_nodes[level_begin + (int)(t / T.R)];
@@ -338,7 +338,7 @@ PRL_GLOBAL void prl_k_ev_level(PrlDevTree T, PrlDevState S, int level_begin, int
 }
 
 // root exploitability: sum_h (ev_br - ev) * reach  (ValueFiller.py:96-101). One workgroup.
-PRL_GLOBAL void prl_k_exploitability(PrlDevTree T, PrlDevState S, float* out2) {
+PRL_DEV PRL_INLINE void prl_exploitability_body(const PrlDevTree& T, const PrlDevState& S, float* out2) {
     float* smem = (float*)prl_smem();
     if (T.n_hole == 1) {
         if (prl_tid() < 2) {
@@ -436,6 +436,13 @@ PRL_DEV PRL_INLINE void prl_average_body(const PrlDevTree& T, const PrlDevState&
     }
 }
 
+PRL_GLOBAL void prl_k_reach_root(PrlDevTree T, PrlDevState S) { prl_reach_root_body(T, S); }
+PRL_GLOBAL void prl_k_reach_level(PrlDevTree T, PrlDevState S, int level_begin, int level_count) { prl_reach_level_body(T, S, level_begin, level_count); }
+PRL_GLOBAL void prl_k_terminal_1card(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ term_nodes, int n_term) {
+    prl_terminal_1card_body(T, S, term_nodes, n_term);
+}
+PRL_GLOBAL void prl_k_ev_level(PrlDevTree T, PrlDevState S, int level_begin, int level_count) { prl_ev_level_body(T, S, level_begin, level_count); }
+PRL_GLOBAL void prl_k_exploitability(PrlDevTree T, PrlDevState S, float* out2) { prl_exploitability_body(T, S, out2); }
 PRL_GLOBAL void prl_k_regret_strategy(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ nodes, int n_nodes_p, int p, int variant, int iter) {
     prl_regret_strategy_body(T, S, nodes, n_nodes_p, p, variant, iter);
 }
@@ -476,6 +483,68 @@ PRL_GLOBAL void prl_k_regret_strategy_dev(PrlDevTree T, PrlDevState S, const int
 PRL_GLOBAL void prl_k_average_dev(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ nodes, int n_nodes_p, int p, int variant,
                                   const PrlIterDev* __restrict__ ip) {
     prl_average_body(T, S, nodes, n_nodes_p, p, variant, ip->iter, ip->mode, ip->m_old, ip->m_new);
+}
+
+// ---- small trees (1-hole-card games, n_nodes * R of a few thousand: StandardLeduc, DiscretizedNLLeduc): the tree state is
+// L2-resident and an iteration is ~35 dependent launches of ~5 us each. ONE workgroup runs `n_iters` whole iterations in one
+// launch instead: the same per-(node, hand) bodies as the level kernels, workgroup barriers where the kernel boundaries were.
+struct PrlSmallIterArgs {
+    const int32_t* level_start;  // device copy of the BFS level offsets, [n_levels + 1]
+    const int32_t* term_nodes; int32_t n_term;
+    const int32_t* nodes_p[2]; int32_t n_nodes_p[2];
+    int32_t variant, delay, n_iters;
+    PrlIterDev* ip;
+};
+PRL_DEV PRL_INLINE void prl_small_ev(const PrlDevTree& T, const PrlDevState& S, const PrlSmallIterArgs& A) {
+    prl_terminal_1card_body(T, S, A.term_nodes, A.n_term);
+    prl_sync();
+    for (int d = T.n_levels - 2; d >= 0; --d) {
+        prl_ev_level_body(T, S, A.level_start[d], A.level_start[d + 1] - A.level_start[d]);
+        prl_sync();
+    }
+    prl_exploitability_body(T, S, S.expl);
+    prl_sync();
+}
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations(PrlDevTree T, PrlDevState S, PrlSmallIterArgs A) {
+    for (int k = 0; k < A.n_iters; ++k) {
+        if (prl_tid() == 0) {  // prl_k_iter_begin
+            const int it = A.ip->iter;
+            int mode = 0;
+            double m_old = 0., m_new = 0.;
+            if (A.variant == PRL_CFR_PLUS) {
+                if (it > A.delay) {
+                    const long long cw = ((long long)it * (it + 1) - (long long)A.delay * (A.delay + 1)) / 2;
+                    const long long nw = it - A.delay + 1;
+                    m_old = (double)cw / (double)(cw + nw);
+                    m_new = (double)nw / (double)(cw + nw);
+                    mode = 2;
+                } else if (it == A.delay) mode = 1;
+            }
+            A.ip->mode = mode; A.ip->m_old = m_old; A.ip->m_new = m_new;
+        }
+        prl_sync();
+        for (int p = 0; p < 2; ++p) {
+            if (p == 1) prl_small_ev(T, S, A);
+            prl_regret_strategy_body(T, S, A.nodes_p[p], A.n_nodes_p[p], p, A.variant, A.ip->iter);
+            prl_sync();
+            prl_reach_root_body(T, S);
+            prl_sync();
+            for (int d = 1; d < T.n_levels; ++d) {
+                prl_reach_level_body(T, S, A.level_start[d], A.level_start[d + 1] - A.level_start[d]);
+                prl_sync();
+            }
+            prl_average_body(T, S, A.nodes_p[p], A.n_nodes_p[p], p, A.variant, A.ip->iter, A.ip->mode, A.ip->m_old, A.ip->m_new);
+            prl_sync();
+        }
+        prl_small_ev(T, S, A);
+        if (prl_tid() == 0) {  // prl_k_iter_end
+            const int it = A.ip->iter + 1;
+            A.ip->iter = it;
+            A.ip->hist[2 * (size_t)it] = S.expl[0];
+            A.ip->hist[2 * (size_t)it + 1] = S.expl[1];
+        }
+        prl_sync();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -526,6 +595,16 @@ void prl_launch_regret_strategy(const PrlDevTree& T, const PrlDevState& S, const
 void prl_launch_average(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, int iter, int mode,
                         double m_old, double m_new, void* stream) {
     if (n > 0) PRL_LAUNCH(prl_k_average, prl_grid_for((size_t)n * T.R, 256), 256, 0, stream, T, S, d_nodes, n, p, variant, iter, mode, m_old, m_new);
+}
+
+void prl_launch_small_iterations(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_level_start, const int32_t* d_term_nodes, int n_term,
+                                 const int32_t* d_nodes_p0, int n0, const int32_t* d_nodes_p1, int n1, int variant, int delay, int n_iters,
+                                 PrlIterDev* d_ip, void* stream) {
+    PrlSmallIterArgs A;
+    A.level_start = d_level_start; A.term_nodes = d_term_nodes; A.n_term = n_term;
+    A.nodes_p[0] = d_nodes_p0; A.nodes_p[1] = d_nodes_p1; A.n_nodes_p[0] = n0; A.n_nodes_p[1] = n1;
+    A.variant = variant; A.delay = delay; A.n_iters = n_iters; A.ip = d_ip;
+    PRL_LAUNCH(prl_k_small_iterations, 1, 1024, 0, stream, T, S, A);
 }
 
 void prl_launch_iter_begin(PrlIterDev* d_ip, int variant, int delay, void* stream) { PRL_LAUNCH(prl_k_iter_begin, 1, 64, 0, stream, d_ip, variant, delay); }
