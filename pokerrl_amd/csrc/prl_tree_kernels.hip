@@ -245,24 +245,24 @@ PRL_DEV PRL_INLINE void prl_terminal_equity_2card(const PrlDevTree& T, const flo
     prl_sync();
 }
 
+// one workgroup per (terminal, seat): the two seats' equities of a terminal are independent
 PRL_GLOBAL void prl_k_terminal_2card(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ term_nodes, int n_term) {
     float* smem = (float*)prl_smem();
-    for (int ti = (int)prl_bid(); ti < n_term; ti += (int)prl_nblocks()) {
-        const int node = term_nodes[ti];
+    for (int ti = (int)prl_bid(); ti < 2 * n_term; ti += (int)prl_nblocks()) {
+        const int node = term_nodes[ti >> 1];
+        const int p = ti & 1;
         const int bid = T.board_id[node];
         const bool fold = T.kind[node] == PRL_NODE_TERM_FOLD;
         const float pot = (float)T.main_pot[node];
-        for (int p = 0; p < 2; ++p) {
-            float* oe = S.ev + prl_vidx(T, node, p);
-            float* ob = S.ev_br + prl_vidx(T, node, p);
-            if (!fold && bid < 0) {  // all-in before the deal is not representable in a 2-round 1-chance-level tree with 5 cards
-                for (int h = (int)prl_tid(); h < T.R; h += (int)prl_nthreads()) { oe[h] = 0.f; ob[h] = 0.f; }
-                prl_sync();
-                continue;
-            }
-            const float sign = (fold && T.acted_last[node] == p) ? -1.f : 1.f;
-            prl_terminal_equity_2card(T, S.reach + prl_vidx(T, node, 1 - p), bid < 0 ? T.n_boards : bid, !fold, smem, sign, pot, oe, ob);
+        float* oe = S.ev + prl_vidx(T, node, p);
+        float* ob = S.ev_br + prl_vidx(T, node, p);
+        if (!fold && bid < 0) {  // all-in before the deal is not representable in a 2-round 1-chance-level tree with 5 cards
+            for (int h = (int)prl_tid(); h < T.R; h += (int)prl_nthreads()) { oe[h] = 0.f; ob[h] = 0.f; }
+            prl_sync();
+            continue;
         }
+        const float sign = (fold && T.acted_last[node] == p) ? -1.f : 1.f;
+        prl_terminal_equity_2card(T, S.reach + prl_vidx(T, node, 1 - p), bid < 0 ? T.n_boards : bid, !fold, smem, sign, pot, oe, ob);
     }
 }
 
@@ -576,7 +576,7 @@ void prl_launch_ev(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_l
             PRL_LAUNCH(prl_k_terminal_1card, prl_grid_for((size_t)n_term * 2 * T.R, 256), 256, 0, stream, T, S, d_term_nodes, n_term);
         } else {
             size_t smem = ((size_t)PRL_T2_YPAD + (PRL_T2_YPAD + 8) + 64 + 64 + (size_t)T.n_cards * 65) * sizeof(float);
-            PRL_LAUNCH(prl_k_terminal_2card, n_term < 65536 ? n_term : 65536, 256, smem, stream, T, S, d_term_nodes, n_term);
+            PRL_LAUNCH(prl_k_terminal_2card, 2 * n_term < 65536 ? 2 * n_term : 65536, 256, smem, stream, T, S, d_term_nodes, n_term);
         }
     }
     for (int d = T.n_levels - 2; d >= 0; --d) {
