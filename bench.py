@@ -35,7 +35,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per CFR+ iteration of the board-pass kernels, from the PMC pass (FETCH_SIZE / WRITE_SIZE, corrected as
 # MI355X_MICROARCH.md prescribes), keyed by boards per GPU; see the file named below. None until measured for a size.
 PMC_TRAFFIC_BYTES_PER_ITERATION = {16384: 9.27e9}  # UPDATE1_EVAL1: 2*1.32 GB read + 2.04 GB written; UPDATE0_BR: 2*1.32 + 1.95
-PMC_TRAFFIC_SOURCE = "profiles/r01g_fused_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+PMC_TRAFFIC_SOURCE = "profiles/r01h_fused_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
 
 
 def seeded_boards(n, seed, offset=0):
