@@ -17,6 +17,8 @@
 // SURVEY.md Appendix A); for 2-hole-card ranges the canonical wave-64 scan order of DESIGN.md.
 #include "prl_device.h"
 #include "prl_handeval.h"
+#include <type_traits>
+
 #include "prl_kernels.h"
 #include "prl_solver_types.h"
 
@@ -493,8 +495,40 @@ struct PrlSmallIterArgs {
     const int32_t* term_nodes; int32_t n_term;
     const int32_t* nodes_p[2]; int32_t n_nodes_p[2];
     int32_t variant, delay, n_iters;
+    int32_t state_in_lds;        // the whole per-node / per-column state fits in LDS: iterate there, copy back at the end
+    int32_t n_cols;
     PrlIterDev* ip;
 };
+
+// carve the solver state out of LDS (16-byte aligned pieces) and copy it in (dir = 0) or back out (dir = 1)
+PRL_DEV PRL_INLINE void prl_small_state_lds(const PrlDevTree& T, const PrlDevState& G, int n_cols, PrlDevState& L, int dir) {
+    char* base = prl_smem();
+    size_t off = 0;
+    auto piece = [&](auto*& lp, auto* gp, size_t count) {
+        typedef typename std::remove_reference<decltype(*gp)>::type E;
+        if (!gp) { lp = nullptr; return; }
+        E* l = (E*)(base + off);
+        off += (count * sizeof(E) + 15) & ~(size_t)15;
+        lp = l;
+        for (size_t i = prl_tid(); i < count; i += prl_nthreads()) {
+            if (dir == 0) l[i] = gp[i];
+            else gp[i] = l[i];
+        }
+    };
+    const size_t nv = (size_t)T.n_nodes * 2 * T.R, nc = (size_t)n_cols * T.R;
+    piece(L.strategy, G.strategy, nc);
+    piece(L.strat_f64, G.strat_f64, (size_t)T.n_nodes);
+    piece(L.reach, G.reach, nv);
+    piece(L.ev, G.ev, nv);
+    piece(L.ev_br, G.ev_br, nv);
+    piece(L.br_idx, G.br_idx, (size_t)T.n_nodes * T.R);
+    piece(L.regret, G.regret, nc);
+    piece(L.avg_sum, G.avg_sum, nc);
+    piece(L.avg, G.avg, nc);
+    piece(L.avg_f64, G.avg_f64, (size_t)T.n_nodes);
+    L.expl = G.expl;  // two floats, stay in HBM
+    prl_sync();
+}
 PRL_DEV PRL_INLINE void prl_small_ev(const PrlDevTree& T, const PrlDevState& S, const PrlSmallIterArgs& A) {
     prl_terminal_1card_body(T, S, A.term_nodes, A.n_term);
     prl_sync();
@@ -505,7 +539,9 @@ PRL_DEV PRL_INLINE void prl_small_ev(const PrlDevTree& T, const PrlDevState& S, 
     prl_exploitability_body(T, S, S.expl);
     prl_sync();
 }
-PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations(PrlDevTree T, PrlDevState S, PrlSmallIterArgs A) {
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations(PrlDevTree T, PrlDevState SG, PrlSmallIterArgs A) {
+    PrlDevState S = SG;
+    if (A.state_in_lds) prl_small_state_lds(T, SG, A.n_cols, S, 0);
     for (int k = 0; k < A.n_iters; ++k) {
         if (prl_tid() == 0) {  // prl_k_iter_begin
             const int it = A.ip->iter;
@@ -545,6 +581,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations(PrlDevTree T, Prl
         }
         prl_sync();
     }
+    if (A.state_in_lds) prl_small_state_lds(T, SG, A.n_cols, S, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -600,11 +637,19 @@ void prl_launch_average(const PrlDevTree& T, const PrlDevState& S, const int32_t
 void prl_launch_small_iterations(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_level_start, const int32_t* d_term_nodes, int n_term,
                                  const int32_t* d_nodes_p0, int n0, const int32_t* d_nodes_p1, int n1, int variant, int delay, int n_iters,
                                  PrlIterDev* d_ip, void* stream) {
+    // does the whole state fit in LDS (StandardLeduc: ~140 KB)? then the iterations run on it there
+    auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t nv = (size_t)T.n_nodes * 2 * T.R, nc = (size_t)T.n_cols * T.R;
+    size_t lds = al(nc * 8) + al(T.n_nodes) + 3 * al(nv * 4) + (S.br_idx ? al((size_t)T.n_nodes * T.R * 4) : 0) + al(nc * 4) +
+                 (S.avg_sum ? al(nc * 4) : 0) + al(nc * 8) + al(T.n_nodes);
+    const bool in_lds = lds <= 160 * 1024 - 256;
     PrlSmallIterArgs A;
+    A.state_in_lds = in_lds ? 1 : 0;
+    A.n_cols = T.n_cols;
     A.level_start = d_level_start; A.term_nodes = d_term_nodes; A.n_term = n_term;
     A.nodes_p[0] = d_nodes_p0; A.nodes_p[1] = d_nodes_p1; A.n_nodes_p[0] = n0; A.n_nodes_p[1] = n1;
     A.variant = variant; A.delay = delay; A.n_iters = n_iters; A.ip = d_ip;
-    PRL_LAUNCH(prl_k_small_iterations, 1, 1024, 0, stream, T, S, A);
+    PRL_LAUNCH(prl_k_small_iterations, 1, 1024, in_lds ? lds : 0, stream, T, S, A);
 }
 
 void prl_launch_iter_begin(PrlIterDev* d_ip, int variant, int delay, void* stream) { PRL_LAUNCH(prl_k_iter_begin, 1, 64, 0, stream, d_ip, variant, delay); }
