@@ -6,7 +6,7 @@ bench.py -- CFR+ node-updates/s on a synthetic Flop5Holdem public tree (BASELINE
 
 A "step" is one CFRBase.iteration() (reference semantics, PokerRL/cfr/_CFRBase.py:122-134: both seats updated, EVs
 recomputed, current-strategy exploitability available) of CFR+ (delay 0) on the Flop5Holdem betting tree (blinds 50/100,
-stacks 20000, pot-size raises; PokerRL/game/games.py:222-254) x B seeded boards per GPU, 1326-hand ranges, float32 state
+stacks 20000, pot-size raises; PokerRL/game/games.py:222-254) x B seeded boards per GPU (default 262144, a size SURVEY.md 8d config 3 names; 71 GB of HBM), 1326-hand ranges, float32 state
 with the reference's float64 average strategy. Inputs are resident in HBM before the timed region. Prints ONE JSON line.
 
 node-updates/s = (tree nodes incl. root) x iterations / s  (SURVEY.md section 8d).
@@ -34,8 +34,10 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per CFR+ iteration of the board-pass kernels, from the PMC pass (FETCH_SIZE / WRITE_SIZE, corrected as
 # MI355X_MICROARCH.md prescribes), keyed by boards per GPU; see the file named below. None until measured for a size.
-PMC_TRAFFIC_BYTES_PER_ITERATION = {16384: 9.27e9}  # UPDATE1_EVAL1: 2*1.32 GB read + 2.04 GB written; UPDATE0_BR: 2*1.32 + 1.95
-PMC_TRAFFIC_SOURCE = "profiles/r01h_fused_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+# measured at 16384 boards (r01h: UPDATE1_EVAL1 2 * 1.32 GB read + 2.04 GB written, UPDATE0_BR 2 * 1.32 + 1.95 = 9.27 GB per iteration)
+# and at 262144 boards (r01i: 2 * 21.13 + 32.61 and 2 * 21.12 + 31.25 = 148.4 GB): every board subtree moves the same bytes
+PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION = 9.27e9 / 16384
+PMC_TRAFFIC_SOURCE = "profiles/r01i_fused_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
 
 
 def seeded_boards(n, seed, offset=0):
@@ -75,7 +77,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--boards", type=int, default=int(os.environ.get("PRL_BENCH_BOARDS", "16384")), help="boards per GPU")
+    ap.add_argument("--boards", type=int, default=int(os.environ.get("PRL_BENCH_BOARDS", "262144")), help="boards per GPU")
     ap.add_argument("--engine", default=os.environ.get("PRL_BENCH_ENGINE", "auto"))
     ap.add_argument("--variant", default="plus", choices=["plus", "linear", "vanilla"],
                     help="CFR variant (the metric is quoted on CFR+; BASELINE config 3 also names LinearCFR)")
@@ -162,7 +164,7 @@ def main():
             "hbm_bytes_allocated": int(solver.get("bytes_allocated")[0]),
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": PMC_TRAFFIC_BYTES_PER_ITERATION.get(args.boards) if solver.engine == "fused" else None,
+                     "traffic": PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION * args.boards if (solver.engine == "fused" and args.variant == "plus") else None,
                      "traffic_source": PMC_TRAFFIC_SOURCE,
                      "kernel": "prl_k_fhp_pass" if n_pass else "all kernels of the iteration",
                      "launches_per_iteration": n_pass / float(args.steps) if n_pass else None,
