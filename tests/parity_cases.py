@@ -267,3 +267,15 @@ def check_checkpoint_resume(L, fused, variant="plus", n_before=3, n_after=2):
     with pytest.raises(Exception):
         mk2 = _native.NativeSolver(t, variant, 0, engine="fused" if fused else "levels", _lib=L)  # different delay
         mk2.load_state(blob)
+
+
+def seeded_strategy_for_sharding(n_trunk_cols, n_boards, R, seed):
+    """float32 [n_cols, R] column-major strategy of a Flop5Holdem tree (trunk: SB {fold, raise}, BB {fold, call}; per board the 6
+    decision nodes with 2,2,3,2,3,2 actions), normalised per node and hand; the same array whatever the sharding."""
+    rng = np.random.RandomState(seed)
+    sizes = [2] * (n_trunk_cols // 2) + [2, 2, 3, 2, 3, 2] * n_boards
+    cols = []
+    for a in sizes:
+        x = rng.random_sample((a, R)).astype(np.float32)
+        cols.append(x / x.sum(axis=0, keepdims=True))
+    return np.concatenate(cols).astype(np.float32)

@@ -38,6 +38,14 @@ def main():
     s.iterations(n_iters - 1)
     out = dict(expl_history=s.get("expl_history"), regret=s.get("regret"), avg=s.get("avg"), eval_avg=s.eval_avg(),
                exchanges=np.int64(ex.calls), n_trunk_cols=np.int64(t.n_cols - n_local * 14))
+    # exact best response of an explicit strategy (BASELINE config 4: BR with the boards partitioned over the GPUs): every
+    # rank loads the trunk columns + its own boards' columns of the same seeded strategy
+    nt, per = int(t.n_cols - n_local * 14), n_local * 14
+    full = pc.seeded_strategy_for_sharding(nt, world * n_local, t.range_size, seed + 1)
+    local = np.concatenate([full[:nt], full[nt + rank * per: nt + (rank + 1) * per]])
+    s.set_strategy(local)
+    s.compute_ev()
+    out["br_of_random"] = s.exploitability()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
     dist.barrier()
     dist.destroy_process_group()

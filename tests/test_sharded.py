@@ -54,17 +54,21 @@ def check_against_union(L, ranks, world, n_local, n_iters, delay, seed):
     s = _native.NativeSolver(t, "plus", delay, engine="fused", _lib=L)
     s.iterations(n_iters)
     hist, regret, avg, ev_avg = s.get("expl_history"), s.get("regret"), s.get("avg"), s.eval_avg()
+    s.set_strategy(pc.seeded_strategy_for_sharding(t.n_cols - world * n_local * 14, world * n_local, t.range_size, seed + 1))
+    s.compute_ev()
+    br = s.exploitability()
     per = n_local * 14
     for r, out in enumerate(ranks):
         nt = int(out["n_trunk_cols"])
         assert np.array_equal(out["expl_history"], hist), "rank %d: exploitability history" % r
         assert np.array_equal(out["eval_avg"], ev_avg), "rank %d: average-strategy exploitability" % r
+        assert np.array_equal(out["br_of_random"], br), "rank %d: best response of an explicit strategy" % r
         for name, full in (("regret", regret), ("avg", avg)):
             assert np.array_equal(out[name][:nt], full[:nt]), "rank %d: trunk %s" % (r, name)
             assert np.array_equal(out[name][nt:], full[nt + r * per: nt + (r + 1) * per]), "rank %d: board %s" % (r, name)
         # one exchange per EV pass: reset (1), iteration() = 3, every further batched iteration 2, the batch's closing
         # evaluation 1, eval_avg 1
-        assert int(out["exchanges"]) == 1 + 3 + (2 * (n_iters - 1) + 1 if n_iters > 1 else 0) + 1
+        assert int(out["exchanges"]) == 1 + 3 + (2 * (n_iters - 1) + 1 if n_iters > 1 else 0) + 1, out["exchanges"]
 
 
 def chance_sum_reference(vals):
