@@ -296,7 +296,7 @@ int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t* board_deal
  *   draws the agent's actions as episode episode_base + e + 1; reward_scalar / ev_normalizer: env.REWARD_SCALAR, EV_NORMALIZER.
  *   out_winnings[n_envs] float32 = reward[lbr_seat] * REWARD_SCALAR * EV_NORMALIZER; out_stats4: env steps, LBR look-ahead
  *   decisions, (range, board) equities, agent actions; out_device_ms: kernel time (HIP events). LBR may only decide with at
- *   most one board card to come (hold'em: lbr_check_to_round >= TURN). */
+ *   most two board cards to come (hold'em: lbr_check_to_round >= FLOP). */
 int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* agent_game, const PrlRules* rules, int32_t n_envs, int32_t agent_seat,
                           int32_t check_to_round, int32_t agent_kind, uint32_t agent_seed, uint32_t episode_base, double reward_scalar,
                           double ev_normalizer, const int8_t* cards, float* out_winnings, uint64_t* out_stats4, float* out_device_ms);

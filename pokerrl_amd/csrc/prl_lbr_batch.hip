@@ -26,7 +26,8 @@ extern "C" int32_t prl_device_available(void);
 
 #define LBRB_THREADS 576
 #define LBRB_MAX_Q 13      // check/call + up to 12 raise sizes considered by LBR
-#define LBRB_MAX_BOARDS 64  // boards per equity: at most one card to come (52-card turn: 46)
+#define LBRB_MAX_BOARDS 64  // boards per equity kept in LDS: one card to come (52-card turn: 46)
+#define LBRB_MAX_BOARDS_2 1088  // two cards to come (hold'em flop: C(47, 2) = 1081 -- the agent's cards are unknown to LBR): the equities go through an HBM scratch row
 
 struct PrlLbrBatchParams {
     PrlGame g_lbr, g_agent;
@@ -37,6 +38,7 @@ struct PrlLbrBatchParams {
     const int8_t* cards;          // [n_envs][n_deal]: seat 0's hole cards, seat 1's, then the board in deal order
     float* winnings;              // [n_envs]
     unsigned long long* stats;    // [4] env steps, LBR look-ahead decisions, (range, board) equities, agent actions
+    float* eq_scratch;            // [grid][LBRB_MAX_Q][LBRB_MAX_BOARDS_2] when LBR may decide with two cards to come, else NULL
 };
 
 PRL_HD PRL_INLINE uint32_t lbrb_mix32(uint32_t x) {
@@ -186,8 +188,8 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
     const int R = P.rules.range_size, tid = (int)prl_tid();
     float* rg = (float*)lbrb_smem;                 // [R] the agent's range
     float* cand = rg + R;                          // [LBRB_MAX_Q][R] candidate ranges of a look-ahead
-    float* eq = cand + (size_t)LBRB_MAX_Q * R;     // [LBRB_MAX_Q][LBRB_MAX_BOARDS]
-    uint8_t* cls = (uint8_t*)(eq + LBRB_MAX_Q * LBRB_MAX_BOARDS);  // [R]
+    float* eq_lds = cand + (size_t)LBRB_MAX_Q * R;  // [LBRB_MAX_Q][LBRB_MAX_BOARDS]
+    uint8_t* cls = (uint8_t*)(eq_lds + LBRB_MAX_Q * LBRB_MAX_BOARDS);  // [R]
     uint16_t* hole_lut = (uint16_t*)(((size_t)(cls + R) + 15) & ~(size_t)15);  // [R] c1 | c2 << 8
     LbrbShared& S = *(LbrbShared*)(((size_t)(hole_lut + R) + 15) & ~(size_t)15);
     LbrbLeaves& Lf = *(LbrbLeaves*)(((size_t)(&S + 1) + 15) & ~(size_t)15);
@@ -266,7 +268,10 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                     prl_sync();
                     const PrlLbrGame g = S.lg;
                     const int n_q = S.n_q, n_boards = S.n_boards;
-                    if (g.n_to_deal > 1 || n_boards > LBRB_MAX_BOARDS) {  // create() rejects configurations that get here
+                    const bool big = n_boards > LBRB_MAX_BOARDS;
+                    float* eq = big ? P.eq_scratch + (size_t)prl_bid() * LBRB_MAX_Q * LBRB_MAX_BOARDS_2 : eq_lds;
+                    const int eq_stride = big ? LBRB_MAX_BOARDS_2 : LBRB_MAX_BOARDS;
+                    if (g.n_to_deal > 2 || n_boards > LBRB_MAX_BOARDS_2 || (big && !P.eq_scratch)) {  // run() rejects configurations that get here
                         if (tid == 0) S.done = 1;
                         continue;
                     }
@@ -315,10 +320,10 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                         const int q = t / n_boards, b = t % n_boards;
                         int8_t fb[5];
                         prl_lbr_board_at(g, S.pc, S.n_pc, b, fb);
-                        eq[q * LBRB_MAX_BOARDS + b] = prl_lbr_board_equity(g, fb, cls, cand + (size_t)q * R, hole_lut);
+                        eq[q * eq_stride + b] = prl_lbr_board_equity(g, fb, cls, cand + (size_t)q * R, hole_lut);
                     }
                     prl_sync();
-                    if (tid < n_q) S.wp[tid] = prl_lbr_reduce_range(g, cand + (size_t)tid * R, eq + tid * LBRB_MAX_BOARDS);
+                    if (tid < n_q) S.wp[tid] = prl_lbr_reduce_range(g, cand + (size_t)tid * R, eq + tid * eq_stride);
                     prl_sync();
                     if (tid == 0) {
                         const int n_u = P.limit ? 3 : 2 + P.g_lbr.n_bet_sizes;
@@ -445,12 +450,14 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
     }
     if (lbr_game->game_type == PRL_GAME_NOLIMIT || agent_game->game_type != lbr_game->game_type) { prl_set_error("batched LBR: fixed-limit or discretized games"); return PRL_ERR_UNSUPPORTED; }
     if (lbr_game->game_type == PRL_GAME_DISCRETIZED && lbr_game->n_bet_sizes + 1 > LBRB_MAX_Q) { prl_set_error("batched LBR: at most 12 LBR bet sizes"); return PRL_ERR_UNSUPPORTED; }
-    // the look-ahead equity is sized for at most one board card to come where LBR decides
+    // the look-ahead equity handles at most two board cards to come where LBR decides
+    int to_deal_max = 0;
     {
         int dealt_before_first_decision = 0;
         const int first_round = check_to_round >= 0 ? check_to_round : 0;
         for (int r = 0; r <= first_round && r < 4; ++r) dealt_before_first_decision += rules->board_cards_in_round[r];
-        if (nb - dealt_before_first_decision > 1) { prl_set_error("batched LBR: LBR may only decide with at most one board card to come (lbr_check_to_round)"); return PRL_ERR_UNSUPPORTED; }
+        to_deal_max = nb - dealt_before_first_decision;
+        if (to_deal_max > 2) { prl_set_error("batched LBR: LBR may only decide with at most two board cards to come (lbr_check_to_round)"); return PRL_ERR_UNSUPPORTED; }
     }
     PrlLbrBatchParams P;
     memset(&P, 0, sizeof(P));
@@ -460,7 +467,7 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
     P.seed = agent_seed; P.episode_base = episode_base; P.reward_scalar = reward_scalar; P.ev_normalizer = ev_normalizer;
     const int R = rules->range_size;
     const size_t smem = ((size_t)(1 + LBRB_MAX_Q) * R + LBRB_MAX_Q * LBRB_MAX_BOARDS) * sizeof(float) + R + 16 + (size_t)R * 2 + 16 + sizeof(LbrbShared) + 16 + sizeof(LbrbLeaves);
-    int8_t* d_cards = nullptr; float* d_win = nullptr; unsigned long long* d_stats = nullptr;
+    int8_t* d_cards = nullptr; float* d_win = nullptr; unsigned long long* d_stats = nullptr; float* d_eq = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = PRL_OK;
 #define LB_TRY(x) do { if ((x) != hipSuccess) { prl_set_error("HIP error in prl_lbr_batch_run"); rc = PRL_ERR_HIP; goto done; } } while (0)
@@ -477,6 +484,10 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int grid = n_envs < cus * 8 ? n_envs : cus * 8;  // persistent workgroups; every one plays its hands start to finish
+        if (to_deal_max == 2) {
+            LB_TRY(hipMalloc((void**)&d_eq, (size_t)grid * LBRB_MAX_Q * LBRB_MAX_BOARDS_2 * sizeof(float)));
+            P.eq_scratch = d_eq;
+        }
         LB_TRY(hipEventRecord(e0, nullptr));
         PRL_LAUNCH(prl_k_lbr_batch, grid, LBRB_THREADS, smem, nullptr, P);
         LB_TRY(hipEventRecord(e1, nullptr));
@@ -489,6 +500,6 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
 done:
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    (void)hipFree(d_cards); (void)hipFree(d_win); (void)hipFree(d_stats);
+    (void)hipFree(d_cards); (void)hipFree(d_win); (void)hipFree(d_stats); (void)hipFree(d_eq);
     return rc;
 }

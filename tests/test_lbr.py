@@ -188,7 +188,7 @@ def test_batched_lbr_nl_leduc_vs_reference_emu(emu_lib, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["StandardLeduc", "DiscretizedNLLeduc", "DiscretizedNLHoldem"])
+@pytest.mark.parametrize("tag", ["StandardLeduc", "DiscretizedNLLeduc", "DiscretizedNLHoldem", "DiscretizedNLHoldem_flop"])
 def test_gpu_batched_lbr_vs_reference(tag, tmp_path):
     check_batched_vs_golden(tag, tmp_path)
 
