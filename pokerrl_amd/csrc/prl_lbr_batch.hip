@@ -354,6 +354,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                     prl_sync();
                     action = S.action;
                 }
+                prl_sync();  // every lane has read the state it branched on (seat to act, round) before lane 0 steps the env
                 if (tid == 0) {
                     if (!P.limit && action >= 2) {  // step by pot fraction (:287-289)
                         const int amt = prl_fraction_of_pot_raise(S.st, P.g_lbr.bet_fracs[action - 2], S.st.cur);

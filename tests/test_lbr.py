@@ -187,6 +187,12 @@ def test_batched_lbr_nl_leduc_vs_reference_emu(emu_lib, tmp_path):
     check_batched_vs_golden("DiscretizedNLLeduc", tmp_path, max_hands=40)
 
 
+def test_batched_lbr_holdem_vs_reference_emu(emu_lib, tmp_path):
+    """1326-hand ranges through the emulator: every inter-lane hand-off of the kernel is exercised with the fibers run strictly
+    one after another (this is how a missing barrier before lane 0's env step was found)."""
+    check_batched_vs_golden("DiscretizedNLHoldem", tmp_path, max_hands=2)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["StandardLeduc", "DiscretizedNLLeduc", "DiscretizedNLHoldem", "DiscretizedNLHoldem_flop"])
 def test_gpu_batched_lbr_vs_reference(tag, tmp_path):
