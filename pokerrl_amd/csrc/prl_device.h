@@ -101,6 +101,45 @@ PRL_DEV PRL_INLINE float prl_wave_scan_canonical(float v) {
     return v;
 }
 
+// N independent canonical scans at once. Issued one by one, every masked step above pays its own "s_nop 1"; side by side the
+// steps of the other vectors ARE the wait states, so a group of 8 or 9 vectors needs a single s_nop (an s_nop costs the
+// wave an issue turn like any other instruction, and this kernel family is bound by issue turns per wave).
+#if !defined(PRL_EMU)
+#define PRL_B15(i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+#define PRL_B31(i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+PRL_DEV PRL_INLINE void prl_scan_tail8(float* v) {
+    asm("s_nop 1\n\t" PRL_B15(0) PRL_B15(1) PRL_B15(2) PRL_B15(3) PRL_B15(4) PRL_B15(5) PRL_B15(6) PRL_B15(7)
+        PRL_B31(0) PRL_B31(1) PRL_B31(2) PRL_B31(3) PRL_B31(4) PRL_B31(5) PRL_B31(6) PRL_B31(7)
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+PRL_DEV PRL_INLINE void prl_scan_tail9(float* v) {
+    asm("s_nop 1\n\t" PRL_B15(0) PRL_B15(1) PRL_B15(2) PRL_B15(3) PRL_B15(4) PRL_B15(5) PRL_B15(6) PRL_B15(7) PRL_B15(8)
+        PRL_B31(0) PRL_B31(1) PRL_B31(2) PRL_B31(3) PRL_B31(4) PRL_B31(5) PRL_B31(6) PRL_B31(7) PRL_B31(8)
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+}
+#undef PRL_B15
+#undef PRL_B31
+#endif
+template <int N>
+PRL_DEV PRL_INLINE void prl_wave_scan_canonical_n(float (&v)[N]) {
+#if defined(PRL_EMU)
+    for (int i = 0; i < N; ++i) v[i] = prl_wave_scan_canonical(v[i]);
+#else
+    static_assert(N == 9 || N == 17, "group sizes are spelled out for the two callers");
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float x = v[i];
+        x = x + prl_dpp_row_shr<1>(x);
+        x = x + prl_dpp_row_shr<2>(x);
+        x = x + prl_dpp_row_shr<4>(x);
+        x = x + prl_dpp_row_shr<8>(x);
+        v[i] = x;
+    }
+    prl_scan_tail9(v);
+    if constexpr (N == 17) prl_scan_tail8(v + 9);
+#endif
+}
+
 // lane-local helpers on 64-bit masks
 PRL_HD PRL_INLINE int prl_popc64(unsigned long long x) {
 #if defined(__HIP_DEVICE_COMPILE__)

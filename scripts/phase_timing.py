@@ -1,5 +1,5 @@
 """Per-phase shader-clock breakdown of the fused board pass (instrumented library: python -m pokerrl_amd.build --variant
-timing PRL_FHP_TIMING). Usage: python scripts/phase_timing.py [boards] [iters]"""
+timing PRL_FHP_TIMING). Usage: python scripts/phase_timing.py [boards] [iters] [warm-up iterations]"""
 import ctypes
 import os
 import sys
@@ -21,7 +21,7 @@ from helpers import env_args  # noqa: E402  (tests/helpers.py, on sys.path throu
 
 t = _native.NativeTree(G.Flop5Holdem.native_game(env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)), G.Flop5Holdem.native_rules(), boards, _lib=L)
 s = _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
-s.iterations(2)
+s.iterations(int(sys.argv[3]) if len(sys.argv) > 3 else 2)
 s.sync()
 out = (ctypes.c_ulonglong * 8)()
 L.prl_debug_fhp_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int32]
@@ -35,3 +35,5 @@ tot = v[:6].sum()
 print("ms/iter %.3f   clocks summed over wave-0 of every board pass: %.3e" % (ms / iters, tot))
 for n, x in zip(names, v[:6]):
     print("%-24s %6.2f %%   %10.0f clk per board-iteration" % (n, 100 * x / tot, x / n_boards / iters))
+if v[7] > 0:
+    print("waves with every loaded regret inside the fast-division box: %.2f %% of %d wave-boards" % (100 * v[6] / v[7], v[7]))
