@@ -104,6 +104,7 @@ def main():
     from pokerrl_amd.game import games as G
 
     _native.require_device()
+    _native.set_device(local_rank if world > 1 else 0)  # the library allocates on this process's GPU, like torch above
     # every rank owns a contiguous block of the global board list (weak scaling: fixed boards per GPU)
     boards = seeded_boards(args.boards, 0, offset=rank * args.boards)
     tree = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)

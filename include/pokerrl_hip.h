@@ -99,6 +99,9 @@ typedef struct PrlStepInfo {
 const char* prl_last_error(void);
 /* 1 if a HIP device is usable by this library build, else 0 (never throws) */
 int32_t prl_device_available(void);
+/* one process per GPU: make HIP device `ordinal` (the launcher's LOCAL_RANK) the device of every handle this thread creates
+   from now on; handles keep the device they were created on. Returns PRL_ERR_NO_DEVICE if the ordinal does not exist. */
+int32_t prl_set_device(int32_t ordinal);
 /* compile-time identification: "hip-gfx950" for the product build */
 const char* prl_build_flavor(void);
 

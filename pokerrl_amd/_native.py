@@ -92,6 +92,8 @@ def bind(path):
     L.prl_last_error.restype = ctypes.c_char_p
     L.prl_build_flavor.restype = ctypes.c_char_p
     L.prl_device_available.restype = ctypes.c_int32
+    L.prl_set_device.argtypes = [ctypes.c_int32]
+    L.prl_set_device.restype = ctypes.c_int32
     for name in ("prl_lut_idx_2_hole_cards", "prl_lut_hole_cards_2_idx", "prl_lut_card_in_what_range_idxs"):
         getattr(L, name).argtypes = [ctypes.POINTER(PrlRules), ctypes.c_void_p]
         getattr(L, name).restype = ctypes.c_int32
@@ -190,6 +192,11 @@ def check(status, L=None):
 
 def device_available():
     return bool(lib().prl_device_available())
+
+
+def set_device(ordinal):
+    """one process per GPU: bind this process's handles to HIP device `ordinal` (LOCAL_RANK)"""
+    check(lib().prl_set_device(int(ordinal)))
 
 
 def require_device():

@@ -36,6 +36,13 @@ int32_t prl_device_available(void) {
     return n > 0 ? 1 : 0;
 }
 
+int32_t prl_set_device(int32_t ordinal) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || ordinal < 0 || ordinal >= n) { prl_set_error("no such HIP device"); return PRL_ERR_NO_DEVICE; }
+    PRL_HIP_TRY(hipSetDevice(ordinal));
+    return PRL_OK;
+}
+
 const char* prl_build_flavor(void) {
 #if defined(PRL_EMU)
     return "emu-host (tests only)";

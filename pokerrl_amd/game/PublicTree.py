@@ -7,8 +7,7 @@ pass -- strategy fill, reach push-down, EV / best-response pull-up -- is a HIP k
 `node.ev`, `node.reach_probs`, `node.strategy` ... copies the corresponding slice out of HBM on demand (lazy host
 mirrors); assigning `node.strategy` stages the value and uploads all staged strategies before the next pass.
 
-Differences: `export_to_file` / `get_tree_as_dict` (debug JSON for a JS visualiser, PublicTree.py:313-420) are not
-provided; `stop_at_street` other than None is not supported (the hot path always builds full trees, _CFRBase.py:64-69).
+Differences: `stop_at_street` other than None is not supported (the hot path always builds full trees, _CFRBase.py:64-69).
 For 2-hole-card games the chance outcomes must be given (`boards=`): the reference cannot enumerate them at all
  and the full C(52,5) set does not fit one GPU.
 """
@@ -16,6 +15,8 @@ import numpy as np
 
 from pokerrl_amd import _native
 from pokerrl_amd.game.Poker import Poker
+
+from pokerrl_amd.game.PokerEnvStateDictEnums import EnvDictIdxs, PlayerDictIdxs
 
 KIND_DECISION, KIND_CHANCE, KIND_FOLD, KIND_SHOWDOWN = 0, 1, 2, 3
 
@@ -155,6 +156,7 @@ class PublicTree:
         self._cache = {}
         self._staged = {}
         self._env_states = {}
+        self._replay_env = None
 
     # ---- reference properties -----------------------------------------------------------------------------------------
     stack_size = property(lambda s: s._stack_size)
@@ -234,10 +236,27 @@ class PublicTree:
         self._invalidate()
 
     def fill_with_agent_policy(self, agent):
-        """one query per decision node (StrategyFiller.py:88-116): strategy = agent probs restricted to the legal actions"""
+        """one query per decision node (StrategyFiller.py:88-116): strategy = agent probs restricted to the legal actions.
+
+        SURVEY section 8f-1 (batched agent querying): an agent that defines
+        ``get_a_probs_for_each_hand_in_nodes(nodes) -> [len(nodes), RANGE_SIZE, N_ACTIONS]`` is asked ONCE for all decision
+        nodes (DFS pre-order, the order the reference visits them in) instead of once per node, so a neural agent can run
+        one batched forward; it positions its own env copies from ``node.env_state`` / the node's action history."""
         t = self._native_tree
         strat, dtype = np.zeros((t.n_cols, t.range_size), np.float64), None
-        for n in np.where(self._kind == KIND_DECISION)[0]:
+        decision = np.where(self._kind == KIND_DECISION)[0]
+        batched = getattr(agent, "get_a_probs_for_each_hand_in_nodes", None)
+        if callable(batched):
+            nodes = [self.node(int(n)) for n in decision]
+            probs = np.asarray(batched(nodes))
+            assert probs.shape[:2] == (len(nodes), t.range_size), probs.shape
+            for n, node, pr in zip(decision, nodes, probs):
+                strat[self._first_col[n]:self._first_col[n] + self._n_children[n]] = pr[:, node.allowed_actions].T
+            self._staged.clear()
+            self._solver.set_strategy(strat if probs.dtype == np.float64 else strat.astype(np.float32))
+            self._invalidate()
+            return
+        for n in decision:
             node = self.node(int(n))
             agent.set_to_public_tree_node_state(node=node)
             assert node.p_id_acting_next == agent._internal_env_wrapper.env.current_player.seat_id, node.p_id_acting_next
@@ -261,8 +280,18 @@ class PublicTree:
         c._solver.set_strategy(self._vec("strategy"))
         return c
 
+    def get_tree_as_dict(self):
+        """PublicTree.py:143-144: the nested PokerViz dictionary (pokerrl_amd/game/_tree_export.py)"""
+        from pokerrl_amd.game import _tree_export
+        self._flush()
+        return _tree_export.tree_as_dict(self)
+
     def export_to_file(self, name="data"):
-        return None  # PokerViz JSON export is out of scope
+        """PublicTree.py:146-149: writes <dir_tree_vis_data>/<name>.js ("const data=" + JSON) if a directory is set"""
+        if self.dir_tree_vis_data is not None:
+            from pokerrl_amd.game import _tree_export
+            return _tree_export.write_js(self.dir_tree_vis_data, name, self.get_tree_as_dict())
+        return None
 
     # ---- internals ----------------------------------------------------------------------------------------------------
     def _invalidate(self):
@@ -301,28 +330,58 @@ class PublicTree:
         return out
 
     def _env_state_of(self, idx):
-        """public env state of a node (PokerEnv.state_dict layout), rebuilt by replaying the actions from the root"""
+        """public env state of a node (PokerEnv.state_dict layout) with the reference's conventions (PublicTree.py:205-293):
+        decision nodes hold the env's state after the action; terminal and chance-pending nodes hold the state after the action
+        but BEFORE the money moves (bets not swept, nothing paid, parent's round / board / deck); a chance outcome holds the
+        post-transition state of its parent with this node's board on the table and those cards out of the deck."""
         if idx in self._env_states:
             return self._env_states[idx]
         import copy
-        env = self._env_bldr.get_new_env(is_evaluating=True, stack_size=self._stack_size)
-        path, i = [], idx
-        while i > 0:
-            path.append(i)
-            i = int(self._parent[i])
-        a = env.get_args()
-        a.RETURN_PRE_TRANSITION_STATE_IN_INFO = False
-        env.set_args(a)
-        env.reset()
-        lh = self._env_bldr.lut_holder
-        for n in reversed(path):
-            act = int(self._action[n])
-            if act == -1:  # chance outcome: put this node's board on the table
-                board_1d = self._native_tree.boards[self._board_id[n]]
-                env.board[:len(board_1d)] = lh.get_2d_cards(np.asarray(board_1d))
-                env.deck.remove_cards(env.board[:len(board_1d)])
-            elif self._kind[n] < KIND_FOLD:
-                env.step(act)
-        st = copy.deepcopy(env.state_dict())
+        if self._replay_env is None:
+            self._replay_env = self._env_bldr.get_new_env(is_evaluating=True, stack_size=self._stack_size)
+            a = self._replay_env.get_args()
+            a.RETURN_PRE_TRANSITION_STATE_IN_INFO = True
+            self._replay_env.set_args(a)
+        env = self._replay_env
+        if idx == 0:
+            env.reset()
+            st = copy.deepcopy(env.state_dict())
+        elif int(self._action[idx]) == -1:
+            pending = int(self._parent[idx])
+            before = self._env_state_of(int(self._parent[pending]))
+            env.load_state_dict(copy.deepcopy(before))
+            env.step(int(self._action[pending]))  # sweeps the bets and opens the next round (its random deal is replaced below)
+            board_1d = np.asarray(self._native_tree.boards[self._board_id[idx]])
+            env.board[:] = before[EnvDictIdxs.board_2d]
+            env.board[:len(board_1d)] = self._env_bldr.lut_holder.get_2d_cards(board_1d)
+            env.deck.load_state_dict(copy.deepcopy(before[EnvDictIdxs.deck]))
+            env.deck.remove_cards(env.board[:len(board_1d)])
+            st = copy.deepcopy(env.state_dict())
+        else:
+            before = self._env_state_of(int(self._parent[idx]))
+            env.load_state_dict(copy.deepcopy(before))
+            _o, _r, _done, info = env.step(int(self._action[idx]))
+            if self._kind[idx] == KIND_DECISION:
+                st = copy.deepcopy(env.state_dict())
+            elif self._kind[idx] == KIND_CHANCE:
+                # PokerEnv.py:761-766: the state after the (check / call) action and before _next_round -- bets still in front
+                # of the players, old pot, old round, the actor still "current". Rebuilt from the states around the step.
+                post = env.state_dict()
+                st = {k: v for k, v in copy.deepcopy(before).items() if not (isinstance(k, str) and k.startswith("_"))}
+                actor = before[EnvDictIdxs.current_player]
+                st[EnvDictIdxs.last_action] = copy.deepcopy(post[EnvDictIdxs.last_action])
+                st[EnvDictIdxs.n_actions_this_episode] = before[EnvDictIdxs.n_actions_this_episode] + 1
+                for p in range(self._n_seats):
+                    seat, b, a = st[EnvDictIdxs.seats][p], before[EnvDictIdxs.seats][p], post[EnvDictIdxs.seats][p]
+                    paid = b[PlayerDictIdxs.stack] - a[PlayerDictIdxs.stack]  # the sweep itself does not touch the stacks
+                    seat[PlayerDictIdxs.stack] = a[PlayerDictIdxs.stack]
+                    seat[PlayerDictIdxs.current_bet] = b[PlayerDictIdxs.current_bet] + paid
+                    seat[PlayerDictIdxs.is_allin] = a[PlayerDictIdxs.is_allin]
+                    seat[PlayerDictIdxs.has_acted_this_round] = True if p == actor else b[PlayerDictIdxs.has_acted_this_round]
+            else:
+                st = {k: v for k, v in copy.deepcopy(info["state_dict_before_money_move"]).items() if not (isinstance(k, str) and k.startswith("_"))}
+                st[EnvDictIdxs.current_round] = before[EnvDictIdxs.current_round]
+                st[EnvDictIdxs.board_2d] = np.copy(before[EnvDictIdxs.board_2d])
+                st[EnvDictIdxs.deck] = copy.deepcopy(before[EnvDictIdxs.deck])
         self._env_states[idx] = st
         return st

@@ -94,8 +94,25 @@ def _uniform_agent_cls():
     return UniformAgent
 
 
+def _batched_uniform_agent_cls():
+    class BatchedUniformAgent(_uniform_agent_cls()):
+        """the batched query protocol: one call for all decision nodes, the per-node query must not be used"""
+
+        def get_a_probs_for_each_hand(self):
+            raise AssertionError("per-node query used although the batched protocol is available")
+
+        def get_a_probs_for_each_hand_in_nodes(self, nodes):
+            out = np.zeros((len(nodes), self.env_bldr.rules.RANGE_SIZE, self.env_bldr.N_ACTIONS), dtype=np.float32)
+            for i, node in enumerate(nodes):
+                out[i][:, node.allowed_actions] = 1.0 / len(node.allowed_actions)
+            return out
+
+    return BatchedUniformAgent
+
+
+@pytest.mark.parametrize("batched", [False, True])
 @pytest.mark.parametrize("game_cls,expected", [(StandardLeduc, 2373.6114501953125), (DiscretizedNLLeduc, 12864.71435546875)])
-def test_local_br_master_uniform_agent(tmp_path, game_cls, expected):
+def test_local_br_master_uniform_agent(tmp_path, game_cls, expected, batched):
     """BR of a uniform agent through LocalBRMaster.evaluate (reference values, float32 agent probs)."""
     from pokerrl_amd.eval.br.LocalBRMaster import LocalBRMaster
     from pokerrl_amd.game.wrappers import HistoryEnvBuilder
@@ -110,7 +127,7 @@ def test_local_br_master_uniform_agent(tmp_path, game_cls, expected):
         env_bldr_cls=HistoryEnvBuilder, start_chips=None, eval_modes_of_algo=("UNIFORM",), eval_stack_sizes=None,
         module_args={"env": game_cls.ARGS_CLS(n_seats=2, bet_sizes_list_as_frac_of_pot=bet_sets.POT_ONLY)}, path_data=str(tmp_path))
     chief = Chief(t_prof)
-    br = LocalBRMaster(t_prof=t_prof, chief_handle=chief, eval_agent_cls=_uniform_agent_cls())
+    br = LocalBRMaster(t_prof=t_prof, chief_handle=chief, eval_agent_cls=_batched_uniform_agent_cls() if batched else _uniform_agent_cls())
     br.update_weights()
     br.evaluate(iter_nr=0)
     vals, _ = chief.get_new_values()
@@ -148,3 +165,40 @@ def test_public_tree_api_like_test_tree():
     assert np.array_equal(c0.reach_probs[0], root.reach_probs[0]) and np.all(c1.reach_probs[0] == 0)
     st = c0.env_state
     assert st["current_player"] == 1 and st["main_pot"] == 2
+
+
+@pytest.mark.parametrize("tag", ["StandardLeduc", "DiscretizedNLLeduc"])
+def test_tree_export_like_reference(tag, tmp_path):
+    """PublicTree.get_tree_as_dict / export_to_file (PublicTree.py:143-149,313-420) -- the reference's PokerViz
+    dictionary after fill_uniform_random + compute_ev, compared through the SHA-256 of its JSON (tests/golden/make_tree_export_golden.py)."""
+    import hashlib
+    import json
+    from pokerrl_amd.game.PublicTree import PublicTree
+    from pokerrl_amd.game.wrappers import HistoryEnvBuilder
+    g = golden("tree_export.npz")
+    if tag == "StandardLeduc":
+        game_cls, stack = StandardLeduc, [13, 13]
+        args = game_cls.ARGS_CLS(n_seats=2, starting_stack_sizes_list=stack)
+    else:
+        game_cls, stack = DiscretizedNLLeduc, [20000, 20000]
+        args = game_cls.ARGS_CLS(n_seats=2, starting_stack_sizes_list=stack, bet_sizes_list_as_frac_of_pot=bet_sets.POT_ONLY)
+    tree = PublicTree(env_bldr=HistoryEnvBuilder(env_cls=game_cls, env_args=args), stack_size=stack, stop_at_street=None)
+    tree.build_tree()
+    tree.fill_uniform_random()
+    tree.compute_ev()
+    d = tree.get_tree_as_dict()
+    texts = []
+    todo = [d]
+    while todo:  # pre-order
+        n = todo.pop()
+        texts.append(n["text"])
+        todo.extend(reversed(n["children"]))
+    assert len(texts) == int(g[tag + "_n"])
+    ref_sample = json.loads(str(g[tag + "_sample"]))
+    for i, ref in zip(g[tag + "_pick"], ref_sample):
+        assert texts[int(i)] == ref, (int(i), {k: (texts[int(i)][k], ref[k]) for k in ref if texts[int(i)][k] != ref[k]})
+    assert hashlib.sha256(json.dumps(d).encode()).hexdigest() == str(g[tag + "_sha256"])
+    tree.dir_tree_vis_data = str(tmp_path)
+    path = tree.export_to_file("viz")
+    with open(path) as f:
+        assert f.read() == "const data=" + json.dumps(d)
