@@ -16,15 +16,15 @@ class EvaluatorMasterBase:
         self._log_conf_interval = log_conf_interval
         c = chief_handle.create_experiment
         pre = t_prof.name + " "
-        self._exp_name_total = {
-            m: [c(pre + m + "_stack_" + str(s[0]) + ": " + eval_type + " Total") for s in t_prof.eval_stack_sizes]
-            for m in t_prof.eval_modes_of_algo}
         self._exp_names_conf = None
-        if log_conf_interval:
+        if log_conf_interval:  # registered before the totals, as in the reference (:88-107): chiefs number experiments in this order
             self._exp_names_conf = {
                 m: [[c(pre + m + "_stack_" + str(s[0]) + ": " + eval_type + " Conf_" + b) for b in ("lower95", "upper95")]
                     for s in t_prof.eval_stack_sizes]
                 for m in t_prof.eval_modes_of_algo}
+        self._exp_name_total = {
+            m: [c(pre + m + "_stack_" + str(s[0]) + ": " + eval_type + " Total") for s in t_prof.eval_stack_sizes]
+            for m in t_prof.eval_modes_of_algo}
         if self._is_multi_stack:
             self._exp_name_multi_stack = {m: c(pre + m + "Multi_Stack" + ": " + eval_type + " Averaged Total")
                                           for m in t_prof.eval_modes_of_algo}

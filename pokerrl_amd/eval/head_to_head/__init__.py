@@ -1,0 +1,4 @@
+from pokerrl_amd.eval.head_to_head.H2HArgs import H2HArgs
+from pokerrl_amd.eval.head_to_head.LocalHead2HeadMaster import LocalHead2HeadMaster
+
+__all__ = ["H2HArgs", "LocalHead2HeadMaster"]

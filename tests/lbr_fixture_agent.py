@@ -46,7 +46,8 @@ def policy(env, seed, range_size, n_actions):
 
 def make_agent_cls(EvalAgentBase, seed=7, record=None):
     class HashAgent(EvalAgentBase):
-        ALL_MODES = ["HASH"]
+        ALL_MODES = ["HASH", "HASH2"]  # head-to-head tests pit the two modes against each other: mode k plays seed + k
+        BASE_SEED = seed
         SEED = seed
         RECORD = record  # optional list: deck state of every episode
 
@@ -60,6 +61,7 @@ def make_agent_cls(EvalAgentBase, seed=7, record=None):
 
         def set_mode(self, mode):  # called once at the start of every LocalLBRWorker.run: the draws restart per run
             super().set_mode(mode)
+            self.SEED = self.BASE_SEED + (self.ALL_MODES.index(mode) if mode in self.ALL_MODES else 0)
             self._episode = 0
             self._step = 0
 

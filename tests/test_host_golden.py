@@ -244,3 +244,48 @@ def test_c_abi_exports_every_declared_symbol():
     missing = [n for n in sorted(names) if not hasattr(L, n)]
     assert not missing, missing
     assert _native.build_flavor() == "hip-gfx950"
+
+
+@pytest.mark.parametrize("tag", ["StandardLeduc", "DiscretizedNLLeduc", "DiscretizedNLHoldem"])
+def test_head_to_head_vs_reference(tag, tmp_path):
+    """LocalHead2HeadMaster on the native-backed env -- per-hand winnings and logged scalars of the reference's
+    evaluator for the two modes of the fixture agent (tests/golden/make_h2h_golden.py). Host-side functions of the library only."""
+    import json
+    import lbr_fixture_agent as fx
+    from pokerrl_amd.eval.head_to_head import H2HArgs, LocalHead2HeadMaster
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    from pokerrl_amd.game.wrappers import HistoryEnvBuilder
+    from pokerrl_amd.rl.base_cls.EvalAgentBase import EvalAgentBase
+    from pokerrl_amd.rl.base_cls.TrainingProfileBase import TrainingProfileBase
+    g = golden("h2h_%s.npz" % tag)
+    game_cls, bets = {"StandardLeduc": (G.StandardLeduc, None), "DiscretizedNLLeduc": (G.DiscretizedNLLeduc, bet_sets.B_3),
+                      "DiscretizedNLHoldem": (G.DiscretizedNLHoldem, bet_sets.B_5)}[tag]
+
+    class Chief:
+        def __init__(self):
+            self.names, self.log = [], []
+
+        def create_experiment(self, name):
+            self.names.append(name)
+            return name
+
+        def add_scalar(self, exp, graph, step, value):
+            self.log.append([exp, graph, int(step), float(value)])
+
+    t_prof = TrainingProfileBase(
+        name="h2h", log_verbose=False, log_export_freq=1, checkpoint_freq=10 ** 9, eval_agent_export_freq=10 ** 9,
+        game_cls=game_cls, env_bldr_cls=HistoryEnvBuilder, start_chips=None, eval_modes_of_algo=("HASH", "HASH2"), eval_stack_sizes=None,
+        module_args={"env": game_cls.ARGS_CLS(n_seats=2, bet_sizes_list_as_frac_of_pot=bets) if bets is not None
+                     else game_cls.ARGS_CLS(n_seats=2), "h2h": H2HArgs(n_hands=int(g["n_hands"]))}, path_data=str(tmp_path))
+    chief = Chief()
+    m = LocalHead2HeadMaster(t_prof=t_prof, chief_handle=chief, eval_agent_cls=fx.make_agent_cls(EvalAgentBase, seed=11))
+    m.set_modes(["HASH", "HASH2"])
+    np.random.seed(int(g["np_seed"]))
+    w = m.play(stack_size=t_prof.eval_stack_sizes[0])
+    assert w.dtype == np.float32 and np.array_equal(w, g["winnings"])
+    np.random.seed(int(g["np_seed"]))
+    m.set_modes(["HASH", "HASH2"])  # restarts the fixture agents' draw counters
+    m.evaluate(iter_nr=3)
+    assert chief.names == json.loads(str(g["experiments"]))
+    assert chief.log == json.loads(str(g["log"]))
