@@ -134,6 +134,7 @@ bool prl_fhp_shape_matches(const PrlFlatTree& t, int* chance_node, int* first_bo
 
 int prl_launch_fhp_pass(const PrlFhpParams& prm, int mode, int src0, int src1, void* stream);
 void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_cols, void* stream);
+void prl_launch_fhp_avg_from_sum(const PrlFhpParams& prm, void* stream);  // Vanilla / Linear: avg columns of the boards from avg_sum
 // W = floats per board / unit: 2R for both seats' vectors, R for one seat's
 void prl_launch_fhp_chance_sum(const float* d_board_vals, int n_boards, int W, float* d_scratch, float* d_dest, void* stream);
 // sharded solve (prl_solver_create_sharded): local reduction up to `level`, all-gather, then the remaining levels

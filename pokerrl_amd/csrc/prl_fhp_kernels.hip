@@ -85,6 +85,27 @@ PRL_GLOBAL void prl_k_fhp_strategy_from_regret(PrlFhpParams prm, double* out_col
     }
 }
 
+// Vanilla / Linear CFR: the average strategy of the board columns from the running sums, avg = avg_sum / sum_a avg_sum or
+// uniform (VanillaCFR.py:54-77, LinearCFR.py:53-76: float32 division, stored in the float64 column array). The board pass
+// only maintains avg_sum; this runs when the average is read (evaluation, prl_solver_get, checkpoint).
+PRL_GLOBAL void prl_k_fhp_avg_from_sum(PrlFhpParams prm) {
+    const size_t per_board = (size_t)PrlFhpShape::N_DEC * prm.R;
+    const size_t total = (size_t)prm.n_boards * per_board;
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        const size_t b = t / per_board;
+        const int j = (int)((t % per_board) / prm.R);
+        const size_t h = t % prm.R;
+        const int node = PrlFhpShape::dec_node(j);
+        const int A = PrlFhpShape::nch(node), col0 = PrlFhpShape::col0(node);
+        const size_t base = ((size_t)prm.col_base + b * PrlFhpShape::N_COLS + col0) * (size_t)prm.R + h;
+        float as[3];
+        for (int i = 0; i < A; ++i) as[i] = prm.avg_sum[base + (size_t)i * prm.R];
+        float sum = as[0];
+        for (int i = 1; i < A; ++i) sum = sum + as[i];
+        for (int i = 0; i < A; ++i) prm.avg[base + (size_t)i * prm.R] = sum == 0.f ? 1.0 / (double)A : (double)(as[i] / sum);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // canonical chance sum over the per-board root values: blocks of 32 boards, groups of 32 blocks, then the groups
 // level 0: in = per-board [n][2][R] -> out = per-block; level 1: per-block -> per-group; level 2: per-group -> dest [2][R]
@@ -116,6 +137,12 @@ void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_co
     if (prm.n_boards <= 0) return;
     size_t items = (size_t)prm.n_boards * PrlFhpShape::N_DEC * prm.R;
     PRL_LAUNCH(prl_k_fhp_strategy_from_regret, fhp_grid_for(items, 256), 256, 0, stream, prm, out_cols);
+}
+
+void prl_launch_fhp_avg_from_sum(const PrlFhpParams& prm, void* stream) {
+    if (prm.n_boards <= 0) return;
+    size_t items = (size_t)prm.n_boards * PrlFhpShape::N_DEC * prm.R;
+    PRL_LAUNCH(prl_k_fhp_avg_from_sum, fhp_grid_for(items, 256), 256, 0, stream, prm);
 }
 
 // per-board [n_boards][2][R] -> dest [2][R] in the canonical nested order; scratch >= (ceil(n/32) + ceil(n/1024)) * 2R floats

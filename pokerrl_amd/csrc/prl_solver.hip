@@ -74,6 +74,7 @@ struct prl_solver {
     int user_strategy_f64 = -1;         // -1: strategy comes from regrets / uniform
     int src[2] = {PRL_SRC_UNIFORM64, PRL_SRC_UNIFORM64};
     bool board_avg_f64 = false;
+    bool board_avg_stale = false;  // FUSED Vanilla / Linear: avg_sum moved on, the avg columns of the boards have not been recomputed yet
     float* d_regret = nullptr;  // [full_cols][R]
     double* d_avg = nullptr;    // [full_cols][R]
 };
@@ -140,6 +141,18 @@ int do_update_reach(prl_solver* s, const PrlDevState& st) {
     return PRL_OK;
 }
 
+// FUSED Vanilla / Linear: the board pass maintains avg_sum only; readers of the average call this first
+static int ensure_board_avg(prl_solver* s) {
+    if (!s->fused || !s->board_avg_stale) return PRL_OK;
+    PrlFhpParams p = s->fp;
+    p.avg_sum = s->S.avg_sum;
+    p.avg = s->d_avg;
+    prl_launch_fhp_avg_from_sum(p, s->stream);
+    PRL_HIP_TRY(hipGetLastError());
+    s->board_avg_stale = false;
+    return PRL_OK;
+}
+
 // FUSED: board pass + canonical chance sum into the trunk's chance node (st = trunk state to read reach from / write to)
 int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, int src1, const double* strat_arr) {
     PrlFhpParams p = s->fp;
@@ -159,6 +172,7 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
                 p.avgsum_iter[q] = s->avg_pending[q];
                 s->avg_pending[q] = -1;
                 s->board_avg_f64 = true;
+                s->board_avg_stale = true;
             }
     }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -568,6 +582,7 @@ int32_t prl_solver_save_state(prl_solver_t* s, void* out, uint64_t bytes) {
     const StateLayout L = state_layout(s, s->iter);
     if (bytes < L.total) { prl_set_error("save_state: buffer too small"); return PRL_ERR_ARG; }
     if (s->avg_pending[0] >= 0 || s->avg_pending[1] >= 0 || s->expl_pending) { prl_set_error("save_state: iteration not closed"); return PRL_ERR_STATE; }
+    TRY(ensure_board_avg(s));
     PrlStateHeader h;
     memset(&h, 0, sizeof(h));
     h.magic = PRL_STATE_MAGIC; h.version = 1; h.variant = s->variant; h.delay = s->delay; h.fused = s->fused; h.iter = s->iter;
@@ -610,7 +625,7 @@ int32_t prl_solver_load_state(prl_solver_t* s, const void* in, uint64_t bytes) {
     PRL_HIP_TRY(hipMemcpy(s->S.strat_f64, b + L.strat_f64, (size_t)s->T.n_nodes, hipMemcpyHostToDevice));
     PRL_HIP_TRY(hipMemcpy(s->S.avg_f64, b + L.avg_f64, (size_t)s->T.n_nodes, hipMemcpyHostToDevice));
     PRL_HIP_TRY(hipMemcpy(s->d_expl_hist, b + L.hist, (size_t)(h.iter + 1) * 2 * 4, hipMemcpyHostToDevice));
-    s->iter = h.iter; s->src[0] = h.src0; s->src[1] = h.src1; s->board_avg_f64 = h.board_avg_f64 != 0;
+    s->iter = h.iter; s->src[0] = h.src0; s->src[1] = h.src1; s->board_avg_f64 = h.board_avg_f64 != 0; s->board_avg_stale = false;
     s->user_strategy_f64 = -1; s->expl_pending = false; s->have_half = false; s->avg_pending[0] = s->avg_pending[1] = -1;
     s->ev_valid = false;
     return do_update_reach(s, s->S);
@@ -686,7 +701,7 @@ int32_t prl_solver_reset(prl_solver_t* s) {
     PRL_HIP_TRY(hipMemsetAsync(s->d_avg, 0, nc * sizeof(double), s->stream));
     PRL_HIP_TRY(hipMemsetAsync(s->S.avg_f64, 0, (size_t)s->T.n_nodes, s->stream));
     if (s->S.avg_sum) PRL_HIP_TRY(hipMemsetAsync(s->S.avg_sum, 0, nc * sizeof(float), s->stream));
-    s->board_avg_f64 = false;
+    s->board_avg_f64 = false; s->board_avg_stale = false;
     TRY(prl_solver_fill_uniform(s));
     TRY(ensure_ev(s));
     return record_expl(s);
@@ -968,6 +983,7 @@ int32_t prl_solver_eval_avg(prl_solver_t* s, float* out2) {
         TRY(alloc_node_vectors(s, &s->Seval, false));
         s->eval_ready = true;
     }
+    TRY(ensure_board_avg(s));
     PrlDevState E = s->Seval;
     E.strategy = s->d_avg;  // trunk columns precede the board columns, so the trunk view indexes the same array
     E.strat_f64 = s->S.avg_f64;
@@ -1016,7 +1032,7 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
             src = s->S.strategy; bytes = nc * 8; break;
         case PRL_SF_STRAT_F64: src = s->S.strat_f64; bytes = (size_t)s->T.n_nodes; break;
         case PRL_SF_REGRET: src = s->d_regret; bytes = nc * 4; break;
-        case PRL_SF_AVG: src = s->d_avg; bytes = nc * 8; break;
+        case PRL_SF_AVG: TRY(ensure_board_avg(s)); src = s->d_avg; bytes = nc * 8; break;
         case PRL_SF_AVG_F64: src = s->S.avg_f64; bytes = (size_t)s->T.n_nodes; break;
         case PRL_SF_AVG_SUM: src = s->S.avg_sum; bytes = nc * 4; break;
         case PRL_SF_BR_IDX: TRY(ensure_ev(s)); src = s->S.br_idx; bytes = (size_t)s->T.n_nodes * s->T.R * 4; break;
