@@ -174,7 +174,7 @@ def main():
                      "achieved_whole_iteration": bytes_iter * args.steps / (dev_ms * 1e-3) / 1e9},
     }
     if rank == 0:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_boards, args.cpu_iters)
         import ctypes
         ctypes.CDLL(None).fflush(None)  # RCCL's start-up banner sits in the C stdio buffer: push it out before the JSON line
