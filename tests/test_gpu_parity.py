@@ -171,3 +171,33 @@ def test_gpu_fhp_properties_at_scale(L):
     fc, nc, kind = t.field("first_col"), t.field("n_children"), t.field("kind")
     for n in np.where(kind == 0)[0][:200]:
         assert np.allclose(strat[fc[n]:fc[n] + nc[n]].sum(axis=0), 1, atol=1e-5)
+
+
+def test_gpu_fused_properties_at_bench_size(L):
+    """bench.py's workload at full size (262144 boards, 71 GB) on the fused engine: the size-independent properties the engine
+    exposes at that size -- exploitability of the current and of the average strategy positive and falling, the closing
+    evaluation equal to the last history entry -- and run-to-run determinism of every one of those numbers (bits), which a race
+    anywhere in the 262144-board passes would break."""
+    import bench
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    from helpers import native_tree
+    boards = bench.seeded_boards(262144, 0)
+    runs = []
+    for _ in range(2):
+        t = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)
+        s = _native.NativeSolver(t, "plus", 0, engine="fused")
+        s.iterations(3)
+        avg3 = s.eval_avg().copy()
+        s.iterations(3)
+        hist = s.get("expl_history").copy()
+        avg6 = s.eval_avg().copy()
+        cur = s.exploitability().copy()
+        runs.append((hist, avg3, avg6, cur))
+        assert hist.shape == (7, 2) and np.all(hist > 0) and hist[6].mean() < hist[0].mean()
+        assert np.array_equal(cur, hist[6])
+        assert np.all(avg6 > 0) and avg6.mean() < avg3.mean() < hist[0].mean()
+        del s, t
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a, b)
