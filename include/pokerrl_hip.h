@@ -304,6 +304,16 @@ int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* agent_game, co
                           int32_t check_to_round, int32_t agent_kind, uint32_t agent_seed, uint32_t episode_base, double reward_scalar,
                           double ev_normalizer, const int8_t* cards, float* out_winnings, uint64_t* out_stats4, float* out_device_ms);
 
+/* Batched head-to-head (PokerRL/eval/head_to_head/LocalHead2HeadMaster.py:82-126 on the batched env): n_envs
+ * hands between two of the library's synthetic agents, one GPU lane per hand (betting engine, the acting agent's row of its
+ * policy, action draw, dealing, payout with the hand ranks). ref_*: the agent whose winnings are reported, sitting in ref_seat;
+ * opp_*: its opponent; kinds / seeds / episode_base / cards / reward_scalar / ev_normalizer as in prl_lbr_batch_run; every
+ * agent counts its own action draws per hand. out_winnings[n_envs] float32 = reward[ref_seat] * REWARD_SCALAR * EV_NORMALIZER;
+ * out_stats2: env steps, showdowns. Same game for both agents (the reference assumes one action space). */
+int32_t prl_h2h_batch_run(const PrlGame* game, const PrlRules* rules, int32_t n_envs, int32_t ref_seat, int32_t ref_kind, uint32_t ref_seed,
+                          int32_t opp_kind, uint32_t opp_seed, uint32_t episode_base, double reward_scalar, double ev_normalizer,
+                          const int8_t* cards, float* out_winnings, uint64_t* out_stats2, float* out_device_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,6 +147,9 @@ def _bind_solver(L):
     L.prl_lbr_batch_run.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), i32, i32, i32, i32,
                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.prl_lbr_batch_run.restype = i32
+    L.prl_h2h_batch_run.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), i32, i32, i32, ctypes.c_uint32, i32, ctypes.c_uint32,
+                                    ctypes.c_uint32, ctypes.c_double, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.prl_h2h_batch_run.restype = i32
     L.prl_solver_state_size.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.prl_solver_state_size.restype = i32
     L.prl_solver_save_state.argtypes = [vp, vp, ctypes.c_uint64]

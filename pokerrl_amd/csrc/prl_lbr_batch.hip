@@ -504,3 +504,131 @@ done:
     (void)hipFree(d_cards); (void)hipFree(d_win); (void)hipFree(d_stats); (void)hipFree(d_eq);
     return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched head-to-head (LocalHead2HeadMaster.py:82-126 on the batched env): two synthetic agents
+// play n_envs hands, ONE LANE PER HAND -- a head-to-head hand touches only the two players' own rows of the policy, so the
+// whole episode (betting engine, the acting agent's probabilities for its hand, the action draw, dealing, payout with the
+// 7-card ranks) is scalar work; hands of a wave diverge freely. Same agents, draws and float32 arithmetic as two
+// tests/lbr_fixture_agent.py HashAgents (modes "HASH" / "HASH2") under pokerrl_amd.eval.head_to_head.LocalHead2HeadMaster.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PrlH2hBatchParams {
+    PrlGame game;
+    PrlRules rules;
+    int32_t n_envs, ref_seat, n_deal, limit;
+    int32_t kind[2];              // [0] the reference agent (its winnings are reported), [1] the opponent
+    uint32_t seed[2];
+    uint32_t episode_base;
+    double reward_scalar, ev_normalizer;
+    const int8_t* cards;          // [n_envs][n_deal]: seat 0's hole cards, seat 1's, then the board in deal order
+    float* winnings;              // [n_envs]
+    unsigned long long* stats;    // [2] env steps, showdowns
+};
+
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_h2h_batch(PrlH2hBatchParams P) {
+    const int e = (int)(prl_bid() * prl_nthreads() + prl_tid());
+    unsigned long long n_steps = 0, n_show = 0;
+    if (e < P.n_envs) {
+        const int nh = P.rules.n_hole_cards, nb = P.rules.n_board_cards;
+        const int8_t* cards = P.cards + (size_t)e * P.n_deal;
+        const int8_t* deck_board = cards + 2 * nh;
+        const uint32_t episode = P.episode_base + (uint32_t)e + 1u;
+        PrlEnvState st;
+        prl_env_reset(P.game, st);
+        int8_t board[5] = {0, 0, 0, 0, 0};
+        int n_dealt = 0;
+        int step_ctr[2] = {0, 0};  // per agent: its own get_action calls of this episode
+        int hand_idx[2];
+        for (int p = 0; p < 2; ++p) hand_idx[p] = lbrb_hand_idx(P.rules, cards + p * nh);
+        PrlLbrGame hg;
+        hg.n_hole = nh; hg.n_cards = P.rules.n_cards; hg.n_suits = P.rules.n_suits; hg.rank_rule = P.rules.rank_rule; hg.R = P.rules.range_size;
+        hg.n_board_total = nb;
+        for (bool done = false; !done;) {
+            const int seat = st.cur;
+            const int who = seat == P.ref_seat ? 0 : 1;
+            int32_t legal[PRL_MAX_BET_SIZES + 2];
+            const int n_legal = prl_legal_actions(P.game, st, legal);
+            const uint32_t key = lbrb_state_key(P.seed[who], st, board, n_dealt, nb, P.rules.n_suits);
+            const uint32_t x = lbrb_mix32(P.seed[who] * 0x51ED27u + episode * 0x9E3779B1u + (uint32_t)step_ctr[who]);
+            const float u = (float)(x >> 8) / 16777216.0f;
+            step_ctr[who] += 1;
+            int a = legal[n_legal - 1];
+            float c = 0.f;
+            for (int j = 0; j < n_legal; ++j) {
+                c = c + lbrb_agent_prob(P.kind[who], key, hand_idx[seat], legal, n_legal, legal[j]);
+                if (u < c) { a = legal[j]; break; }
+            }
+            PrlStepInfo info;
+            if (!P.limit && a >= 2) {  // discretized games step by pot fraction
+                const int amt = prl_fraction_of_pot_raise(st, P.game.bet_fracs[a - 2], st.cur);
+                prl_env_step_processed(P.game, st, PRL_BET_RAISE, amt, &info);
+            } else prl_env_step(P.game, st, a, &info);
+            n_steps += 1;
+            if (info.is_terminal) {
+                if (info.rundown)
+                    for (; n_dealt < nb; ++n_dealt) board[n_dealt] = deck_board[n_dealt];
+                const int pot = st.main_pot, rs = P.ref_seat;
+                double award = 0.0;
+                if (st.folded[0] || st.folded[1]) award = st.folded[rs] ? 0.0 : (double)pot;
+                else {
+                    const int32_t r0 = prl_lbr_rank(hg, hand_idx[rs], board), r1 = prl_lbr_rank(hg, hand_idx[1 - rs], board);
+                    award = r0 > r1 ? (double)pot : (r0 < r1 ? 0.0 : (double)pot / 2.0);
+                    n_show += 1;
+                }
+                const double rew = ((double)st.stack[rs] + award - (double)P.game.start_stack[rs]) / P.reward_scalar;  // PokerEnv.py:1069-1072
+                P.winnings[e] = (float)(rew * P.reward_scalar * P.ev_normalizer);                                     // LocalHead2HeadMaster.py:122-124
+                done = true;
+            } else if (info.chance_acts) {
+                const int n_new = P.rules.board_cards_in_round[st.round];
+                for (int i = 0; i < n_new; ++i) { board[n_dealt] = deck_board[n_dealt]; n_dealt += 1; }
+            }
+        }
+    }
+    // one pair of atomics per wave: butterfly sum of the per-lane counts (each far below 2^31)
+    int cs = (int)n_steps, cw = (int)n_show;
+    const int lane = (int)(prl_tid() & 63);
+    for (int off = 32; off > 0; off >>= 1) { cs += prl_shfl_i(cs, lane ^ off); cw += prl_shfl_i(cw, lane ^ off); }
+    if (lane == 0) { prl_atomic_add_u64(P.stats + 0, (unsigned long long)cs); prl_atomic_add_u64(P.stats + 1, (unsigned long long)cw); }
+}
+
+extern "C" int32_t prl_h2h_batch_run(const PrlGame* game, const PrlRules* rules, int32_t n_envs, int32_t ref_seat, int32_t ref_kind, uint32_t ref_seed,
+                                     int32_t opp_kind, uint32_t opp_seed, uint32_t episode_base, double reward_scalar, double ev_normalizer,
+                                     const int8_t* cards, float* out_winnings, uint64_t* out_stats2, float* out_device_ms) {
+    if (!game || !rules || !cards || !out_winnings || n_envs <= 0 || ref_seat < 0 || ref_seat > 1) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    if (!prl_device_available()) { prl_set_error("no HIP device: batched head-to-head has no CPU fallback"); return PRL_ERR_NO_DEVICE; }
+    const int nh = rules->n_hole_cards, nb = rules->n_board_cards;
+    if (nh < 1 || nh > 2 || rules->n_cards > PRL_LBR_MAX_CARDS || nb > 5 || (nh == 2 && (rules->n_cards != 52 || nb != 5))) {
+        prl_set_error("batched head-to-head: 1-hole-card games or 52-card hold'em"); return PRL_ERR_UNSUPPORTED;
+    }
+    if (game->game_type == PRL_GAME_NOLIMIT) { prl_set_error("batched head-to-head: fixed-limit or discretized games"); return PRL_ERR_UNSUPPORTED; }
+    PrlH2hBatchParams P;
+    memset(&P, 0, sizeof(P));
+    P.game = *game; P.rules = *rules; P.n_envs = n_envs; P.ref_seat = ref_seat; P.n_deal = 2 * nh + nb; P.limit = game->game_type == PRL_GAME_LIMIT;
+    P.kind[0] = ref_kind; P.kind[1] = opp_kind; P.seed[0] = ref_seed; P.seed[1] = opp_seed;
+    P.episode_base = episode_base; P.reward_scalar = reward_scalar; P.ev_normalizer = ev_normalizer;
+    int8_t* d_cards = nullptr; float* d_win = nullptr; unsigned long long* d_stats = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = PRL_OK;
+#define HB_TRY(x) do { if ((x) != hipSuccess) { prl_set_error("HIP error in prl_h2h_batch_run"); rc = PRL_ERR_HIP; goto done; } } while (0)
+    HB_TRY(hipMalloc((void**)&d_cards, (size_t)n_envs * P.n_deal));
+    HB_TRY(hipMalloc((void**)&d_win, (size_t)n_envs * sizeof(float)));
+    HB_TRY(hipMalloc((void**)&d_stats, 2 * sizeof(unsigned long long)));
+    HB_TRY(hipMemcpy(d_cards, cards, (size_t)n_envs * P.n_deal, hipMemcpyHostToDevice));
+    HB_TRY(hipMemset(d_stats, 0, 2 * sizeof(unsigned long long)));
+    P.cards = d_cards; P.winnings = d_win; P.stats = d_stats;
+    HB_TRY(hipEventCreate(&e0));
+    HB_TRY(hipEventCreate(&e1));
+    HB_TRY(hipEventRecord(e0, nullptr));
+    PRL_LAUNCH(prl_k_h2h_batch, (n_envs + 255) / 256, 256, 0, nullptr, P);
+    HB_TRY(hipEventRecord(e1, nullptr));
+    HB_TRY(hipDeviceSynchronize());
+    if (out_device_ms) HB_TRY(hipEventElapsedTime(out_device_ms, e0, e1));
+    HB_TRY(hipMemcpy(out_winnings, d_win, (size_t)n_envs * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_stats2) HB_TRY(hipMemcpy(out_stats2, d_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+#undef HB_TRY
+done:
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_cards); (void)hipFree(d_win); (void)hipFree(d_stats);
+    return rc;
+}

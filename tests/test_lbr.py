@@ -199,6 +199,58 @@ def test_gpu_batched_lbr_vs_reference(tag, tmp_path):
     check_batched_vs_golden(tag, tmp_path)
 
 
+H2H_CASES = {"StandardLeduc": (StandardLeduc, None), "DiscretizedNLLeduc": (DiscretizedNLLeduc, bet_sets.B_3),
+             "DiscretizedNLHoldem": (DiscretizedNLHoldem, bet_sets.B_5)}
+
+
+def check_batched_h2h_vs_golden(tag, tmp_path):
+    """SURVEY 8f-3 on the batched env: the one-lane-per-hand engine plays the golden head-to-head hands (same decks, same agent
+    draws) -- per-hand winnings bit-identical to the reference's LocalHead2HeadMaster (tests/golden/h2h_*.npz)"""
+    from pokerrl_amd.eval.head_to_head import BatchedHead2Head, H2HArgs, LocalHead2HeadMaster
+    game_cls, bets = H2H_CASES[tag]
+    g = np.load(os.path.join(HERE, "golden", "h2h_%s.npz" % tag))
+    n = int(g["n_hands"])
+    env_args = game_cls.ARGS_CLS(n_seats=2, bet_sizes_list_as_frac_of_pot=bets) if bets is not None else game_cls.ARGS_CLS(n_seats=2)
+    t_prof = TrainingProfileBase(
+        name="h2h", log_verbose=False, log_export_freq=1, checkpoint_freq=10 ** 9, eval_agent_export_freq=10 ** 9, game_cls=game_cls,
+        env_bldr_cls=HistoryEnvBuilder, start_chips=None, eval_modes_of_algo=("HASH", "HASH2"), eval_stack_sizes=None,
+        module_args={"env": env_args, "h2h": H2HArgs(n_hands=n)}, path_data=str(tmp_path))
+
+    class Chief:
+        def create_experiment(self, name):
+            return name
+
+        def add_scalar(self, *a):
+            pass
+
+    # the decks of the golden run: replay the reference's shuffles with the host evaluator (same np.random consumption)
+    record = []
+    m = LocalHead2HeadMaster(t_prof=t_prof, chief_handle=Chief(), eval_agent_cls=fx.make_agent_cls(EvalAgentBase, seed=11, record=record))
+    m.set_modes(["HASH", "HASH2"])
+    np.random.seed(int(g["np_seed"]))
+    host = m.play(stack_size=t_prof.eval_stack_sizes[0])
+    assert np.array_equal(host, g["winnings"])
+    lut = game_cls.get_lut_holder()
+    b = BatchedHead2Head(t_prof, kinds=("hash", "hash"), seeds=(11, 12))
+    decks = decks_from_record(record[::2], lut, b.n_deal - 2 * b._rules.n_hole_cards)  # both agents record every episode
+    assert decks.shape[0] == 2 * n
+    got = b.play(n_hands=n, decks=decks)
+    want = g["winnings"]
+    assert np.array_equal(got, want), "%s: %d of %d hands differ (first at %s)" % (tag, int(np.sum(got != want)), 2 * n, np.flatnonzero(got != want)[:5])
+    assert b.last_stats["env_steps"] >= n
+
+
+@pytest.mark.parametrize("tag", ["StandardLeduc", "DiscretizedNLLeduc", "DiscretizedNLHoldem"])
+def test_batched_h2h_vs_reference_emu(emu_lib, tag, tmp_path):
+    check_batched_h2h_vs_golden(tag, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["StandardLeduc", "DiscretizedNLLeduc", "DiscretizedNLHoldem"])
+def test_gpu_batched_h2h_vs_reference(tag, tmp_path):
+    check_batched_h2h_vs_golden(tag, tmp_path)
+
+
 @pytest.fixture()
 def emu_lib(monkeypatch):
     sys.path.insert(0, os.path.join(HERE, "emu"))
