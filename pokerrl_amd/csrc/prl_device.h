@@ -9,6 +9,7 @@
 #include "prl_emu.h"
 #define PRL_LAUNCH_BOUNDS(n)
 inline void prl_atomic_add_u64(unsigned long long* p, unsigned long long v) { *p += v; }  // the emulator runs one fiber at a time
+inline void prl_lds_add_i(int* p, int v) { *p += v; }
 #else
 #include <hip/hip_runtime.h>
 
@@ -17,6 +18,7 @@ inline void prl_atomic_add_u64(unsigned long long* p, unsigned long long v) { *p
 
 #define PRL_LAUNCH_BOUNDS(n) __launch_bounds__(n)
 PRL_DEV PRL_INLINE void prl_atomic_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+PRL_DEV PRL_INLINE void prl_lds_add_i(int* p, int v) { atomicAdd(p, v); }  // integer add on an LDS word (order-free)
 PRL_DEV PRL_INLINE unsigned prl_tid() { return threadIdx.x; }
 PRL_DEV PRL_INLINE unsigned prl_bid() { return blockIdx.x; }
 PRL_DEV PRL_INLINE unsigned prl_nthreads() { return blockDim.x; }

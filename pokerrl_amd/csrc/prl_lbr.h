@@ -17,7 +17,7 @@
 template <int D, class Next>
 PRL_HD PRL_INLINE float prl_np_sum_stream(int n, Next& next) {
     struct Frame { int n; int stage; float left; };
-    Frame fr[12];  // depth <= log2(n / 128) + 1
+    Frame fr[8];  // depth <= log2(n / 128) + 1: n <= 128 * 2^7 (ranges have at most 1326 entries)
     int sp = 0;
     fr[0].n = n; fr[0].stage = 0; fr[0].left = 0.f;
     float ret = 0.f;
@@ -117,18 +117,25 @@ PRL_HD PRL_INLINE unsigned long long prl_lbr_hand_mask(const PrlLbrGame& g, int 
 
 // PokerRange.set_cards_to_zero_prob(board) -> normalize (PokerRange.py:45-50, :67-84; an all-zero range becomes uniform),
 // then the sums over the hands LBR beats (+ half the ties) (:509-510). `cl` is the classification of the FIRST board.
+// n_big / n_eq: how many hands are in class 1 / 2 (the same for every board and range of a look-ahead: count once), or -1.
 PRL_HD PRL_INLINE float prl_lbr_board_equity(const PrlLbrGame& g, const int8_t* full_board, const uint8_t* cl, const float* rg,
-                                             const uint16_t* hole_lut = nullptr) {
+                                             const uint16_t* hole_lut = nullptr, int n_big = -1, int n_eq = -1) {
     unsigned long long bmask = 0ull;
     for (int i = 0; i < g.n_board_total; ++i) bmask |= 1ull << full_board[i];
-    auto blocked = [&](int h) { return (prl_lbr_hand_mask(g, h, hole_lut) & bmask) != 0ull; };
+    // with the hole-card table: two shifts of the board mask instead of building the hand's own 64-bit mask
+    auto blocked = [&](int h) {
+        if (g.n_hole == 2 && hole_lut) { const unsigned v = hole_lut[h]; return (((bmask >> (v & 0xFFu)) | (bmask >> (v >> 8))) & 1ull) != 0ull; }
+        return (prl_lbr_hand_mask(g, h, hole_lut) & bmask) != 0ull;
+    };
     int h0 = 0;
     auto nx = [&]() { const int h = h0++; return blocked(h) ? 0.f : rg[h]; };
     const float norm = prl_np_sum_stream<4>(g.R, nx);
     const float unif = (float)(1.0 / (double)g.R);
     auto value = [&](int h) { return norm == 0.f ? unif : (blocked(h) ? 0.f : rg[h]) / norm; };
-    int n_big = 0, n_eq = 0;
-    for (int h = 0; h < g.R; ++h) { n_big += cl[h] == 1; n_eq += cl[h] == 2; }
+    if (n_big < 0) {
+        n_big = 0; n_eq = 0;
+        for (int h = 0; h < g.R; ++h) { n_big += cl[h] == 1; n_eq += cl[h] == 2; }
+    }
     int hb = 0, he = 0;
     auto next_big = [&]() { while (cl[hb] != 1) ++hb; return value(hb++); };
     auto next_eq = [&]() { while (cl[he] != 2) ++he; return value(he++); };
@@ -164,9 +171,11 @@ PRL_HD PRL_INLINE void prl_lbr_board_at(const PrlLbrGame& g, const int8_t* pc, i
     }
 }
 
-// card-removal-aware board probabilities and the running float32 sum over the boards (:432-468, :470-497)
-PRL_HD PRL_INLINE float prl_lbr_reduce_range(const PrlLbrGame& g, const float* rg, const float* e /* [n_boards] */) {
-    float cp[PRL_LBR_MAX_CARDS];
+// card-removal-aware board probabilities and the running float32 sum over the boards (:432-468, :470-497).
+// cp / cp2: work arrays of n_cards floats each (cp2 only when two cards are to come); pc: the possible cards, ascending.
+// The batched engine passes LDS for them: per-lane private arrays of this size would cap the waves the runtime keeps in flight.
+PRL_HD PRL_INLINE float prl_lbr_reduce_range_w(const PrlLbrGame& g, const float* rg, const float* e /* [n_boards] */, float* cp, float* cp2,
+                                               const int8_t* pc, int n_pc) {
     for (int c = 0; c < g.n_cards; ++c) {
         float p;
         if (g.n_hole == 1) p = rg[c];
@@ -190,8 +199,6 @@ PRL_HD PRL_INLINE float prl_lbr_reduce_range(const PrlLbrGame& g, const float* r
         if (s > 0.f)
             for (int c = 0; c < g.n_cards; ++c) cp[c] = cp[c] / s;
     }
-    int8_t pc[PRL_LBR_MAX_CARDS];
-    const int n_pc = prl_lbr_possible_cards(g, pc);
     float win = 0.f;
     bool first = true;
     auto add = [&](float x) { win = first ? x : win + x; first = false; };  // 0.0 (Python float) + float32 -> float32
@@ -201,7 +208,6 @@ PRL_HD PRL_INLINE float prl_lbr_reduce_range(const PrlLbrGame& g, const float* r
         for (int i = 0; i < n_pc; ++i) add(e[b++] * cp[pc[i]]);
     } else {
         for (int i = 0; i + 1 < n_pc; ++i) {
-            float cp2[PRL_LBR_MAX_CARDS];
             for (int c = 0; c < g.n_cards; ++c) cp2[c] = cp[c];
             cp2[pc[i]] = 0.f;
             int k = 0;
@@ -215,4 +221,10 @@ PRL_HD PRL_INLINE float prl_lbr_reduce_range(const PrlLbrGame& g, const float* r
     float fact = 1.f;
     for (int m = 2; m <= g.n_to_deal; ++m) fact = fact * (float)m;
     return win * fact;  // :463-468
+}
+PRL_HD PRL_INLINE float prl_lbr_reduce_range(const PrlLbrGame& g, const float* rg, const float* e /* [n_boards] */) {
+    float cp[PRL_LBR_MAX_CARDS], cp2[PRL_LBR_MAX_CARDS];
+    int8_t pc[PRL_LBR_MAX_CARDS];
+    const int n_pc = prl_lbr_possible_cards(g, pc);
+    return prl_lbr_reduce_range_w(g, rg, e, cp, cp2, pc, n_pc);
 }

@@ -11,6 +11,7 @@
 //           action), key = hash chain over the public betting state and the board, normalised per hand in float32;
 //           tests/lbr_fixture_agent.py is the same policy as a host EvalAgent (the reference plays against that one)
 // The agent's action is drawn with a counter-based hash of (seed, episode, step): no RNG state.
+#include <cstdlib>
 #include <string.h>
 
 #include <string>
@@ -25,9 +26,20 @@
 extern "C" int32_t prl_device_available(void);
 
 #define LBRB_THREADS 576
-#define LBRB_MAX_Q 13      // check/call + up to 12 raise sizes considered by LBR
+#define LBRB_MAX_Q 12      // check/call + up to 11 raise sizes considered by LBR (OFF_TREE_11); sized so that TWO workgroups fit the 160 KB of LDS of a CU
+#define LBRB_MAX_LEGAL 16  // fold, check/call and up to 14 bet sizes of either player: per-lane arrays of this size stay small (private memory
+                           // per lane bounds how many waves the runtime keeps in flight)
 #define LBRB_MAX_BOARDS 64  // boards per equity kept in LDS: one card to come (52-card turn: 46)
 #define LBRB_MAX_BOARDS_2 1088  // two cards to come (hold'em flop: C(47, 2) = 1081 -- the agent's cards are unknown to LBR): the equities go through an HBM scratch row
+
+// PRL_LBRB_TIMING builds (python -m pokerrl_amd.build --variant lbrtiming PRL_LBRB_TIMING): lane 0 of every workgroup accumulates
+// the shader clock between the marks below into stats[4 + i]; prl_lbr_batch_run prints the breakdown to stderr.
+#ifdef PRL_LBRB_TIMING
+#define LBRB_TICK(i) do { if (tid == 0) { const long long t_ = clock64(); atomicAdd(P.stats + 4 + (i), (unsigned long long)(t_ - t_prev)); t_prev = t_; } } while (0)
+#else
+#define LBRB_TICK(i) do { } while (0)
+#endif
+#define LBRB_N_STATS 16
 
 struct PrlLbrBatchParams {
     PrlGame g_lbr, g_agent;
@@ -82,9 +94,10 @@ PRL_HD PRL_INLINE int lbrb_hand_idx(const PrlRules& r, const int8_t* hc) {
 }
 
 struct LbrbShared {
+    int32_t n_big, n_eq;           // class sizes of the look-ahead's first board
     PrlEnvState st;
     PrlStepInfo info;
-    int32_t legal[PRL_MAX_BET_SIZES + 2];
+    int32_t legal[LBRB_MAX_LEGAL];
     int32_t n_legal, action, done, n_dealt, step_ctr, n_q, n_boards, lbr_idx;
     uint32_t key;
     float total;
@@ -129,7 +142,7 @@ PRL_DEV PRL_INLINE void lbrb_build_leaves(LbrbLeaves& Lf, int n) {  // one threa
 // sum over the recursion tree of the per-block sums (blocks in order): same halving as above, post-order adds
 PRL_DEV PRL_INLINE float lbrb_combine(const LbrbLeaves& Lf, int n) {
     struct Frame { int n; int stage; float left; };
-    Frame fr[12];
+    Frame fr[8];  // n <= 128 * 2^7
     int sp = 0, leaf = 0;
     fr[0].n = n; fr[0].stage = 0; fr[0].left = 0.f;
     float ret = 0.f;
@@ -183,7 +196,13 @@ PRL_DEV PRL_INLINE void lbrb_normalize(float* rg, int R, LbrbLeaves& Lf, LbrbSha
     prl_sync();
 }
 
-PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParams P) {
+// two workgroups (18 waves) per CU: at most 102 VGPRs per lane, i.e. 5 waves per SIMD
+#if defined(PRL_EMU)
+#define LBRB_LB
+#else
+#define LBRB_LB __launch_bounds__(LBRB_THREADS, 5)
+#endif
+PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
     char* lbrb_smem = prl_smem();
     const int R = P.rules.range_size, tid = (int)prl_tid();
     float* rg = (float*)lbrb_smem;                 // [R] the agent's range
@@ -193,9 +212,13 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
     uint16_t* hole_lut = (uint16_t*)(((size_t)(cls + R) + 15) & ~(size_t)15);  // [R] c1 | c2 << 8
     LbrbShared& S = *(LbrbShared*)(((size_t)(hole_lut + R) + 15) & ~(size_t)15);
     LbrbLeaves& Lf = *(LbrbLeaves*)(((size_t)(&S + 1) + 15) & ~(size_t)15);
+    float* cpw = (float*)(((size_t)(&Lf + 1) + 15) & ~(size_t)15);  // [LBRB_MAX_Q][PRL_LBR_MAX_CARDS] card probabilities of the look-ahead
     if (tid == 0) lbrb_build_leaves(Lf, R);
     const int nh = P.rules.n_hole_cards, lbr_seat = 1 - P.agent_seat, n_board_total = P.rules.n_board_cards;
     unsigned long long n_steps = 0, n_look = 0, n_eq = 0, n_agent = 0;
+#ifdef PRL_LBRB_TIMING
+    long long t_prev = clock64();
+#endif
     for (int h = tid; h < R; h += LBRB_THREADS) {
         int c1 = h, c2 = h;
         if (nh == 2) prl_hole_cards_2(h, P.rules.n_cards, &c1, &c2);
@@ -225,6 +248,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
             for (int h = tid; h < R; h += LBRB_THREADS) rg[h] = (prl_lbr_hand_mask(hg, h, hole_lut) & m) ? 0.f : unif;
         }
         lbrb_normalize(rg, R, Lf, S);
+        LBRB_TICK(0);  // reset + range init
 
         while (true) {
             prl_sync();
@@ -255,7 +279,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                             prl_env_step(P.g_lbr, s2, a, &inf);
                             S.raise_action[nq] = a;
                             S.pot_after[nq] = s2.main_pot + s2.bet[0] + s2.bet[1];
-                            int32_t lg2[PRL_MAX_BET_SIZES + 2];
+                            int32_t lg2[LBRB_MAX_LEGAL];
                             const int nl2 = prl_legal_actions(P.g_agent, s2, lg2);
                             S.raise_n_legal[nq] = nl2;
                             for (int k = 0; k < 8; ++k) S.raise_legal[nq][k] = k < nl2 ? lg2[k] : -1;
@@ -266,6 +290,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                         S.n_q = nq;
                     }
                     prl_sync();
+                    LBRB_TICK(1);  // look-ahead set-up (scalar)
                     const PrlLbrGame g = S.lg;
                     const int n_q = S.n_q, n_boards = S.n_boards;
                     const bool big = n_boards > LBRB_MAX_BOARDS;
@@ -278,7 +303,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                     // candidate 0: the range as it is; candidate q: after "agent does not fold to raise q" (:131-141, :241-251)
                     for (int h = tid; h < R; h += LBRB_THREADS) cand[h] = rg[h];
                     for (int q = 1; q < n_q; ++q) {
-                        int32_t lg2[PRL_MAX_BET_SIZES + 2];
+                        int32_t lg2[LBRB_MAX_LEGAL];
                         const int nl2 = S.raise_n_legal[q];
                         // the hash needs the whole legal list: recompute it (cheap, scalar) when it is longer than the cache
                         if (nl2 > 8) {
@@ -294,9 +319,19 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                     {
                         int8_t fb0[5];
                         prl_lbr_board_at(g, S.pc, S.n_pc, 0, fb0);
-                        for (int h = tid; h < R; h += LBRB_THREADS) cls[h] = prl_lbr_classify_hand(g, S.lbr_idx, h, fb0);
+                        if (tid == 0) { S.n_big = 0; S.n_eq = 0; }
+                        prl_sync();
+                        int nb1 = 0, ne1 = 0;
+                        for (int h = tid; h < R; h += LBRB_THREADS) {
+                            const uint8_t c = prl_lbr_classify_hand(g, S.lbr_idx, h, fb0);
+                            cls[h] = c;
+                            nb1 += c == 1; ne1 += c == 2;
+                        }
+                        if (nb1) prl_lds_add_i(&S.n_big, nb1);  // class sizes: the same for every (range, board) pair of this look-ahead
+                        if (ne1) prl_lds_add_i(&S.n_eq, ne1);
                     }
                     prl_sync();
+                    LBRB_TICK(2);  // candidate fold probabilities + classification
                     // one lane per raise: fold probability and the not-fold mass, NumPy order
                     if (tid >= 1 && tid < n_q) {
                         const float* pf = cand + (size_t)tid * R;
@@ -308,6 +343,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                         S.notfold_total[tid] = prl_np_sum_stream<4>(R, nx2);         // mul_and_norm(1 - p_fold): normalisation
                     }
                     prl_sync();
+                    LBRB_TICK(3);  // fold / not-fold sums (one lane per raise)
                     for (int q = 1; q < n_q; ++q) {
                         const float t = S.notfold_total[q];
                         for (int h = tid; h < R; h += LBRB_THREADS) {
@@ -316,15 +352,21 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                         }
                     }
                     prl_sync();
+                    LBRB_TICK(4);  // candidate ranges
                     for (int t = tid; t < n_q * n_boards; t += LBRB_THREADS) {
                         const int q = t / n_boards, b = t % n_boards;
                         int8_t fb[5];
                         prl_lbr_board_at(g, S.pc, S.n_pc, b, fb);
-                        eq[q * eq_stride + b] = prl_lbr_board_equity(g, fb, cls, cand + (size_t)q * R, hole_lut);
+                        eq[q * eq_stride + b] = prl_lbr_board_equity(g, fb, cls, cand + (size_t)q * R, hole_lut, S.n_big, S.n_eq);
                     }
                     prl_sync();
-                    if (tid < n_q) S.wp[tid] = prl_lbr_reduce_range(g, cand + (size_t)tid * R, eq + tid * eq_stride);
+                    LBRB_TICK(5);  // (range, board) equities
+                    // work arrays in LDS: the card probabilities next to the shared state; the second set (two cards to come)
+                    // in the LDS equity rows, which are idle then because those equities go through the HBM scratch row
+                    if (tid < n_q) S.wp[tid] = prl_lbr_reduce_range_w(g, cand + (size_t)tid * R, eq + tid * eq_stride, cpw + tid * PRL_LBR_MAX_CARDS,
+                                                                      eq_lds + tid * LBRB_MAX_BOARDS, S.pc, S.n_pc);
                     prl_sync();
+                    LBRB_TICK(6);  // board probabilities + reduction (one lane per candidate)
                     if (tid == 0) {
                         const int n_u = P.limit ? 3 : 2 + P.g_lbr.n_bet_sizes;
                         float best = 0.f;  // utility[FOLD] = 0; illegal actions are -1 (:209-212)
@@ -353,6 +395,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                     }
                     prl_sync();
                     action = S.action;
+                    LBRB_TICK(7);  // utilities + arg-max
                 }
                 prl_sync();  // every lane has read the state it branched on (seat to act, round) before lane 0 steps the env
                 if (tid == 0) {
@@ -391,6 +434,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                 }
             }
             prl_sync();
+            LBRB_TICK(8);  // agent action + range update + env step
             // ---------------- after the step: cards, range, payout (PokerEnv._step + the facade's _after_step) ---------------
             n_steps += tid == 0;
             const PrlStepInfo info = S.info;
@@ -430,6 +474,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(LBRB_THREADS) prl_k_lbr_batch(PrlLbrBatchParam
                     if (prl_lbr_hand_mask(hg, h, hole_lut) & m) rg[h] = 0.f;
                 lbrb_normalize(rg, R, Lf, S);
             }
+            LBRB_TICK(9);  // after the step: dealing / range update / payout
         }
     }
     if (tid == 0) {
@@ -450,7 +495,8 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
         prl_set_error("batched LBR: 1-hole-card games or 52-card hold'em"); return PRL_ERR_UNSUPPORTED;
     }
     if (lbr_game->game_type == PRL_GAME_NOLIMIT || agent_game->game_type != lbr_game->game_type) { prl_set_error("batched LBR: fixed-limit or discretized games"); return PRL_ERR_UNSUPPORTED; }
-    if (lbr_game->game_type == PRL_GAME_DISCRETIZED && lbr_game->n_bet_sizes + 1 > LBRB_MAX_Q) { prl_set_error("batched LBR: at most 12 LBR bet sizes"); return PRL_ERR_UNSUPPORTED; }
+    if (lbr_game->n_bet_sizes + 2 > LBRB_MAX_LEGAL || agent_game->n_bet_sizes + 2 > LBRB_MAX_LEGAL) { prl_set_error("batched LBR: at most 14 bet sizes per player"); return PRL_ERR_UNSUPPORTED; }
+    if (lbr_game->game_type == PRL_GAME_DISCRETIZED && lbr_game->n_bet_sizes + 1 > LBRB_MAX_Q) { prl_set_error("batched LBR: at most 11 LBR bet sizes"); return PRL_ERR_UNSUPPORTED; }
     // the look-ahead equity handles at most two board cards to come where LBR decides
     int to_deal_max = 0;
     {
@@ -467,16 +513,16 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
     P.n_deal = 2 * nh + nb; P.limit = lbr_game->game_type == PRL_GAME_LIMIT;
     P.seed = agent_seed; P.episode_base = episode_base; P.reward_scalar = reward_scalar; P.ev_normalizer = ev_normalizer;
     const int R = rules->range_size;
-    const size_t smem = ((size_t)(1 + LBRB_MAX_Q) * R + LBRB_MAX_Q * LBRB_MAX_BOARDS) * sizeof(float) + R + 16 + (size_t)R * 2 + 16 + sizeof(LbrbShared) + 16 + sizeof(LbrbLeaves);
+    const size_t smem = ((size_t)(1 + LBRB_MAX_Q) * R + LBRB_MAX_Q * LBRB_MAX_BOARDS) * sizeof(float) + R + 16 + (size_t)R * 2 + 16 + sizeof(LbrbShared) + 16 + sizeof(LbrbLeaves) + 16 + (size_t)LBRB_MAX_Q * PRL_LBR_MAX_CARDS * sizeof(float);
     int8_t* d_cards = nullptr; float* d_win = nullptr; unsigned long long* d_stats = nullptr; float* d_eq = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = PRL_OK;
 #define LB_TRY(x) do { if ((x) != hipSuccess) { prl_set_error("HIP error in prl_lbr_batch_run"); rc = PRL_ERR_HIP; goto done; } } while (0)
     LB_TRY(hipMalloc((void**)&d_cards, (size_t)n_envs * P.n_deal));
     LB_TRY(hipMalloc((void**)&d_win, (size_t)n_envs * sizeof(float)));
-    LB_TRY(hipMalloc((void**)&d_stats, 4 * sizeof(unsigned long long)));
+    LB_TRY(hipMalloc((void**)&d_stats, LBRB_N_STATS * sizeof(unsigned long long)));
     LB_TRY(hipMemcpy(d_cards, cards, (size_t)n_envs * P.n_deal, hipMemcpyHostToDevice));
-    LB_TRY(hipMemset(d_stats, 0, 4 * sizeof(unsigned long long)));
+    LB_TRY(hipMemset(d_stats, 0, LBRB_N_STATS * sizeof(unsigned long long)));
     LB_TRY(hipMemset(d_win, 0, (size_t)n_envs * sizeof(float)));
     P.cards = d_cards; P.winnings = d_win; P.stats = d_stats;
     LB_TRY(hipEventCreate(&e0));
@@ -489,6 +535,17 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
             LB_TRY(hipMalloc((void**)&d_eq, (size_t)grid * LBRB_MAX_Q * LBRB_MAX_BOARDS_2 * sizeof(float)));
             P.eq_scratch = d_eq;
         }
+#if !defined(PRL_EMU)
+        if (getenv("PRL_LBRB_DEBUG")) {
+            int nb = -1;
+            hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, prl_k_lbr_batch, LBRB_THREADS, smem);
+            hipFuncAttributes fa;
+            memset(&fa, 0, sizeof(fa));
+            hipError_t fe = hipFuncGetAttributes(&fa, (const void*)prl_k_lbr_batch);
+            fprintf(stderr, "lbrb: smem %zu, occupancy %d workgroups per CU (err %d); regs %d, static smem %zu, local %zu, maxDyn %d (err %d)\n", smem, nb, (int)oe,
+                    fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fa.maxDynamicSharedSizeBytes, (int)fe);
+        }
+#endif
         LB_TRY(hipEventRecord(e0, nullptr));
         PRL_LAUNCH(prl_k_lbr_batch, grid, LBRB_THREADS, smem, nullptr, P);
         LB_TRY(hipEventRecord(e1, nullptr));
@@ -497,6 +554,17 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
     if (out_device_ms) LB_TRY(hipEventElapsedTime(out_device_ms, e0, e1));
     LB_TRY(hipMemcpy(out_winnings, d_win, (size_t)n_envs * sizeof(float), hipMemcpyDeviceToHost));
     if (out_stats4) LB_TRY(hipMemcpy(out_stats4, d_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+#ifdef PRL_LBRB_TIMING
+    {
+        unsigned long long h[LBRB_N_STATS];
+        LB_TRY(hipMemcpy(h, d_stats, sizeof(h), hipMemcpyDeviceToHost));
+        static const char* names[10] = {"reset + range init", "look-ahead set-up", "fold probs + classify", "fold / not-fold sums", "candidate ranges",
+                                        "(range, board) equities", "board probs + reduction", "utilities + arg-max", "agent action + range + step", "after step"};
+        double tot = 0;
+        for (int i = 0; i < 10; ++i) tot += (double)h[4 + i];
+        for (int i = 0; i < 10; ++i) fprintf(stderr, "lbrb phase %-28s %6.2f %%  %12.0f clk per hand\n", names[i], 100.0 * h[4 + i] / tot, (double)h[4 + i] / n_envs);
+    }
+#endif
 #undef LB_TRY
 done:
     if (e0) (void)hipEventDestroy(e0);
@@ -546,7 +614,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_h2h_batch(PrlH2hBatchParams P) {
         for (bool done = false; !done;) {
             const int seat = st.cur;
             const int who = seat == P.ref_seat ? 0 : 1;
-            int32_t legal[PRL_MAX_BET_SIZES + 2];
+            int32_t legal[LBRB_MAX_LEGAL];
             const int n_legal = prl_legal_actions(P.game, st, legal);
             const uint32_t key = lbrb_state_key(P.seed[who], st, board, n_dealt, nb, P.rules.n_suits);
             const uint32_t x = lbrb_mix32(P.seed[who] * 0x51ED27u + episode * 0x9E3779B1u + (uint32_t)step_ctr[who]);
@@ -601,6 +669,7 @@ extern "C" int32_t prl_h2h_batch_run(const PrlGame* game, const PrlRules* rules,
         prl_set_error("batched head-to-head: 1-hole-card games or 52-card hold'em"); return PRL_ERR_UNSUPPORTED;
     }
     if (game->game_type == PRL_GAME_NOLIMIT) { prl_set_error("batched head-to-head: fixed-limit or discretized games"); return PRL_ERR_UNSUPPORTED; }
+    if (game->n_bet_sizes + 2 > LBRB_MAX_LEGAL) { prl_set_error("batched head-to-head: at most 14 bet sizes"); return PRL_ERR_UNSUPPORTED; }
     PrlH2hBatchParams P;
     memset(&P, 0, sizeof(P));
     P.game = *game; P.rules = *rules; P.n_envs = n_envs; P.ref_seat = ref_seat; P.n_deal = 2 * nh + nb; P.limit = game->game_type == PRL_GAME_LIMIT;
