@@ -174,22 +174,23 @@ PRL_HD PRL_INLINE void prl_lbr_board_at(const PrlLbrGame& g, const int8_t* pc, i
 // card-removal-aware board probabilities and the running float32 sum over the boards (:432-468, :470-497).
 // cp / cp2: work arrays of n_cards floats each (cp2 only when two cards are to come); pc: the possible cards, ascending.
 // The batched engine passes LDS for them: per-lane private arrays of this size would cap the waves the runtime keeps in flight.
-PRL_HD PRL_INLINE float prl_lbr_reduce_range_w(const PrlLbrGame& g, const float* rg, const float* e /* [n_boards] */, float* cp, float* cp2,
-                                               const int8_t* pc, int n_pc) {
-    for (int c = 0; c < g.n_cards; ++c) {
-        float p;
-        if (g.n_hole == 1) p = rg[c];
-        else {
-            int k = 0;  // the 51 hands holding c, ascending range index (= LUT_CARD_IN_WHAT_RANGE_IDXS[c])
-            auto nx = [&]() {
-                const int o = k < c ? k : k + 1;
-                ++k;
-                return rg[o < c ? prl_range_idx_2(o, c, g.n_cards) : prl_range_idx_2(c, o, g.n_cards)];
-            };
-            p = prl_np_sum_stream<0>(g.n_cards - 1, nx);
-        }
-        cp[c] = 1.f - p;
+// 1 - P(the agent holds card c) under range rg (:432-447): for 2-card hands the NumPy sum over the 51 hands holding c
+PRL_HD PRL_INLINE float prl_lbr_card_not_held(const PrlLbrGame& g, const float* rg, int c) {
+    float p;
+    if (g.n_hole == 1) p = rg[c];
+    else {
+        int k = 0;  // the 51 hands holding c, ascending range index (= LUT_CARD_IN_WHAT_RANGE_IDXS[c])
+        auto nx = [&]() {
+            const int o = k < c ? k : k + 1;
+            ++k;
+            return rg[o < c ? prl_range_idx_2(o, c, g.n_cards) : prl_range_idx_2(c, o, g.n_cards)];
+        };
+        p = prl_np_sum_stream<0>(g.n_cards - 1, nx);
     }
+    return 1.f - p;
+}
+// the rest of the reduction; cp[c] = prl_lbr_card_not_held(g, rg, c) on entry (the batched engine fills it with one lane per card)
+PRL_HD PRL_INLINE float prl_lbr_reduce_range_cp(const PrlLbrGame& g, const float* e /* [n_boards] */, float* cp, float* cp2, const int8_t* pc, int n_pc) {
     for (int i = 0; i < g.n_hole; ++i) cp[g.lbr_hand[i]] = 0.f;
     for (int i = 0; i < g.n_dealt; ++i) cp[g.board[i]] = 0.f;
     {
@@ -221,6 +222,11 @@ PRL_HD PRL_INLINE float prl_lbr_reduce_range_w(const PrlLbrGame& g, const float*
     float fact = 1.f;
     for (int m = 2; m <= g.n_to_deal; ++m) fact = fact * (float)m;
     return win * fact;  // :463-468
+}
+PRL_HD PRL_INLINE float prl_lbr_reduce_range_w(const PrlLbrGame& g, const float* rg, const float* e /* [n_boards] */, float* cp, float* cp2,
+                                               const int8_t* pc, int n_pc) {
+    for (int c = 0; c < g.n_cards; ++c) cp[c] = prl_lbr_card_not_held(g, rg, c);
+    return prl_lbr_reduce_range_cp(g, e, cp, cp2, pc, n_pc);
 }
 PRL_HD PRL_INLINE float prl_lbr_reduce_range(const PrlLbrGame& g, const float* rg, const float* e /* [n_boards] */) {
     float cp[PRL_LBR_MAX_CARDS], cp2[PRL_LBR_MAX_CARDS];

@@ -363,8 +363,13 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     LBRB_TICK(5);  // (range, board) equities
                     // work arrays in LDS: the card probabilities next to the shared state; the second set (two cards to come)
                     // in the LDS equity rows, which are idle then because those equities go through the HBM scratch row
-                    if (tid < n_q) S.wp[tid] = prl_lbr_reduce_range_w(g, cand + (size_t)tid * R, eq + tid * eq_stride, cpw + tid * PRL_LBR_MAX_CARDS,
-                                                                      eq_lds + tid * LBRB_MAX_BOARDS, S.pc, S.n_pc);
+                    for (int t = tid; t < n_q * g.n_cards; t += LBRB_THREADS) {  // one lane per (candidate, card): 51-term sums side by side
+                        const int q = t / g.n_cards, c = t % g.n_cards;
+                        cpw[q * PRL_LBR_MAX_CARDS + c] = prl_lbr_card_not_held(g, cand + (size_t)q * R, c);
+                    }
+                    prl_sync();
+                    if (tid < n_q) S.wp[tid] = prl_lbr_reduce_range_cp(g, eq + tid * eq_stride, cpw + tid * PRL_LBR_MAX_CARDS, eq_lds + tid * LBRB_MAX_BOARDS,
+                                                                       S.pc, S.n_pc);
                     prl_sync();
                     LBRB_TICK(6);  // board probabilities + reduction (one lane per candidate)
                     if (tid == 0) {
