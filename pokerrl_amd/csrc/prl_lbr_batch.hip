@@ -269,25 +269,34 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                         S.n_pc = prl_lbr_possible_cards(g, S.pc);
                         S.n_boards = prl_lbr_n_boards(g);
                         S.n_legal = prl_legal_actions(P.g_lbr, S.st, S.legal);
-                        int nq = 1;
-                        for (int j = 0; j < S.n_legal && nq < LBRB_MAX_Q; ++j) {
-                            const int a = S.legal[j];
-                            if (a == PRL_FOLD || a == PRL_CHECK_CALL) continue;
+                    }
+                    prl_sync();
+                    {
+                        // one lane per legal raise (the legal list is ascending: fold / check-call first, then the raise sizes, so
+                        // raise number q is the position in the list minus the non-raises before it)
+                        const int n_legal = S.n_legal;
+                        int first_raise = 0;
+                        while (first_raise < n_legal && (S.legal[first_raise] == PRL_FOLD || S.legal[first_raise] == PRL_CHECK_CALL)) ++first_raise;
+                        int n_raises = n_legal - first_raise;
+                        if (n_raises > LBRB_MAX_Q - 1) n_raises = LBRB_MAX_Q - 1;
+                        if (tid < n_raises) {
+                            const int q = 1 + tid, a = S.legal[first_raise + tid];
                             // simulate LBR's raise; what the agent would answer in that state (its own bet set decides legality)
                             PrlEnvState s2 = S.st;
                             PrlStepInfo inf;
                             prl_env_step(P.g_lbr, s2, a, &inf);
-                            S.raise_action[nq] = a;
-                            S.pot_after[nq] = s2.main_pot + s2.bet[0] + s2.bet[1];
+                            S.raise_action[q] = a;
+                            S.pot_after[q] = s2.main_pot + s2.bet[0] + s2.bet[1];
                             int32_t lg2[LBRB_MAX_LEGAL];
                             const int nl2 = prl_legal_actions(P.g_agent, s2, lg2);
-                            S.raise_n_legal[nq] = nl2;
-                            for (int k = 0; k < 8; ++k) S.raise_legal[nq][k] = k < nl2 ? lg2[k] : -1;
-                            S.raise_key[nq] = lbrb_state_key(P.seed, s2, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
-                            if (P.limit) S.step_ctr += 1;  // the limit branch asks get_action(step_env=False): one draw is consumed (:120)
-                            ++nq;
+                            S.raise_n_legal[q] = nl2;
+                            for (int k = 0; k < 8; ++k) S.raise_legal[q][k] = k < nl2 ? lg2[k] : -1;
+                            S.raise_key[q] = lbrb_state_key(P.seed, s2, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
                         }
-                        S.n_q = nq;
+                        if (tid == 0) {
+                            if (P.limit) S.step_ctr += n_raises;  // the limit branch asks get_action(step_env=False): one draw per raise is consumed (:120)
+                            S.n_q = 1 + n_raises;
+                        }
                     }
                     prl_sync();
                     LBRB_TICK(1);  // look-ahead set-up (scalar)
@@ -333,14 +342,18 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     prl_sync();
                     LBRB_TICK(2);  // candidate fold probabilities + classification
                     // one lane per raise: fold probability and the not-fold mass, NumPy order
+                    // two lanes per raise, in different waves so that the two sums run side by side
                     if (tid >= 1 && tid < n_q) {
                         const float* pf = cand + (size_t)tid * R;
                         int k = 0;
                         auto nx = [&]() { const float v = rg[k] * pf[k]; ++k; return v; };
                         S.fold_prob[tid] = prl_np_sum_stream<4>(R, nx);              // np.sum(range * a_probs[:, FOLD])
+                    } else if (tid >= 64 + 1 && tid < 64 + n_q) {
+                        const int q = tid - 64;
+                        const float* pf = cand + (size_t)q * R;
                         int k2 = 0;
                         auto nx2 = [&]() { const float v = rg[k2] * (1.f - pf[k2]); ++k2; return v; };
-                        S.notfold_total[tid] = prl_np_sum_stream<4>(R, nx2);         // mul_and_norm(1 - p_fold): normalisation
+                        S.notfold_total[q] = prl_np_sum_stream<4>(R, nx2);           // mul_and_norm(1 - p_fold): normalisation
                     }
                     prl_sync();
                     LBRB_TICK(3);  // fold / not-fold sums (one lane per raise)
