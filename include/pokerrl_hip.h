@@ -314,6 +314,11 @@ int32_t prl_h2h_batch_run(const PrlGame* game, const PrlRules* rules, int32_t n_
                           int32_t opp_kind, uint32_t opp_seed, uint32_t episode_base, double reward_scalar, double ev_normalizer,
                           const int8_t* cards, float* out_winnings, uint64_t* out_stats2, float* out_device_ms);
 
+/* Counter-based decks for the batched engines (no reference counterpart: the reference shuffles with np.random, one hand at a
+ * time): hand i gets the first n_deal cards of a Fisher-Yates shuffle of 0..n_cards_in_deck-1 keyed by (seed, first_hand + i),
+ * so any split of the hands over GPUs deals the same cards. out_cards: host int8 [n_hands][n_deal] (n_deal <= 16). */
+int32_t prl_deal_decks(int32_t n_hands, int32_t n_cards_in_deck, int32_t n_deal, uint64_t seed, uint64_t first_hand, int8_t* out_cards);
+
 #ifdef __cplusplus
 }
 #endif

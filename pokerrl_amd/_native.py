@@ -150,6 +150,8 @@ def _bind_solver(L):
     L.prl_h2h_batch_run.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), i32, i32, i32, ctypes.c_uint32, i32, ctypes.c_uint32,
                                     ctypes.c_uint32, ctypes.c_double, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.prl_h2h_batch_run.restype = i32
+    L.prl_deal_decks.argtypes = [i32, i32, i32, ctypes.c_uint64, ctypes.c_uint64, vp]
+    L.prl_deal_decks.restype = i32
     L.prl_solver_state_size.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.prl_solver_state_size.restype = i32
     L.prl_solver_save_state.argtypes = [vp, vp, ctypes.c_uint64]

@@ -719,3 +719,42 @@ done:
     (void)hipFree(d_cards); (void)hipFree(d_win); (void)hipFree(d_stats);
     return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Counter-based decks for the batched engines: hand i's cards depend on (seed, first_hand + i) only, so any split of the
+// hands over GPUs deals the same cards. A partial Fisher-Yates shuffle of 0..n_cards-1 driven by a SplitMix-style hash, one
+// lane per hand (pokerrl_amd/eval/lbr/BatchedLBR.py: deal_decks_host is the same algorithm in NumPy).
+// ---------------------------------------------------------------------------------------------------------------------
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_deal_decks(int n_hands, int n_cards, int n_deal, unsigned long long seed, unsigned long long first_hand, int8_t* out) {
+    const int i = (int)(prl_bid() * prl_nthreads() + prl_tid());
+    if (i >= n_hands) return;
+    const unsigned long long idx = (first_hand + (unsigned long long)i + 1ull) * 0x9E3779B97F4A7C15ull + seed;
+    // the deck as a sparse permutation: only the (at most n_deal) touched positions are remembered
+    int pos[16], val[16];
+    int n_touched = 0;
+    auto get = [&](int p) { for (int k = 0; k < n_touched; ++k) if (pos[k] == p) return val[k]; return p; };
+    auto set = [&](int p, int v) { for (int k = 0; k < n_touched; ++k) if (pos[k] == p) { val[k] = v; return; } pos[n_touched] = p; val[n_touched] = v; ++n_touched; };
+    for (int d = 0; d < n_deal; ++d) {
+        unsigned long long x = idx + (unsigned long long)(d + 1) * 0xBF58476D1CE4E5B9ull;
+        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+        x ^= x >> 27; x *= 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        const int j = d + (int)(x % (unsigned long long)(n_cards - d));
+        const int a = get(d), b = get(j);
+        set(d, b);
+        set(j, a);
+        out[(size_t)i * n_deal + d] = (int8_t)b;
+    }
+}
+
+extern "C" int32_t prl_deal_decks(int32_t n_hands, int32_t n_cards_in_deck, int32_t n_deal, uint64_t seed, uint64_t first_hand, int8_t* out_cards) {
+    if (!out_cards || n_hands <= 0 || n_deal <= 0 || n_deal > 8 * 2 || n_deal > n_cards_in_deck || n_cards_in_deck > 127) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    if (!prl_device_available()) { prl_set_error("no HIP device"); return PRL_ERR_NO_DEVICE; }
+    int8_t* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)n_hands * n_deal) != hipSuccess) { prl_set_error("hipMalloc failed"); return PRL_ERR_HIP; }
+    PRL_LAUNCH(prl_k_deal_decks, (n_hands + 255) / 256, 256, 0, nullptr, n_hands, n_cards_in_deck, n_deal, (unsigned long long)seed, (unsigned long long)first_hand, d);
+    const hipError_t e = hipMemcpy(out_cards, d, (size_t)n_hands * n_deal, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) { prl_set_error("HIP error in prl_deal_decks"); return PRL_ERR_HIP; }
+    return PRL_OK;
+}

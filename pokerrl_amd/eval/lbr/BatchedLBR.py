@@ -18,6 +18,14 @@ AGENT_KINDS = {"uniform": 0, "hash": 1}
 
 
 def deal_decks(n_hands, n_cards_in_deck, n_deal, seed, first_hand=0):
+    """Counter-based decks, dealt on the GPU (prl_deal_decks); deal_decks_host is the same algorithm in NumPy (tests compare them)."""
+    out = np.zeros((n_hands, n_deal), np.int8)
+    _native.check(_native.lib().prl_deal_decks(int(n_hands), int(n_cards_in_deck), int(n_deal), int(seed) & (2 ** 64 - 1), int(first_hand),
+                                               out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+def deal_decks_host(n_hands, n_cards_in_deck, n_deal, seed, first_hand=0):
     """Counter-based decks: hand i's cards depend on (seed, i) only, so any split of the hands over GPUs deals the same cards.
     A partial Fisher-Yates shuffle of 0..n_cards-1 driven by a SplitMix-style hash; returns int8 [n_hands, n_deal]."""
     with np.errstate(over="ignore"):

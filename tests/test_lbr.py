@@ -251,6 +251,25 @@ def test_gpu_batched_h2h_vs_reference(tag, tmp_path):
     check_batched_h2h_vs_golden(tag, tmp_path)
 
 
+def check_deal_decks():
+    """prl_deal_decks (one lane per hand) against the NumPy statement of the same counter-based shuffle"""
+    from pokerrl_amd.eval.lbr.BatchedLBR import deal_decks, deal_decks_host
+    for n, nc, nd, seed, first in [(1000, 52, 9, 0, 0), (777, 52, 9, 12345678901234567, 5000), (300, 6, 3, 3, 1 << 40), (64, 24, 3, 9, 7)]:
+        a, b = deal_decks(n, nc, nd, seed, first), deal_decks_host(n, nc, nd, seed, first)
+        assert a.dtype == np.int8 and np.array_equal(a, b)
+        assert all(len(set(row)) == nd for row in a.tolist()) and a.min() >= 0 and a.max() < nc
+    assert np.array_equal(deal_decks(10, 52, 9, 1, 90), deal_decks(100, 52, 9, 1, 0)[90:])  # a hand's cards do not depend on the split
+
+
+def test_deal_decks_emu(emu_lib):
+    check_deal_decks()
+
+
+@pytest.mark.gpu
+def test_gpu_deal_decks():
+    check_deal_decks()
+
+
 @pytest.fixture()
 def emu_lib(monkeypatch):
     sys.path.insert(0, os.path.join(HERE, "emu"))
