@@ -27,6 +27,8 @@ def main():
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    from pokerrl_amd import _native as _nat
+    _nat.set_device(int(os.environ.get("LOCAL_RANK", "0")))  # the library allocates on this process's GPU
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -33,6 +33,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        from pokerrl_amd import _native as _nat
+        _nat.set_device(int(os.environ.get("LOCAL_RANK", "0")))  # the library allocates on this process's GPU
         dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
     from pokerrl_amd.eval.lbr import BatchedLBR, LBRArgs, LocalLBRWorker
     from pokerrl_amd.game import bet_sets
