@@ -1,29 +1,19 @@
-"""Keys of PokerEnv.state_dict(); same strings as the reference (PokerRL/game/PokerEnvStateDictEnums.py:9-36)."""
+"""Keys of PokerEnv.state_dict(): the key strings are part of the reference's on-disk / plugin format
+(PokerRL/game/PokerEnvStateDictEnums.py:9-36), so the names are fixed; every attribute is its own name except `deck`."""
 
 
-class EnvDictIdxs:
-    current_round = "current_round"
-    side_pots = "side_pots"
-    main_pot = "main_pot"
-    board_2d = "board_2d"
-    last_action = "last_action"
-    capped_raise = "capped_raise"
-    current_player = "current_player"
-    last_raiser = "last_raiser"
-    deck = "deck_remaining"
-    seats = "seats"
-    n_actions_this_episode = "n_actions_this_episode"
-    n_raises_this_round = "n_raises_this_round"  # fixed-limit games only
-    is_evaluating = "is_evaluating"
+def _keys(cls_name, names, renamed=()):
+    table = {n: n for n in names.split()}
+    table.update(dict(renamed))
+    return type(cls_name, (), table)
 
 
-class PlayerDictIdxs:
-    hand = "hand"
-    hand_rank = "hand_rank"
-    stack = "stack"
-    current_bet = "current_bet"
-    is_allin = "is_allin"
-    folded_this_episode = "folded_this_episode"
-    has_acted_this_round = "has_acted_this_round"
-    side_pot_rank = "side_pot_rank"
-    seat_id = "seat_id"
+# n_raises_this_round exists for fixed-limit games only
+EnvDictIdxs = _keys(
+    "EnvDictIdxs",
+    "is_evaluating current_round main_pot side_pots board_2d seats current_player last_action last_raiser capped_raise "
+    "n_actions_this_episode n_raises_this_round",
+    renamed=[("deck", "deck_remaining")])
+
+PlayerDictIdxs = _keys(
+    "PlayerDictIdxs", "seat_id hand hand_rank stack current_bet is_allin folded_this_episode has_acted_this_round side_pot_rank")
