@@ -87,6 +87,30 @@ PRL_HD PRL_INLINE float lbrb_agent_prob(int kind, uint32_t key, int h, const int
     return wa / sum;
 }
 
+// The agent's action for hand h given the uniform draw u: the first legal action whose cumulative probability exceeds u,
+// else the last one (tests/lbr_fixture_agent.py: get_action). Same float32 values as summing lbrb_agent_prob over the legal
+// actions -- the weights' sum is formed once instead of once per action.
+PRL_HD PRL_INLINE int lbrb_agent_draw(int kind, uint32_t key, int h, const int32_t* legal, int n_legal, float u) {
+    float sum = 0.f;
+    if (kind != 0)
+        for (int j = 0; j < n_legal; ++j) {
+            const uint32_t x = lbrb_mix32(key + (uint32_t)h * 0x9E3779B1u + (uint32_t)legal[j] * 0x85EBCA6Bu);
+            sum = sum + (float)(((x >> 8) & 0xFFFFu) + 1u);
+        }
+    float c = 0.f;
+    for (int j = 0; j < n_legal; ++j) {
+        float p;
+        if (kind == 0) p = (float)(1.0 / (double)n_legal);
+        else {
+            const uint32_t x = lbrb_mix32(key + (uint32_t)h * 0x9E3779B1u + (uint32_t)legal[j] * 0x85EBCA6Bu);
+            p = (float)(((x >> 8) & 0xFFFFu) + 1u) / sum;
+        }
+        c = c + p;
+        if (u < c) return legal[j];
+    }
+    return legal[n_legal - 1];
+}
+
 PRL_HD PRL_INLINE int lbrb_hand_idx(const PrlRules& r, const int8_t* hc) {
     if (r.n_hole_cards == 1) return hc[0];
     const int a = hc[0] < hc[1] ? hc[0] : hc[1], b = hc[0] < hc[1] ? hc[1] : hc[0];
@@ -431,13 +455,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     const uint32_t x = lbrb_mix32(P.seed * 0x51ED27u + episode * 0x9E3779B1u + (uint32_t)S.step_ctr);
                     const float u = (float)(x >> 8) / 16777216.0f;
                     S.step_ctr += 1;
-                    int a = S.legal[S.n_legal - 1];
-                    float c = 0.f;
-                    for (int j = 0; j < S.n_legal; ++j) {
-                        c = c + lbrb_agent_prob(P.agent_kind, S.key, hi, S.legal, S.n_legal, S.legal[j]);
-                        if (u < c) { a = S.legal[j]; break; }
-                    }
-                    S.action = a;
+                    S.action = lbrb_agent_draw(P.agent_kind, S.key, hi, S.legal, S.n_legal, u);
                     n_agent += 1;
                 }
                 prl_sync();
@@ -638,12 +656,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_h2h_batch(PrlH2hBatchParams P) {
             const uint32_t x = lbrb_mix32(P.seed[who] * 0x51ED27u + episode * 0x9E3779B1u + (uint32_t)step_ctr[who]);
             const float u = (float)(x >> 8) / 16777216.0f;
             step_ctr[who] += 1;
-            int a = legal[n_legal - 1];
-            float c = 0.f;
-            for (int j = 0; j < n_legal; ++j) {
-                c = c + lbrb_agent_prob(P.kind[who], key, hand_idx[seat], legal, n_legal, legal[j]);
-                if (u < c) { a = legal[j]; break; }
-            }
+            const int a = lbrb_agent_draw(P.kind[who], key, hand_idx[seat], legal, n_legal, u);
             PrlStepInfo info;
             if (!P.limit && a >= 2) {  // discretized games step by pot fraction
                 const int amt = prl_fraction_of_pot_raise(st, P.game.bet_fracs[a - 2], st.cur);
