@@ -289,3 +289,37 @@ def test_head_to_head_vs_reference(tag, tmp_path):
     m.evaluate(iter_nr=3)
     assert chief.names == json.loads(str(g["experiments"]))
     assert chief.log == json.loads(str(g["log"]))
+
+
+def test_product_fails_loudly_without_a_device():
+    """No CPU fallback: in a GPU-less container every device entry point of the PRODUCT library reports PRL_ERR_NO_DEVICE (or
+    a bad-argument error first) with a message, and the Python host raises instead of computing anything on the CPU."""
+    if _native.device_available():
+        pytest.skip("a HIP device is present")
+    L = _native.lib()
+    assert L.prl_set_device(0) < 0 and b"HIP device" in L.prl_last_error()
+    with pytest.raises(_native.NativeError):
+        _native.require_device()
+    out = np.zeros((4, 9), np.int8)
+    assert L.prl_deal_decks(4, 52, 9, 0, 0, out.ctypes.data_as(ctypes.c_void_p)) < 0
+    from pokerrl_amd.eval.lbr.BatchedLBR import deal_decks
+    with pytest.raises(_native.NativeError):
+        deal_decks(4, 52, 9, 0)
+    from pokerrl_amd.game import bet_sets as bs
+    t = native_tree(G.StandardLeduc, 13, None, all_single_card_boards(G.StandardLeduc))  # trees are host objects
+    with pytest.raises(_native.NativeError):
+        _native.NativeSolver(t, "plus", 0)  # solver state lives in HBM
+    del bs
+
+
+def test_c_abi_rejects_bad_arguments():
+    """error behaviour of the flat ABI: negative status + prl_last_error(), never a crash, for NULL / out-of-range arguments"""
+    L = _native.lib()
+    out = np.zeros((4, 9), np.int8)
+    for args in [(0, 52, 9), (4, 52, 0), (4, 52, 17), (4, 5, 9), (4, 200, 9)]:
+        assert L.prl_deal_decks(args[0], args[1], args[2], 0, 0, out.ctypes.data_as(ctypes.c_void_p)) < 0
+        assert L.prl_last_error()
+    assert L.prl_deal_decks(4, 52, 9, 0, 0, None) < 0
+    assert L.prl_set_device(-1) < 0
+    assert L.prl_lbr_batch_run(None, None, None, 1, 0, -1, 1, 7, 0, 1.0, 1.0, None, None, None, None) < 0
+    assert L.prl_h2h_batch_run(None, None, 1, 0, 1, 1, 1, 2, 0, 1.0, 1.0, None, None, None, None) < 0
