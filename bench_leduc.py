@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--solves", type=int, default=256,
+                    help="independent solves advanced by ONE launch, one workgroup (CU) each (prl_solver_iterations_many); 1 = a single tree")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     import torch
@@ -59,11 +61,34 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         dist.barrier()
+    many = None
+    if args.solves > 1 and s.engine == "levels":
+        # a Leduc-sized tree occupies ONE CU: the GPU is filled by solving many trees at once -- here the same game at
+        # args.solves different stack sizes (different trees), one workgroup each, all advanced by one launch per call
+        stacks = [stack + i for i in range(args.solves)]
+        trees = [native_tree(game_cls, st, bets, boards) for st in stacks]
+        solvers = [_native.NativeSolver(t, args.variant, 0, engine="levels") for t in trees]
+        try:
+            _native.NativeSolver.iterations_many(solvers, args.warmup)
+            for x in solvers:
+                x.sync()
+            t2 = time.perf_counter()
+            _native.NativeSolver.iterations_many(solvers, args.steps)
+            for x in solvers:
+                x.sync()
+            dt_many = time.perf_counter() - t2
+            nodes_many = sum(t.n_nodes for t in trees)
+            many = {"solves": args.solves, "stack_sizes": [stacks[0], stacks[-1]], "nodes_total": nodes_many, "seconds": dt_many,
+                    "node_updates_per_s": nodes_many * args.steps / dt_many, "ms_per_step": dt_many * 1e3 / args.steps,
+                    "mean_exploitability": float(np.mean([np.mean(x.exploitability()) for x in solvers]) * game_cls.EV_NORMALIZER)}
+        except _native.NativeError as e:  # trees too large for the single-workgroup kernel (BigLeduc at large stacks)
+            many = {"error": str(e)}
     out = {"metric": "%s CFR node-updates/s on the %s public tree (replicas)" % (args.variant, args.game),
            "value": tree.n_nodes * args.steps * world / dt, "unit": "node-updates/s", "n_gpus": world, "steps": args.steps,
            "ms_per_step": dt * 1e3 / args.steps, "device_ms_per_step": dev_ms / args.steps, "nodes": tree.n_nodes, "range_size": tree.range_size,
            "exploitability_mA_or_mbb_per_g": float(np.mean(s.exploitability()) * game_cls.EV_NORMALIZER), "engine": s.engine, "graph_replay": s.graph_replay,
-           "note": "tree state fits in L2: launch / latency bound, no roofline claim (SURVEY.md 8d)", "data": "synthetic"}
+           "note": "tree state fits in L2: launch / latency bound, no roofline claim (SURVEY.md 8d)", "data": "synthetic",
+           "many_solves_one_launch": many}
     if rank == 0:
         r = game_cls.native_rules()
         o = oracle.Oracle({k: tree.field(k) for k in oracle.Oracle.FIELDS}, boards, r.n_hole_cards, r.n_cards, r.n_suits, r.rank_rule)

@@ -245,6 +245,10 @@ void prl_solver_destroy(prl_solver_t* solver);
 int32_t prl_solver_reset(prl_solver_t* solver);                        /* _CFRBase.reset            :110-120 */
 int32_t prl_solver_iteration(prl_solver_t* solver);                    /* _CFRBase.iteration        :122-134 (w/o avg eval) */
 int32_t prl_solver_iterations(prl_solver_t* solver, int32_t n);
+/* n iterations of MANY independent solvers in one launch, one workgroup (one CU) per solver: the way to fill a GPU with
+ * Leduc-sized trees (a sweep over games / stack sizes / bet sets; BASELINE configs 1-2). Every solver must be a small
+ * 1-hole-card tree on the LEVELS engine (n_nodes * range_size <= 32768); each advances exactly as prl_solver_iterations(s, n). */
+int32_t prl_solver_iterations_many(prl_solver_t** solvers, int32_t n_solvers, int32_t n);
 int32_t prl_solver_eval_avg(prl_solver_t* solver, float* out_expl2);   /* _evaluate_avg_strats      :218-262 */
 int32_t prl_solver_fill_uniform(prl_solver_t* solver);                 /* PublicTree.fill_uniform_random     */
 int32_t prl_solver_set_strategy(prl_solver_t* solver, const void* strategy_cols, int32_t is_f64); /* fill_with_agent_policy */

@@ -150,6 +150,8 @@ def _bind_solver(L):
     L.prl_h2h_batch_run.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), i32, i32, i32, ctypes.c_uint32, i32, ctypes.c_uint32,
                                     ctypes.c_uint32, ctypes.c_double, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.prl_h2h_batch_run.restype = i32
+    L.prl_solver_iterations_many.argtypes = [ctypes.POINTER(vp), i32, i32]
+    L.prl_solver_iterations_many.restype = i32
     L.prl_deal_decks.argtypes = [i32, i32, i32, ctypes.c_uint64, ctypes.c_uint64, vp]
     L.prl_deal_decks.restype = i32
     L.prl_solver_state_size.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
@@ -417,6 +419,15 @@ class NativeSolver:
         ms, pms, cnt = ctypes.c_float(), ctypes.c_float(), ctypes.c_int32()
         self._call("prl_solver_time_iterations_ex", int(n), ctypes.byref(ms), ctypes.byref(pms), ctypes.byref(cnt))
         return float(ms.value), float(pms.value), int(cnt.value)
+
+    @staticmethod
+    def iterations_many(solvers, n):
+        """n iterations of many independent small-tree solvers in ONE launch, one workgroup per solver (prl_solver_iterations_many)"""
+        if not solvers:
+            return
+        L = solvers[0]._L
+        arr = (ctypes.c_void_p * len(solvers))(*[s._h for s in solvers])
+        check(L.prl_solver_iterations_many(arr, len(solvers), int(n)), L)
 
     def exploitability(self):
         out = np.zeros(2, np.float32)

@@ -16,11 +16,16 @@ inline void prl_lds_add_i(int* p, int v) { *p += v; }
 #define PRL_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(smem), (hipStream_t)(stream), __VA_ARGS__)
 
+// 1 x grid_y workgroups: the kernel picks its work item with prl_bid_y(); prl_bid() is 0 and prl_nblocks() is 1, so device
+// functions written for a grid-stride launch cover all of their items inside the one workgroup
+#define PRL_LAUNCH_Y(kernel, grid_y, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3(1u, (unsigned)(grid_y)), dim3((unsigned)(block)), (size_t)(smem), (hipStream_t)(stream), __VA_ARGS__)
 #define PRL_LAUNCH_BOUNDS(n) __launch_bounds__(n)
 PRL_DEV PRL_INLINE void prl_atomic_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 PRL_DEV PRL_INLINE void prl_lds_add_i(int* p, int v) { atomicAdd(p, v); }  // integer add on an LDS word (order-free)
 PRL_DEV PRL_INLINE unsigned prl_tid() { return threadIdx.x; }
 PRL_DEV PRL_INLINE unsigned prl_bid() { return blockIdx.x; }
+PRL_DEV PRL_INLINE unsigned prl_bid_y() { return blockIdx.y; }
 PRL_DEV PRL_INLINE unsigned prl_nthreads() { return blockDim.x; }
 PRL_DEV PRL_INLINE unsigned prl_nblocks() { return gridDim.x; }
 PRL_DEV PRL_INLINE unsigned prl_lane() { return threadIdx.x & 63u; }

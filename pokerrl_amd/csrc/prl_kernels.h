@@ -17,6 +17,9 @@ void prl_launch_regret_strategy(const PrlDevTree& T, const PrlDevState& S, const
 void prl_launch_average(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, int iter, int mode,
                         double m_old, double m_new, void* stream);
 struct PrlIterDev;
+struct PrlSmallJob;  // prl_solver_types.h
+size_t prl_small_state_bytes(const PrlDevTree& T, const PrlDevState& S);
+void prl_launch_small_iterations_many(const PrlSmallJob* d_jobs, int n_jobs, size_t lds_bytes, void* stream);
 void prl_launch_small_iterations(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_level_start, const int32_t* d_term_nodes, int n_term,
                                  const int32_t* d_nodes_p0, int n0, const int32_t* d_nodes_p1, int n1, int variant, int delay, int n_iters,
                                  PrlIterDev* d_ip, void* stream);

@@ -849,6 +849,65 @@ static int small_tree_iterations(prl_solver* s, int n) {
     return PRL_OK;
 }
 
+// Many independent small-tree solves in ONE launch, one workgroup (CU) per solver: a Leduc-sized tree occupies a single CU, so
+// a sweep over games / stack sizes / bet sets fills the GPU only this way. Every solver advances n iterations exactly as
+// prl_solver_iterations(s, n) would (same kernel body, same bits).
+extern "C" int32_t prl_solver_iterations_many(prl_solver_t** solvers, int32_t n_solvers, int32_t n) {
+    if (!solvers || n_solvers <= 0 || n_solvers > 65535 || n < 0) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    for (int i = 0; i < n_solvers; ++i) {
+        prl_solver* s = solvers[i];
+        if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }
+        if (s->fused || !s->small_tree) { prl_set_error("iterations_many: every solver must be a small 1-hole-card tree on the LEVELS engine"); return PRL_ERR_UNSUPPORTED; }
+        for (int j = 0; j < i; ++j) if (solvers[j] == s) { prl_set_error("iterations_many: duplicate solver"); return PRL_ERR_ARG; }
+    }
+    if (n == 0) return PRL_OK;
+    std::vector<PrlSmallJob> jobs((size_t)n_solvers);
+    size_t lds_max = 0;
+    for (int i = 0; i < n_solvers; ++i) {
+        prl_solver* s = solvers[i];
+        TRY(ensure_ev(s));  // an iteration starts from the evaluation that closed the previous one
+        TRY(ensure_hist(s, s->iter + n + 1));
+        if (!s->d_ip) TRY(dev_alloc(s, &s->d_ip, (size_t)1));
+        if (!s->d_level_start) TRY(dev_upload(s, &s->d_level_start, s->ft.level_start));
+        PrlIterDev ip;
+        memset(&ip, 0, sizeof(ip));
+        ip.iter = s->iter;
+        ip.hist = s->d_expl_hist;
+        PRL_HIP_TRY(hipMemcpyAsync(s->d_ip, &ip, sizeof(ip), hipMemcpyHostToDevice, s->stream));
+        PRL_HIP_TRY(hipStreamSynchronize(s->stream));  // `ip` is a stack variable; the solver's earlier work is complete
+        const size_t lds = prl_small_state_bytes(s->T, s->S);
+        const bool in_lds = lds <= 160 * 1024 - 256;
+        if (in_lds && lds > lds_max) lds_max = lds;
+        PrlSmallJob& J = jobs[(size_t)i];
+        memset(&J, 0, sizeof(J));
+        J.T = s->T; J.S = s->S; J.level_start = s->d_level_start; J.term_nodes = s->d_term_nodes; J.n_term = s->n_term;
+        J.nodes_p[0] = s->d_nodes_p[0]; J.nodes_p[1] = s->d_nodes_p[1]; J.n_nodes_p[0] = s->n_nodes_p[0]; J.n_nodes_p[1] = s->n_nodes_p[1];
+        J.variant = s->variant; J.delay = s->delay; J.state_in_lds = in_lds ? 1 : 0; J.n_cols = s->T.n_cols; J.ip = s->d_ip;
+    }
+    prl_solver* s0 = solvers[0];
+    PrlSmallJob* d_jobs = nullptr;
+    PRL_HIP_TRY(hipMalloc((void**)&d_jobs, jobs.size() * sizeof(PrlSmallJob)));
+    int rc = PRL_OK;
+    for (int done = 0; done < n && rc == PRL_OK;) {
+        const int k = n - done < 256 ? n - done : 256;  // bounded kernel run time
+        for (auto& J : jobs) J.n_iters = k;
+        if (hipMemcpy(d_jobs, jobs.data(), jobs.size() * sizeof(PrlSmallJob), hipMemcpyHostToDevice) != hipSuccess) { rc = PRL_ERR_HIP; break; }
+        prl_launch_small_iterations_many(d_jobs, n_solvers, lds_max, s0->stream);
+        if (hipStreamSynchronize(s0->stream) != hipSuccess) { rc = PRL_ERR_HIP; break; }
+        done += k;
+    }
+    (void)hipFree(d_jobs);
+    if (rc != PRL_OK) { prl_set_error("HIP error in prl_solver_iterations_many"); return rc; }
+    for (int i = 0; i < n_solvers; ++i) {
+        prl_solver* s = solvers[i];
+        s->iter += n;
+        s->src[0] = s->src[1] = PRL_SRC_REGRET;
+        s->ev_valid = true;
+    }
+    PRL_HIP_TRY(hipGetLastError());
+    return PRL_OK;
+}
+
 #if !defined(PRL_EMU)
 // LEVELS engine: n iterations as n replays of one captured graph. The iteration counter, the CFR+ averaging weights and the
 // exploitability-history slot are read from device memory (PrlIterDev), so the captured launches never change.

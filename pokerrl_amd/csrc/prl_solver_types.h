@@ -53,6 +53,17 @@ struct PrlDevState {
     float* expl;         // [2] root exploitability of the last EV pass
 };
 
+// one entry per independent small-tree solve of a batched launch (prl_solver_iterations_many)
+struct PrlSmallJob {
+    PrlDevTree T;
+    PrlDevState S;
+    const int32_t* level_start;
+    const int32_t* term_nodes; int32_t n_term;
+    const int32_t* nodes_p[2]; int32_t n_nodes_p[2];
+    int32_t variant, delay, n_iters, state_in_lds, n_cols;
+    PrlIterDev* ip;
+};
+
 PRL_HD PRL_INLINE size_t prl_vidx(const PrlDevTree& T, int node, int p) { return ((size_t)node * 2 + (size_t)p) * (size_t)T.R; }
 PRL_HD PRL_INLINE size_t prl_cidx(const PrlDevTree& T, int col) { return (size_t)col * (size_t)T.R; }
 

@@ -539,7 +539,7 @@ PRL_DEV PRL_INLINE void prl_small_ev(const PrlDevTree& T, const PrlDevState& S, 
     prl_exploitability_body(T, S, S.expl);
     prl_sync();
 }
-PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations(PrlDevTree T, PrlDevState SG, PrlSmallIterArgs A) {
+PRL_DEV PRL_INLINE void prl_small_iterations_body(const PrlDevTree& T, const PrlDevState& SG, const PrlSmallIterArgs& A) {
     PrlDevState S = SG;
     if (A.state_in_lds) prl_small_state_lds(T, SG, A.n_cols, S, 0);
     for (int k = 0; k < A.n_iters; ++k) {
@@ -582,6 +582,18 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations(PrlDevTree T, Prl
         prl_sync();
     }
     if (A.state_in_lds) prl_small_state_lds(T, SG, A.n_cols, S, 1);
+}
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations(PrlDevTree T, PrlDevState SG, PrlSmallIterArgs A) { prl_small_iterations_body(T, SG, A); }
+// many independent small trees at once, one workgroup (= one CU) per solve: jobs[blockIdx.y]
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations_many(const PrlSmallJob* jobs) {
+    const PrlSmallJob& J = jobs[prl_bid_y()];  // launched 1 x n_jobs: the per-item bodies below see a grid of ONE workgroup
+    const PrlDevTree T = J.T;
+    const PrlDevState SG = J.S;
+    PrlSmallIterArgs A;
+    A.level_start = J.level_start; A.term_nodes = J.term_nodes; A.n_term = J.n_term;
+    A.nodes_p[0] = J.nodes_p[0]; A.nodes_p[1] = J.nodes_p[1]; A.n_nodes_p[0] = J.n_nodes_p[0]; A.n_nodes_p[1] = J.n_nodes_p[1];
+    A.variant = J.variant; A.delay = J.delay; A.n_iters = J.n_iters; A.state_in_lds = J.state_in_lds; A.n_cols = J.n_cols; A.ip = J.ip;
+    prl_small_iterations_body(T, SG, A);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -634,14 +646,22 @@ void prl_launch_average(const PrlDevTree& T, const PrlDevState& S, const int32_t
     if (n > 0) PRL_LAUNCH(prl_k_average, prl_grid_for((size_t)n * T.R, 256), 256, 0, stream, T, S, d_nodes, n, p, variant, iter, mode, m_old, m_new);
 }
 
+// bytes of LDS the whole solver state of a small tree takes (StandardLeduc: ~140 KB); if it fits, the iterations run on it there
+size_t prl_small_state_bytes(const PrlDevTree& T, const PrlDevState& S) {
+    auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t nv = (size_t)T.n_nodes * 2 * T.R, nc = (size_t)T.n_cols * T.R;
+    return al(nc * 8) + al(T.n_nodes) + 3 * al(nv * 4) + (S.br_idx ? al((size_t)T.n_nodes * T.R * 4) : 0) + al(nc * 4) +
+           (S.avg_sum ? al(nc * 4) : 0) + al(nc * 8) + al(T.n_nodes);
+}
+
+void prl_launch_small_iterations_many(const PrlSmallJob* d_jobs, int n_jobs, size_t lds_bytes, void* stream) {
+    if (n_jobs > 0) PRL_LAUNCH_Y(prl_k_small_iterations_many, n_jobs, 1024, lds_bytes, stream, d_jobs);
+}
+
 void prl_launch_small_iterations(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_level_start, const int32_t* d_term_nodes, int n_term,
                                  const int32_t* d_nodes_p0, int n0, const int32_t* d_nodes_p1, int n1, int variant, int delay, int n_iters,
                                  PrlIterDev* d_ip, void* stream) {
-    // does the whole state fit in LDS (StandardLeduc: ~140 KB)? then the iterations run on it there
-    auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    const size_t nv = (size_t)T.n_nodes * 2 * T.R, nc = (size_t)T.n_cols * T.R;
-    size_t lds = al(nc * 8) + al(T.n_nodes) + 3 * al(nv * 4) + (S.br_idx ? al((size_t)T.n_nodes * T.R * 4) : 0) + al(nc * 4) +
-                 (S.avg_sum ? al(nc * 4) : 0) + al(nc * 8) + al(T.n_nodes);
+    const size_t lds = prl_small_state_bytes(T, S);
     const bool in_lds = lds <= 160 * 1024 - 256;
     PrlSmallIterArgs A;
     A.state_in_lds = in_lds ? 1 : 0;

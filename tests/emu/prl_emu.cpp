@@ -67,8 +67,11 @@ uint64_t wave_ballot(int pred) {
     return g_cur->wave_out;
 }
 
-void launch(const std::function<void()>& body, unsigned grid, unsigned block, size_t smem_bytes) {
-    if (block == 0 || grid == 0) return;
+void launch(const std::function<void()>& body, unsigned grid, unsigned block, size_t smem_bytes) { launch2(body, grid, 1, block, smem_bytes); }
+
+// grid_x x grid_y workgroups; kernels that index their work with blockIdx.y see blockIdx.x = 0 / gridDim.x = 1 when grid_x = 1
+void launch2(const std::function<void()>& body, unsigned grid, unsigned grid_y, unsigned block, size_t smem_bytes) {
+    if (block == 0 || grid == 0 || grid_y == 0) return;
     if (block > 1024) {
         fprintf(stderr, "prl_emu: block size %u > 1024\n", block);
         abort();
@@ -77,12 +80,13 @@ void launch(const std::function<void()>& body, unsigned grid, unsigned block, si
     g_fibers.resize(block);
     std::vector<char> smem(smem_bytes + 64);
     g_body = &body;
+    for (unsigned by = 0; by < grid_y; ++by)
     for (unsigned b = 0; b < grid; ++b) {
         memset(smem.data(), 0xCD, smem.size());  // LDS is uninitialised on real hardware: poison it
         char* smem_base = (char*)(((uintptr_t)smem.data() + 15) & ~(uintptr_t)15);
         for (unsigned t = 0; t < block; ++t) {
             Fiber& f = g_fibers[t];
-            f.ctx = Ctx{t, b, block, grid, smem_base};
+            f.ctx = Ctx{t, b, block, grid, smem_base, by};
             f.state = RUNNABLE;
             getcontext(&f.uc);
             f.uc.uc_stack.ss_sp = g_stacks.data() + (size_t)t * STACK_BYTES;

@@ -16,9 +16,11 @@ namespace prl_emu {
 struct Ctx {
     unsigned tid, bid, bdim, gdim;
     char* smem;
+    unsigned bid_y;
 };
 extern thread_local Ctx* g_ctx;
 void launch(const std::function<void()>& body, unsigned grid, unsigned block, size_t smem_bytes);
+void launch2(const std::function<void()>& body, unsigned grid_x, unsigned grid_y, unsigned block, size_t smem_bytes);
 void block_barrier();
 uint64_t wave_exchange(uint64_t my_value, int src_lane);  // returns the value contributed by src_lane (0 if it exited)
 uint64_t wave_ballot(int pred);
@@ -27,6 +29,10 @@ uint64_t wave_ballot(int pred);
 #define PRL_LAUNCH(kernel, grid, block, smem, stream, ...) \
     prl_emu::launch([=]() { kernel(__VA_ARGS__); }, (unsigned)(grid), (unsigned)(block), (size_t)(smem))
 
+// 1 x grid_y workgroups: the kernel picks its work item with prl_bid_y(); prl_bid() is 0 and prl_nblocks() is 1
+#define PRL_LAUNCH_Y(kernel, grid_y, block, smem, stream, ...) \
+    prl_emu::launch2([=]() { kernel(__VA_ARGS__); }, 1u, (unsigned)(grid_y), (unsigned)(block), (size_t)(smem))
+inline unsigned prl_bid_y() { return prl_emu::g_ctx->bid_y; }
 inline unsigned prl_tid() { return prl_emu::g_ctx->tid; }
 inline unsigned prl_bid() { return prl_emu::g_ctx->bid; }
 inline unsigned prl_nthreads() { return prl_emu::g_ctx->bdim; }

@@ -279,3 +279,28 @@ def seeded_strategy_for_sharding(n_trunk_cols, n_boards, R, seed):
         x = rng.random_sample((a, R)).astype(np.float32)
         cols.append(x / x.sum(axis=0, keepdims=True))
     return np.concatenate(cols).astype(np.float32)
+
+
+def check_iterations_many(L, n_iters=5):
+    """prl_solver_iterations_many: several DIFFERENT small trees (games, stack sizes, variants) advanced by one launch, one
+    workgroup each -- every solver must end in exactly the state (all arrays, history) the C oracle reaches on its tree, and a
+    second batch must continue from there."""
+    from pokerrl_amd.game import games as G
+    cases = [(G.StandardLeduc, 13, None, "plus", 0), (G.StandardLeduc, 7, None, "vanilla", 0), (G.StandardLeduc, 20, None, "linear", 0),
+             (G.StandardLeduc, 13, None, "plus", 2), (G.StandardLeduc, 5, None, "plus", 0)]
+    trios = [make_pair(L, cls, stack, bets, all_single_card_boards(cls), variant, delay) for cls, stack, bets, variant, delay in cases]
+    solvers = [s for _t, s, _o in trios]
+    _native.NativeSolver.iterations_many(solvers, 3)
+    _native.NativeSolver.iterations_many(solvers, n_iters - 3)
+    for i, (_t, s, o) in enumerate(trios):
+        for _ in range(n_iters):
+            o.cfr_iteration()
+        assert s.iter == n_iters
+        assert_state_equal(s, o, "many[%d]" % i)
+        hist = s.get("expl_history")
+        assert hist.shape == (n_iters + 1, 2) and np.array_equal(hist[-1], o.exploitability)
+    # a solver advanced alone afterwards keeps going from the batched state
+    _t, s, o = trios[0]
+    s.iterations(2)
+    o.cfr_iteration(); o.cfr_iteration()
+    assert_state_equal(s, o, "many[0] + 2")

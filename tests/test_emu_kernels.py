@@ -28,6 +28,10 @@ def test_emu_standard_leduc_vs_oracle(L, variant):
     pc.check_cfr_vs_oracle(L, "StandardLeduc", variant, 4)
 
 
+def test_emu_iterations_many(L):
+    pc.check_iterations_many(L)
+
+
 def test_emu_cfrplus_delay(L):
     pc.check_cfr_vs_oracle(L, "StandardLeduc", "plus", 4, delay=2)
 

@@ -72,6 +72,10 @@ def test_gpu_standard_leduc_vs_oracle(L, variant):
     pc.check_cfr_vs_oracle(L, "StandardLeduc", variant, 12)
 
 
+def test_gpu_iterations_many(L):
+    pc.check_iterations_many(L)
+
+
 def test_gpu_cfrplus_delay(L):
     pc.check_cfr_vs_oracle(L, "StandardLeduc", "plus", 6, delay=3)
 
