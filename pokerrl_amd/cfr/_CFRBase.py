@@ -18,6 +18,7 @@ import numpy as np
 
 from pokerrl_amd.game.PublicTree import PublicTree
 from pokerrl_amd.game.wrappers import HistoryEnvBuilder
+from pokerrl_amd import _native
 from pokerrl_amd.rl.rl_util import get_env_cls_from_str
 
 
@@ -70,8 +71,17 @@ class CFRBase:
         """n iterations back to back on the GPU without a host round trip per iteration; logs afterwards from the
         device-side exploitability history (average-strategy evaluation only after the last one)."""
         start = self._iter_counter
+        solvers = [t.solver for t in self._trees]
+        batched = False
+        if len(solvers) > 1:  # one tree per starting stack size: Leduc-sized trees advance together, one workgroup (CU) each
+            try:
+                _native.NativeSolver.iterations_many(solvers, n)
+                batched = True
+            except _native.NativeError:
+                batched = False  # not all of them are small 1-hole-card trees: one after the other
         for t in self._trees:
-            t.solver.iterations(n)
+            if not batched:
+                t.solver.iterations(n)
             t._invalidate()
         self._iter_counter += n
         if log:

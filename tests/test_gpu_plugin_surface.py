@@ -202,3 +202,25 @@ def test_tree_export_like_reference(tag, tmp_path):
     path = tree.export_to_file("viz")
     with open(path) as f:
         assert f.read() == "const data=" + json.dumps(d)
+
+
+def test_cfr_multi_stack_batched_equals_sequential():
+    """a CFR object with several starting stack sizes (one tree each, _CFRBase.py:64-69): iterations(n) advances all trees in one
+    launch (prl_solver_iterations_many); the logged series must equal n single iteration() calls on a twin object"""
+    from pokerrl_amd.cfr.CFRPlus import CFRPlus
+    stacks = [13, 7, 21]
+    a_chief, b_chief = ChiefBase(t_prof=None), ChiefBase(t_prof=None)
+    a = CFRPlus(name="A", game_cls=StandardLeduc, delay=0, agent_bet_set=None, starting_stack_sizes=stacks, chief_handle=a_chief)
+    b = CFRPlus(name="A", game_cls=StandardLeduc, delay=0, agent_bet_set=None, starting_stack_sizes=stacks, chief_handle=b_chief)
+    a.iterations(4)
+    for _ in range(4):
+        b.iteration()
+    va, _ = a_chief.get_new_values()
+    vb, _ = b_chief.get_new_values()
+    cur = [k for k in va if "_Curr_" in k]
+    assert len(cur) >= 3
+    for k in cur:
+        assert va[k] == vb[k], k
+    for ta, tb in zip(a._trees, b._trees):
+        assert np.array_equal(ta.solver.get("regret"), tb.solver.get("regret"))
+        assert np.array_equal(ta.solver.get("avg"), tb.solver.get("avg"))
