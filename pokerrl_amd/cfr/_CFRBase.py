@@ -59,10 +59,24 @@ class CFRBase:
             t._invalidate()
         self._log_curr_strat_expl()
 
-    def iteration(self):  # _CFRBase.py:122-134
+    def _advance(self, n):
+        """n iterations of every tree (one tree per starting stack size): Leduc-sized trees advance together in one launch, one
+        workgroup (CU) each (prl_solver_iterations_many); otherwise one tree after the other"""
+        solvers = [t.solver for t in self._trees]
+        batched = False
+        if len(solvers) > 1:
+            try:
+                _native.NativeSolver.iterations_many(solvers, n)
+                batched = True
+            except _native.NativeError:
+                batched = False  # not all of them are small 1-hole-card trees
         for t in self._trees:
-            t.solver.iteration()
+            if not batched:
+                t.solver.iterations(n)
             t._invalidate()
+
+    def iteration(self):  # _CFRBase.py:122-134
+        self._advance(1)
         self._iter_counter += 1
         self._log_curr_strat_expl()
         self._evaluate_avg_strats()
@@ -71,18 +85,7 @@ class CFRBase:
         """n iterations back to back on the GPU without a host round trip per iteration; logs afterwards from the
         device-side exploitability history (average-strategy evaluation only after the last one)."""
         start = self._iter_counter
-        solvers = [t.solver for t in self._trees]
-        batched = False
-        if len(solvers) > 1:  # one tree per starting stack size: Leduc-sized trees advance together, one workgroup (CU) each
-            try:
-                _native.NativeSolver.iterations_many(solvers, n)
-                batched = True
-            except _native.NativeError:
-                batched = False  # not all of them are small 1-hole-card trees: one after the other
-        for t in self._trees:
-            if not batched:
-                t.solver.iterations(n)
-            t._invalidate()
+        self._advance(n)
         self._iter_counter += n
         if log:
             hists = [t.solver.get("expl_history") for t in self._trees]
