@@ -74,7 +74,8 @@ def build_variant(name, defines):
     for s in sources():
         obj = os.path.join(vdir, s + ".o")
         objs.append(obj)
-        cmd = [HIPCC] + COMMON + DEVICE + ["-D" + d for d in defines] + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", os.path.join(CSRC, s), "-o", obj]
+        extra = os.environ.get("PRL_VARIANT_FLAGS", "").split()  # experiments with compiler options, e.g. "-mllvm -amdgpu-sched-strategy=max-ilp"
+        cmd = [HIPCC] + COMMON + DEVICE + extra + ["-D" + d for d in defines] + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", os.path.join(CSRC, s), "-o", obj]
         procs.append(subprocess.Popen(cmd))
     if any(p.wait() != 0 for p in procs):
         raise RuntimeError("hipcc failed")
