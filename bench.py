@@ -85,7 +85,7 @@ def cpu_baseline(n_boards, n_iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--boards", type=int, default=int(os.environ.get("PRL_BENCH_BOARDS", "262144")), help="boards per GPU")
     ap.add_argument("--engine", default=os.environ.get("PRL_BENCH_ENGINE", "auto"))
