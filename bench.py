@@ -37,7 +37,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # measured at 16384 boards (r01h: UPDATE1_EVAL1 2 * 1.32 GB read + 2.04 GB written, UPDATE0_BR 2 * 1.32 + 1.95 = 9.27 GB per iteration)
 # and at 262144 boards (r01i: 2 * 21.13 + 32.61 and 2 * 21.12 + 31.25 = 148.4 GB): every board subtree moves the same bytes
 PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION = 9.27e9 / 16384
-PMC_TRAFFIC_SOURCE = "profiles/r01k_fused_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+PMC_TRAFFIC_SOURCE = "profiles/r01l_fused_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
 
 
 def seeded_boards(n, seed, offset=0):
