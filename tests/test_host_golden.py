@@ -323,3 +323,16 @@ def test_c_abi_rejects_bad_arguments():
     assert L.prl_set_device(-1) < 0
     assert L.prl_lbr_batch_run(None, None, None, 1, 0, -1, 1, 7, 0, 1.0, 1.0, None, None, None, None) < 0
     assert L.prl_h2h_batch_run(None, None, 1, 0, 1, 1, 1, 2, 0, 1.0, 1.0, None, None, None, None) < 0
+
+
+def test_bench_board_sets_are_disjoint_shards():
+    """bench.seeded_boards: sorted distinct 5-card boards; different offsets (= ranks of a sharded run) never share a board"""
+    import bench
+    a, b = bench.seeded_boards(4096, 0), bench.seeded_boards(4096, 0, offset=7 * 4096)
+    both = np.concatenate([a, b]).astype(np.int64)
+    assert both.dtype == np.int64 and a.dtype == np.int8 and a.shape == (4096, 5)
+    assert np.all(np.diff(both, axis=1) > 0) and both.min() >= 0 and both.max() <= 51
+    keys = (both * np.array([52 ** 4, 52 ** 3, 52 ** 2, 52, 1])).sum(axis=1)
+    assert len(np.unique(keys)) == len(keys)
+    assert np.array_equal(bench.seeded_boards(100, 0, offset=50), bench.seeded_boards(150, 0)[50:])
+    assert not np.array_equal(bench.seeded_boards(100, 1), bench.seeded_boards(100, 0))
