@@ -3,6 +3,8 @@ bench.py -- CFR+ node-updates/s on a synthetic Flop5Holdem public tree (BASELINE
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B] [--engine fused|levels] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself through torch.distributed.run on
+127.0.0.1 and relays rank 0's JSON line.
 
 A "step" is one CFRBase.iteration() (reference semantics, PokerRL/cfr/_CFRBase.py:122-134: both seats updated, EVs
 recomputed, current-strategy exploitability available) of CFR+ (delay 0) on the Flop5Holdem betting tree (blinds 50/100,
@@ -27,7 +29,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
@@ -62,14 +63,20 @@ def seeded_boards(n, seed, offset=0):
     return out
 
 
+def fhp_tree(boards, lib=None):
+    """The Flop5Holdem public tree of bench.py's workload (blinds 50/100, stacks 20000, pot-size raises) over `boards`."""
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    return _native.NativeTree.for_game(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards, _lib=lib)
+
+
 def cpu_baseline(n_boards, n_iters):
     """CFR+ on the same kind of tree with the CPU oracle (1 thread): node-updates/s on a bounded sample."""
     import oracle
-    from helpers import native_tree
-    from pokerrl_amd.game import bet_sets
-    from pokerrl_amd.game import games as G
+    oracle.set_threads(1)
     boards = seeded_boards(n_boards, 0)
-    t = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)  # host-side tree builder only
+    t = fhp_tree(boards)  # host-side tree builder only
     o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, 2, 52, 4, 2)
     o.cfr_reset(1, 0)
     t0 = time.perf_counter()
@@ -80,6 +87,23 @@ def cpu_baseline(n_boards, n_iters):
             "sample": "CFR+ delay 0, Flop5Holdem tree x %d boards (%d nodes), %d iterations, oracle/prl_oracle.c, 1 thread, %.1f s"
                       % (n_boards, t.n_nodes, n_iters, dt),
             "final_exploitability_mbb_per_g": float(np.mean(o.exploitability) * 10.0)}
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks (one process per GPU) the way the driver would."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -96,28 +120,35 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=24)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # PRL_BENCH_EMU_LIB (CPU test-suite only, tests/test_sharded.py): the ranks drive the emulator build of the library over
+    # gloo, so that the launch / sharding / exchange / JSON plumbing of an N-rank run is exercised in the GPU-less container
+    emu_lib = os.environ.get("PRL_BENCH_EMU_LIB")
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
+        if emu_lib:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif not emu_lib:
         torch.cuda.set_device(0)
 
-    from helpers import native_tree
     from pokerrl_amd import _native
-    from pokerrl_amd.game import bet_sets
-    from pokerrl_amd.game import games as G
 
-    _native.require_device()
-    _native.set_device(local_rank if world > 1 else 0)  # the library allocates on this process's GPU, like torch above
+    lib = _native.bind(emu_lib) if emu_lib else None
+    if not emu_lib:
+        _native.require_device()
+        _native.set_device(local_rank if world > 1 else 0)  # the library allocates on this process's GPU, like torch above
     # every rank owns a contiguous block of the global board list (weak scaling: fixed boards per GPU)
     boards = seeded_boards(args.boards, 0, offset=rank * args.boards)
-    tree = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)
+    tree = fhp_tree(boards, lib)
     exchange = None
     if world > 1 or os.environ.get("PRL_BENCH_FORCE_EXCHANGE"):  # the env knob runs the all-gather path on one GPU (tests)
         if dist is None:
@@ -126,14 +157,15 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29531")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         from pokerrl_amd.dist import TorchExchange
-        exchange = TorchExchange("cuda")
-        solver = _native.NativeSolver(tree, args.variant, 0, shard=(world, rank, exchange))
+        exchange = TorchExchange("cpu" if emu_lib else "cuda")
+        solver = _native.NativeSolver(tree, args.variant, 0, shard=(world, rank, exchange), _lib=lib)
     else:
-        solver = _native.NativeSolver(tree, args.variant, 0, engine=args.engine)
+        solver = _native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib)
     solver.sync()
 
     def barrier():
-        torch.cuda.synchronize()
+        if not emu_lib:
+            torch.cuda.synchronize()
         solver.sync()
         if dist is not None:
             dist.barrier()
@@ -145,7 +177,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if emu_lib else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

@@ -37,7 +37,6 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
     import oracle
-    from helpers import all_single_card_boards, native_tree
     from pokerrl_amd import _native
     from pokerrl_amd.game import bet_sets
     from pokerrl_amd.game import games as G
@@ -45,8 +44,8 @@ def main():
     game_cls = getattr(G, args.game)
     bets = bet_sets.POT_ONLY if args.game == "DiscretizedNLLeduc" else None
     stack = {"StandardLeduc": 13, "DiscretizedNLLeduc": 20000, "BigLeduc": 100}[args.game]
-    boards = all_single_card_boards(game_cls)
-    tree = native_tree(game_cls, stack, bets, boards)
+    boards = np.arange(game_cls.RULES.N_CARDS_IN_DECK, dtype=np.int8).reshape(-1, 1)  # one board per card, ascending
+    tree = _native.NativeTree.for_game(game_cls, stack, bets, boards)
     s = _native.NativeSolver(tree, args.variant, 0, engine="levels")
     s.iterations(args.warmup)
     s.sync()

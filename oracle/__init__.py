@@ -49,8 +49,22 @@ def lib():
         L.orc_np_sum_f32.argtypes = [vp, i32]
         L.orc_np_sum_f32.restype = ctypes.c_float
         L.orc_prefix_chunked.argtypes = [vp, i32, vp]
+        L.orc_unsupported.argtypes = [vp]
+        L.orc_unsupported.restype = i32
+        L.orc_set_threads.argtypes = [i32]
+        L.orc_max_threads.restype = i32
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    """Worker threads of the per-board / per-node loops (OpenMP). The results never depend on it: a thread only decides who
+    evaluates an independent board subtree. bench.py's cpu_baseline leg runs with 1."""
+    lib().orc_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
 
 
 def _p(a):
@@ -112,6 +126,8 @@ class Oracle:
                                    boards.shape[0], boards.shape[1], *[_p(t[k]) for k in self.FIELDS], _p(boards),
                                    ctypes.c_float(float(self.chance_prob)), ctypes.c_float(float(self.eq_const)))
         self.tree = t
+        if lib().orc_unsupported(self._h):
+            raise NotImplementedError("2-hole-card tree with a showdown terminal before the deal (all-in run-out)")
 
     def __del__(self):
         try:

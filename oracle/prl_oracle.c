@@ -29,6 +29,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -224,6 +225,7 @@ typedef struct {
     uint8_t* avg_f64;     /* [n_nodes] */
     float expl[2];
     int variant, delay, iter;
+    int unsupported;      /* tree holds a terminal this restatement does not cover */
     Plan* plans;          /* [n_boards + 1], last = "no board" identity plan; built lazily */
     uint8_t* plan_ready;
     int32_t* tmp_ranks;
@@ -256,6 +258,10 @@ Orc* orc_create(int n_nodes, int n_cols, int R, int n_hole, int n_cards, int n_s
 #undef DUP
     o->chance_prob = chance_prob;
     o->eq_const = eq_const;
+    /* all-in before the deal on a 2-card tree (ValueFiller.py:160-175 generalised) is not restated: refuse the tree */
+    if (n_hole == 2)
+        for (int n = 0; n < n_nodes; ++n)
+            if (kind[n] == K_SHOWDOWN && board_id[n] < 0) { o->unsupported = 1; }
     o->hole = (int16_t*)malloc(sizeof(int16_t) * 2 * (size_t)R);
     if (n_hole == 1) {
         for (int h = 0; h < R; ++h) { o->hole[2 * h] = (int16_t)h; o->hole[2 * h + 1] = -1; }
@@ -316,7 +322,7 @@ static const Plan* get_plan(Orc* o, int board_id) {
     Plan* p = &o->plans[slot];
     const int R = o->R;
     const int8_t* board = board_id < 0 ? NULL : o->boards + (size_t)board_id * o->board_len;
-    int32_t* rk = o->tmp_ranks;
+    int32_t* rk = (int32_t*)malloc(sizeof(int32_t) * (size_t)R); /* plans of different boards are built by different threads */
     if (board) ranks_on_board(o, board, rk);
     else for (int h = 0; h < R; ++h) rk[h] = 0; /* no board: hand-index order, one tie group (fold nodes only) */
     p->sh = (int16_t*)malloc(sizeof(int16_t) * R);
@@ -354,8 +360,16 @@ static const Plan* get_plan(Orc* o, int board_id) {
         }
         for (int k = m; k < o->n_cards - 1; ++k) row[k] = -1;
     }
+    free(rk);
     o->plan_ready[slot] = 1;
     return p;
+}
+
+/* all plans up front (in parallel): afterwards get_plan() only reads, so board subtrees can be evaluated concurrently */
+static void ensure_plans(Orc* o) {
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int b = 0; b <= o->n_boards; ++b)
+        if (!o->plan_ready[b]) get_plan(o, b == o->n_boards ? -1 : b);
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
@@ -370,7 +384,7 @@ static void fold_equity_1card(const Orc* o, const float* reach_opp, float* eq) {
 /* ValueFiller._get_call_eq_final_street (ValueFiller.py:127-158), 1-card: O(R^2), ascending h_opp, float32 running sum */
 static void showdown_equity_1card(const Orc* o, const float* reach_opp, int board_card, float* eq) {
     int8_t bc = (int8_t)board_card;
-    int32_t* rk = o->tmp_ranks;
+    int32_t rk[256]; /* 1-card ranges: R = number of cards (<= 52) */
     ranks_on_board(o, &bc, rk);
     for (int h = 0; h < o->R; ++h) {
         float e = 0.f;
@@ -467,7 +481,7 @@ static void terminal_values(Orc* o, int node) {
         const float* x = V2(o, reach, node, 1 - p);
         float* e = eq + (size_t)p * R;
         if (o->n_hole == 2) {
-            if (!fold && bid < 0) { memset(e, 0, sizeof(float) * R); continue; } /* all-in pre-flop: unsupported, see DESIGN */
+            if (!fold && bid < 0) abort(); /* refused at orc_create (orc_unsupported) */
             terminal_equity_2card(o, x, bid, fold ? 0 : 1, e);
             for (int h = 0; h < R; ++h) e[h] = e[h] * o->eq_const;
         } else if (fold) {
@@ -531,6 +545,8 @@ static void update_reach(Orc* o, int node) {
             update_reach(o, c);
         }
     } else if (o->kind[node] == K_CHANCE) {
+        /* board subtrees are independent: threads only change who computes a subtree, never the arithmetic inside it */
+#pragma omp parallel for schedule(dynamic, 4) if (o->n_children[node] >= 64)
         for (int i = 0; i < o->n_children[node]; ++i) {
             int c = child_of(o, node, i);
             const int8_t* board = o->boards + (size_t)o->board_id[c] * o->board_len;
@@ -549,13 +565,20 @@ static void compute_ev(Orc* o, int node) {
     const int R = o->R;
     const int A = o->n_children[node];
     if (o->kind[node] >= K_FOLD) { terminal_values(o, node); return; }
-    for (int i = 0; i < A; ++i) compute_ev(o, child_of(o, node, i));
+    if (o->kind[node] == K_CHANCE && A >= 64) {
+        if (o->n_hole == 2) ensure_plans(o);
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int i = 0; i < A; ++i) compute_ev(o, child_of(o, node, i));
+    } else {
+        for (int i = 0; i < A; ++i) compute_ev(o, child_of(o, node, i));
+    }
     if (o->kind[node] == K_CHANCE) {
         /* ValueFiller.py:76-78 sums the chance children in child order (NumPy outer-axis reduce = running add). The
          * canonical order here is the same running add, nested: blocks of 32 children, groups of 32 blocks, then the
          * groups -- identical to the reference for <= 32 boards (every Leduc game) and independent of how many GPUs
          * share the boards of a big tree (each GPU owns whole groups; DESIGN.md "multi-GPU"). */
         for (int p = 0; p < 2; ++p)
+#pragma omp parallel for schedule(static) if (A >= 64)
             for (int h = 0; h < R; ++h)
                 for (int which = 0; which < 2; ++which) {
                     float* arr = which ? o->ev_br : o->ev;
@@ -679,6 +702,7 @@ void orc_cfr_reset(Orc* o, int variant, int delay) { /* _CFRBase.reset (_CFRBase
 
 static void compute_regrets(Orc* o, int p) { /* _CFRBase._compute_regrets (_CFRBase.py:146-185) */
     const int R = o->R;
+#pragma omp parallel for schedule(static, 64) if (o->n_nodes >= 1024)
     for (int n = 0; n < o->n_nodes; ++n) {
         if (o->kind[n] != K_DECISION || o->actor[n] != p) continue;
         const float* strat_ev = V2(o, ev, n, p);
@@ -700,8 +724,9 @@ static void compute_regrets(Orc* o, int p) { /* _CFRBase._compute_regrets (_CFRB
 
 static void compute_new_strategy(Orc* o, int p) { /* VanillaCFR.py:32-52, CFRPlus.py:43-63, LinearCFR.py:33-51 */
     const int R = o->R;
-    float tmp[PRL_ORC_MAX_ACTIONS];
+#pragma omp parallel for schedule(static, 64) if (o->n_nodes >= 1024)
     for (int n = 0; n < o->n_nodes; ++n) {
+        float tmp[PRL_ORC_MAX_ACTIONS];
         if (o->kind[n] != K_DECISION || o->actor[n] != p) continue;
         const int A = o->n_children[n];
         const float unif = (float)(1.0 / (double)A);
@@ -719,8 +744,9 @@ static void compute_new_strategy(Orc* o, int p) { /* VanillaCFR.py:32-52, CFRPlu
 
 static void add_strategy_to_average(Orc* o, int p) { /* VanillaCFR.py:54-77, CFRPlus.py:65-87, LinearCFR.py:53-76 */
     const int R = o->R;
-    float tmp[PRL_ORC_MAX_ACTIONS];
+#pragma omp parallel for schedule(static, 64) if (o->n_nodes >= 1024)
     for (int n = 0; n < o->n_nodes; ++n) {
+        float tmp[PRL_ORC_MAX_ACTIONS];
         if (o->kind[n] != K_DECISION || o->actor[n] != p) continue;
         const int A = o->n_children[n];
         if (o->variant == V_PLUS) {
@@ -809,6 +835,10 @@ uint8_t* orc_avg_f64(Orc* o) { return o->avg_f64; }
 int32_t* orc_br_idx(Orc* o) { return o->br_idx; }
 float* orc_expl(Orc* o) { return o->expl; }
 int orc_iter(Orc* o) { return o->iter; }
+int orc_unsupported(Orc* o) { return o->unsupported; }
+/* worker threads for the per-board / per-node loops (results do not depend on it); bench.py's cpu_baseline uses 1 */
+void orc_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int orc_max_threads(void) { return omp_get_max_threads(); }
 float orc_np_sum_f32(const float* a, int n) { return np_sum_f32(a, n, 1); }
 double orc_np_sum_f64(const double* a, int n) { return np_sum_f64(a, n, 1); }
 void orc_prefix_chunked(const float* y, int n, float* P) { prefix_chunked(y, n, P); }

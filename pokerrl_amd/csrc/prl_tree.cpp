@@ -66,6 +66,14 @@ struct Builder {
             if (info.is_terminal) {
                 // state before payouts; round / board stay the parent's (PublicTree.py:244-251)
                 int kind = (legal[i] == PRL_FOLD) ? PRL_NODE_TERM_FOLD : PRL_NODE_TERM_SHOWDOWN;
+                if (kind == PRL_NODE_TERM_SHOWDOWN && t->board_id[id] < 0 && t->rules.n_hole_cards != 1) {
+                    // all-in before the deal: the reference averages the showdown over every run-out (ValueFiller.py:160-175,
+                    // 1-card ranges only); for 2-card ranges that needs run-out equity tables, which this engine does not have.
+                    // Refuse the tree instead of valuing the terminal at 0.
+                    err = PRL_ERR_UNSUPPORTED;
+                    t->error = "showdown terminal before the deal (all-in run-out) on a 2-hole-card tree is not supported";
+                    return;
+                }
                 new_node(kind, -1, id, i, legal[i], actor, t->round[id], t->board_id[id], info.pot_before_payout, depth + 1);
             } else if (info.chance_acts) {
                 if (t->game.n_rounds != 2 || s2.round != 1) {

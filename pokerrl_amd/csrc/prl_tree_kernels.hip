@@ -258,11 +258,7 @@ PRL_GLOBAL void prl_k_terminal_2card(PrlDevTree T, PrlDevState S, const int32_t*
         const float pot = (float)T.main_pot[node];
         float* oe = S.ev + prl_vidx(T, node, p);
         float* ob = S.ev_br + prl_vidx(T, node, p);
-        if (!fold && bid < 0) {  // all-in before the deal is not representable in a 2-round 1-chance-level tree with 5 cards
-            for (int h = (int)prl_tid(); h < T.R; h += (int)prl_nthreads()) { oe[h] = 0.f; ob[h] = 0.f; }
-            prl_sync();
-            continue;
-        }
+        // (showdown terminals before the deal do not exist here: prl_build_flat_tree refuses such 2-card trees)
         const float sign = (fold && T.acted_last[node] == p) ? -1.f : 1.f;
         prl_terminal_equity_2card(T, S.reach + prl_vidx(T, node, 1 - p), bid < 0 ? T.n_boards : bid, !fold, smem, sign, pot, oe, ob);
     }

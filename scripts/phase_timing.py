@@ -17,9 +17,7 @@ L = _native.bind(os.path.join(here, "pokerrl_amd", "lib", "libpokerrl_hip_timing
 n_boards = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 boards = bench.seeded_boards(n_boards, 0)
-from helpers import env_args  # noqa: E402  (tests/helpers.py, on sys.path through bench)
-
-t = _native.NativeTree(G.Flop5Holdem.native_game(env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)), G.Flop5Holdem.native_rules(), boards, _lib=L)
+t = _native.NativeTree.for_game(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards, _lib=L)
 s = _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
 s.iterations(int(sys.argv[3]) if len(sys.argv) > 3 else 2)
 s.sync()

@@ -190,6 +190,23 @@ def check_fused_vs_oracle(L, n_boards, n_iters, delay=0, variant="plus"):
     return s, o
 
 
+def check_fused_vs_fixture(L, name):
+    """Fused engine against an oracle-generated fixture (tests/golden/make_fhp_golden.py): history + array hashes."""
+    from helpers import h32
+    g = golden("%s.npz" % name)
+    boards = fhp_boards(int(g["n_boards"]), seed=int(g["seed"]))
+    assert h32(boards) == str(g["boards_sha256"])
+    args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
+    t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
+    variant = str(g["variant"])
+    s = _native.NativeSolver(t, variant, 0, engine="fused", _lib=L)
+    s.iterations(int(g["n_iters"]))
+    assert np.array_equal(s.get("expl_history"), g["expl_history"])
+    assert np.array_equal(s.eval_avg(), g["eval_avg"])
+    assert h32(s.get("regret")) == str(g["regret_sha256"])
+    assert h32(s.get("avg")) == str(g["avg_sha256"])
+
+
 def check_fused_batched_vs_oracle(L, n_boards, n_iters, delay=0, variant="plus"):
     """prl_solver_iterations(n) on the fused engine folds every closing evaluation into the next iteration's first board
     pass; the exploitability history and the final state must equal the oracle's (= n single iteration() calls)."""

@@ -57,6 +57,13 @@ def test_emu_fused_engine_three_boards(L):
     pc.check_fused_vs_oracle(L, 3, 2)
 
 
+def test_emu_fused_engine_several_boards_per_workgroup(L, monkeypatch):
+    """PRL_FHP_GRID=2: two persistent workgroups walk 7 boards, so each starts its 2nd..4th board from the LDS prefetch area
+    that was filled while the previous board was being walked (on the GPU that is every board but the first of a CU)."""
+    monkeypatch.setenv("PRL_FHP_GRID", "2")
+    pc.check_fused_vs_oracle(L, 7, 2)
+
+
 def test_emu_fused_engine_cfrplus_delay(L):
     pc.check_fused_vs_oracle(L, 3, 3, delay=1)
 

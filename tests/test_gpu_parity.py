@@ -139,6 +139,21 @@ def test_gpu_fused_linear_batched_vs_oracle_and_levels(L):
     pc.check_fused_vs_levels(L, 2048, 5, variant="linear")
 
 
+@pytest.mark.parametrize("n_boards,variant", [(2048, "plus"), (2048, "linear"), (2048, "vanilla"),
+                                              (4096, "plus"), (4096, "linear"), (4096, "vanilla")])
+def test_gpu_fused_many_boards_per_cu_vs_oracle(L, n_boards, variant):
+    """The benchmark path against the ORACLE with more boards than CUs: every persistent workgroup walks 8 (16) boards, all but
+    its first from the LDS prefetch area. 2048 boards = 2 canonical chance groups of 1024, 4096 = 4 (third summation level).
+    Regrets, averages, implied strategy, current- and average-strategy exploitability, bit for bit, after every iteration."""
+    pc.check_fused_vs_oracle(L, n_boards, 3, variant=variant)
+
+
+def test_gpu_fused_16384_boards_fixture(L):
+    """Oracle-generated fixture (tests/golden/make_fhp_golden.py): exploitability history and SHA-256 of the regrets / averages
+    after 3 CFR+ iterations on 16384 seeded boards (64 boards per CU)."""
+    pc.check_fused_vs_fixture(L, "fhp_16384_plus")
+
+
 @pytest.mark.parametrize("fused,variant", [(False, "vanilla"), (True, "plus"), (True, "linear")])
 def test_gpu_checkpoint_resume(L, fused, variant):
     pc.check_checkpoint_resume(L, fused, variant, n_before=4, n_after=3)

@@ -231,6 +231,20 @@ def test_tree_rejects_multi_street_games():
         native_tree(G.LimitHoldem, 48, [0.0], np.array([[0, 1, 2]], np.int8))
 
 
+def test_tree_rejects_all_in_before_the_deal_on_two_card_ranges():
+    """ValueFiller.py:160-175 averages an all-in-before-the-deal showdown over every run-out, for 1-card ranges only. On a
+    2-card tree neither the oracle nor the kernels restate that: the builder must refuse the tree (PRL_ERR_UNSUPPORTED),
+    not value the terminal at 0. A 250-chip stack puts the pot-sized pre-flop raise all-in."""
+    boards = np.array([[0, 5, 10, 15, 20], [1, 2, 3, 50, 51]], np.int8)
+    with pytest.raises(_native.NativeError, match="before the deal"):
+        native_tree(G.Flop5Holdem, 250, bet_sets.POT_ONLY, boards)
+    t = native_tree(G.Flop5Holdem, 2000, bet_sets.POT_ONLY, boards)  # deep enough: every showdown is after the deal
+    k, bid = t.field("kind"), t.field("board_id")
+    assert not np.any((k == 3) & (bid < 0))
+    # the same short stack on a 1-card game is the reference's V6 case and stays supported (pinned by the B3_short goldens)
+    native_tree(G.DiscretizedNLLeduc, 1500, bet_sets.B_3, np.arange(6, dtype=np.int8).reshape(-1, 1))
+
+
 def test_c_abi_exports_every_declared_symbol():
     """include/pokerrl_hip.h is the contract: every prototype it declares must be exported by the shared library."""
     import os

@@ -118,6 +118,29 @@ def test_sharded_world2_gloo_emu(EMU):
     check_against_union(_native.bind(EMU), ranks, 2, 2, 3, 1, 21)
 
 
+def test_bench_gpus_2_launches_two_ranks_gloo_emu(EMU):
+    """`python bench.py --gpus 2` with no launcher around it (the driver's form for N = 1; for N > 1 it wraps the same command in
+    torch.distributed.run) must start two ranks itself, shard the boards, exchange once per EV pass and report n_gpus = 2. Here
+    the ranks drive the emulator build over gloo; on the GPU box the same code path runs RCCL on the product library."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PRL_BENCH_EMU_LIB"] = EMU
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--boards", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, check=True).stdout
+    line = [x for x in out.splitlines() if x.startswith("{")]
+    assert len(line) == 1, out  # ONE JSON line, printed by rank 0
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["scaling"] == "weak"
+    assert j["config"]["nodes_whole_tree"] == 5 + 15 * 4 and j["config"]["exchanges"] > 0 and j["config"]["iterations_done"] == 2
+    # the two-rank solve of the 4 boards equals the one-rank solve of the same 4 boards
+    one = subprocess.run(cmd[:2] + ["--gpus", "1", "--steps", "1", "--warmup", "1", "--boards", "4", "--no-cpu-baseline"], env=env,
+                         capture_output=True, text=True, timeout=900, check=True).stdout
+    j1 = json.loads([x for x in one.splitlines() if x.startswith("{")][0])
+    assert j1["n_gpus"] == 1 and j1["config"]["exchanges"] == 0
+    assert j1["config"]["exploitability_mbb_per_g"] == j["config"]["exploitability_mbb_per_g"]
+
+
 @pytest.mark.gpu
 def test_gpu_chance_sum_levels_do_not_depend_on_world_size():
     L = _native.lib()
