@@ -199,7 +199,7 @@ def main():
                         " full-width iterations on the Flop5Holdem public tree (blinds 50/100, stacks 20000, "
                         "pot-size raises), %d seeded boards per GPU, 1326-hand ranges" % args.boards,
             "boards_per_gpu": args.boards, "nodes_per_gpu": tree.n_nodes, "action_columns_per_gpu": sum_a,
-            "engine": solver.engine, "fhp_cfg": os.environ.get("PRL_FHP_CFG", "0"),
+            "engine": solver.engine,
             "parallelism": "boards sharded over %d GPU(s), trunk replicated, 1 all-gather of chance-node partial sums per EV pass" % world,
             "nodes_whole_tree": n_nodes_total, "exchanges": exchange.calls if exchange else 0,
             "exchange_ms_mean": (exchange.seconds * 1e3 / max(exchange.calls, 1)) if exchange else None,

@@ -398,14 +398,32 @@ static void showdown_equity_1card(const Orc* o, const float* reach_opp, int boar
     }
 }
 
-/* per-card scan of the sorted-domain vector y restricted to the hands containing card c */
+/* per-card scan of the sorted-domain vector y restricted to the hands containing card c, in the canonical "row16" order
+ * (csrc/prl_device.h: prl_row16_scan): the list, zero-padded to 16 * E entries with E = ceil(n_t / 16), is owned by 16 lanes,
+ * E consecutive entries each; sequential prefix inside a lane, Hillis-Steele scan (d = 1, 2, 4, 8) of the lane totals, and
+ * Q_incl[i*E + k] = carry_i + local_k with carry_i = the scanned total of lane i-1 (0 for lane 0). Q[0] = 0, Q[t] = Q_incl[t-1]. */
 static void card_scan(const Plan* p, const Orc* o, const float* y, int c, float Q[65]) {
     const int16_t* row = p->cl + (size_t)c * (o->n_cards - 1);
-    float v[64];
-    for (int t = 0; t < 64; ++t) v[t] = (t < p->n_t && row[t] >= 0) ? y[row[t]] : 0.f;
-    scan64(v);
-    Q[0] = 0.f;
-    for (int t = 1; t <= 64; ++t) Q[t] = v[t - 1];
+    const int E = (p->n_t + 15) / 16;
+    float x[64], l[64], tot[16], tmp[16];
+    for (int t = 0; t < 64; ++t) x[t] = (t < p->n_t && row[t] >= 0) ? y[row[t]] : 0.f;
+    for (int i = 0; i < 16; ++i) {
+        float run = 0.f;
+        for (int k = 0; k < E; ++k) {
+            run = k == 0 ? x[i * E + k] : run + x[i * E + k];
+            l[i * E + k] = run;
+        }
+        tot[i] = run;
+    }
+    for (int d = 1; d < 16; d <<= 1) {
+        for (int i = 0; i < 16; ++i) tmp[i] = i >= d ? tot[i - d] : 0.f;
+        for (int i = 0; i < 16; ++i) tot[i] = tot[i] + tmp[i];
+    }
+    for (int t = 0; t <= 64; ++t) Q[t] = 0.f;
+    for (int i = 0; i < 16; ++i) {
+        const float carry = i > 0 ? tot[i - 1] : 0.f;
+        for (int k = 0; k < E; ++k) Q[i * E + k + 1] = carry + l[i * E + k];
+    }
 }
 
 /* 2-card terminal equity in the canonical scan order. mode 0 = fold, 1 = showdown. x = opponent reach (hand domain). */

@@ -108,6 +108,21 @@ PRL_DEV PRL_INLINE float prl_wave_scan_canonical(float v) {
     return v;
 }
 
+// Canonical per-card list scan, "row16 order" (DESIGN.md "summation order"): a list of n <= 64 values, zero-padded to 16 * E
+// entries with E = ceil(n / 16); lane i of a ROW of 16 lanes owns entries i*E .. i*E + E-1:
+//   local inclusive prefix l_k = l_(k-1) + x_(i*E+k) (l_0 = x_(i*E)), lane total t_i = l_(E-1);
+//   Hillis-Steele inclusive scan of t over the 16 lanes of the row (d = 1, 2, 4, 8: t_i += t_(i-d), lanes i < d add 0);
+//   carry_i = the scanned t_(i-1) (0 for lane 0);  Q_incl[i*E + k] = carry_i + l_k.
+// One wave scans four lists at once, and on a 5-card board (46 entries, E = 3) twelve waves scan the lists of all 47 live
+// cards in one go. The oracle (oracle/prl_oracle.c: card_scan) replays exactly this association.
+PRL_DEV PRL_INLINE float prl_row16_scan(float t) {  // inclusive, every lane of the wave must call it
+    t = t + prl_dpp_row_shr<1>(t);
+    t = t + prl_dpp_row_shr<2>(t);
+    t = t + prl_dpp_row_shr<4>(t);
+    t = t + prl_dpp_row_shr<8>(t);
+    return t;
+}
+
 // N independent canonical scans at once. Issued one by one, every masked step above pays its own "s_nop 1"; side by side the
 // steps of the other vectors ARE the wait states, so a group of 8 or 9 vectors needs a single s_nop (an s_nop costs the
 // wave an issue turn like any other instruction, and this kernel family is bound by issue turns per wave).

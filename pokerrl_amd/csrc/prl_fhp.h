@@ -106,7 +106,6 @@ struct PrlFhpParams {
     int32_t col_base;           // global action column of board 0, local column 0
     int32_t variant, iter;
     int32_t max_grid;
-    int32_t cfg;                // launch configuration of the board-pass kernel (prl_fhp_kernels.hip)
     float chance_prob, eq_const;
     float pot[PrlFhpShape::N_NODES];   // main pot of the terminal nodes (by local node id)
     const float* chance_reach;  // [2][R] reach at the chance node (trunk state)
@@ -121,9 +120,9 @@ struct PrlFhpParams {
     const double* strat_arr;    // explicit strategy (average strategy / caller-provided), [n_cols][R]
     float* board_out;           // [n_boards][prl_fhp_out_width(mode)][R] root vectors of every board subtree
     const uint16_t* hole_packed;// [R] c1 | c2 << 8
-    int32_t plan_stride, cl_stride;
-    const int16_t *plan_pos, *plan_hgs, *plan_hge, *plan_gs;
-    const uint16_t* plan_clw;
+    int32_t plan_stride;
+    const int16_t *plan_pos, *plan_hgs, *plan_hge;
+    const uint32_t* plan_clx;   // [n_boards][PRL_CLX_WORDS] per-lane records of the per-card scans (prl_solver_types.h)
     const int32_t* plan_nlive;
     unsigned long long* timing; // PRL_FHP_TIMING builds: [8] shader-clock accumulators per phase (prologue, B, C, D, E, epilogue)
 };

@@ -6,7 +6,7 @@
 // each chance outcome the board subtree is independent (ValueFiller.py:76-78 is a plain sum over boards), its shape is the
 // same for every board (betting never looks at the cards) and per hand everything except terminal equity is hand-local.
 // So: one workgroup walks ONE board subtree depth-first with the subtree shape known at COMPILE time (prl_fhp_shape.h):
-//   * 704 lanes x 2 adjacent hands cover the 1326 hands; reach / ev / regrets of the current DFS path live in VGPRs;
+//   * 768 lanes (663 of them x 2 adjacent hands cover the 1326 hands); reach / ev / regrets of the current DFS path live in VGPRs;
 //   * HBM traffic per board and pass: 14 regret columns + ~15 KB of showdown plan in (prefetched into LDS by LDS-DMA while
 //     the previous board is walked), the updated seat's 7 regret columns and float64 average columns read-modify-written,
 //     one row of 1-4 root vectors out -- nothing else;
@@ -21,12 +21,10 @@
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// launch configurations of the board-pass kernel: the same source instantiated with different (threads, hand slots,
-// occupancy) triples; selected at run time (PrlFhpParams::cfg) so that they can be A/B-measured on the GPU.
-//   cfg 0: 704 lanes x 2 slots (11 waves per CU): a lane owns two ADJACENT hands, so every global access of the hand
-//          domain is one 8- or 16-byte vector instruction (the address unit takes ~16 clocks per wave instruction
-//          whatever its width)
-//   cfg 1: 448 lanes x 3 slots (7 waves per CU), scalar accesses
+// launch configuration of the board-pass kernel: 768 lanes = 12 waves per CU, 3 per SIMD. A lane owns two ADJACENT hands (663
+// lanes hold the 1326 hands), so every global access of the hand domain is one 8- or 16-byte vector instruction (the address
+// unit takes ~16 clocks per wave instruction whatever its width); in the per-card scans a lane owns 3 list entries of one of
+// the 48 card slots (4 per wave), so the 47 live cards of a board are scanned in one round.
 // ---------------------------------------------------------------------------------------------------------------------
 #if defined(PRL_EMU)
 #define FHP_LB(t, w)
@@ -34,21 +32,10 @@
 #define FHP_LB(t, w) __launch_bounds__(t, w)
 #endif
 
-#define FHP_THREADS 704
+#define FHP_THREADS 768
 #define FHP_SLOTS 2
-#define FHP_LAUNCH_BOUNDS FHP_LB(704, 3)
+#define FHP_LAUNCH_BOUNDS FHP_LB(768, 3)
 namespace fhp_cfg0 {
-#include "prl_fhp_pass.inc"
-}
-#undef FHP_THREADS
-#undef FHP_SLOTS
-#undef FHP_LAUNCH_BOUNDS
-#undef FHP_LDS_BYTES
-
-#define FHP_THREADS 448
-#define FHP_SLOTS 3
-#define FHP_LAUNCH_BOUNDS FHP_LB(448, 2)
-namespace fhp_cfg1 {
 #include "prl_fhp_pass.inc"
 }
 #undef FHP_THREADS
@@ -56,10 +43,7 @@ namespace fhp_cfg1 {
 #undef FHP_LAUNCH_BOUNDS
 
 int prl_launch_fhp_pass(const PrlFhpParams& prm, int mode, int src0, int src1, void* stream) {
-    switch (prm.cfg) {
-        case 1: return fhp_cfg1::launch_pass(prm, mode, src0, src1, stream);
-        default: return fhp_cfg0::launch_pass(prm, mode, src0, src1, stream);
-    }
+    return fhp_cfg0::launch_pass(prm, mode, src0, src1, stream);
 }
 
 // materialise the strategy implied by the regrets (tests / prl_solver_get): [n_board_cols][R] float64

@@ -5,6 +5,9 @@
 //   pos[h]  sorted position of hand h, -1 if a hole card is on the board
 //   gs/ge   tie group [gs, ge) of every sorted position (equal hand ranks)
 //   cl[c]   for every card c, the sorted positions of the live hands that contain c, ascending (46 entries on a 5-card board)
+//   clx     (5-card boards of the 52-card deck only: the fused board pass) the same lists cut into the records its per-card
+//           scans consume, one 8-byte record per lane of a 768-lane workgroup: lane t serves list entries 3i .. 3i+2 (i = t % 16)
+//           of the (t / 16)-th live card -- see PRL_CLX_* in prl_solver_types.h
 // This is the generalisation of the reference's per-terminal `handranks` loop (ValueFiller.py:140-143) to 1326-hand
 // ranges: ranks come from the same evaluator as get_hand_rank_all_hands_on_given_boards (prl_handeval.h), computed here
 // in-kernel so that no rank table ever round-trips through the host. Plan index n_boards is the "no board" plan
@@ -17,7 +20,7 @@
 #include "prl_solver_types.h"
 
 PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
-                                 int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint16_t* plan_clw) {
+                                 int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx) {
     uint32_t* keys = (uint32_t*)prl_smem();  // [2048]
     int* n_live_s = (int*)(keys + 2048);
     const int tid = (int)prl_tid(), nt = (int)prl_nthreads();
@@ -79,7 +82,6 @@ PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, in
         int16_t* cl = plan_cl + (size_t)b * T.cl_stride;
         int16_t* hgs = plan_hgs + (size_t)b * T.plan_stride;
         int16_t* hge = plan_hge + (size_t)b * T.plan_stride;
-        uint16_t* clw = plan_clw + (size_t)b * T.cl_stride;
         for (int h = tid; h < T.R; h += nt) { pos[h] = -1; sh[h] = -1; gs[h] = 0; ge[h] = 0; hgs[h] = 0; hge[h] = 0; }
         prl_sync();
         for (int i = tid; i < n; i += nt) {
@@ -99,25 +101,53 @@ PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, in
         }
         for (int c = tid; c < T.n_cards; c += nt) {
             int16_t* row = cl + (size_t)c * (T.n_cards - 1);
-            uint16_t* roww = clw + (size_t)c * (T.n_cards - 1);
             int m = 0;
             for (int i = 0; i < n; ++i) {
                 const int h = (int)(keys[i] & 0x7FFu);
-                if (T.hole[2 * h] == c || T.hole[2 * h + 1] == c) {
-                    roww[m] = (uint16_t)(i | (T.hole[2 * h] == c ? 0x8000 : 0));
-                    row[m++] = (int16_t)i;
-                }
+                if (T.hole[2 * h] == c || T.hole[2 * h + 1] == c) row[m++] = (int16_t)i;
             }
-            for (; m < T.n_cards - 1; ++m) { row[m] = -1; roww[m] = 0xFFFFu; }
+            for (; m < T.n_cards - 1; ++m) row[m] = -1;
         }
         if (tid == 0) plan_nlive[b] = n;
         prl_sync();
+        // records of the fused board pass (row16 order with 3 entries per lane: lists of 33..48 entries, at most 48 live cards)
+        const int n_t = T.n_cards - 1 - (has_board ? T.board_len : 0);
+        if (plan_clx && has_board && T.n_cards - T.board_len <= PRL_CLX_SLOTS && n_t > 32 && n_t <= 48) {
+            uint32_t* clx = plan_clx + (size_t)b * PRL_CLX_WORDS;
+            const uint32_t inv = (uint32_t)PRL_CLX_ZERO_POS | PRL_CLX_HEAD | PRL_CLX_TAIL;
+            for (int i = tid; i < PRL_CLX_WORDS / 2; i += nt) {  // slots without a card, entries past the end of a list
+                clx[2 * i] = inv | (inv << 16);
+                clx[2 * i + 1] = inv | ((uint32_t)(i & 15) << 16) | ((uint32_t)(i & 15) << 20) | (63u << 24);
+            }
+            prl_sync();
+            for (int c = tid; c < T.n_cards; c += nt) {
+                if ((on_board >> c) & 1ull) continue;
+                const int slot = c - prl_popc64(on_board & ((1ull << c) - 1ull));
+                const int16_t* row = cl + (size_t)c * (T.n_cards - 1);
+                auto head = [&](int e) { return e == 0 || gs[row[e]] != gs[row[e - 1]]; };       // first of its tie group in this list
+                auto tail = [&](int e) { return e == n_t - 1 || gs[row[e + 1]] != gs[row[e]]; };
+                auto entry = [&](int e) -> uint32_t {
+                    if (e >= n_t) return inv;
+                    const int h = (int)(keys[row[e]] & 0x7FFu);
+                    return (uint32_t)row[e] | (head(e) ? PRL_CLX_HEAD : 0u) | (tail(e) ? PRL_CLX_TAIL : 0u) |
+                           (T.hole[2 * h] == c ? PRL_CLX_LOWER : 0u) | PRL_CLX_VALID;
+                };
+                for (int i = 0; i < 16; ++i) {
+                    int la = i, lb = i;
+                    if (3 * i < n_t) { int e = 3 * i; while (!head(e)) --e; la = e / 3; }
+                    if (3 * i + 2 < n_t) { int e = 3 * i + 2; while (!tail(e)) ++e; lb = e / 3; }
+                    clx[(slot * 16 + i) * 2] = entry(3 * i) | (entry(3 * i + 1) << 16);
+                    clx[(slot * 16 + i) * 2 + 1] = entry(3 * i + 2) | ((uint32_t)la << 16) | ((uint32_t)lb << 20) | ((uint32_t)c << 24);
+                }
+            }
+            prl_sync();
+        }
     }
 }
 
 void prl_launch_plan_build(const PrlDevTree& T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
-                           int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint16_t* plan_clw, void* stream) {
+                           int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx, void* stream) {
     int grid = n_plans < 32768 ? n_plans : 32768;
     PRL_LAUNCH(prl_k_plan_build, grid, 256, 2048 * sizeof(uint32_t) + 16, stream, T, n_plans, plan_sh, plan_pos, plan_gs, plan_ge, plan_cl,
-               plan_nlive, plan_hgs, plan_hge, plan_clw);
+               plan_nlive, plan_hgs, plan_hge, plan_clx);
 }

@@ -452,7 +452,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         T.plan_stride = T.R;
         T.cl_stride = T.n_cards * (T.n_cards - 1);
         int16_t *sh, *pos, *gs, *ge, *cl, *hgs, *hge;
-        uint16_t* clw;
+        uint32_t* clx = nullptr;
         int32_t* nl;
         FAIL_IF(dev_alloc(s, &sh, (size_t)n_plans * T.plan_stride));
         FAIL_IF(dev_alloc(s, &pos, (size_t)n_plans * T.plan_stride));
@@ -462,16 +462,16 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         FAIL_IF(dev_alloc(s, &nl, (size_t)n_plans));
         FAIL_IF(dev_alloc(s, &hgs, (size_t)n_plans * T.plan_stride));
         FAIL_IF(dev_alloc(s, &hge, (size_t)n_plans * T.plan_stride));
-        FAIL_IF(dev_alloc(s, &clw, (size_t)n_plans * T.cl_stride));
+        if (fused) FAIL_IF(dev_alloc(s, &clx, (size_t)n_plans * PRL_CLX_WORDS));
         PrlDevTree Tb = T;
         Tb.n_boards = full.n_boards;
-        prl_launch_plan_build(Tb, n_plans, sh, pos, gs, ge, cl, nl, hgs, hge, clw, s->stream);
+        prl_launch_plan_build(Tb, n_plans, sh, pos, gs, ge, cl, nl, hgs, hge, clx, s->stream);
         // the LEVELS kernels address plan `board_id`, or plan index T.n_boards for "no board"; in the FUSED engine the
         // trunk tree has n_boards == 0, so its plan pointers are based at the last (no-board) plan
         const size_t off = fused ? (size_t)full.n_boards : 0;
         T.plan_sh = sh + off * T.plan_stride; T.plan_pos = pos + off * T.plan_stride; T.plan_gs = gs + off * T.plan_stride;
         T.plan_ge = ge + off * T.plan_stride; T.plan_cl = cl + off * T.cl_stride; T.plan_nlive = nl + off;
-        T.plan_hgs = hgs + off * T.plan_stride; T.plan_hge = hge + off * T.plan_stride; T.plan_clw = clw + off * T.cl_stride;
+        T.plan_hgs = hgs + off * T.plan_stride; T.plan_hge = hge + off * T.plan_stride; T.plan_clx = clx ? clx + off * PRL_CLX_WORDS : nullptr;
         if (fused) {
             PrlFhpParams& fp = s->fp;
             fp.n_boards = full.n_boards; fp.R = T.R; fp.col_base = col_base;
@@ -481,15 +481,13 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
                 fp.max_grid = cus > 0 ? cus : 256;
             }
             {
-                const char* e = getenv("PRL_FHP_CFG");  // tuning knob: launch configuration of the board-pass kernel
-                fp.cfg = e ? atoi(e) : 0;
                 const char* g = getenv("PRL_FHP_GRID");
                 if (g && atoi(g) > 0) fp.max_grid = atoi(g);
             }
             fp.chance_prob = T.chance_prob; fp.eq_const = T.eq_const;
             for (int n = 0; n < PrlFhpShape::N_NODES; ++n) fp.pot[n] = pots[n];
-            fp.plan_stride = T.plan_stride; fp.cl_stride = T.cl_stride;
-            fp.plan_pos = pos; fp.plan_hgs = hgs; fp.plan_hge = hge; fp.plan_gs = gs; fp.plan_clw = clw; fp.plan_nlive = nl;
+            fp.plan_stride = T.plan_stride;
+            fp.plan_pos = pos; fp.plan_hgs = hgs; fp.plan_hge = hge; fp.plan_clx = clx; fp.plan_nlive = nl;
             FAIL_IF(dev_upload(s, &fp.hole_packed, hole_packed));
         }
     }

@@ -16,6 +16,22 @@ struct PrlIterDev { int32_t iter, mode; double m_old, m_new; float* hist; };
 
 #define PRL_CHANCE_BLOCK 32   // canonical chance-sum order: blocks of 32 children, groups of 32 blocks
 
+// Records of the fused board pass's per-card scans (prl_plan_kernels.hip builds them, prl_fhp_pass.inc consumes them): lane t of
+// a 768-lane workgroup serves entries 3i, 3i+1, 3i+2 (i = t % 16) of the list of the (t / 16)-th live card, cards ascending.
+//   word 0: entry 3i | entry 3i+1 << 16        word 1: entry 3i+2 | laneA << 16 | laneB << 20 | card << 24
+//   entry : sorted position (11 bits) | HEAD (first of its tie group within this list) | TAIL (last of it) | LOWER (the card is
+//           the lower card of that hand) | VALID; entries past the end of a list / slots without a card point at the always-zero
+//           position PRL_CLX_ZERO_POS and are their own group
+//   laneA : lane (0..15 of the row) holding the head of the tie group that entry 3i belongs to; laneB: lane holding the tail of
+//           the group of entry 3i+2
+#define PRL_CLX_SLOTS 48
+#define PRL_CLX_WORDS (PRL_CLX_SLOTS * 16 * 2)
+#define PRL_CLX_ZERO_POS 1087u   // = FHP_NPAD - 1
+#define PRL_CLX_HEAD 0x0800u
+#define PRL_CLX_TAIL 0x1000u
+#define PRL_CLX_LOWER 0x2000u
+#define PRL_CLX_VALID 0x4000u
+
 struct PrlDevTree {
     int32_t n_nodes, n_cols, R, n_hole, n_cards, n_suits, rank_rule, n_boards, board_len, n_levels;
     const int32_t *kind, *actor, *parent, *child_idx, *acted_last, *board_id, *main_pot, *n_children, *first_col,
@@ -36,7 +52,7 @@ struct PrlDevTree {
     // hand-domain / flagged copies used by the fused board kernels (prl_fhp_kernels.hip)
     const int16_t* plan_hgs;     // [n_plans][R]   gs[pos[h]] (0 for blocked hands)
     const int16_t* plan_hge;     // [n_plans][R]   ge[pos[h]]
-    const uint16_t* plan_clw;    // [n_plans][n_cards][n_cards-1]  position | (c is the LOWER card of that hand) << 15; 0xFFFF pad
+    const uint32_t* plan_clx;    // [n_plans][PRL_CLX_WORDS] per-lane records of the fused board pass (below); 5-card boards only
 };
 
 struct PrlDevState {

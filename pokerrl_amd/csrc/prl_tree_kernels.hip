@@ -201,15 +201,28 @@ PRL_DEV PRL_INLINE void prl_terminal_equity_2card(const PrlDevTree& T, const flo
     for (int i = tid; i < n; i += nt) y[i] = x[sh[i]];
     prl_sync();
     prl_block_prefix(y, n, P, tot, carry);
-    {   // per-card scans: wave w takes cards w, w + n_waves, ...
-        const int wave = tid >> 6, n_waves = nt >> 6, lane = tid & 63;
-        for (int c = wave; c < T.n_cards; c += n_waves) {
-            const int16_t* row = cl + (size_t)c * (T.n_cards - 1);
-            int q = lane < n_t ? (int)row[lane] : -1;
-            float v = q >= 0 ? y[q] : 0.f;
-            v = prl_wave_scan(v);
-            if (lane == 0) Q[c * 65] = 0.f;
-            Q[c * 65 + lane + 1] = v;
+    {   // per-card scans in the row16 order (prl_device.h): a wave takes four cards at a time, one per row of 16 lanes
+        const int wave = tid >> 6, n_waves = nt >> 6, lane = tid & 63, row = lane >> 4, l16 = lane & 15;
+        const int E = (n_t + 15) >> 4;  // entries per lane, <= 4
+        for (int c0 = 4 * wave; c0 < T.n_cards; c0 += 4 * n_waves) {
+            const int c = c0 + row;
+            const bool okc = c < T.n_cards;
+            const int16_t* lst = cl + (size_t)(okc ? c : 0) * (T.n_cards - 1);
+            float l[4] = {0.f, 0.f, 0.f, 0.f};
+            float run = 0.f;
+            for (int k = 0; k < E; ++k) {
+                const int e = l16 * E + k;
+                const int q = (okc && e < n_t) ? (int)lst[e] : -1;
+                const float v = q >= 0 ? y[q] : 0.f;
+                run = k == 0 ? v : run + v;
+                l[k] = run;
+            }
+            const float t = prl_row16_scan(run);
+            const float carry = prl_dpp_row_shr<1>(t);
+            if (okc) {
+                if (l16 == 0) Q[c * 65] = 0.f;
+                for (int k = 0; k < E; ++k) Q[c * 65 + l16 * E + k + 1] = carry + l[k];
+            }
         }
     }
     prl_sync();
