@@ -1,10 +1,16 @@
-# A/B of library variants on one box: bash scripts/gpu_ab.sh BOARDS variant... ("" = product library); prints value / ms per iteration / per-pass kernel ms
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+#!/bin/bash
+# same-box A/B of board-pass variants: every lib given (name=path) runs bench.py twice, interleaved; prints ms per iteration
+# usage: scripts/gpu_ab.sh <boards> name=lib.so [name=lib.so ...]
 B=$1; shift
-for rep in 1; do
-for v in "$@"; do
-  lib=pokerrl_amd/lib/libpokerrl_hip_$v.so; [ "$v" = product ] && lib=pokerrl_amd/lib/libpokerrl_hip.so
-  POKERRL_AMD_LIB=$GRAFT_REPO_ROOT/$lib timeout 300 python bench.py --boards $B --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/ab_$v.log 2>&1
-  echo "variant '${v}': $(grep -o '"value": [0-9.e+]*\|"ms_per_step": [0-9.]*\|"kernel_ms_per_iteration": [0-9.]*' gpurun_out/ab_$v.log | tr '\n' ' ')"
-done
+mkdir -p gpurun_out
+for rep in 1 2; do
+  for nv in "$@"; do
+    n=${nv%%=*}; l=${nv#*=}
+    POKERRL_AMD_LIB=$PWD/$l python bench.py --steps 10 --warmup 2 --boards $B --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/ab_${n}_$rep.json
+    python - <<PY
+import json
+j=json.loads(open("gpurun_out/ab_${n}_$rep.json").read())
+print("%-12s rep $rep  %.3f ms/iter  kernel %.3f ms  frac %.4f  %.1f M/s" % ("$n", j["ms_per_step"], j["roofline"]["kernel_ms_per_iteration"], j["roofline"]["frac"], j["value"]/1e6))
+PY
+  done
 done
