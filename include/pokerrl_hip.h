@@ -188,6 +188,10 @@ int32_t prl_env_reset_host(const PrlGame* game, PrlEnvState* state);
 int32_t prl_env_step_host(const PrlGame* game, PrlEnvState* state, int32_t action_int, PrlStepInfo* out_info);
 /* processed (type, amount) form == PokerEnv.step_from_processed_tuple */
 int32_t prl_env_step_processed_host(const PrlGame* game, PrlEnvState* state, int32_t type, int32_t amount, PrlStepInfo* out_info);
+/* the action half of a step only: the current player's action is fixed and applied, no bet sweep / round transition / payout.
+ * This is PokerEnv._step's info["state_dict_before_money_move"] state (PokerEnv.py:761-766). action_int form if !is_processed. */
+int32_t prl_env_apply_action_host(const PrlGame* game, PrlEnvState* state, int32_t action_int, int32_t is_processed, int32_t type, int32_t amount,
+                                  PrlStepInfo* out_info);
 int32_t prl_env_legal_actions_host(const PrlGame* game, const PrlEnvState* state, int32_t* out_actions, int32_t* out_n);
 int32_t prl_env_fraction_of_pot_raise_host(const PrlEnvState* state, double fraction, int32_t seat, int32_t* out_total);
 

@@ -19,7 +19,11 @@ PRL_MAX_BET_SIZES = 96
 
 
 class NativeError(RuntimeError):
-    pass
+    """A negative status from the library; `.status` is the PRL_ERR_* code (include/pokerrl_hip.h)."""
+    status = None
+
+
+ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_OOM, ERR_STATE = -1, -2, -3, -4, -5, -6
 
 
 class PrlRules(ctypes.Structure):
@@ -120,6 +124,9 @@ def bind(path):
     L.prl_env_step_processed_host.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlEnvState), ctypes.c_int32,
                                               ctypes.c_int32, ctypes.POINTER(PrlStepInfo)]
     L.prl_env_step_processed_host.restype = ctypes.c_int32
+    L.prl_env_apply_action_host.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlEnvState), ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(PrlStepInfo)]
+    L.prl_env_apply_action_host.restype = ctypes.c_int32
     L.prl_env_legal_actions_host.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlEnvState), ctypes.c_void_p,
                                              ctypes.POINTER(ctypes.c_int32)]
     L.prl_env_legal_actions_host.restype = ctypes.c_int32
@@ -194,7 +201,9 @@ def _bind_solver(L):
 def check(status, L=None):
     if status != 0:
         L = L or lib()
-        raise NativeError("libpokerrl_hip error %d: %s" % (status, L.prl_last_error().decode("utf-8", "replace")))
+        e = NativeError("libpokerrl_hip error %d: %s" % (status, L.prl_last_error().decode("utf-8", "replace")))
+        e.status = int(status)
+        raise e
 
 
 def device_available():

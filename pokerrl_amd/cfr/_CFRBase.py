@@ -68,8 +68,10 @@ class CFRBase:
             try:
                 _native.NativeSolver.iterations_many(solvers, n)
                 batched = True
-            except _native.NativeError:
-                batched = False  # not all of them are small 1-hole-card trees
+            except _native.NativeError as e:
+                if e.status != _native.ERR_UNSUPPORTED:  # a HIP failure part-way through must surface, not be re-run
+                    raise
+                batched = False  # not all of them are small 1-hole-card trees (refused before anything was launched)
         for t in self._trees:
             if not batched:
                 t.solver.iterations(n)

@@ -198,6 +198,24 @@ int32_t prl_env_step_processed_host(const PrlGame* game, PrlEnvState* state, int
     return PRL_OK;
 }
 
+int32_t prl_env_apply_action_host(const PrlGame* game, PrlEnvState* state, int32_t action_int, int32_t is_processed, int32_t type, int32_t amount,
+                                  PrlStepInfo* out_info) {
+    if (!game || !state || !out_info) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
+    if (is_processed) {
+        if (type < 0 || type > 2) { prl_set_error("action type out of range"); return PRL_ERR_ARG; }
+    } else {
+        const int n_act = game->game_type == PRL_GAME_DISCRETIZED ? game->n_bet_sizes + 2 : 3;
+        if (action_int < 0 || action_int >= n_act) { prl_set_error("action out of range"); return PRL_ERR_ARG; }
+        prl_adjust_action(*game, *state, action_int, &type, &amount);
+    }
+    *out_info = PrlStepInfo();
+    int ft, fa;
+    prl_env_apply_action(*game, *state, type, amount, &ft, &fa);
+    out_info->fixed_type = ft;
+    out_info->fixed_amount = fa;
+    return PRL_OK;
+}
+
 int32_t prl_env_legal_actions_host(const PrlGame* game, const PrlEnvState* state, int32_t* out_actions, int32_t* out_n) {
     if (!game || !state || !out_actions || !out_n) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
     *out_n = prl_legal_actions(*game, *state, out_actions);

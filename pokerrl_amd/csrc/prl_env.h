@@ -130,9 +130,10 @@ PRL_HD PRL_INLINE int prl_should_continue(const PrlEnvState& s) {  // PokerEnv.p
     return 1;
 }
 
-// One betting step with a PROCESSED action (type, amount) for the current player. Cards are not handled here: on a
-// round transition the caller deals (chance_acts), on a showdown the caller evaluates hands. Mirrors PokerEnv._step.
-PRL_HD PRL_INLINE void prl_env_step_processed(const PrlGame& g, PrlEnvState& s, int type, int amount, PrlStepInfo* info) {
+// The first half of a betting step: the PROCESSED action (type, amount) of the current player is fixed and applied, nothing
+// else moves -- bets stay in front of the players, round / current player / raise caps unchanged. This is the state
+// PokerEnv._step hands out as info["state_dict_before_money_move"] on a round transition (PokerEnv.py:681-728,761-766).
+PRL_HD PRL_INLINE void prl_env_apply_action(const PrlGame& g, PrlEnvState& s, int type, int amount, int* out_ftype, int* out_famount) {
     int ftype, famount;
     prl_fixed_action(g, s, type, amount, &ftype, &famount);
     int p = s.cur;
@@ -159,6 +160,16 @@ PRL_HD PRL_INLINE void prl_env_step_processed(const PrlGame& g, PrlEnvState& s, 
         if (g.game_type == PRL_GAME_LIMIT) s.n_raises_round += 1;
     }
     s.last_action[0] = ftype; s.last_action[1] = famount; s.last_action[2] = p;
+    *out_ftype = ftype;
+    *out_famount = famount;
+}
+
+// One betting step with a PROCESSED action (type, amount) for the current player. Cards are not handled here: on a
+// round transition the caller deals (chance_acts), on a showdown the caller evaluates hands. Mirrors PokerEnv._step.
+PRL_HD PRL_INLINE void prl_env_step_processed(const PrlGame& g, PrlEnvState& s, int type, int amount, PrlStepInfo* info) {
+    int ftype, famount;
+    const int p = s.cur;
+    prl_env_apply_action(g, s, type, amount, &ftype, &famount);
 
     info->fixed_type = ftype; info->fixed_amount = famount;
     info->is_terminal = 0; info->chance_acts = 0; info->terminal_is_fold = 0; info->rundown = 0; info->pot_before_payout = 0;

@@ -49,6 +49,7 @@ struct prl_solver {
     bool fused = false;
     // sharded solve (prl_solver_create_sharded)
     int world = 1, rank = 0, xlevel = 0, n_units = 0;  // summation level exchanged, units per rank
+    uint64_t fingerprint = 0;  // boards + game + rules + (world, rank): what a checkpoint must match besides the array shapes
     prl_exchange_fn exchange = nullptr;
     bool exchange_async = false;  // the callback enqueues on s->stream: no host synchronisation around it
     void* exchange_user = nullptr;
@@ -388,6 +389,16 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     prl_solver* s = new prl_solver();
     s->world = world;
     s->rank = rank;
+    {   // FNV-1a over everything a checkpoint of this solver is tied to (prl_solver_load_state)
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+        mix(full.boards.data(), full.boards.size());
+        mix(&full.game, sizeof(full.game));
+        mix(&full.rules, sizeof(full.rules));
+        const int32_t wr[2] = {world, rank};
+        mix(wr, sizeof(wr));
+        s->fingerprint = h;
+    }
     s->exchange = exchange;
     s->exchange_user = exchange_user;
     s->variant = variant;
@@ -551,7 +562,9 @@ namespace {
 struct PrlStateHeader {
     uint32_t magic, version;
     int32_t variant, delay, fused, iter, full_cols, R, trunk_cols, trunk_nodes, src0, src1, board_avg_f64, has_avg_sum;
+    uint64_t fingerprint;  // prl_solver::fingerprint of the saving solver
 };
+const uint32_t PRL_STATE_VERSION = 2;
 const uint32_t PRL_STATE_MAGIC = 0x50524C53u;  // "PRLS"
 
 struct StateLayout { size_t regret, avg, avg_sum, strategy, strat_f64, avg_f64, hist, total; };
@@ -583,7 +596,7 @@ int32_t prl_solver_save_state(prl_solver_t* s, void* out, uint64_t bytes) {
     TRY(ensure_board_avg(s));
     PrlStateHeader h;
     memset(&h, 0, sizeof(h));
-    h.magic = PRL_STATE_MAGIC; h.version = 1; h.variant = s->variant; h.delay = s->delay; h.fused = s->fused; h.iter = s->iter;
+    h.magic = PRL_STATE_MAGIC; h.version = PRL_STATE_VERSION; h.fingerprint = s->fingerprint; h.variant = s->variant; h.delay = s->delay; h.fused = s->fused; h.iter = s->iter;
     h.full_cols = s->full_cols; h.R = s->R; h.trunk_cols = s->T.n_cols; h.trunk_nodes = s->T.n_nodes; h.src0 = s->src[0]; h.src1 = s->src[1];
     h.board_avg_f64 = s->board_avg_f64; h.has_avg_sum = s->S.avg_sum != nullptr;
     char* b = (char*)out;
@@ -604,12 +617,17 @@ int32_t prl_solver_load_state(prl_solver_t* s, const void* in, uint64_t bytes) {
     if (!s || !in || bytes < sizeof(PrlStateHeader)) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
     PrlStateHeader h;
     memcpy(&h, in, sizeof(h));
-    if (h.magic != PRL_STATE_MAGIC || h.version != 1) { prl_set_error("load_state: not a solver state blob"); return PRL_ERR_ARG; }
+    if (h.magic != PRL_STATE_MAGIC || h.version != PRL_STATE_VERSION) { prl_set_error("load_state: not a solver state blob (or one of another library version)"); return PRL_ERR_ARG; }
     if (h.variant != s->variant || h.delay != s->delay || h.fused != (int32_t)s->fused || h.full_cols != s->full_cols || h.R != s->R ||
         h.trunk_cols != s->T.n_cols || h.trunk_nodes != s->T.n_nodes || h.has_avg_sum != (int32_t)(s->S.avg_sum != nullptr) || h.iter < 0) {
         prl_set_error("load_state: the blob was saved by a solver with a different tree / variant / delay / engine");
         return PRL_ERR_STATE;
     }
+    if (h.fingerprint != s->fingerprint) {
+        prl_set_error("load_state: the blob belongs to another board list / game / stack sizes or to another rank's shard");
+        return PRL_ERR_STATE;
+    }
+    if (h.src0 < 0 || h.src0 > PRL_SRC_ARR32 || h.src1 < 0 || h.src1 > PRL_SRC_ARR32) { prl_set_error("load_state: corrupt header"); return PRL_ERR_ARG; }
     const StateLayout L = state_layout(s, h.iter);
     if (bytes < L.total) { prl_set_error("load_state: truncated blob"); return PRL_ERR_ARG; }
     const char* b = (const char*)in;

@@ -177,6 +177,7 @@ class PublicTree:
     # ---- construction -------------------------------------------------------------------------------------------------
     def build_tree(self, variant="vanilla", delay=0):
         import copy
+        self._variant, self._delay = variant, delay  # copy() builds its solver the same way
         env_cls, rules = self._env_bldr.env_cls, self._env_bldr.rules
         args = copy.deepcopy(self._env_bldr.env_args)
         args.starting_stack_sizes_list = copy.deepcopy(self._stack_size)
@@ -276,8 +277,17 @@ class PublicTree:
     def copy(self):
         c = PublicTree(self._env_bldr, self._stack_size, None, self._put_out_new_round_after_limit, self._is_debugging, self._boards,
                        self._engine)
-        c.build_tree()
-        c._solver.set_strategy(self._vec("strategy"))
+        c.build_tree(variant=getattr(self, "_variant", "vanilla"), delay=getattr(self, "_delay", 0))
+        self._flush()
+        try:  # a solver in a CFR run: the whole persistent state (regrets, averages, iteration counter) moves over
+            c._solver.load_state(self._solver.save_state())
+        except _native.NativeError as e:
+            if e.status != _native.ERR_STATE:  # ERR_STATE = an explicit strategy is loaded (fill_with_agent_policy ...): copy that
+                raise
+            strat = self._vec("strategy")
+            f64 = bool(self._solver.get("strat_f64").any())
+            c._solver.set_strategy(strat if f64 else strat.astype(np.float32))
+        c._invalidate()
         return c
 
     def get_tree_as_dict(self):
@@ -365,19 +375,8 @@ class PublicTree:
                 st = copy.deepcopy(env.state_dict())
             elif self._kind[idx] == KIND_CHANCE:
                 # PokerEnv.py:761-766: the state after the (check / call) action and before _next_round -- bets still in front
-                # of the players, old pot, old round, the actor still "current". Rebuilt from the states around the step.
-                post = env.state_dict()
-                st = {k: v for k, v in copy.deepcopy(before).items() if not (isinstance(k, str) and k.startswith("_"))}
-                actor = before[EnvDictIdxs.current_player]
-                st[EnvDictIdxs.last_action] = copy.deepcopy(post[EnvDictIdxs.last_action])
-                st[EnvDictIdxs.n_actions_this_episode] = before[EnvDictIdxs.n_actions_this_episode] + 1
-                for p in range(self._n_seats):
-                    seat, b, a = st[EnvDictIdxs.seats][p], before[EnvDictIdxs.seats][p], post[EnvDictIdxs.seats][p]
-                    paid = b[PlayerDictIdxs.stack] - a[PlayerDictIdxs.stack]  # the sweep itself does not touch the stacks
-                    seat[PlayerDictIdxs.stack] = a[PlayerDictIdxs.stack]
-                    seat[PlayerDictIdxs.current_bet] = b[PlayerDictIdxs.current_bet] + paid
-                    seat[PlayerDictIdxs.is_allin] = a[PlayerDictIdxs.is_allin]
-                    seat[PlayerDictIdxs.has_acted_this_round] = True if p == actor else b[PlayerDictIdxs.has_acted_this_round]
+                # of the players, old pot, old round, the actor still "current": what the env hands out in its step info
+                st = {k: v for k, v in copy.deepcopy(info["state_dict_before_money_move"]).items() if not (isinstance(k, str) and k.startswith("_"))}
             else:
                 st = {k: v for k, v in copy.deepcopy(info["state_dict_before_money_move"]).items() if not (isinstance(k, str) and k.startswith("_"))}
                 st[EnvDictIdxs.current_round] = before[EnvDictIdxs.current_round]

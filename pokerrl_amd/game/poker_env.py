@@ -213,41 +213,51 @@ class PokerEnv:
                 out_info = {"chance_acts": False, "state_dict_before_money_move": pre}
         elif info.chance_acts:
             if self.RETURN_PRE_TRANSITION_STATE_IN_INFO:
-                out_info = {"chance_acts": True, "state_dict_before_money_move": self._pre_step_state}
+                out_info = {"chance_acts": True, "state_dict_before_money_move": self._state_before_money_move()}
             self._deal_round(self._st.round)
         elif self.RETURN_PRE_TRANSITION_STATE_IN_INFO:
             out_info = {"chance_acts": False, "state_dict_before_money_move": None}
         return self._returns(bool(info.is_terminal), out_info)
 
-    def _snapshot_before(self):
+    def _snapshot_before(self, action_int=-1, processed=None):
         self._round_before_step = self._st.round
-        if self.RETURN_PRE_TRANSITION_STATE_IN_INFO:
-            self._pre_step_state = None  # filled lazily below for round transitions
+        if self.RETURN_PRE_TRANSITION_STATE_IN_INFO:  # what _state_before_money_move() needs if this step closes the round
+            self._pre_step = (bytes(ctypes.string_at(ctypes.addressof(self._st), ctypes.sizeof(self._st))), action_int, processed)
 
     def step(self, action):
         if self._game.game_type == 2:  # NoLimit envs take (type, chips) tuples
             return self.step_from_processed_tuple(action)
-        self._snapshot_before()
-        pre = self._state_after_action_before_sweep(int(action)) if self.RETURN_PRE_TRANSITION_STATE_IN_INFO else None
+        self._snapshot_before(action_int=int(action))
         _native.check(self._L.prl_env_step_host(ctypes.byref(self._game), ctypes.byref(self._st), int(action), ctypes.byref(self._info)))
-        self._pre_step_state = pre
         return self._after_step()
 
     def step_from_processed_tuple(self, action):
-        self._snapshot_before()
+        self._snapshot_before(processed=(int(action[0]), int(action[1])))
         _native.check(self._L.prl_env_step_processed_host(ctypes.byref(self._game), ctypes.byref(self._st), int(action[0]),
                                                           int(action[1]), ctypes.byref(self._info)))
-        self._pre_step_state = None
         return self._after_step()
 
     def step_raise_pot_frac(self, pot_frac):
         amt = self.get_fraction_of_pot_raise(fraction=pot_frac, player_that_bets=self.current_player)
         return self.step_from_processed_tuple((Poker.BET_RAISE, amt))
 
-    def _state_after_action_before_sweep(self, action):
-        """state_dict_before_money_move of a round transition = the state after the action was applied but before the
-        bets were swept (PokerEnv.py:761-766). Obtained by replaying the step on a copy with the sweep undone."""
-        return None  # only the public tree builder needs it, and that lives in the native library
+    def _state_before_money_move(self):
+        """info["state_dict_before_money_move"] of a round transition (PokerEnv.py:761-766): state_dict() after the action was
+        applied and BEFORE _next_round -- bets still in front of the players, old pot / round / board / deck, the actor still
+        current. The native engine replays the action half of the step (prl_env_apply_action_host) on the saved pre-step state;
+        called before the new round's cards are dealt."""
+        saved, action_int, processed = self._pre_step
+        size = ctypes.sizeof(self._st)
+        now = bytes(ctypes.string_at(ctypes.addressof(self._st), size))
+        ctypes.memmove(ctypes.addressof(self._st), saved, size)
+        info = _native.PrlStepInfo()
+        t, a = processed if processed is not None else (0, 0)
+        _native.check(self._L.prl_env_apply_action_host(ctypes.byref(self._game), ctypes.byref(self._st), max(action_int, 0),
+                                                        int(processed is not None), t, a, ctypes.byref(info)))
+        try:
+            return self.state_dict()
+        finally:
+            ctypes.memmove(ctypes.addressof(self._st), now, size)
 
     # ---- queries ------------------------------------------------------------------------------------------------------
     def get_legal_actions(self):

@@ -67,3 +67,92 @@ def test_env_state_dict_round_trip():
             k += 1
         # chip conservation (test_pokerEnv.py:61-102)
         assert a.seats[0].stack + a.seats[1].stack == 2 * 20000
+
+
+# ---- state dictionaries: the step info's pre-transition state and every node's env_state of the public tree -----------------
+def _state_row(s, lut_holder):
+    """the row layout of tests/golden/make_envstate_golden.py: row_of()"""
+    from pokerrl_amd.game.Poker import Poker
+    from pokerrl_amd.game.PokerEnvStateDictEnums import EnvDictIdxs
+    seats = s[EnvDictIdxs.seats]
+    cr, la = s[EnvDictIdxs.capped_raise], s[EnvDictIdxs.last_action]
+    none = lambda v: -1 if v is None else int(v)  # noqa: E731
+    b1d = lut_holder.get_1d_cards(s[EnvDictIdxs.board_2d])
+    deck = s[EnvDictIdxs.deck]["deck_remaining"]
+    return [int(s[EnvDictIdxs.current_round]), int(s[EnvDictIdxs.main_pot]), int(seats[0]["current_bet"]), int(seats[1]["current_bet"]),
+            int(round(float(seats[0]["stack"]))), int(round(float(seats[1]["stack"]))), int(seats[0]["is_allin"]), int(seats[1]["is_allin"]),
+            int(seats[0]["folded_this_episode"]), int(seats[1]["folded_this_episode"]), int(seats[0]["has_acted_this_round"]),
+            int(seats[1]["has_acted_this_round"]), none(s[EnvDictIdxs.current_player]), none(s[EnvDictIdxs.last_raiser]),
+            0 if cr is None else 1, -1 if cr is None else none(cr[0]), -1 if cr is None else none(cr[1]),
+            int(s[EnvDictIdxs.n_actions_this_episode]), int(s.get(EnvDictIdxs.n_raises_this_round, 0) or 0), none(la[0]), none(la[1]), none(la[2]),
+            int(b1d[0]) if b1d[0] != Poker.CARD_NOT_DEALT_TOKEN_1D else -1, int(len(deck))]
+
+
+STEP_GAMES = ["StandardLeduc", "DiscretizedNLLeduc_B3", "LimitHoldem", "DiscretizedNLHoldem_B5", "NoLimitHoldem_short", "Flop5Holdem_short"]
+
+
+@pytest.mark.parametrize("name", STEP_GAMES)
+def test_step_info_pre_transition_state_matches_reference(name):
+    """RETURN_PRE_TRANSITION_STATE_IN_INFO (PokerEnv.py:737-787): None while the round goes on; on a round transition the state
+    after the action and BEFORE the bets are swept; at the end of the hand the state before the payout."""
+    from pokerrl_amd.game import games as G
+    g = golden("env_states.npz")
+    rows, cfg = g["step_" + name], g["step_" + name + "_cfg"]
+    cls = getattr(G, name.split("_")[0])
+    stack, bets = int(cfg[0]), [float(b) / 1000 for b in cfg[1:]]
+    args = cls.ARGS_CLS(n_seats=2, starting_stack_sizes_list=[stack, stack], bet_sizes_list_as_frac_of_pot=bets)
+    bldr = HistoryEnvBuilder(env_cls=cls, env_args=args)
+    env = bldr.get_new_env(is_evaluating=True, stack_size=args.starting_stack_sizes_list)
+    a = env.get_args()
+    a.RETURN_PRE_TRANSITION_STATE_IN_INFO = True
+    env.set_args(a)
+    np.random.seed(sum(map(ord, name)) + 7)
+    is_nl = cls is G.NoLimitHoldem
+    ep, n_chance = -1, 0
+    for r in rows:
+        if int(r[0]) != ep:
+            ep = int(r[0])
+            env.reset()
+        act, amount, done, chance, has_pre = (int(x) for x in r[1:6])
+        _, _, d, info = env.step((act, amount) if is_nl else act)
+        assert d == bool(done) and bool(info["chance_acts"]) == bool(chance)
+        pre = info["state_dict_before_money_move"]
+        assert (pre is not None) == bool(has_pre), (name, ep)
+        if pre is not None:
+            mine, ref = _state_row(pre, bldr.lut_holder), [int(x) for x in r[6:]]
+            if not cls.IS_FIXED_LIMIT_GAME:
+                ref[18] = mine[18]
+            assert mine == ref, (name, ep, chance, mine, ref)
+            n_chance += chance
+    assert n_chance >= 10
+
+
+@pytest.mark.gpu  # PublicTree.build_tree() creates the device-resident solver
+@pytest.mark.parametrize("name", ["StandardLeduc", "DiscretizedNLLeduc_POT", "DiscretizedNLLeduc_B3_short"])
+def test_gpu_public_tree_env_states_match_reference(name):
+    """node.env_state of EVERY node (PublicTree.py:205-293), incl. the chance-pending nodes' pre-transition state with the
+    raise counter the reference leaves untouched (PokerEnv.py:724 increments it for raises only)."""
+    from helpers import GAMES
+    from pokerrl_amd.game.PublicTree import PublicTree
+    cls, stack, bets = GAMES[name]
+    args = cls.ARGS_CLS(n_seats=2, starting_stack_sizes_list=[stack, stack], bet_sizes_list_as_frac_of_pot=bets)
+    bldr = HistoryEnvBuilder(env_cls=cls, env_args=args)
+    tree = PublicTree(env_bldr=bldr, stack_size=args.starting_stack_sizes_list, stop_at_street=None)
+    tree.build_tree()
+    ref = golden("env_states.npz")["tree_" + name]
+    rows = []
+
+    def visit(n):
+        rows.append(_state_row(n.env_state, bldr.lut_holder))
+        for c in n.children:
+            visit(c)
+
+    visit(tree.root)
+    mine = np.array(rows, np.int64)
+    assert mine.shape == ref.shape
+    # the deck of a node below a chance node is not comparable: the reference derives it from the deck AFTER the random deal of
+    # its own transition (parent.new_round_state, PublicTree.py:191,219-222), so its length depends on which card np.random drew
+    mine[:, 23], ref = 0, ref.copy()
+    ref[:, 23] = 0
+    bad = np.argwhere(mine != ref)
+    assert len(bad) == 0, (name, bad[:5].tolist(), mine[bad[0][0]].tolist(), ref[bad[0][0]].tolist())
