@@ -266,6 +266,10 @@ int32_t prl_solver_time_iterations(prl_solver_t* solver, int32_t n, float* out_m
  * duration and count (the per-kernel figure bench.py's roofline is computed from; out_pass_* may be NULL) */
 int32_t prl_solver_time_iterations_ex(prl_solver_t* solver, int32_t n, float* out_ms, float* out_pass_ms, int32_t* out_n_pass);
 
+/* n x (prl_solver_update_reach + prl_solver_compute_ev) of the strategy the solver holds -- one exact best-response evaluation each
+ * (LocalBRMaster.py:67-80 without the agent query) -- bracketed by HIP events like prl_solver_time_iterations_ex */
+int32_t prl_solver_time_evaluations(prl_solver_t* solver, int32_t n, float* out_ms, float* out_pass_ms, int32_t* out_n_pass);
+
 enum {
     PRL_SF_REACH = 0,        /* float32 [n_nodes][2][R]  node.reach_probs                      */
     PRL_SF_EV = 1,           /* float32 [n_nodes][2][R]  node.ev                               */

@@ -149,6 +149,8 @@ def _bind_solver(L):
     L.prl_solver_create_sharded.restype = i32
     L.prl_solver_time_iterations_ex.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i32)]
     L.prl_solver_time_iterations_ex.restype = i32
+    L.prl_solver_time_evaluations.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i32)]
+    L.prl_solver_time_evaluations.restype = i32
     L.prl_lbr_checkdown_equity.argtypes = [ctypes.POINTER(PrlRules), vp, i32, vp, vp, i32, vp]
     L.prl_lbr_checkdown_equity.restype = i32
     L.prl_lbr_batch_run.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), i32, i32, i32, i32,
@@ -434,6 +436,12 @@ class NativeSolver:
         """-> (total device ms, summed ms of the board-pass kernel launches, number of those launches)."""
         ms, pms, cnt = ctypes.c_float(), ctypes.c_float(), ctypes.c_int32()
         self._call("prl_solver_time_iterations_ex", int(n), ctypes.byref(ms), ctypes.byref(pms), ctypes.byref(cnt))
+        return float(ms.value), float(pms.value), int(cnt.value)
+
+    def time_evaluations(self, n):
+        """n x (update_reach + compute_ev) of the loaded strategy -> (total device ms, summed board-pass kernel ms, launches)."""
+        ms, pms, cnt = ctypes.c_float(), ctypes.c_float(), ctypes.c_int32()
+        self._call("prl_solver_time_evaluations", int(n), ctypes.byref(ms), ctypes.byref(pms), ctypes.byref(cnt))
         return float(ms.value), float(pms.value), int(cnt.value)
 
     @staticmethod

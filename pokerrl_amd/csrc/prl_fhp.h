@@ -18,7 +18,7 @@
 #include "prl_tree.h"
 
 enum { PRL_SRC_REGRET = 0, PRL_SRC_UNIFORM64 = 1, PRL_SRC_ARR64 = 2, PRL_SRC_ARR32 = 3,
-       PRL_SRC_STRAT32 = 4 /* kernel-internal: the register file already holds float32 strategies */ };
+       PRL_SRC_STRAT32 = 4 /* PrlFhpParams::regret points at float32 STRATEGY columns (regret layout): played as is */ };
 // UPDATE0 / UPDATE1: that seat's values + regret / average update. EVAL: both seats + best response.
 // UPDATE0_EVAL: EVAL and UPDATE0 of the same strategy in one pass (the evaluation that closes iteration t and the first
 // half of iteration t + 1 read the same regrets).

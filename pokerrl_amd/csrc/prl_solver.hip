@@ -72,6 +72,7 @@ struct prl_solver {
     int chance_trunk = -1;    // trunk id of the chance node
     float* d_sum_scratch = nullptr;
     double* d_user_strategy = nullptr;  // [full_cols][R], explicit strategy (prl_solver_set_strategy), lazily allocated
+    float* d_user_strategy32 = nullptr; // FUSED: an explicit float32 strategy stays float32, [full_cols][R] like the regrets (best-response pass)
     int user_strategy_f64 = -1;         // -1: strategy comes from regrets / uniform
     int src[2] = {PRL_SRC_UNIFORM64, PRL_SRC_UNIFORM64};
     bool board_avg_f64 = false;
@@ -155,8 +156,9 @@ static int ensure_board_avg(prl_solver* s) {
 }
 
 // FUSED: board pass + canonical chance sum into the trunk's chance node (st = trunk state to read reach from / write to)
-int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, int src1, const double* strat_arr) {
+int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, int src1, const double* strat_arr, const float* strat32 = nullptr) {
     PrlFhpParams p = s->fp;
+    if (strat32) p.regret = const_cast<float*>(strat32);  // PRL_SRC_STRAT32: float32 strategy columns in the regret array's layout (read only)
     p.iter = s->iter;
     p.variant = s->variant;
     p.chance_reach = st.reach + prl_vidx(s->T, s->chance_trunk, 0);
@@ -239,11 +241,17 @@ int do_compute_ev(prl_solver* s, const PrlDevState& st, int fused_mode = PRL_FHP
     if (s->fused) {
         const double* arr = nullptr;
         int s0 = s->src[0], s1 = s->src[1];
-        if (s->user_strategy_f64 >= 0) {
+        const float* arr32 = nullptr;
+        if (s->user_strategy_f64 == 1) {
             arr = s->d_user_strategy;
-            s0 = s1 = s->user_strategy_f64 ? PRL_SRC_ARR64 : PRL_SRC_ARR32;
+            s0 = s1 = PRL_SRC_ARR64;
+        } else if (s->user_strategy_f64 == 0) {
+            // exact best response of an explicit float32 strategy (LocalBRMaster.py:67-80): one evaluation pass that streams the
+            // strategy like regrets (LDS prefetch), plays it as is -- no regret matching, no regret / average traffic
+            arr32 = s->d_user_strategy32;
+            s0 = s1 = PRL_SRC_STRAT32;
         }
-        TRY(fused_board_pass(s, st, fused_mode, s0, s1, arr));
+        TRY(fused_board_pass(s, st, fused_mode, s0, s1, arr, arr32));
     }
     prl_launch_ev(s->T, st, s->ft.level_start.data(), s->d_term_nodes, s->n_term, s->stream);
     PRL_HIP_TRY(hipGetLastError());
@@ -748,8 +756,13 @@ int32_t prl_solver_set_strategy(prl_solver_t* s, const void* strat, int32_t is_f
         src = tmp.data();
     }
     if (s->fused) {
-        if (!s->d_user_strategy) TRY(dev_alloc(s, &s->d_user_strategy, nc));
-        PRL_HIP_TRY(hipMemcpyAsync(s->d_user_strategy, src, nc * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        if (is_f64) {
+            if (!s->d_user_strategy) TRY(dev_alloc(s, &s->d_user_strategy, nc));
+            PRL_HIP_TRY(hipMemcpyAsync(s->d_user_strategy, src, nc * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        } else {
+            if (!s->d_user_strategy32) TRY(dev_alloc(s, &s->d_user_strategy32, nc));
+            PRL_HIP_TRY(hipMemcpyAsync(s->d_user_strategy32, strat, nc * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        }
         s->user_strategy_f64 = is_f64 ? 1 : 0;
     }
     // LEVELS: the whole array; FUSED: the trunk columns (they precede the board columns)
@@ -1021,6 +1034,42 @@ int32_t prl_solver_time_iterations_ex(prl_solver_t* s, int32_t n, float* out_ms,
     return rc;
 }
 
+// n x (update_reach + compute_ev) of the strategy the solver currently holds (LocalBRMaster.evaluate's work per call, minus the
+// agent query), timed like prl_solver_time_iterations_ex: total device ms, summed board-pass kernel ms, number of launches
+int32_t prl_solver_time_evaluations(prl_solver_t* s, int32_t n, float* out_ms, float* out_pass_ms, int32_t* out_n_pass) {
+    if (!s || !out_ms || n < 0) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    hipEvent_t e0, e1;
+    PRL_HIP_TRY(hipEventCreate(&e0));
+    PRL_HIP_TRY(hipEventCreate(&e1));
+    s->time_passes = s->fused && out_pass_ms != nullptr;
+    PRL_HIP_TRY(hipEventRecord(e0, s->stream));
+    int rc = PRL_OK;
+    for (int i = 0; i < n && rc == PRL_OK; ++i) {
+        s->ev_valid = false;
+        rc = do_update_reach(s, s->S);
+        if (rc == PRL_OK) rc = ensure_ev(s);
+    }
+    s->time_passes = false;
+    if (rc == PRL_OK) {
+        PRL_HIP_TRY(hipEventRecord(e1, s->stream));
+        PRL_HIP_TRY(hipEventSynchronize(e1));
+        PRL_HIP_TRY(hipEventElapsedTime(out_ms, e0, e1));
+        float pass_ms = 0.f;
+        for (size_t i = 0; i + 1 < s->pass_events.size(); i += 2) {
+            float t = 0.f;
+            PRL_HIP_TRY(hipEventElapsedTime(&t, s->pass_events[i], s->pass_events[i + 1]));
+            pass_ms += t;
+        }
+        if (out_pass_ms) *out_pass_ms = pass_ms;
+        if (out_n_pass) *out_n_pass = (int32_t)(s->pass_events.size() / 2);
+    }
+    for (hipEvent_t e : s->pass_events) (void)hipEventDestroy(e);
+    s->pass_events.clear();
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
 int32_t prl_solver_time_iterations(prl_solver_t* s, int32_t n, float* out_ms) {
     return prl_solver_time_iterations_ex(s, n, out_ms, nullptr, nullptr);
 }
@@ -1091,7 +1140,15 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
         case PRL_SF_EV_BR: TRY(ensure_ev(s)); src = s->S.ev_br; bytes = nv * 4; break;
         case PRL_SF_STRATEGY:
             if (s->fused) {
-                if (s->user_strategy_f64 >= 0) { src = s->d_user_strategy; bytes = nc * 8; break; }
+                if (s->user_strategy_f64 == 1) { src = s->d_user_strategy; bytes = nc * 8; break; }
+                if (s->user_strategy_f64 == 0) {  // stored as float32: widened on the way out (exact)
+                    std::vector<float> f(nc);
+                    PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+                    PRL_HIP_TRY(hipMemcpy(f.data(), s->d_user_strategy32, nc * 4, hipMemcpyDeviceToHost));
+                    double* o = (double*)out;
+                    for (size_t i = 0; i < nc; ++i) o[i] = (double)f[i];
+                    return PRL_OK;
+                }
                 if (s->src[0] != PRL_SRC_REGRET || s->src[1] != PRL_SRC_REGRET) {  // uniform float64 fill
                     prl_set_error("fused engine: strategy is the implicit uniform fill until both seats have been updated");
                     return PRL_ERR_STATE;

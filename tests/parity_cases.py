@@ -207,6 +207,34 @@ def check_fused_vs_fixture(L, name):
     assert h32(s.get("avg")) == str(g["avg_sha256"])
 
 
+def check_fused_br_vs_oracle(L, n_boards, seed=3):
+    """Exact best response of an explicit strategy on the fused engine (LocalBRMaster.py:67-80: fill, reach, EV + BR, root
+    exploitability) against the oracle, float32 (the best-response-only pass: strategy streamed like regrets) and float64."""
+    boards = fhp_boards(n_boards)
+    args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
+    t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
+    s = _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, 2, 52, 4, 2)
+    o.cfr_reset(1, 0)
+    nt = t.n_cols - 14 * n_boards
+    for f64 in (False, True):
+        strat = seeded_strategy_for_sharding(nt, n_boards, t.range_size, seed + int(f64))
+        if f64:
+            rng = np.random.RandomState(seed)
+            strat = strat.astype(np.float64) * (1.0 + 1e-9 * rng.random_sample(strat.shape))  # not float32-representable
+        s.set_strategy(strat)
+        o.set_strategy(strat.astype(np.float64), f64)
+        s.compute_ev()
+        o.compute_ev()
+        assert np.array_equal(s.exploitability(), o.exploitability), (f64, s.exploitability(), o.exploitability)
+        assert np.array_equal(s.get("strategy"), strat.astype(np.float64))
+    s.reset()  # and the solver iterates again afterwards
+    o.cfr_reset(1, 0)
+    s.iterations(2)
+    o.cfr_iteration(); o.cfr_iteration()
+    assert np.array_equal(s.exploitability(), o.exploitability)
+
+
 def check_fused_batched_vs_oracle(L, n_boards, n_iters, delay=0, variant="plus"):
     """prl_solver_iterations(n) on the fused engine folds every closing evaluation into the next iteration's first board
     pass; the exploitability history and the final state must equal the oracle's (= n single iteration() calls)."""

@@ -64,6 +64,10 @@ def test_emu_fused_engine_several_boards_per_workgroup(L, monkeypatch):
     pc.check_fused_vs_oracle(L, 7, 2)
 
 
+def test_emu_fused_engine_best_response_of_explicit_strategy(L):
+    pc.check_fused_br_vs_oracle(L, 3)
+
+
 def test_emu_fused_engine_cfrplus_delay(L):
     pc.check_fused_vs_oracle(L, 3, 3, delay=1)
 

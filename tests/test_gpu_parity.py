@@ -154,6 +154,12 @@ def test_gpu_fused_16384_boards_fixture(L):
     pc.check_fused_vs_fixture(L, "fhp_16384_plus")
 
 
+@pytest.mark.parametrize("n_boards", [40, 2048])
+def test_gpu_fused_best_response_only_pass_vs_oracle(L, n_boards):
+    """BASELINE config 4: exact best response of an explicit strategy; float32 strategies go through the best-response-only pass"""
+    pc.check_fused_br_vs_oracle(L, n_boards)
+
+
 @pytest.mark.parametrize("fused,variant", [(False, "vanilla"), (True, "plus"), (True, "linear")])
 def test_gpu_checkpoint_resume(L, fused, variant):
     pc.check_checkpoint_resume(L, fused, variant, n_before=4, n_after=3)
