@@ -195,6 +195,45 @@ int32_t prl_env_apply_action_host(const PrlGame* game, PrlEnvState* state, int32
 int32_t prl_env_legal_actions_host(const PrlGame* game, const PrlEnvState* state, int32_t* out_actions, int32_t* out_n);
 int32_t prl_env_fraction_of_pot_raise_host(const PrlEnvState* state, double fraction, int32_t seat, int32_t* out_total);
 
+/* 4b. The same engine batched on the device: n_envs independent heads-up envs, public betting state as struct-of-arrays in    */
+/*    HBM (PRL_EB_N_COLS int32 columns of n_envs entries), one GPU lane per env. replaces stepping n PokerEnv objects one by one   */
+/*    (PokerEnv.py:681-789,885-941,1075-1122,1161-1197,1313-1330; LimitPokerEnv.py:27-59; DiscretizedPokerEnv.py:44-135).       */
+/*    Cards stay with the caller as in section 4 (deal on chance_acts, rank the hands on a showdown).                            */
+/*    Host-pointer calls copy in / out and synchronise; the *_device forms take device pointers and only enqueue on the batch's   */
+/*    stream (prl_envbatch_state_device hands out the stream and the state columns).                                              */
+/* ---------------------------------------------------------------------------------------------------------------- */
+typedef struct prl_envbatch prl_envbatch_t;
+#define PRL_EB_N_COLS 13
+/* state columns (prl_envbatch_get_state: out_cols[PRL_EB_N_COLS][n_envs]) */
+enum {
+    PRL_EB_ROUND = 0, PRL_EB_MAIN_POT = 1, PRL_EB_BET0 = 2, PRL_EB_BET1 = 3, PRL_EB_STACK0 = 4, PRL_EB_STACK1 = 5,
+    PRL_EB_FLAGS = 6,      /* bit 0,1 is_allin[seat]; 2,3 folded; 4,5 has_acted_this_round; 6 current_player; 7 capped raise pending; 8 episode over */
+    PRL_EB_SEATS = 7,      /* (last_raiser + 1) | (capped_raise[0] + 1) << 8 | (capped_raise[1] + 1) << 16; 0 = None */
+    PRL_EB_N_ACTIONS_EP = 8, PRL_EB_N_RAISES_ROUND = 9, PRL_EB_LAST_ACTION_TYPE = 10, PRL_EB_LAST_ACTION_AMOUNT = 11, PRL_EB_LAST_ACTION_SEAT = 12
+};
+int32_t prl_envbatch_create(const PrlGame* game, int32_t n_envs, prl_envbatch_t** out_batch);  /* all envs reset */
+void prl_envbatch_destroy(prl_envbatch_t* batch);
+/* reset the envs with mask[i] != 0 (NULL = all) */
+int32_t prl_envbatch_reset(prl_envbatch_t* batch, const uint8_t* mask);
+/* one step of every env: actions[i] = env action int (amounts == NULL; PokerEnv.step) or action type with amounts[i] chips
+ * (step_from_processed_tuple). An env whose episode is over, or with actions[i] < 0, is skipped. out_info4[4][n_envs] (may be NULL):
+ * is_terminal (-1 = skipped), chance_acts, pot before the payout, terminal kind (1 fold, 2 showdown on the last street, 3 all-in run-out) */
+int32_t prl_envbatch_step(prl_envbatch_t* batch, const int32_t* actions, const int32_t* amounts, int32_t* out_info4);
+int32_t prl_envbatch_step_device(prl_envbatch_t* batch, const int32_t* d_actions, const int32_t* d_amounts, int32_t* d_info4);
+/* get_legal_actions of every env: out_mask4[4][n_envs] = 128-bit set of legal action ints (word k covers actions 32k..32k+31),
+ * out_count[n_envs] = how many (0 when the episode is over) */
+int32_t prl_envbatch_legal_masks(prl_envbatch_t* batch, uint32_t* out_mask4, int32_t* out_count);
+/* ids of the envs whose episode is still running (wave ballot + prefix compaction; order: ascending within each group of 64 envs) */
+int32_t prl_envbatch_active(prl_envbatch_t* batch, int32_t* out_idx, int32_t* out_count);
+int32_t prl_envbatch_get_state(prl_envbatch_t* batch, int32_t* out_cols);
+int32_t prl_envbatch_state_device(prl_envbatch_t* batch, void** out_d_cols, void** out_hip_stream);
+/* n_steps uniform-random legal steps per env, finished hands restart (counter-based generator keyed by seed, env, step);
+ * out_stats3 = steps, finished hands, sum of their pots; prl_env_random_rollout_host plays the same hands on the host */
+int32_t prl_envbatch_random_rollout(prl_envbatch_t* batch, int32_t n_steps, uint32_t seed, uint64_t* out_stats3, float* out_device_ms);
+/* the same play with the state in HBM between steps: n_launches launches of ONE step per env (13 words in, 13 out per env and step) */
+int32_t prl_envbatch_random_steps(prl_envbatch_t* batch, int32_t n_launches, uint32_t seed, uint64_t* out_stats3, float* out_device_ms);
+int32_t prl_env_random_rollout_host(const PrlGame* game, int32_t n_envs, int32_t n_steps, uint32_t seed, uint64_t* out_stats3);
+
 /* ---------------------------------------------------------------------------------------------------------------- */
 /* 5. Device-resident tabular solver: public-tree CFR / CFR+ / Linear CFR and exact best response on one GPU.          */
 /*    replaces  PokerRL/cfr/_CFRBase.py:110-262 (+ VanillaCFR.py, CFRPlus.py, LinearCFR.py),                           */

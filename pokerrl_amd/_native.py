@@ -163,6 +163,18 @@ def _bind_solver(L):
     L.prl_solver_iterations_many.restype = i32
     L.prl_deal_decks.argtypes = [i32, i32, i32, ctypes.c_uint64, ctypes.c_uint64, vp]
     L.prl_deal_decks.restype = i32
+    L.prl_envbatch_create.argtypes = [ctypes.POINTER(PrlGame), i32, ctypes.POINTER(vp)]
+    L.prl_envbatch_create.restype = i32
+    L.prl_envbatch_destroy.argtypes = [vp]
+    L.prl_envbatch_destroy.restype = None
+    for name, args in (("prl_envbatch_reset", [vp, vp]), ("prl_envbatch_step", [vp, vp, vp, vp]), ("prl_envbatch_step_device", [vp, vp, vp, vp]),
+                       ("prl_envbatch_legal_masks", [vp, vp, vp]), ("prl_envbatch_active", [vp, vp, vp]), ("prl_envbatch_get_state", [vp, vp]),
+                       ("prl_envbatch_state_device", [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]),
+                       ("prl_envbatch_random_rollout", [vp, i32, ctypes.c_uint32, vp, ctypes.POINTER(ctypes.c_float)]),
+                       ("prl_envbatch_random_steps", [vp, i32, ctypes.c_uint32, vp, ctypes.POINTER(ctypes.c_float)]),
+                       ("prl_env_random_rollout_host", [ctypes.POINTER(PrlGame), i32, i32, ctypes.c_uint32, vp])):
+        getattr(L, name).argtypes = args
+        getattr(L, name).restype = i32
     L.prl_solver_state_size.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.prl_solver_state_size.restype = i32
     L.prl_solver_save_state.argtypes = [vp, vp, ctypes.c_uint64]
@@ -264,6 +276,90 @@ def hand_rank_boards(boards_1d):
     out = np.empty((b.shape[0], 1326), dtype=np.int32)
     check(lib().prl_hand_rank_boards(_ptr(b), b.shape[0], _ptr(out)))
     return out
+
+
+EB_COLS = ("round", "main_pot", "bet0", "bet1", "stack0", "stack1", "flags", "seats", "n_actions_ep", "n_raises_round",
+           "last_action_type", "last_action_amount", "last_action_seat")
+
+
+class NativeEnvBatch:
+    """Owns a prl_envbatch_t*: n_envs heads-up envs stepped together on the GPU, public state as struct-of-arrays in HBM
+    (include/pokerrl_hip.h section 4b). Cards are the caller's, as with the single-env engine."""
+
+    def __init__(self, game, n_envs, _lib=None):
+        self._L = _lib or lib()
+        self._h = ctypes.c_void_p()
+        self._game = game
+        self.n_envs = int(n_envs)
+        check(self._L.prl_envbatch_create(ctypes.byref(game), self.n_envs, ctypes.byref(self._h)), self._L)
+
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        assert m is None or m.shape == (self.n_envs,)
+        check(self._L.prl_envbatch_reset(self._h, None if m is None else _ptr(m)), self._L)
+
+    def step(self, actions, amounts=None):
+        """-> info int32 [4, n_envs]: is_terminal (-1 = env skipped), chance_acts, pot before the payout, terminal kind"""
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        b = None if amounts is None else np.ascontiguousarray(amounts, dtype=np.int32)
+        assert a.shape == (self.n_envs,) and (b is None or b.shape == a.shape)
+        info = np.empty((4, self.n_envs), np.int32)
+        check(self._L.prl_envbatch_step(self._h, _ptr(a), None if b is None else _ptr(b), _ptr(info)), self._L)
+        return info
+
+    def legal_masks(self):
+        """-> (uint32 [4, n_envs] bit sets of legal action ints, int32 [n_envs] counts)"""
+        m, c = np.empty((4, self.n_envs), np.uint32), np.empty(self.n_envs, np.int32)
+        check(self._L.prl_envbatch_legal_masks(self._h, _ptr(m), _ptr(c)), self._L)
+        return m, c
+
+    def legal_actions(self, i):
+        m, _c = self.legal_masks()
+        return [a for a in range(128) if (int(m[a >> 5, i]) >> (a & 31)) & 1]
+
+    def active(self):
+        idx, n = np.empty(self.n_envs, np.int32), np.zeros(1, np.int32)
+        check(self._L.prl_envbatch_active(self._h, _ptr(idx), _ptr(n)), self._L)
+        return idx[:int(n[0])]
+
+    def state(self):
+        """-> dict of int32 [n_envs] columns (EB_COLS) + the unpacked flag / seat fields under the PrlEnvState names"""
+        cols = np.empty((len(EB_COLS), self.n_envs), np.int32)
+        check(self._L.prl_envbatch_get_state(self._h, _ptr(cols)), self._L)
+        d = {k: cols[i] for i, k in enumerate(EB_COLS)}
+        f, w = d["flags"], d["seats"]
+        for k, bit in (("allin0", 0), ("allin1", 1), ("folded0", 2), ("folded1", 3), ("acted0", 4), ("acted1", 5), ("cur", 6),
+                       ("capped_happened", 7), ("done", 8)):
+            d[k] = (f >> bit) & 1
+        d["last_raiser"], d["capped_raiser"], d["capped_cant_reopen"] = (w & 0xFF) - 1, ((w >> 8) & 0xFF) - 1, ((w >> 16) & 0xFF) - 1
+        return d
+
+    def random_rollout(self, n_steps, seed):
+        """n_steps uniform-random legal steps per env on the device -> (steps, finished hands, sum of their pots, kernel ms)"""
+        st, ms = np.zeros(3, np.uint64), ctypes.c_float()
+        check(self._L.prl_envbatch_random_rollout(self._h, int(n_steps), int(seed) & 0xFFFFFFFF, _ptr(st), ctypes.byref(ms)), self._L)
+        return int(st[0]), int(st[1]), int(st[2]), float(ms.value)
+
+    def random_steps(self, n_launches, seed):
+        """the same play, ONE step per env and kernel launch (state in HBM between the steps) -> (steps, hands, pots, device ms)"""
+        st, ms = np.zeros(3, np.uint64), ctypes.c_float()
+        check(self._L.prl_envbatch_random_steps(self._h, int(n_launches), int(seed) & 0xFFFFFFFF, _ptr(st), ctypes.byref(ms)), self._L)
+        return int(st[0]), int(st[1]), int(st[2]), float(ms.value)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.prl_envbatch_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def env_random_rollout_host(game, n_envs, n_steps, seed, _lib=None):
+    L = _lib or lib()
+    st = np.zeros(3, np.uint64)
+    check(L.prl_env_random_rollout_host(ctypes.byref(game), int(n_envs), int(n_steps), int(seed) & 0xFFFFFFFF, _ptr(st)), L)
+    return int(st[0]), int(st[1]), int(st[2])
 
 
 class NativeTree:

@@ -10,6 +10,7 @@
 #define PRL_LAUNCH_BOUNDS(n)
 inline void prl_atomic_add_u64(unsigned long long* p, unsigned long long v) { *p += v; }  // the emulator runs one fiber at a time
 inline void prl_lds_add_i(int* p, int v) { *p += v; }
+inline int prl_atomic_add_i(int* p, int v) { int o = *p; *p += v; return o; }
 #else
 #include <hip/hip_runtime.h>
 
@@ -23,6 +24,7 @@ inline void prl_lds_add_i(int* p, int v) { *p += v; }
 #define PRL_LAUNCH_BOUNDS(n) __launch_bounds__(n)
 PRL_DEV PRL_INLINE void prl_atomic_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 PRL_DEV PRL_INLINE void prl_lds_add_i(int* p, int v) { atomicAdd(p, v); }  // integer add on an LDS word (order-free)
+PRL_DEV PRL_INLINE int prl_atomic_add_i(int* p, int v) { return atomicAdd(p, v); }  // returns the value before the add
 PRL_DEV PRL_INLINE unsigned prl_tid() { return threadIdx.x; }
 PRL_DEV PRL_INLINE unsigned prl_bid() { return blockIdx.x; }
 PRL_DEV PRL_INLINE unsigned prl_bid_y() { return blockIdx.y; }
