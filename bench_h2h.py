@@ -12,7 +12,7 @@ import time
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(HERE, "tests"))
+sys.path.insert(0, HERE)
 
 
 def main():
@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--hands", type=int, default=1 << 20, help="hands per seat assignment (the run plays 2x this)")
     ap.add_argument("--host-hands", type=int, default=100)
     args = ap.parse_args()
-    import lbr_fixture_agent as fx
+    from pokerrl_amd.rl import hash_agent as fx
     from pokerrl_amd import _native
     from pokerrl_amd.eval.head_to_head import BatchedHead2Head, H2HArgs, LocalHead2HeadMaster
     from pokerrl_amd.game import bet_sets

@@ -1,11 +1,17 @@
 """
 bench_lbr.py -- LBR hands/s with the device-resident batched engine (BASELINE.json config 5; secondary metric, bench.py is the
 driver's contract). DiscretizedNLHoldem (blinds 50/100, stacks 20000), agent bet set B_5, LBR bet set OFF_TREE_11,
-lbr_check_to_round = TURN, synthetic hash agent, counter-based decks keyed by (seed, hand id).
+lbr_check_to_round = TURN (LBRArgs.py:16-18,31-35), 2^20 hands per agent seat, synthetic hash agent, counter-based decks keyed
+by (seed, hand id).
 
-    python bench_lbr.py [--hands N] [--agent hash|uniform] [--cpu-hands M]
-N > 1 GPUs: hands are independent; rank r plays hands [r * N, (r + 1) * N) of the same counter-based deck stream and the
-(sum, sum of squares, n) are all-reduced (torch.distributed, nccl) -- launch with torch.distributed.run.
+    python bench_lbr.py [--gpus N] [--hands H] [--agent hash|uniform] [--cpu-hands M]
+
+N > 1 GPUs (`--gpus N` starts the ranks itself; or torch.distributed.run): hands are independent (LocalLBRMaster.py:53-69 splits
+them over workers the same way); rank r plays hands [r * H/N, (r + 1) * H/N) of the same deck / agent-draw streams and
+(sum, sum of squares, n) are all-reduced over RCCL (BatchedLBR.run_sharded) -- strong scaling of a fixed evaluation.
+cpu_baseline: this package's host LocalLBRWorker (the Python episode loop of the reference, pinned to the reference's per-hand
+winnings by tests/golden/lbr_*.npz; its equity queries run on the GPU) timed in the same run on a bounded number of hands.
+The reference's own worker measured 30 hands/s on one core in this configuration; it cannot run on the GPU box.
 """
 import argparse
 import json
@@ -16,26 +22,35 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--hands", type=int, default=1 << 18, help="hands per seat per GPU")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--hands", type=int, default=1 << 20, help="hands per agent seat (whole job)")
     ap.add_argument("--agent", default="hash")
-    ap.add_argument("--cpu-hands", type=int, default=40, help="hands of the host LocalLBRWorker timed as the baseline (0 = skip)")
+    ap.add_argument("--cpu-hands", type=int, default=200, help="hands of the host LocalLBRWorker timed as the baseline (0 = skip)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import subprocess
+
+        import bench
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(bench.free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
+    torch.cuda.set_device(local_rank)
+    from pokerrl_amd import _native
+    _native.require_device()
+    _native.set_device(local_rank)  # the library allocates on this process's GPU
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        from pokerrl_amd import _native as _nat
-        _nat.set_device(int(os.environ.get("LOCAL_RANK", "0")))  # the library allocates on this process's GPU
-        dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from pokerrl_amd.eval.lbr import BatchedLBR, LBRArgs, LocalLBRWorker
     from pokerrl_amd.game import bet_sets
     from pokerrl_amd.game.games import DiscretizedNLHoldem
@@ -50,40 +65,51 @@ def main():
                      "lbr": LBRArgs(lbr_bet_set=bet_sets.OFF_TREE_11, n_lbr_hands_per_seat=args.hands, lbr_check_to_round=Poker.TURN)},
         path_data=tempfile.mkdtemp())
     b = BatchedLBR(t_prof, agent_kind=args.agent, agent_seed=7)
-    b.run(agent_seat_id=0, n_hands=min(args.hands, 4096), deck_seed=1)  # warm-up
+    b.run(agent_seat_id=0, n_hands=4096, deck_seed=99)  # warm-up
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    barrier()
     t0 = time.perf_counter()
-    scores, stats = [], []
+    res, stats = [], []
     for seat in (0, 1):
-        scores.append(b.run(agent_seat_id=seat, n_hands=args.hands, deck_seed=seat, first_hand=rank * args.hands))
+        res.append(b.run_sharded(seat, args.hands, deck_seed=seat))
         stats.append(dict(b.last_stats))
+    barrier()
     dt = time.perf_counter() - t0
-    x = np.concatenate(scores).astype(np.float64)
-    agg = np.array([x.sum(), (x * x).sum(), x.shape[0], dt], dtype=np.float64)
     if dist is not None:
-        t = torch.tensor(agg[:3], device="cuda")
-        dist.all_reduce(t)
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        agg[:3], dt = t.cpu().numpy(), float(tt.item())
-    n = agg[2]
-    mean = agg[0] / n
-    sd = np.sqrt(max(agg[1] / n - mean * mean, 0.0))
+        dt = float(tt.item())
+    n = sum(r[2] for r in res)
+    # both seats pooled (LocalLBRMaster.py:61-69 concatenates the seats' scores before _get_95confidence)
+    mean = sum(r[0] * r[2] for r in res) / n
     dev_s = sum(s["device_ms"] for s in stats) * 1e-3
     out = {"metric": "LBR hands/s (DiscretizedNLHoldem, batched rollouts on the GPU)", "value": n / dt, "unit": "hands/s", "n_gpus": world,
-           "hands_total": int(n), "seconds": dt, "device_seconds_rank0": dev_s,
-           "env_steps_per_s": sum(s["env_steps"] for s in stats) / dev_s, "lbr_lookaheads_per_s": sum(s["lbr_lookaheads"] for s in stats) / dev_s,
-           "hand_evals_per_s": sum(s["range_board_equities"] for s in stats) * 1326 / dev_s,
-           "lbr_winnings_mbb_per_g": mean, "conf95": 1.96 * sd / np.sqrt(n), "agent": args.agent, "data": "synthetic"}
-    if rank == 0 and args.cpu_hands > 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import lbr_fixture_agent as fx
+           "steps": 1, "warmup": 1, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": "LBR vs a synthetic tabular agent on DiscretizedNLHoldem (agent bets B_5, LBR bets OFF_TREE_11, LBR acts from the "
+                                  "turn on), %d hands per agent seat over %d GPU(s), every hand played start to finish by one workgroup" % (args.hands, world),
+                      "hands_total": int(n), "device_seconds_rank0": dev_s, "agent": args.agent,
+                      "env_steps_per_s_rank0": sum(s["env_steps"] for s in stats) / dev_s,
+                      "lbr_lookaheads_per_s_rank0": sum(s["lbr_lookaheads"] for s in stats) / dev_s,
+                      "hand_evals_per_s_rank0": sum(s["range_board_equities"] for s in stats) * 1326 / dev_s,
+                      "lbr_winnings_mbb_per_g": mean, "conf95_per_seat": [r[1] for r in res]}}
+    if rank == 0 and args.cpu_hands > 0 and world == 1:
+        from pokerrl_amd.rl import hash_agent as fx
         from pokerrl_amd.rl.base_cls.EvalAgentBase import EvalAgentBase
         w = LocalLBRWorker(t_prof=t_prof, chief_handle=None, eval_agent_cls=fx.make_agent_cls(EvalAgentBase, seed=7))
         np.random.seed(0)
         t1 = time.perf_counter()
         w.run(agent_seat_id=0, n_iterations=args.cpu_hands, mode="HASH", stack_size=[20000, 20000])
-        out["host_worker_hands_per_s"] = args.cpu_hands / (time.perf_counter() - t1)
-        out["host_worker_note"] = "LocalLBRWorker drop-in (Python episode loop, one GPU equity call per LBR decision), %d hands" % args.cpu_hands
+        dtc = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": args.cpu_hands / dtc, "unit": "hands/s", "cores": 1, "kind": "port",
+                               "sample": "pokerrl_amd.eval.lbr.LocalLBRWorker (the reference's Python episode loop, equity queries on the GPU), "
+                                         "%d hands, same agent and bet sets, %.1f s; the reference's own worker: ~30 hands/s per core (BASELINE.md)"
+                                         % (args.cpu_hands, dtc)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -91,3 +91,24 @@ class BatchedLBR:
         self.last_stats = {"env_steps": int(stats[0]), "lbr_lookaheads": int(stats[1]), "range_board_equities": int(stats[2]),
                            "agent_actions": int(stats[3]), "device_ms": float(ms.value)}
         return out
+
+    def run_sharded(self, agent_seat_id, n_hands_total, deck_seed=0, episode_base=0, group=None, device="cuda"):
+        """LocalLBRMaster's hand split (LocalLBRMaster.py:53-69) over the ranks of a torch.distributed group, one process per GPU:
+        rank r plays hands [r * n, (r + 1) * n) of the SAME counter-based deck / agent-draw streams (n = n_hands_total / world),
+        so every hand is played exactly as the one-GPU run plays it; (sum, sum of squares, count) are all-reduced.
+        Returns (mean, +-95 % half width, n_hands_total, this rank's float32 winnings) -- EvaluatorMasterBase.py:127-132's numbers.
+        Without an initialised process group it is the one-rank run."""
+        import torch
+        import torch.distributed as dist
+        world, rank = (dist.get_world_size(group), dist.get_rank(group)) if dist.is_available() and dist.is_initialized() else (1, 0)
+        assert n_hands_total % world == 0, "hands are split evenly over the ranks"
+        n = n_hands_total // world
+        x = self.run(agent_seat_id, n, deck_seed=deck_seed, episode_base=episode_base + rank * n, first_hand=rank * n)
+        x64 = x.astype(np.float64)
+        agg = torch.tensor([x64.sum(), (x64 * x64).sum(), float(n)], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(agg, group=group)
+        tot, sq, cnt = (float(v) for v in agg.cpu())
+        mean = tot / cnt
+        sd = np.sqrt(max(sq / cnt - mean * mean, 0.0))
+        return mean, 1.96 * sd / np.sqrt(cnt), int(cnt), x

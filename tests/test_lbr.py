@@ -251,6 +251,63 @@ def test_gpu_batched_h2h_vs_reference(tag, tmp_path):
     check_batched_h2h_vs_golden(tag, tmp_path)
 
 
+def test_lbr_hand_split_two_ranks_equals_one_rank_gloo_emu(tmp_path):
+    """SURVEY 8e, LBR row (LocalLBRMaster.py:53-69: hands split evenly over the workers): BatchedLBR.run_sharded with world_size 2
+    over gloo -- every rank plays its half of the same counter-based deck / agent-draw streams -- must give the per-hand winnings
+    of the one-rank run, concatenated in rank order, and the same all-reduced (mean, confidence, n)."""
+    import subprocess
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    import build_emu
+    from test_sharded import _free_port
+    lib = build_emu.build()
+    n_total, seed = 96, 5
+
+    def run(world, d):
+        port = _free_port()
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "lbr_split_worker.py"), lib, str(d), str(n_total), str(seed)],
+                                  env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+                 for r in range(world)]
+        for p in procs:
+            assert p.wait(timeout=900) == 0
+        return [dict(np.load(os.path.join(str(d), "rank%d.npz" % r))) for r in range(world)]
+
+    d1, d2 = tmp_path / "w1", tmp_path / "w2"
+    d1.mkdir(); d2.mkdir()
+    one, two = run(1, d1)[0], run(2, d2)
+    for seat in (0, 1):
+        k = "x%d" % seat
+        assert np.array_equal(np.concatenate([two[0][k], two[1][k]]), one[k]), seat
+        for r in (0, 1):
+            assert int(two[r]["n%d" % seat]) == n_total
+            assert float(two[r]["mean%d" % seat]) == pytest.approx(float(one["mean%d" % seat]), rel=1e-12)  # float64 sums, two addends swapped
+            assert float(two[r]["conf%d" % seat]) == pytest.approx(float(one["conf%d" % seat]), rel=1e-9)
+    assert len(set(one["x0"].tolist())) > 5  # not a degenerate run
+
+
+@pytest.mark.gpu
+def test_gpu_batched_lbr_equals_host_worker_at_scale(tmp_path):
+    """10 000 hold'em hands (5 000 per agent seat, LBR acting from the flop on: 990-board look-aheads included): the device-resident
+    engine against this package's host LocalLBRWorker -- the drop-in that is itself pinned to the reference's per-hand winnings
+    (tests/golden/lbr_*.npz) -- on the SAME decks and agent draws. Every one of the 10 000 winnings must be bit-identical."""
+    game_cls, agent_bets, lbr_kwargs = CASES["DiscretizedNLHoldem_flop"]
+    n = int(os.environ.get("PRL_LBR_SCALE_HANDS", "5000"))
+    t_prof = make_t_prof(game_cls, agent_bets, lbr_kwargs, n, tmp_path)
+    record = []
+    w = LocalLBRWorker(t_prof=t_prof, chief_handle=None, eval_agent_cls=fx.make_agent_cls(EvalAgentBase, seed=7, record=record))
+    b = BatchedLBR(t_prof, agent_kind="hash", agent_seed=7)
+    lut = game_cls.get_lut_holder()
+    n_flop_decisions = 0
+    for seat in (0, 1):
+        np.random.seed(100 + seat)
+        n0 = len(record)
+        host = w.run(agent_seat_id=seat, n_iterations=n, mode="HASH", stack_size=[game_cls.DEFAULT_STACK_SIZE] * 2)
+        decks = decks_from_record(record[n0:], lut, b.n_deal - 2 * b._rules.n_hole_cards)
+        got = b.run(agent_seat_id=seat, n_hands=n, decks=decks)
+        assert np.array_equal(got, host), "seat %d: %d of %d hands differ (first at %s)" % (seat, int(np.sum(got != host)), n, np.flatnonzero(got != host)[:5])
+        n_flop_decisions += b.last_stats["lbr_lookaheads"]
+    assert n_flop_decisions > n  # LBR really looked ahead
+
+
 def check_deal_decks():
     """prl_deal_decks (one lane per hand) against the NumPy statement of the same counter-based shuffle"""
     from pokerrl_amd.eval.lbr.BatchedLBR import deal_decks, deal_decks_host
