@@ -115,6 +115,11 @@ int8_t get_1d_card(const int8_t* card_2d);                       /* CppLUT.py:73
 void get_2d_card(int8_t card_1d, int8_t* out_card_2d);           /* CppLUT.py:84-94   (c/4, c%4)           */
 void get_idx_2_hole_card_lut(int8_t** out_1326x2);               /* CppLUT.py:38-41                          */
 void get_hole_card_2_idx_lut(int16_t** out_52x52);               /* CppLUT.py:43-47   upper triangle only   */
+/* CppLUT.py:27-34,49-71: bound by CppLibHoldemLuts.__init__, never called by the reference (its binary's versions crash); row i =
+ * the i-th k-card board in ascending lexicographic order of ascending 1d cards: 22 100 x 3, 270 725 x 4, 2 598 960 x 5 */
+void get_idx_2_flop_lut(int8_t** out_22100x3);
+void get_idx_2_turn_lut(int8_t** out_270725x4);
+void get_idx_2_river_lut(int8_t** out_2598960x5);
 /* CppHandeval.py:34-43: hand_2d[2][2], board_2d[5][2] as (rank, suit) rows. Scalar call -> host evaluator. */
 int32_t get_hand_rank_52_holdem(int8_t** hand_2d, int8_t** board_2d);
 /* CppHandeval.py:45-65: out[N][1326] pre-filled with -1 by the caller; boards_1d[N][5]; the two LUT arguments of the

@@ -42,6 +42,25 @@ void get_hole_card_2_idx_lut(int16_t** out) {  // only the upper triangle is wri
         for (int c2 = c1 + 1; c2 < 52; ++c2) out[c1][c2] = (int16_t)prl_range_idx_2(c1, c2, 52);
 }
 
+// The three board-index tables of lib_luts.so (CppLUT.py:49-71). The reference never calls them -- its binary's versions crash
+//  -- but CppLibHoldemLuts.__init__ binds their argtypes (CppLUT.py:27-34), so a drop-in must EXPORT them
+// or the wrapper's constructor raises. Implemented with the obvious contract: row i = the i-th k-card board of the 52-card
+// deck in ascending lexicographic order of ascending 1d cards (22 100 / 270 725 / 2 598 960 rows, caller-allocated).
+static void prl_fill_board_lut(int8_t** out, int k) {
+    int c[5] = {0, 1, 2, 3, 4};
+    for (size_t row = 0;; ++row) {
+        for (int i = 0; i < k; ++i) out[row][i] = (int8_t)c[i];
+        int i = k - 1;
+        while (i >= 0 && c[i] == 52 - k + i) --i;
+        if (i < 0) break;
+        ++c[i];
+        for (int j = i + 1; j < k; ++j) c[j] = c[j - 1] + 1;
+    }
+}
+void get_idx_2_flop_lut(int8_t** out) { prl_fill_board_lut(out, 3); }
+void get_idx_2_turn_lut(int8_t** out) { prl_fill_board_lut(out, 4); }
+void get_idx_2_river_lut(int8_t** out) { prl_fill_board_lut(out, 5); }
+
 int32_t get_hand_rank_52_holdem(int8_t** hand_2d, int8_t** board_2d) {
     uint32_t s[4] = {0, 0, 0, 0};
     for (int i = 0; i < 2; ++i) s[hand_2d[i][1] & 3] |= 1u << hand_2d[i][0];
