@@ -1,17 +1,21 @@
-// Compile-time description of the Flop5Holdem board subtree + runtime parameters of the fused board kernels.
+// Compile-time descriptions of board subtrees ("shapes") + runtime parameters of the fused board kernels.
 //
-// Shape (local node ids in DFS pre-order; reference game: PokerRL/game/games.py:222-254, pot-size raises, at most two
-// raises per round, BB acts first post-flop -- captured from the reference env in tests/golden/tree_Flop5Holdem_1board.npz):
+// A shape is the DFS pre-order listing of a board subtree: per node its kind, the seat to act and the number of children --
+// everything else (children, parents, action columns, who folded, terminal slots ...) is DERIVED from that listing by constexpr
+// code (PrlFhpDerive), so registering another betting structure is three arrays and one line in prl_fhp_kernels.hip. The board
+// pass is instantiated once per registered shape (the walk is a compile-time DFS: per-hand values live in registers, which is
+// what makes the pass fast), and prl_fhp_match_shape() picks the instantiation whose listing equals the flat tree of the actual
+// game; trees with any other subtree fall back to the general level-synchronous engine. Pots are runtime data.
 //
-//   0 seat1 {check -> 1, bet -> 9}
-//   1   seat0 {check -> 2 SHOWDOWN, bet -> 3}
-//   3     seat1 {fold -> 4, call -> 5 SHOWDOWN, raise -> 6}
-//   6       seat0 {fold -> 7, call -> 8 SHOWDOWN}
-//   9   seat0 {fold -> 10, call -> 11 SHOWDOWN, raise -> 12}
-//   12    seat1 {fold -> 13, call -> 14 SHOWDOWN}
-//
-// Only the SHAPE is compiled in; pots are runtime data, and prl_fhp_shape_matches() checks the flat tree of the actual
-// game against it before the fused engine is selected (otherwise the general level-synchronous engine is used).
+// Registered (reference game: PokerRL/game/games.py:222-254, pot-size raises, BB acts first post-flop; captured from the
+// reference env in tests/golden/tree_Flop5Holdem_1board.npz and by walking the env for the variants):
+//   FHP15  Flop5Holdem, two raises per round, stacks >= 1100 (the benchmark tree):
+//     0 seat1 {check -> 1, bet -> 9};  1 seat0 {check -> 2 SD, bet -> 3};  3 seat1 {fold 4, call 5 SD, raise -> 6};
+//     6 seat0 {fold 7, call 8 SD};  9 seat0 {fold 10, call 11 SD, raise -> 12};  12 seat1 {fold 13, call 14 SD}
+//   FHP9   the same game when the first post-flop bet is the last one: stacks 400..900 (the bet is all-in), or one raise per
+//          post-flop round:  0 seat1 {check -> 1, bet -> 6};  1 seat0 {check -> 2 SD, bet -> 3};  3 seat1 {fold 4, call 5 SD};
+//          6 seat0 {fold 7, call 8 SD}
+//   FHP21  three raises post-flop (MAX_N_RAISES_PER_ROUND[FLOP] = 3): 21 nodes, 20 action columns
 #pragma once
 #include "prl_defs.h"
 #include "prl_solver_types.h"
@@ -46,68 +50,116 @@ constexpr int prl_fhp_out_width(int mode) {
          : (prl_fhp_runs_seat(mode, 0) && prl_fhp_runs_seat(mode, 1) ? 2 : 1) * (prl_fhp_with_br(mode) ? 2 : 1);
 }
 
-struct PrlFhpShape {
-    static constexpr int N_NODES = 15;
-    static constexpr int N_COLS = 14;
-    static constexpr int N_DEC = 6;
-    static constexpr int N_DEC_PER_SEAT = 3;
+#define PRL_FHP_MAX_NODES 32
+#define PRL_FHP_MAX_DEC 12
 
-    static constexpr int kind(int n) {
-        constexpr int K[N_NODES] = {0, 0, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3};
-        return K[n];
-    }
-    static constexpr int actor(int n) {
-        constexpr int A[N_NODES] = {1, 0, -1, 1, -1, -1, 0, -1, -1, 0, -1, -1, 1, -1, -1};
-        return A[n];
-    }
-    static constexpr int nch(int n) {
-        constexpr int C[N_NODES] = {2, 2, 0, 3, 0, 0, 2, 0, 0, 3, 0, 0, 2, 0, 0};
-        return C[n];
+// the three arrays of a shape
+struct PrlFhpSpec15 {
+    static constexpr int N_NODES = 15;
+    static constexpr int K(int n) { constexpr int t[N_NODES] = {0, 0, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3}; return t[n]; }
+    static constexpr int A(int n) { constexpr int t[N_NODES] = {1, 0, -1, 1, -1, -1, 0, -1, -1, 0, -1, -1, 1, -1, -1}; return t[n]; }
+    static constexpr int C(int n) { constexpr int t[N_NODES] = {2, 2, 0, 3, 0, 0, 2, 0, 0, 3, 0, 0, 2, 0, 0}; return t[n]; }
+};
+struct PrlFhpSpec9 {
+    static constexpr int N_NODES = 9;
+    static constexpr int K(int n) { constexpr int t[N_NODES] = {0, 0, 3, 0, 2, 3, 0, 2, 3}; return t[n]; }
+    static constexpr int A(int n) { constexpr int t[N_NODES] = {1, 0, -1, 1, -1, -1, 0, -1, -1}; return t[n]; }
+    static constexpr int C(int n) { constexpr int t[N_NODES] = {2, 2, 0, 2, 0, 0, 2, 0, 0}; return t[n]; }
+};
+struct PrlFhpSpec21 {
+    static constexpr int N_NODES = 21;
+    static constexpr int K(int n) { constexpr int t[N_NODES] = {0, 0, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3}; return t[n]; }
+    static constexpr int A(int n) { constexpr int t[N_NODES] = {1, 0, -1, 1, -1, -1, 0, -1, -1, 1, -1, -1, 0, -1, -1, 1, -1, -1, 0, -1, -1}; return t[n]; }
+    static constexpr int C(int n) { constexpr int t[N_NODES] = {2, 2, 0, 3, 0, 0, 3, 0, 0, 2, 0, 0, 3, 0, 0, 3, 0, 0, 2, 0, 0}; return t[n]; }
+};
+
+// everything the walk needs, derived from a spec (all constexpr: evaluated by the compiler for the template recursion)
+template <class S>
+struct PrlFhpDerive {
+    static constexpr int N_NODES = S::N_NODES;
+    static constexpr int kind(int n) { return S::K(n); }
+    static constexpr int actor(int n) { return S::A(n); }
+    static constexpr int nch(int n) { return S::C(n); }
+    static constexpr int subtree_size(int n) {
+        int size = 1;
+        for (int i = 0, c = n + 1; i < nch(n); ++i) { const int t = subtree_size(c); size += t; c += t; }
+        return size;
     }
     static constexpr int child(int n, int i) {
-        constexpr int C[N_NODES][3] = {{1, 9, -1}, {2, 3, -1}, {-1, -1, -1}, {4, 5, 6},  {-1, -1, -1}, {-1, -1, -1}, {7, 8, -1}, {-1, -1, -1},
-                                       {-1, -1, -1}, {10, 11, 12}, {-1, -1, -1}, {-1, -1, -1}, {13, 14, -1}, {-1, -1, -1}, {-1, -1, -1}};
-        return C[n][i];
-    }
-    static constexpr int col0(int n) {
-        constexpr int C[N_NODES] = {0, 2, -1, 4, -1, -1, 7, -1, -1, 9, -1, -1, 12, -1, -1};
-        return C[n];
-    }
-    // seat that folded at a fold node (= the parent's actor)
-    static constexpr int folder(int n) {
-        constexpr int F[N_NODES] = {-1, -1, -1, -1, 1, -1, -1, 0, -1, -1, 0, -1, -1, 1, -1};
-        return F[n];
-    }
-    // slot of a terminal node among the 9 terminal vectors of a seat: showdown nodes 0..4, fold nodes 5..8
-    static constexpr int term_slot(int n) {
-        constexpr int T[N_NODES] = {-1, -1, 0, -1, 5, 1, -1, 6, 2, -1, 7, 3, -1, 8, 4};
-        return T[n];
+        if (i >= nch(n)) return -1;
+        int c = n + 1;
+        for (int k = 0; k < i; ++k) c += subtree_size(c);
+        return c;
     }
     static constexpr int parent(int n) {
-        constexpr int P[N_NODES] = {-1, 0, 1, 1, 3, 3, 3, 6, 6, 0, 9, 9, 9, 12, 12};
-        return P[n];
+        for (int p = n - 1; p >= 0; --p)
+            for (int i = 0; i < nch(p); ++i)
+                if (child(p, i) == n) return p;
+        return -1;
     }
-    static constexpr int col_actor(int col) {
-        constexpr int A[N_COLS] = {1, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1, 1};
-        return A[col];
+    static constexpr int count_kind(int k, int below) { int c = 0; for (int m = 0; m < below; ++m) c += kind(m) == k; return c; }
+    static constexpr int N_DEC = count_kind(PRL_NODE_DECISION, N_NODES);
+    static constexpr int N_SHOW = count_kind(PRL_NODE_TERM_SHOWDOWN, N_NODES);
+    static constexpr int N_FOLD = count_kind(PRL_NODE_TERM_FOLD, N_NODES);
+    static constexpr int col0(int n) {  // first action column of a decision node (columns in DFS order)
+        if (kind(n) != PRL_NODE_DECISION) return -1;
+        int c = 0;
+        for (int m = 0; m < n; ++m) c += kind(m) == PRL_NODE_DECISION ? nch(m) : 0;
+        return c;
     }
+    static constexpr int n_cols_() { int c = 0; for (int m = 0; m < N_NODES; ++m) c += kind(m) == PRL_NODE_DECISION ? nch(m) : 0; return c; }
+    static constexpr int N_COLS = n_cols_();
+    static constexpr int folder(int n) { return kind(n) == PRL_NODE_TERM_FOLD ? actor(parent(n)) : -1; }  // the seat that folded
+    // slot of a terminal among a seat's terminal vectors: showdown nodes 0 .. N_SHOW-1, then the fold nodes
+    static constexpr int term_slot(int n) {
+        return kind(n) == PRL_NODE_TERM_SHOWDOWN ? count_kind(PRL_NODE_TERM_SHOWDOWN, n)
+             : kind(n) == PRL_NODE_TERM_FOLD ? N_SHOW + count_kind(PRL_NODE_TERM_FOLD, n) : -1;
+    }
+    static constexpr int col_node(int col) {
+        for (int m = 0; m < N_NODES; ++m)
+            if (kind(m) == PRL_NODE_DECISION && col0(m) <= col && col < col0(m) + nch(m)) return m;
+        return -1;
+    }
+    static constexpr int col_actor(int col) { return actor(col_node(col)); }
     static constexpr int dec_node(int j) {
-        constexpr int D[N_DEC] = {0, 1, 3, 6, 9, 12};
-        return D[j];
-    }
-    static constexpr int seat_node(int seat, int j) {
-        constexpr int D[2][N_DEC_PER_SEAT] = {{1, 6, 9}, {0, 3, 12}};
-        return D[seat][j];
+        for (int m = 0, k = 0; m < N_NODES; ++m)
+            if (kind(m) == PRL_NODE_DECISION && k++ == j) return m;
+        return -1;
     }
 };
+
+// runtime view of a registered shape (host: matching; device: the small bookkeeping kernels)
+struct PrlFhpShapeDesc {
+    int32_t n_nodes, n_cols, n_dec;
+    int32_t kind[PRL_FHP_MAX_NODES], actor[PRL_FHP_MAX_NODES], nch[PRL_FHP_MAX_NODES], parent[PRL_FHP_MAX_NODES], col0[PRL_FHP_MAX_NODES],
+        folder[PRL_FHP_MAX_NODES];
+    int32_t dec_nch[PRL_FHP_MAX_DEC], dec_col0[PRL_FHP_MAX_DEC];
+};
+template <class D>
+inline PrlFhpShapeDesc prl_fhp_describe() {
+    PrlFhpShapeDesc d = {};
+    d.n_nodes = D::N_NODES; d.n_cols = D::N_COLS; d.n_dec = D::N_DEC;
+    static_assert(D::N_NODES <= PRL_FHP_MAX_NODES && D::N_DEC <= PRL_FHP_MAX_DEC, "enlarge PRL_FHP_MAX_*");
+    for (int n = 0; n < D::N_NODES; ++n) {
+        d.kind[n] = D::kind(n); d.actor[n] = D::actor(n); d.nch[n] = D::nch(n); d.parent[n] = D::parent(n); d.col0[n] = D::col0(n);
+        d.folder[n] = D::folder(n);
+    }
+    for (int j = 0; j < D::N_DEC; ++j) { d.dec_nch[j] = D::nch(D::dec_node(j)); d.dec_col0[j] = D::col0(D::dec_node(j)); }
+    return d;
+}
+enum { PRL_FHP_SHAPE_15 = 0, PRL_FHP_SHAPE_9 = 1, PRL_FHP_SHAPE_21 = 2, PRL_FHP_N_SHAPES = 3 };
+const PrlFhpShapeDesc& prl_fhp_shape_desc(int shape_id);  // prl_fhp_kernels.hip
 
 struct PrlFhpParams {
     int32_t n_boards, R;
     int32_t col_base;           // global action column of board 0, local column 0
     int32_t variant, iter;
     int32_t max_grid;
+    int32_t shape;              // PRL_FHP_SHAPE_*: which instantiation of the board pass walks this tree
+    int32_t n_cols_board, n_dec;  // action columns / decision nodes per board subtree, and per decision node (DFS order):
+    int32_t dec_nch[PRL_FHP_MAX_DEC], dec_col0[PRL_FHP_MAX_DEC];
     float chance_prob, eq_const;
-    float pot[PrlFhpShape::N_NODES];   // main pot of the terminal nodes (by local node id)
+    float pot[PRL_FHP_MAX_NODES];      // main pot of the terminal nodes (by local node id)
     const float* chance_reach;  // [2][R] reach at the chance node (trunk state)
     float* regret;              // [n_cols][R] (global column ids)
     double* avg;                // [n_cols][R] average strategy, updated by the update passes when avg_mode != 0
@@ -127,9 +179,10 @@ struct PrlFhpParams {
     unsigned long long* timing; // PRL_FHP_TIMING builds: [8] shader-clock accumulators per phase (prologue, B, C, D, E, epilogue)
 };
 
-// host: does the flat tree consist of a trunk + ONE chance node whose board subtrees all have the compiled shape?
-// On success fills the chance node id, the first board node, the global column base and the terminal pots.
-bool prl_fhp_shape_matches(const PrlFlatTree& t, int* chance_node, int* first_board_node, int* col_base, float* pots /*[15]*/);
+// host: does the flat tree consist of a trunk + ONE chance node whose board subtrees all have one of the registered shapes?
+// On success returns the shape id (else -1) and fills the chance node id, the first board node, the global column base and the
+// terminal pots.
+int prl_fhp_match_shape(const PrlFlatTree& t, int* chance_node, int* first_board_node, int* col_base, float* pots /*[PRL_FHP_MAX_NODES]*/);
 
 int prl_launch_fhp_pass(const PrlFhpParams& prm, int mode, int src0, int src1, void* stream);
 void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_cols, void* stream);

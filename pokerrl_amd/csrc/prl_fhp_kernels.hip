@@ -35,28 +35,62 @@
 #define FHP_THREADS 768
 #define FHP_SLOTS 2
 #define FHP_LAUNCH_BOUNDS FHP_LB(768, 3)
-namespace fhp_cfg0 {
+#define FHP_SPEC PrlFhpSpec15
+namespace fhp_shape15 {
 #include "prl_fhp_pass.inc"
 }
+#undef FHP_SPEC
+#define FHP_SPEC PrlFhpSpec9
+namespace fhp_shape9 {
+#include "prl_fhp_pass.inc"
+}
+#undef FHP_SPEC
+#if !defined(PRL_FHP_NO_SHAPE21)
+#define FHP_SPEC PrlFhpSpec21
+namespace fhp_shape21 {
+#include "prl_fhp_pass.inc"
+}
+#undef FHP_SPEC
+#endif
 #undef FHP_THREADS
 #undef FHP_SLOTS
 #undef FHP_LAUNCH_BOUNDS
 
+const PrlFhpShapeDesc& prl_fhp_shape_desc(int shape_id) {
+    static const PrlFhpShapeDesc d[PRL_FHP_N_SHAPES] = {prl_fhp_describe<PrlFhpDerive<PrlFhpSpec15>>(), prl_fhp_describe<PrlFhpDerive<PrlFhpSpec9>>(),
+                                                        prl_fhp_describe<PrlFhpDerive<PrlFhpSpec21>>()};
+    return d[shape_id];
+}
+
+bool prl_fhp_shape_compiled(int shape_id) {
+#if !defined(PRL_FHP_NO_SHAPE21)
+    return shape_id >= 0 && shape_id < PRL_FHP_N_SHAPES;
+#else
+    return shape_id == PRL_FHP_SHAPE_15 || shape_id == PRL_FHP_SHAPE_9;
+#endif
+}
+
 int prl_launch_fhp_pass(const PrlFhpParams& prm, int mode, int src0, int src1, void* stream) {
-    return fhp_cfg0::launch_pass(prm, mode, src0, src1, stream);
+    switch (prm.shape) {
+        case PRL_FHP_SHAPE_15: return fhp_shape15::launch_pass(prm, mode, src0, src1, stream);
+        case PRL_FHP_SHAPE_9: return fhp_shape9::launch_pass(prm, mode, src0, src1, stream);
+#if !defined(PRL_FHP_NO_SHAPE21)
+        case PRL_FHP_SHAPE_21: return fhp_shape21::launch_pass(prm, mode, src0, src1, stream);
+#endif
+        default: return PRL_ERR_UNSUPPORTED;
+    }
 }
 
 // materialise the strategy implied by the regrets (tests / prl_solver_get): [n_board_cols][R] float64
 PRL_GLOBAL void prl_k_fhp_strategy_from_regret(PrlFhpParams prm, double* out_cols) {
-    const size_t per_board = (size_t)PrlFhpShape::N_DEC * prm.R;
+    const size_t per_board = (size_t)prm.n_dec * prm.R;
     const size_t total = (size_t)prm.n_boards * per_board;
     for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
         const size_t b = t / per_board;
         const int j = (int)((t % per_board) / prm.R);
         const size_t h = t % prm.R;
-        const int node = PrlFhpShape::dec_node(j);
-        const int A = PrlFhpShape::nch(node), col0 = PrlFhpShape::col0(node);
-        const size_t base = ((size_t)prm.col_base + b * PrlFhpShape::N_COLS + col0) * (size_t)prm.R + h;
+        const int A = prm.dec_nch[j], col0 = prm.dec_col0[j];
+        const size_t base = ((size_t)prm.col_base + b * prm.n_cols_board + col0) * (size_t)prm.R + h;
         float tt[3];
         float sum = 0.f;
         for (int i = 0; i < A; ++i) {
@@ -73,15 +107,14 @@ PRL_GLOBAL void prl_k_fhp_strategy_from_regret(PrlFhpParams prm, double* out_col
 // uniform (VanillaCFR.py:54-77, LinearCFR.py:53-76: float32 division, stored in the float64 column array). The board pass
 // only maintains avg_sum; this runs when the average is read (evaluation, prl_solver_get, checkpoint).
 PRL_GLOBAL void prl_k_fhp_avg_from_sum(PrlFhpParams prm) {
-    const size_t per_board = (size_t)PrlFhpShape::N_DEC * prm.R;
+    const size_t per_board = (size_t)prm.n_dec * prm.R;
     const size_t total = (size_t)prm.n_boards * per_board;
     for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
         const size_t b = t / per_board;
         const int j = (int)((t % per_board) / prm.R);
         const size_t h = t % prm.R;
-        const int node = PrlFhpShape::dec_node(j);
-        const int A = PrlFhpShape::nch(node), col0 = PrlFhpShape::col0(node);
-        const size_t base = ((size_t)prm.col_base + b * PrlFhpShape::N_COLS + col0) * (size_t)prm.R + h;
+        const int A = prm.dec_nch[j], col0 = prm.dec_col0[j];
+        const size_t base = ((size_t)prm.col_base + b * prm.n_cols_board + col0) * (size_t)prm.R + h;
         float as[3];
         for (int i = 0; i < A; ++i) as[i] = prm.avg_sum[base + (size_t)i * prm.R];
         float sum = as[0];
@@ -127,13 +160,13 @@ static inline int fhp_grid_for(size_t items, int block) {
 
 void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_cols, void* stream) {
     if (prm.n_boards <= 0) return;
-    size_t items = (size_t)prm.n_boards * PrlFhpShape::N_DEC * prm.R;
+    size_t items = (size_t)prm.n_boards * prm.n_dec * prm.R;
     PRL_LAUNCH(prl_k_fhp_strategy_from_regret, fhp_grid_for(items, 256), 256, 0, stream, prm, out_cols);
 }
 
 void prl_launch_fhp_avg_from_sum(const PrlFhpParams& prm, void* stream) {
     if (prm.n_boards <= 0) return;
-    size_t items = (size_t)prm.n_boards * PrlFhpShape::N_DEC * prm.R;
+    size_t items = (size_t)prm.n_boards * prm.n_dec * prm.R;
     PRL_LAUNCH(prl_k_fhp_avg_from_sum, fhp_grid_for(items, 256), 256, 0, stream, prm);
 }
 

@@ -334,38 +334,47 @@ void make_trunk(const PrlFlatTree& t, int chance_node, int first_board_node, int
 
 }  // namespace
 
-bool prl_fhp_shape_matches(const PrlFlatTree& t, int* chance_node, int* first_board_node, int* col_base, float* pots) {
-    if (t.rules.n_hole_cards != 2 || t.rules.n_cards != 52 || t.board_len != 5) return false;
+bool prl_fhp_shape_compiled(int shape_id);  // prl_fhp_kernels.hip
+
+int prl_fhp_match_shape(const PrlFlatTree& t, int* chance_node, int* first_board_node, int* col_base, float* pots) {
+    if (t.rules.n_hole_cards != 2 || t.rules.n_cards != 52 || t.board_len != 5) return -1;
     int ch = -1;
     for (int i = 0; i < t.n_nodes; ++i)
         if (t.kind[i] == PRL_NODE_CHANCE) {
-            if (ch >= 0) return false;  // exactly one chance node
+            if (ch >= 0) return -1;  // exactly one chance node
             ch = i;
         }
-    if (ch < 0 || t.n_children[ch] != t.n_boards) return false;
-    const int N = PrlFhpShape::N_NODES;
+    if (ch < 0 || t.n_children[ch] != t.n_boards) return -1;
     const int first = ch + 1;
-    if (first + (long long)t.n_boards * N != t.n_nodes) return false;  // the board subtrees are the tail of the DFS order
-    for (int b = 0; b < t.n_boards; ++b) {
-        const int base = first + b * N;
-        if (t.board_id[base] != b) return false;
-        if (b > 0 && b < t.n_boards - 1) continue;  // subtrees are replicas by construction; check the first and the last
-        for (int n = 0; n < N; ++n) {
-            const int g = base + n;
-            if (t.kind[g] != PrlFhpShape::kind(n) || t.n_children[g] != PrlFhpShape::nch(n)) return false;
-            if (t.kind[g] == PRL_NODE_DECISION && t.actor[g] != PrlFhpShape::actor(n)) return false;
-            if (n > 0 && t.parent[g] != base + PrlFhpShape::parent(n)) return false;
-            if (t.kind[g] == PRL_NODE_TERM_FOLD && t.acted_last[g] != PrlFhpShape::folder(n)) return false;
-            if (t.kind[g] == PRL_NODE_DECISION && t.first_col[g] != t.first_col[base] + PrlFhpShape::col0(n)) return false;
-        }
-    }
     for (int i = 0; i < first; ++i)
-        if (t.kind[i] == PRL_NODE_DECISION && t.first_col[i] >= t.first_col[first]) return false;  // trunk columns precede
-    *chance_node = ch;
-    *first_board_node = first;
-    *col_base = t.first_col[first];
-    for (int n = 0; n < N; ++n) pots[n] = (float)t.main_pot[first + n];
-    return true;
+        if (t.kind[i] == PRL_NODE_DECISION && t.first_col[i] >= t.first_col[first]) return -1;  // trunk columns precede
+    for (int sid = 0; sid < PRL_FHP_N_SHAPES; ++sid) {
+        if (!prl_fhp_shape_compiled(sid)) continue;
+        const PrlFhpShapeDesc& d = prl_fhp_shape_desc(sid);
+        const int N = d.n_nodes;
+        if (first + (long long)t.n_boards * N != t.n_nodes) continue;  // the board subtrees are the tail of the DFS order
+        bool ok = true;
+        for (int b = 0; b < t.n_boards && ok; ++b) {
+            const int base = first + b * N;
+            if (t.board_id[base] != b) { ok = false; break; }
+            if (b > 0 && b < t.n_boards - 1) continue;  // subtrees are replicas by construction; check the first and the last
+            for (int n = 0; n < N && ok; ++n) {
+                const int g = base + n;
+                if (t.kind[g] != d.kind[n] || t.n_children[g] != d.nch[n]) ok = false;
+                else if (t.kind[g] == PRL_NODE_DECISION && t.actor[g] != d.actor[n]) ok = false;
+                else if (n > 0 && t.parent[g] != base + d.parent[n]) ok = false;
+                else if (t.kind[g] == PRL_NODE_TERM_FOLD && t.acted_last[g] != d.folder[n]) ok = false;
+                else if (t.kind[g] == PRL_NODE_DECISION && t.first_col[g] != t.first_col[base] + d.col0[n]) ok = false;
+            }
+        }
+        if (!ok) continue;
+        *chance_node = ch;
+        *first_board_node = first;
+        *col_base = t.first_col[first];
+        for (int n = 0; n < N; ++n) pots[n] = (float)t.main_pot[first + n];
+        return sid;
+    }
+    return -1;
 }
 
 extern "C" {
@@ -385,14 +394,15 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     for (int i = 0; i < full.n_nodes; ++i)
         if (full.kind[i] == PRL_NODE_DECISION && full.n_children[i] > 96) { prl_set_error("more than 96 actions at a node"); return PRL_ERR_UNSUPPORTED; }
     int ch_node = -1, first_board = -1, col_base = -1;
-    float pots[PrlFhpShape::N_NODES];
-    const bool shape_ok = prl_fhp_shape_matches(full, &ch_node, &first_board, &col_base, pots);
+    float pots[PRL_FHP_MAX_NODES];
+    const int shape_id = prl_fhp_match_shape(full, &ch_node, &first_board, &col_base, pots);
+    const bool shape_ok = shape_id >= 0;
     bool fused = false;
     if (engine == PRL_ENGINE_FUSED) {
-        if (!shape_ok) { prl_set_error("fused engine needs a Flop5Holdem-shaped tree"); return PRL_ERR_UNSUPPORTED; }
+        if (!shape_ok) { prl_set_error("fused engine: the board subtree of this tree is not one of the registered shapes (prl_fhp.h)"); return PRL_ERR_UNSUPPORTED; }
         fused = true;
     } else if (engine == PRL_ENGINE_AUTO) fused = shape_ok;
-    if (exchange && !fused) { prl_set_error("sharded solve: FUSED engine only (Flop5Holdem-shaped tree)"); return PRL_ERR_UNSUPPORTED; }
+    if (exchange && !fused) { prl_set_error("sharded solve: FUSED engine only (a board subtree of a registered shape, prl_fhp.h)"); return PRL_ERR_UNSUPPORTED; }
 
     prl_solver* s = new prl_solver();
     s->world = world;
@@ -416,7 +426,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     s->full_nodes = full.n_nodes;
     s->full_cols = full.n_cols;
     s->R = r.range_size;
-    if (fused) make_trunk(full, ch_node, first_board, full.n_boards * PrlFhpShape::N_NODES, &s->ft, &s->chance_trunk);
+    if (fused) make_trunk(full, ch_node, first_board, full.n_boards * prl_fhp_shape_desc(shape_id).n_nodes, &s->ft, &s->chance_trunk);
     else s->ft = full;
     const PrlFlatTree& ft = s->ft;
 #define FAIL_IF(x) do { int e_ = (x); if (e_) { prl_solver_destroy(s); return e_; } } while (0)
@@ -504,7 +514,10 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
                 if (g && atoi(g) > 0) fp.max_grid = atoi(g);
             }
             fp.chance_prob = T.chance_prob; fp.eq_const = T.eq_const;
-            for (int n = 0; n < PrlFhpShape::N_NODES; ++n) fp.pot[n] = pots[n];
+            const PrlFhpShapeDesc& sd = prl_fhp_shape_desc(shape_id);
+            fp.shape = shape_id; fp.n_cols_board = sd.n_cols; fp.n_dec = sd.n_dec;
+            for (int j = 0; j < sd.n_dec; ++j) { fp.dec_nch[j] = sd.dec_nch[j]; fp.dec_col0[j] = sd.dec_col0[j]; }
+            for (int n = 0; n < sd.n_nodes; ++n) fp.pot[n] = pots[n];
             fp.plan_stride = T.plan_stride;
             fp.plan_pos = pos; fp.plan_hgs = hgs; fp.plan_hge = hge; fp.plan_clx = clx; fp.plan_nlive = nl;
             FAIL_IF(dev_upload(s, &fp.hole_packed, hole_packed));

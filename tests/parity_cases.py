@@ -166,13 +166,22 @@ FUSED_FIELDS = ("regret", "avg")
 VARIANT_ID = {"vanilla": 0, "plus": 1, "linear": 2}
 
 
-def check_fused_vs_oracle(L, n_boards, n_iters, delay=0, variant="plus"):
+def fhp_game(stack=20000, flop_raises=None):
+    """Flop5Holdem's PrlGame; flop_raises overrides MAX_N_RAISES_PER_ROUND[FLOP] (games.py:239: 2)"""
+    g = G.Flop5Holdem.native_game(env_args(G.Flop5Holdem, stack, bet_sets.POT_ONLY))
+    if flop_raises is not None:
+        g.max_raises[1] = flop_raises
+    return g
+
+
+def check_fused_vs_oracle(L, n_boards, n_iters, delay=0, variant="plus", stack=20000, flop_raises=None, nodes_per_board=15):
     """Fused board-block engine (per-node vectors on chip) against the oracle: every regret / average column of every
-    board, the strategy implied by the regrets, current- and average-strategy exploitability, after every iteration."""
+    board, the strategy implied by the regrets, current- and average-strategy exploitability, after every iteration.
+    stack / flop_raises select other betting structures (other registered board-subtree shapes, csrc/prl_fhp.h)."""
     boards = fhp_boards(n_boards)
-    args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
-    t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
-    s = _native.NativeSolver(t, variant, delay, engine="fused", _lib=L)
+    t = _native.NativeTree(fhp_game(stack, flop_raises), G.Flop5Holdem.native_rules(), boards, _lib=L)
+    assert t.n_nodes == 5 + nodes_per_board * n_boards
+    s = _native.NativeSolver(t, variant, delay, engine="auto", _lib=L)  # AUTO must pick the fused engine for a registered shape
     assert s.engine == "fused"
     o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, 2, 52, 4, 2)
     o.cfr_reset(VARIANT_ID[variant], delay)

@@ -68,6 +68,28 @@ def test_emu_fused_engine_best_response_of_explicit_strategy(L):
     pc.check_fused_br_vs_oracle(L, 3)
 
 
+@pytest.mark.parametrize("stack,flop_raises", [(700, None), (20000, 1)])
+def test_emu_fused_engine_nine_node_board_subtree(L, stack, flop_raises):
+    """the second registered shape (csrc/prl_fhp.h: FHP9): short stacks make the first post-flop bet all-in, or one raise per round"""
+    pc.check_fused_vs_oracle(L, 3, 2, stack=stack, flop_raises=flop_raises, nodes_per_board=9)
+    pc.check_fused_vs_oracle(L, 3, 2, variant="linear", stack=stack, flop_raises=flop_raises, nodes_per_board=9)
+
+
+def test_emu_fused_engine_twentyone_node_board_subtree(L):
+    """the third registered shape (FHP21: three post-flop raises, 20 action columns): its regret block does not fit the LDS
+    prefetch area, so this instantiation reads the regrets from HBM at the board start"""
+    pc.check_fused_vs_oracle(L, 3, 2, flop_raises=3, nodes_per_board=21)
+
+
+def test_emu_unregistered_board_subtree_falls_back_to_levels(L):
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import games as G
+    t = _native.NativeTree(pc.fhp_game(20000, flop_raises=4), G.Flop5Holdem.native_rules(), pc.fhp_boards(3), _lib=L)
+    assert _native.NativeSolver(t, "plus", 0, engine="auto", _lib=L).engine == "levels"
+    with pytest.raises(_native.NativeError):
+        _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
+
+
 def test_emu_fused_engine_cfrplus_delay(L):
     pc.check_fused_vs_oracle(L, 3, 3, delay=1)
 

@@ -154,6 +154,15 @@ def test_gpu_fused_16384_boards_fixture(L):
     pc.check_fused_vs_fixture(L, "fhp_16384_plus")
 
 
+@pytest.mark.parametrize("stack,flop_raises,nodes,n_boards,variant", [
+    (700, None, 9, 40, "plus"), (700, None, 9, 1024, "linear"), (20000, 1, 9, 300, "vanilla"),
+    (20000, 3, 21, 40, "plus"), (20000, 3, 21, 600, "linear")])
+def test_gpu_fused_other_registered_shapes_vs_oracle(L, stack, flop_raises, nodes, n_boards, variant):
+    """engine=auto picks the fused engine for every registered board-subtree shape (csrc/prl_fhp.h): FHP9 (short stacks / one
+    raise per round) and FHP21 (three post-flop raises), each bit-exact against the oracle with several boards per CU"""
+    pc.check_fused_vs_oracle(L, n_boards, 3, variant=variant, stack=stack, flop_raises=flop_raises, nodes_per_board=nodes)
+
+
 @pytest.mark.parametrize("n_boards", [40, 2048])
 def test_gpu_fused_best_response_only_pass_vs_oracle(L, n_boards):
     """BASELINE config 4: exact best response of an explicit strategy; float32 strategies go through the best-response-only pass"""
