@@ -82,6 +82,13 @@ def lib():
     """Loads the shared library once. Raises NativeError (never falls back) if it is absent."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm ships its own HIP runtime. Whichever HIP runtime a process initialises first owns the GPU for that process:
+        # with this library loaded first, a later `import torch` finds "No HIP GPUs" (seen on the MI355X box). Neural agents and
+        # torch.distributed (RCCL) live in the same process as the solver, so torch goes first whenever it is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = bind(LIB_PATH)
     return _lib
 
