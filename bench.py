@@ -33,12 +33,13 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per CFR+ iteration of the board-pass kernels, from the PMC pass (FETCH_SIZE / WRITE_SIZE, corrected as
-# MI355X_MICROARCH.md prescribes), keyed by boards per GPU; see the file named below. None until measured for a size.
-# measured at 16384 boards (r01h: UPDATE1_EVAL1 2 * 1.32 GB read + 2.04 GB written, UPDATE0_BR 2 * 1.32 + 1.95 = 9.27 GB per iteration)
-# and at 262144 boards (r01i: 2 * 21.13 + 32.61 and 2 * 21.12 + 31.25 = 148.4 GB): every board subtree moves the same bytes
-PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION = 9.27e9 / 16384
-PMC_TRAFFIC_SOURCE = "profiles/r01l_fused_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+# HBM bytes per CFR+ iteration of the board-pass kernels, from the PMC passes (FETCH_SIZE / WRITE_SIZE in their own rocprofv3 runs,
+# FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads). Measured at 262144 boards (profiles/r02m_fused_pmc.txt):
+# UPDATE1_EVAL1 2 * 20.93 GB read + 32.62 GB written, UPDATE0_BR 2 * 20.91 + 31.26 = 147.6 GB per iteration; every board subtree moves
+# the same bytes (563 KB per board and iteration: 14 regret columns + the plan in, 7 regret columns out, 7 float64 average columns in
+# and out -- the reference's float64 average is 53 % of it -- and the root vectors), so other sizes scale linearly.
+PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION = 147.56e9 / 262144
+PMC_TRAFFIC_SOURCE = "profiles/r02m_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
 
 
 def seeded_boards(n, seed, offset=0):
