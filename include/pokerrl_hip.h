@@ -152,6 +152,10 @@ typedef struct prl_tree prl_tree_t;
 /* boards: the chance outcomes, one row of `board_len` 1d cards per board, in child order */
 int32_t prl_tree_build(const PrlGame* game, const PrlRules* rules, const int8_t* boards, int32_t n_boards,
                        int32_t board_len, prl_tree_t** out_tree);
+/* PublicTree(stop_at_street = stop_at_round) (PublicTree.py:72,173,185): nodes of a betting round >= stop_at_round are not expanded
+ * -- decision nodes without children. Structure and states only: prl_solver_create* refuses a partial tree. stop_at_round < 0 = full. */
+int32_t prl_tree_build_partial(const PrlGame* game, const PrlRules* rules, const int8_t* boards, int32_t n_boards, int32_t board_len,
+                               int32_t stop_at_round, prl_tree_t** out_tree);
 void prl_tree_destroy(prl_tree_t* tree);
 
 enum {

@@ -372,14 +372,18 @@ def env_random_rollout_host(game, n_envs, n_steps, seed, _lib=None):
 class NativeTree:
     """Owns a prl_tree_t* (host-side flat public tree)."""
 
-    def __init__(self, game, rules, boards_1d, _lib=None):
+    def __init__(self, game, rules, boards_1d, _lib=None, stop_at_round=None):
         boards = np.ascontiguousarray(boards_1d, dtype=np.int8)
         assert boards.ndim == 2
         self._L = _lib or lib()
         self._h = ctypes.c_void_p()
         self._game, self._rules = game, rules
-        check(self._L.prl_tree_build(ctypes.byref(game), ctypes.byref(rules), _ptr(boards), boards.shape[0],
-                                     boards.shape[1], ctypes.byref(self._h)), self._L)
+        self.is_partial = stop_at_round is not None
+        self._L.prl_tree_build_partial.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                                   ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+        self._L.prl_tree_build_partial.restype = ctypes.c_int32
+        check(self._L.prl_tree_build_partial(ctypes.byref(game), ctypes.byref(rules), _ptr(boards), boards.shape[0], boards.shape[1],
+                                             -1 if stop_at_round is None else int(stop_at_round), ctypes.byref(self._h)), self._L)
         info = np.zeros(TI_COUNT, dtype=np.int32)
         check(self._L.prl_tree_info(self._h, _ptr(info)), self._L)
         self.info = info

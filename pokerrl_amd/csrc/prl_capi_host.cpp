@@ -128,11 +128,16 @@ struct prl_tree {
 
 int32_t prl_tree_build(const PrlGame* game, const PrlRules* rules, const int8_t* boards, int32_t n_boards,
                        int32_t board_len, prl_tree_t** out_tree) {
+    return prl_tree_build_partial(game, rules, boards, n_boards, board_len, -1, out_tree);
+}
+
+int32_t prl_tree_build_partial(const PrlGame* game, const PrlRules* rules, const int8_t* boards, int32_t n_boards, int32_t board_len,
+                               int32_t stop_at_round, prl_tree_t** out_tree) {
     if (!game || !rules || !boards || !out_tree) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
     int e = check_rules(rules);
     if (e) return e;
     prl_tree* h = new prl_tree();
-    e = prl_build_flat_tree(*game, *rules, boards, n_boards, board_len, &h->t);
+    e = prl_build_flat_tree(*game, *rules, boards, n_boards, board_len, &h->t, stop_at_round);
     if (e) {
         prl_set_error(h->t.error);
         delete h;

@@ -385,6 +385,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     if (variant < 0 || variant > 2 || delay < 0 || engine < 0 || engine > 2) { prl_set_error("bad variant / delay / engine"); return PRL_ERR_ARG; }
     if (!prl_device_available()) { prl_set_error("no HIP device: the solver has no CPU fallback"); return PRL_ERR_NO_DEVICE; }
     const PrlFlatTree& full = *prl_tree_flat(tree);
+    if (full.is_partial) { prl_set_error("partial tree (stop_at_street): structure only, there is nothing to solve below the cut"); return PRL_ERR_UNSUPPORTED; }
     const PrlRules& r = full.rules;
     if (r.n_hole_cards == 1 && (r.range_size > 128 || full.board_len != 1)) { prl_set_error("1-card games: R <= 128, 1 board card"); return PRL_ERR_UNSUPPORTED; }
     if (r.n_hole_cards == 2 && (r.n_cards != 52 || r.n_suits != 4 || full.board_len != 5 || r.rank_rule != 2)) {

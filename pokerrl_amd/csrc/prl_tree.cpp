@@ -9,6 +9,7 @@ struct Builder {
     PrlFlatTree* t;
     const int8_t* boards;
     int n_boards, board_len;
+    int stop_at_round;  // nodes of a round >= this are left unexpanded (PublicTree.py:173: stop_at_street); INT_MAX = full tree
     int err = 0;
 
     int new_node(int kind, int actor, int parent, int child_idx, int action, int acted_last, int round, int board_id,
@@ -50,6 +51,10 @@ struct Builder {
 
     void expand(int id, const PrlEnvState& st) {
         if (err) return;
+        if (st.round >= stop_at_round) {  // a non-terminal LEAF: it keeps its actor, has no children and no action columns
+            t->is_partial = true;
+            return;
+        }
         int32_t legal[PRL_MAX_BET_SIZES + 2];
         int n = prl_legal_actions(t->game, st, legal);
         if (n <= 0) { err = PRL_ERR_STATE; t->error = "decision node without legal actions"; return; }
@@ -111,7 +116,7 @@ struct Builder {
 }  // namespace
 
 int prl_build_flat_tree(const PrlGame& game, const PrlRules& rules, const int8_t* boards, int n_boards, int board_len,
-                        PrlFlatTree* out) {
+                        PrlFlatTree* out, int stop_at_round) {
     PrlFlatTree& t = *out;
     t = PrlFlatTree();
     t.rules = rules;
@@ -122,7 +127,7 @@ int prl_build_flat_tree(const PrlGame& game, const PrlRules& rules, const int8_t
     t.board_len = board_len;
     t.boards.assign(boards, boards + (size_t)n_boards * board_len);
 
-    Builder b{&t, boards, n_boards, board_len};
+    Builder b{&t, boards, n_boards, board_len, stop_at_round < 0 ? 0x7FFFFFFF : stop_at_round};
     PrlEnvState st;
     prl_env_reset(game, st);
     // the root is the first actor's decision node (PublicTree.py:111-124); its `action` is the reference's "CHANCE"

@@ -34,9 +34,12 @@ struct PrlFlatTree {
     std::vector<int8_t> boards;
     // levels (BFS depth) for the level-synchronous kernels
     std::vector<int32_t> level_start, level_nodes;
+    bool is_partial = false;  // built with stop_at_round: decision nodes without children exist (structure only: no solver)
     std::string error;
 };
 
 // Builds the full public tree of a 2-round game (one chance level: Leduc family, Flop5Holdem). Returns 0 or PRL_ERR_*.
+// stop_at_round >= 0: nodes whose betting round is >= stop_at_round are not expanded (PublicTree's stop_at_street,
+// PublicTree.py:72,173,185); such a partial tree carries structure and states only -- the solver refuses it.
 int prl_build_flat_tree(const PrlGame& game, const PrlRules& rules, const int8_t* boards, int n_boards, int board_len,
-                        PrlFlatTree* out);
+                        PrlFlatTree* out, int stop_at_round = -1);

@@ -7,7 +7,8 @@ pass -- strategy fill, reach push-down, EV / best-response pull-up -- is a HIP k
 `node.ev`, `node.reach_probs`, `node.strategy` ... copies the corresponding slice out of HBM on demand (lazy host
 mirrors); assigning `node.strategy` stages the value and uploads all staged strategies before the next pass.
 
-Differences: `stop_at_street` other than None is not supported (the hot path always builds full trees, _CFRBase.py:64-69).
+`stop_at_street` builds the reference's partial tree (nodes of a round >= the limit are not expanded): structure, env states and
+legal actions only -- the passes (fill / reach / ev) need the whole tree and raise on a partial one.
 For 2-hole-card games the chance outcomes must be given (`boards=`): the reference cannot enumerate them at all
  and the full C(52,5) set does not fit one GPU.
 """
@@ -74,6 +75,10 @@ class TreeNode:
         t = self.tree
         if t._kind[self._i] != KIND_DECISION:
             return []
+        if t._n_children[self._i] == 0:  # unexpanded node of a partial tree (stop_at_street): ask the env, as the reference does
+            env = t._get_replay_env()
+            env.load_state_dict(self.env_state, blank_private_info=True)
+            return [int(a) for a in env.get_legal_actions()]
         c0 = t._first_col[self._i]
         return [int(a) for a in t._col_action[c0:c0 + t._n_children[self._i]]]
 
@@ -138,13 +143,14 @@ class PublicTree:
 
     def __init__(self, env_bldr, stack_size, stop_at_street, put_out_new_round_after_limit=False, is_debugging=False, boards=None,
                  engine="levels"):
-        if stop_at_street is not None:
-            raise NotImplementedError("partial trees (stop_at_street) are not on the hot path; build full trees")
         self._env_bldr = env_bldr
         self._stack_size = stack_size
         self._is_debugging = is_debugging
         self._put_out_new_round_after_limit = put_out_new_round_after_limit
-        self._stop_at_street = max(env_bldr.rules.ALL_ROUNDS_LIST) + 1
+        # PublicTree.py:72,173: nodes of a round >= stop_at_street stay unexpanded. A partial tree has structure and states only
+        # (node.children / env_state / allowed_actions ...): the device solver needs the whole tree, every pass raises.
+        self._stop_at_street = max(env_bldr.rules.ALL_ROUNDS_LIST) + 1 if stop_at_street is None else int(stop_at_street)
+        self._is_partial = self._stop_at_street <= max(env_bldr.rules.ALL_ROUNDS_LIST)
         self._boards = boards
         self._engine = engine
         self._n_seats = env_bldr.N_SEATS
@@ -186,12 +192,13 @@ class PublicTree:
             if rules.N_HOLE_CARDS != 1:
                 raise ValueError("2-hole-card public trees need an explicit list of boards (boards=[[c1..c5], ...])")
             boards = np.arange(rules.N_CARDS_IN_DECK, dtype=np.int8).reshape(-1, 1)  # PublicTree.py:193-203: cards ascending
-        self._native_tree = _native.NativeTree(env_cls.native_game(args), env_cls.native_rules(), boards)
+        self._native_tree = _native.NativeTree(env_cls.native_game(args), env_cls.native_rules(), boards,
+                                               stop_at_round=self._stop_at_street if self._is_partial else None)
         t = self._native_tree
         for f in ("kind", "actor", "parent", "action", "acted_last", "depth", "n_children", "first_col", "child_start", "child_list",
                   "col_action", "board_id", "main_pot", "round", "child_idx"):
             setattr(self, "_" + f, t.field(f))
-        self._solver = _native.NativeSolver(t, variant, delay, engine=self._engine)
+        self._solver = None if self._is_partial else _native.NativeSolver(t, variant, delay, engine=self._engine)
         self.root = self.node(0)
         self._invalidate()
 
@@ -206,6 +213,8 @@ class PublicTree:
 
     @property
     def solver(self):
+        if self._solver is None:
+            raise RuntimeError("partial tree (stop_at_street=%d): it has structure and states only; the solver needs the whole tree" % self._stop_at_street)
         return self._solver
 
     @property
@@ -215,12 +224,12 @@ class PublicTree:
     # ---- passes (PublicTree.py:128-141) -------------------------------------------------------------------------------
     def compute_ev(self):
         self._flush()
-        self._solver.compute_ev()
+        self.solver.compute_ev()
         self._invalidate()
 
     def fill_uniform_random(self):
         self._staged.clear()
-        self._solver.fill_uniform()
+        self.solver.fill_uniform()
         self._invalidate()
 
     def fill_random_random(self):
@@ -233,7 +242,7 @@ class PublicTree:
             x /= np.expand_dims(np.sum(x, axis=1), axis=-1)
             strat[self._first_col[n]:self._first_col[n] + a] = x.T
         self._staged.clear()
-        self._solver.set_strategy(strat)
+        self.solver.set_strategy(strat)
         self._invalidate()
 
     def fill_with_agent_policy(self, agent):
@@ -254,7 +263,7 @@ class PublicTree:
             for n, node, pr in zip(decision, nodes, probs):
                 strat[self._first_col[n]:self._first_col[n] + self._n_children[n]] = pr[:, node.allowed_actions].T
             self._staged.clear()
-            self._solver.set_strategy(strat if probs.dtype == np.float64 else strat.astype(np.float32))
+            self.solver.set_strategy(strat if probs.dtype == np.float64 else strat.astype(np.float32))
             self._invalidate()
             return
         for n in decision:
@@ -266,12 +275,12 @@ class PublicTree:
             sel = probs[:, node.allowed_actions]
             strat[self._first_col[n]:self._first_col[n] + self._n_children[n]] = sel.T
         self._staged.clear()
-        self._solver.set_strategy(strat if dtype == np.float64 else strat.astype(np.float32))
+        self.solver.set_strategy(strat if dtype == np.float64 else strat.astype(np.float32))
         self._invalidate()
 
     def update_reach_probs(self):
         self._flush()
-        self._solver.update_reach()
+        self.solver.update_reach()
         self._invalidate()
 
     def copy(self):
@@ -280,12 +289,12 @@ class PublicTree:
         c.build_tree(variant=getattr(self, "_variant", "vanilla"), delay=getattr(self, "_delay", 0))
         self._flush()
         try:  # a solver in a CFR run: the whole persistent state (regrets, averages, iteration counter) moves over
-            c._solver.load_state(self._solver.save_state())
+            c._solver.load_state(self.solver.save_state())
         except _native.NativeError as e:
             if e.status != _native.ERR_STATE:  # ERR_STATE = an explicit strategy is loaded (fill_with_agent_policy ...): copy that
                 raise
             strat = self._vec("strategy")
-            f64 = bool(self._solver.get("strat_f64").any())
+            f64 = bool(self.solver.get("strat_f64").any())
             c._solver.set_strategy(strat if f64 else strat.astype(np.float32))
         c._invalidate()
         return c
@@ -310,7 +319,7 @@ class PublicTree:
     def _vec(self, name):
         if name not in self._cache:
             self._flush()
-            self._cache[name] = self._solver.get(name)
+            self._cache[name] = self.solver.get(name)
         return self._cache[name]
 
     def _stage_strategy(self, idx, value):
@@ -322,22 +331,30 @@ class PublicTree:
         if not self._staged:
             return
         staged, self._staged = self._staged, {}
-        cur = self._solver.get("strategy")
-        f64 = bool(self._solver.get("strat_f64").any()) or any(v.dtype == np.float64 for v in staged.values())
+        cur = self.solver.get("strategy")
+        f64 = bool(self.solver.get("strat_f64").any()) or any(v.dtype == np.float64 for v in staged.values())
         for idx, v in staged.items():
             cur[self._first_col[idx]:self._first_col[idx] + self._n_children[idx]] = v.T
-        self._solver.set_strategy(cur if f64 else cur.astype(np.float32))
+        self.solver.set_strategy(cur if f64 else cur.astype(np.float32))
         self._invalidate()
 
     def _chance_strategy(self, idx):
         """[R, n_boards] float32: board probability for hands not blocked by the board (StrategyFiller.py:148-169)"""
         t, lut = self._native_tree, self._env_bldr.lut_holder.LUT_IDX_2_HOLE_CARDS
-        p = self._solver.get("constants")[0]
+        p = self.solver.get("constants")[0]
         out = np.zeros((t.range_size, t.n_boards), np.float32)
         for b in range(t.n_boards):
             blocked = np.isin(lut, t.boards[b]).any(axis=1)
             out[~blocked, b] = p
         return out
+
+    def _get_replay_env(self):
+        if self._replay_env is None:
+            self._replay_env = self._env_bldr.get_new_env(is_evaluating=True, stack_size=self._stack_size)
+            a = self._replay_env.get_args()
+            a.RETURN_PRE_TRANSITION_STATE_IN_INFO = True
+            self._replay_env.set_args(a)
+        return self._replay_env
 
     def _env_state_of(self, idx):
         """public env state of a node (PokerEnv.state_dict layout) with the reference's conventions (PublicTree.py:205-293):
@@ -347,12 +364,7 @@ class PublicTree:
         if idx in self._env_states:
             return self._env_states[idx]
         import copy
-        if self._replay_env is None:
-            self._replay_env = self._env_bldr.get_new_env(is_evaluating=True, stack_size=self._stack_size)
-            a = self._replay_env.get_args()
-            a.RETURN_PRE_TRANSITION_STATE_IN_INFO = True
-            self._replay_env.set_args(a)
-        env = self._replay_env
+        env = self._get_replay_env()
         if idx == 0:
             env.reset()
             st = copy.deepcopy(env.state_dict())

@@ -350,3 +350,35 @@ def test_bench_board_sets_are_disjoint_shards():
     assert len(np.unique(keys)) == len(keys)
     assert np.array_equal(bench.seeded_boards(100, 0, offset=50), bench.seeded_boards(150, 0)[50:])
     assert not np.array_equal(bench.seeded_boards(100, 1), bench.seeded_boards(100, 0))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# partial trees: PublicTree(stop_at_street=...) (PublicTree.py:72,173,185) -- host-side structure, no device needed
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["StandardLeduc", "DiscretizedNLLeduc_POT"])
+@pytest.mark.parametrize("stop", [0, 1])
+def test_partial_tree_matches_reference(name, stop):
+    """the reference's tree with stop_at_street (tests/golden/make_partial_tree_golden.py): same nodes in the same DFS order, leaves
+    where the round reaches the limit, the reference's n_nodes / n_nonterm counters; the solver refuses such a tree"""
+    from pokerrl_amd.game.PublicTree import PublicTree
+    from pokerrl_amd.game.wrappers import HistoryEnvBuilder
+    cls, stack, bets = GAMES[name]
+    args = env_args(cls, stack, bets)
+    g = golden("tree_partial.npz")
+    key = "%s_stop%d_" % (name, stop)
+    tree = PublicTree(env_bldr=HistoryEnvBuilder(env_cls=cls, env_args=args), stack_size=args.starting_stack_sizes_list, stop_at_street=stop)
+    tree.build_tree()
+    t = tree.native_tree
+    kind = t.field("kind")
+    assert np.array_equal(kind, g[key + "kind"])
+    assert np.array_equal(t.field("parent"), g[key + "parent"]) and np.array_equal(t.field("n_children"), g[key + "n_children"])
+    assert np.array_equal(t.field("round"), g[key + "round"]) and np.array_equal(t.field("depth"), g[key + "depth"])
+    assert np.array_equal(np.where(kind == 0, t.field("actor"), -1), g[key + "actor"])
+    assert [tree.n_nodes, tree.n_nonterm] == g[key + "counters"].tolist()
+    leaves = [n for n in tree.nodes() if not n.is_terminal and not n.children]
+    assert leaves and all(n.env_state["current_round"] >= stop for n in leaves if n.p_id_acting_next != tree.CHANCE_ID)
+    assert all(len(n.allowed_actions) >= 2 for n in leaves if n.p_id_acting_next != tree.CHANCE_ID)  # legal actions of an unexpanded node
+    with pytest.raises(RuntimeError, match="partial tree"):
+        tree.compute_ev()
+    with pytest.raises(_native.NativeError):  # "partial tree" on a GPU box, "no usable HIP device" here
+        _native.NativeSolver(t, "plus", 0)
