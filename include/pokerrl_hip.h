@@ -304,6 +304,9 @@ int32_t prl_solver_iterations_many(prl_solver_t** solvers, int32_t n_solvers, in
 int32_t prl_solver_eval_avg(prl_solver_t* solver, float* out_expl2);   /* _evaluate_avg_strats      :218-262 */
 int32_t prl_solver_fill_uniform(prl_solver_t* solver);                 /* PublicTree.fill_uniform_random     */
 int32_t prl_solver_set_strategy(prl_solver_t* solver, const void* strategy_cols, int32_t is_f64); /* fill_with_agent_policy */
+/* float64 data with a per-NODE dtype flag (NULL = all float64): the reference mixes float64 strategies (uniform fill, averages) with
+ * float32 ones (after regret matching) in one tree and the arithmetic dtype follows the node's strategy. LEVELS engine. */
+int32_t prl_solver_set_strategy_mixed(prl_solver_t* solver, const void* strategy_cols, int32_t is_f64, const uint8_t* node_is_f64);
 int32_t prl_solver_update_reach(prl_solver_t* solver);                 /* PublicTree.update_reach_probs      */
 int32_t prl_solver_compute_ev(prl_solver_t* solver);                   /* PublicTree.compute_ev              */
 int32_t prl_solver_exploitability(prl_solver_t* solver, float* out_expl2); /* root.exploitability, raw float32 per seat */

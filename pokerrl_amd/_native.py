@@ -504,6 +504,16 @@ class NativeSolver:
         assert a.shape == (self.n_cols, self.R), (a.shape, (self.n_cols, self.R))
         self._call("prl_solver_set_strategy", _ptr(a), int(a.dtype == np.float64))
 
+    def set_strategy_mixed(self, strategy_cols_f64, node_is_f64):
+        """float64 [n_cols, R] + uint8 [n_nodes]: 1 where the node's strategy is float64 in the reference's sense (else the stored
+        values are float32-representable and the node's arithmetic is float32)"""
+        a = np.ascontiguousarray(strategy_cols_f64, dtype=np.float64)
+        f = np.ascontiguousarray(node_is_f64, dtype=np.uint8)
+        assert a.shape == (self.n_cols, self.R)
+        self._L.prl_solver_set_strategy_mixed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        self._L.prl_solver_set_strategy_mixed.restype = ctypes.c_int32
+        self._call("prl_solver_set_strategy_mixed", _ptr(a), 1, _ptr(f))
+
     def update_reach(self):
         self._call("prl_solver_update_reach")
 

@@ -759,7 +759,15 @@ int32_t prl_solver_fill_uniform(prl_solver_t* s) {  // PublicTree.fill_uniform_r
 // arbitrary strategy, column-major [n_cols][R] (= node.strategy.T per decision node, DFS order); float32 or float64 host data.
 // Equivalent of fill_with_agent_policy / fill_random_random + update_reach_probs (StrategyFiller.py:26-43).
 int32_t prl_solver_set_strategy(prl_solver_t* s, const void* strat, int32_t is_f64) {
+    return prl_solver_set_strategy_mixed(s, strat, is_f64, nullptr);
+}
+
+// node_is_f64 (may be NULL = every node like the array): per NODE, whether its strategy is a float64 array in the reference's tree
+// (uniform fills and averages are float64, regret-matched strategies float32 -- the arithmetic dtype follows it, SURVEY 8a dtype
+// ledger); needs float64 host data. What lets Python-side CFR variants (CFRBase's hook methods) mix both as the reference does.
+int32_t prl_solver_set_strategy_mixed(prl_solver_t* s, const void* strat, int32_t is_f64, const uint8_t* node_is_f64) {
     if (!s || !strat) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
+    if (node_is_f64 && (!is_f64 || s->fused)) { prl_set_error("per-node strategy dtypes: float64 data, LEVELS engine"); return PRL_ERR_ARG; }
     const size_t nc = (size_t)s->full_cols * s->R;
     std::vector<double> tmp;
     const double* src = (const double*)strat;
@@ -781,8 +789,9 @@ int32_t prl_solver_set_strategy(prl_solver_t* s, const void* strat, int32_t is_f
     }
     // LEVELS: the whole array; FUSED: the trunk columns (they precede the board columns)
     PRL_HIP_TRY(hipMemcpyAsync(s->S.strategy, src, (size_t)s->T.n_cols * s->R * sizeof(double), hipMemcpyHostToDevice, s->stream));
-    PRL_HIP_TRY(hipStreamSynchronize(s->stream));  // tmp goes out of scope
-    PRL_HIP_TRY(hipMemsetAsync(s->S.strat_f64, is_f64 ? 1 : 0, (size_t)s->T.n_nodes, s->stream));
+    if (node_is_f64) PRL_HIP_TRY(hipMemcpyAsync(s->S.strat_f64, node_is_f64, (size_t)s->T.n_nodes, hipMemcpyHostToDevice, s->stream));
+    else PRL_HIP_TRY(hipMemsetAsync(s->S.strat_f64, is_f64 ? 1 : 0, (size_t)s->T.n_nodes, s->stream));
+    PRL_HIP_TRY(hipStreamSynchronize(s->stream));  // tmp / the caller's buffers may go away
     s->ev_valid = false;
     return do_update_reach(s, s->S);
 }

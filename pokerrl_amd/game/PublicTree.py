@@ -332,10 +332,17 @@ class PublicTree:
             return
         staged, self._staged = self._staged, {}
         cur = self.solver.get("strategy")
-        f64 = bool(self.solver.get("strat_f64").any()) or any(v.dtype == np.float64 for v in staged.values())
-        for idx, v in staged.items():
+        flags = np.array(self.solver.get("strat_f64"), dtype=np.uint8)
+        for idx, v in staged.items():  # a node keeps the dtype of the array assigned to it, like the reference's node.strategy
             cur[self._first_col[idx]:self._first_col[idx] + self._n_children[idx]] = v.T
-        self.solver.set_strategy(cur if f64 else cur.astype(np.float32))
+            flags[idx] = 1 if v.dtype == np.float64 else 0
+        if self.solver.engine == "fused":
+            f64 = bool(flags.any())
+            self.solver.set_strategy(cur if f64 else cur.astype(np.float32))
+        elif flags.any():
+            self.solver.set_strategy_mixed(cur, flags)
+        else:
+            self.solver.set_strategy(cur.astype(np.float32))
         self._invalidate()
 
     def _chance_strategy(self, idx):
