@@ -149,7 +149,10 @@ int32_t prl_hand_rank_boards_device(const void* d_boards_1d, int32_t n_boards, v
 /* ---------------------------------------------------------------------------------------------------------------- */
 typedef struct prl_tree prl_tree_t;
 
-/* boards: the chance outcomes, one row of `board_len` 1d cards per board, in child order */
+/* boards: the run-outs, one row of `board_len` 1d cards per run-out in deal order. A game that deals once (Leduc, Flop5Holdem) has one
+ * chance level whose children are these rows in order; a game that deals on several streets (hold'em: 3 + 1 + 1) gets one chance level
+ * per street whose children are the distinct prefixes of the listed run-outs. An all-in before the last street of a 2-hole-card game
+ * is dealt out as a chain of chance nodes down to showdown leaves (1-hole-card games keep the reference's run-out terminal). */
 int32_t prl_tree_build(const PrlGame* game, const PrlRules* rules, const int8_t* boards, int32_t n_boards,
                        int32_t board_len, prl_tree_t** out_tree);
 /* PublicTree(stop_at_street = stop_at_round) (PublicTree.py:72,173,185): nodes of a betting round >= stop_at_round are not expanded
@@ -186,6 +189,9 @@ enum {
     PRL_TF_LEVEL_NODES = 18  /* node ids grouped by depth                                       [n_nodes] */
 };
 int32_t prl_tree_get(const prl_tree_t* tree, int32_t field, int32_t* out);
+/* the board table node.board_id indexes: [n_boards][board_len] 1d cards, one row per board PREFIX of every dealing street (cards
+ * not dealt yet = -1); for a game that deals once these are the caller's rows */
+int32_t prl_tree_get_boards(const prl_tree_t* tree, int8_t* out_rows);
 
 
 /* ---------------------------------------------------------------------------------------------------------------- */

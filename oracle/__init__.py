@@ -49,6 +49,7 @@ def lib():
         L.orc_np_sum_f32.argtypes = [vp, i32]
         L.orc_np_sum_f32.restype = ctypes.c_float
         L.orc_prefix_chunked.argtypes = [vp, i32, vp]
+        L.orc_set_chance_weights.argtypes = [vp, vp]
         L.orc_unsupported.argtypes = [vp]
         L.orc_unsupported.restype = i32
         L.orc_set_threads.argtypes = [i32]
@@ -116,8 +117,10 @@ class Oracle:
         boards = np.ascontiguousarray(boards, dtype=np.int8)
         self.boards = boards
         n_ch = int(t["n_children"][t["kind"] == 1][0]) if np.any(t["kind"] == 1) else boards.shape[0]
+        explicit_chance_prob = chance_prob is not None
         if chance_prob is None:
-            chance_prob = chance_prob_f32(n_ch, n_cards, n_hole, boards.shape[1])
+            first_deal = int(np.sum(boards[0] >= 0)) if boards.shape[0] else boards.shape[1]  # rows are board prefixes, level 1 first
+            chance_prob = chance_prob_f32(n_ch, n_cards, n_hole, first_deal)
         if eq_const is None:
             eq_const = eq_const_f32(n_cards, n_hole)
         self.chance_prob, self.eq_const = np.float32(chance_prob), np.float32(eq_const)
@@ -126,6 +129,18 @@ class Oracle:
                                    boards.shape[0], boards.shape[1], *[_p(t[k]) for k in self.FIELDS], _p(boards),
                                    ctypes.c_float(float(self.chance_prob)), ctypes.c_float(float(self.eq_const)))
         self.tree = t
+        # per chance node: 1 / (n_children * C(N' - 2H, k) / C(N', k)) with N' = cards not on the board yet, k = cards dealt there
+        # (one value for a game that deals once; hold'em games deal 3 + 1 + 1)
+        def dealt(row):
+            return 0 if row < 0 else int(np.sum(boards[row] >= 0))
+        w = np.zeros(self.n_nodes, np.float32)
+        for n in np.where(t["kind"] == 1)[0]:
+            before = dealt(int(t["board_id"][n]))
+            child = int(t["child_list"][t["child_start"][n]])
+            k = dealt(int(t["board_id"][child])) - before
+            w[n] = self.chance_prob if (explicit_chance_prob and before == 0) else chance_prob_f32(int(t["n_children"][n]), n_cards - before, n_hole, k)
+        self._chance_w = w
+        lib().orc_set_chance_weights(self._h, _p(w))
         if lib().orc_unsupported(self._h):
             raise NotImplementedError("2-hole-card tree with a showdown terminal before the deal (all-in run-out)")
 

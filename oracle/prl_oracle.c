@@ -213,6 +213,7 @@ typedef struct {
         *first_col, *child_start, *child_list;
     const int8_t* boards;
     float chance_prob, eq_const;
+    float* chance_w;      /* [n_nodes] weight of every outcome of a chance node for a hand it does not block (0 elsewhere) */
     int16_t* hole;        /* [R][2] */
     /* state */
     double* strategy;     /* [n_cols][R] */
@@ -258,6 +259,9 @@ Orc* orc_create(int n_nodes, int n_cols, int R, int n_hole, int n_cards, int n_s
 #undef DUP
     o->chance_prob = chance_prob;
     o->eq_const = eq_const;
+    o->chance_w = (float*)calloc((size_t)n_nodes, sizeof(float));
+    for (int n = 0; n < n_nodes; ++n)
+        if (kind[n] == K_CHANCE) o->chance_w[n] = chance_prob; /* one dealing round; orc_set_chance_weights overrides per node */
     /* all-in before the deal on a 2-card tree (ValueFiller.py:160-175 generalised) is not restated: refuse the tree */
     if (n_hole == 2)
         for (int n = 0; n < n_nodes; ++n)
@@ -297,6 +301,7 @@ void orc_destroy(Orc* o) {
     free((void*)o->acted_last); free((void*)o->round); free((void*)o->board_id); free((void*)o->main_pot);
     free((void*)o->n_children); free((void*)o->first_col); free((void*)o->child_start); free((void*)o->child_list);
     free((void*)o->boards);
+    free(o->chance_w);
     free(o->hole); free(o->strategy); free(o->strat_f64); free(o->reach); free(o->ev); free(o->ev_br); free(o->br_idx);
     free(o->regret); free(o->avg_sum); free(o->avg); free(o->avg_f64); free(o->plans); free(o->plan_ready); free(o->tmp_ranks);
     free(o);
@@ -323,8 +328,12 @@ static const Plan* get_plan(Orc* o, int board_id) {
     const int R = o->R;
     const int8_t* board = board_id < 0 ? NULL : o->boards + (size_t)board_id * o->board_len;
     int32_t* rk = (int32_t*)malloc(sizeof(int32_t) * (size_t)R); /* plans of different boards are built by different threads */
-    if (board) ranks_on_board(o, board, rk);
-    else for (int h = 0; h < R; ++h) rk[h] = 0; /* no board: hand-index order, one tie group (fold nodes only) */
+    /* a row of the board table may be a PREFIX (cards not dealt yet are -1): like "no board" it has no hand ranks -- hand-index
+     * order, one tie group -- but the hands it blocks are out (fold terminals before the last street) */
+    int n_dealt = 0;
+    if (board) for (int i = 0; i < o->board_len; ++i) n_dealt += board[i] >= 0;
+    if (board && n_dealt == o->board_len) ranks_on_board(o, board, rk);
+    else for (int h = 0; h < R; ++h) rk[h] = (board && hand_blocked(o, h, board, o->board_len)) ? -1 : 0;
     p->sh = (int16_t*)malloc(sizeof(int16_t) * R);
     p->pos = (int16_t*)malloc(sizeof(int16_t) * R);
     p->gs = (int16_t*)malloc(sizeof(int16_t) * R);
@@ -348,8 +357,7 @@ static const Plan* get_plan(Orc* o, int board_id) {
         for (int k = i; k < j; ++k) { p->gs[k] = (int16_t)i; p->ge[k] = (int16_t)j; }
         i = j;
     }
-    int n_board = board ? o->board_len : 0;
-    p->n_t = o->n_cards - 1 - n_board;
+    p->n_t = o->n_cards - 1 - n_dealt;
     p->cl = (int16_t*)malloc(sizeof(int16_t) * (size_t)o->n_cards * (o->n_cards - 1));
     for (int c = 0; c < o->n_cards; ++c) {
         int16_t* row = p->cl + (size_t)c * (o->n_cards - 1);
@@ -570,7 +578,7 @@ static void update_reach(Orc* o, int node) {
             const int8_t* board = o->boards + (size_t)o->board_id[c] * o->board_len;
             for (int p = 0; p < 2; ++p)
                 for (int h = 0; h < R; ++h) {
-                    float w = hand_blocked(o, h, board, o->board_len) ? 0.f : o->chance_prob; /* StrategyFiller.py:159-166 */
+                    float w = hand_blocked(o, h, board, o->board_len) ? 0.f : o->chance_w[node]; /* StrategyFiller.py:159-166 */
                     V2(o, reach, c, p)[h] = V2(o, reach, node, p)[h] * w;
                 }
             update_reach(o, c);
@@ -853,6 +861,7 @@ uint8_t* orc_avg_f64(Orc* o) { return o->avg_f64; }
 int32_t* orc_br_idx(Orc* o) { return o->br_idx; }
 float* orc_expl(Orc* o) { return o->expl; }
 int orc_iter(Orc* o) { return o->iter; }
+void orc_set_chance_weights(Orc* o, const float* w) { memcpy(o->chance_w, w, sizeof(float) * (size_t)o->n_nodes); }
 int orc_unsupported(Orc* o) { return o->unsupported; }
 /* worker threads for the per-board / per-node loops (results do not depend on it); bench.py's cpu_baseline uses 1 */
 void orc_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }

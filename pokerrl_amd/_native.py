@@ -391,7 +391,12 @@ class NativeTree:
         self.n_boards, self.board_len = int(info[TI_N_BOARDS]), int(info[TI_BOARD_LEN])
         self.n_levels, self.range_size = int(info[TI_N_LEVELS]), int(info[TI_RANGE_SIZE])
         self.n_decision, self.n_terminal = int(info[TI_N_DECISION]), int(info[TI_N_TERMINAL])
-        self.boards = boards
+        self.boards = boards  # the caller's run-outs
+        rows = np.empty((self.n_boards, self.board_len), np.int8)  # the board table node.board_id indexes (prefix rows, -1 = not dealt)
+        self._L.prl_tree_get_boards.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._L.prl_tree_get_boards.restype = ctypes.c_int32
+        check(self._L.prl_tree_get_boards(self._h, _ptr(rows)), self._L)
+        self.board_rows = rows
         self._cache = {}
 
     @classmethod

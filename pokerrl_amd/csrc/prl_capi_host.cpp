@@ -151,6 +151,12 @@ void prl_tree_destroy(prl_tree_t* tree) { delete tree; }
 
 const PrlFlatTree* prl_tree_flat(const prl_tree_t* tree) { return tree ? &tree->t : nullptr; }
 
+int32_t prl_tree_get_boards(const prl_tree_t* tree, int8_t* out) {
+    if (!tree || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
+    memcpy(out, tree->t.boards.data(), tree->t.boards.size());
+    return PRL_OK;
+}
+
 int32_t prl_tree_info(const prl_tree_t* tree, int32_t* out) {
     if (!tree || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
     const PrlFlatTree& t = tree->t;

@@ -20,17 +20,23 @@
 #include "prl_solver_types.h"
 
 PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
-                                 int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx) {
+                                 int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx, int32_t* plan_ndealt) {
     uint32_t* keys = (uint32_t*)prl_smem();  // [2048]
     int* n_live_s = (int*)(keys + 2048);
     const int tid = (int)prl_tid(), nt = (int)prl_nthreads();
     for (int b = (int)prl_bid(); b < n_plans; b += (int)prl_nblocks()) {
-        const bool has_board = b < T.n_boards;
+        // a row of the board table is a board PREFIX: cards not dealt yet are -1. Only a complete board has hand ranks; a prefix
+        // (and the "no board" plan, b == n_boards) orders the live hands by hand index in one tie group -- what fold terminals
+        // before the last street need: blockers, no ranks.
+        const bool has_row = b < T.n_boards;
+        int n_dealt = 0;
         uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         unsigned long long on_board = 0ull;
-        if (has_board) {
+        if (has_row) {
             for (int i = 0; i < T.board_len; ++i) {
                 int c = T.boards[(size_t)b * T.board_len + i];
+                if (c < 0) continue;
+                ++n_dealt;
                 uint32_t bit = 1u << (c >> 2);
                 int su = c & 3;
                 s0 |= su == 0 ? bit : 0u;
@@ -40,12 +46,14 @@ PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, in
                 on_board |= 1ull << c;
             }
         }
+        const bool has_board = has_row && n_dealt == T.board_len;  // ranks exist
         for (int h = tid; h < 2048; h += nt) {
             uint32_t key = 0xFFFFFFFFu;
             if (h < T.R) {
                 int c1 = T.hole[2 * h], c2 = T.hole[2 * h + 1];
-                if (!has_board) key = (uint32_t)h;
-                else if (!((on_board >> c1) & 1ull) && !((on_board >> c2) & 1ull)) {
+                const bool blocked = ((on_board >> c1) & 1ull) || ((on_board >> c2) & 1ull);
+                if (!has_board) key = blocked ? 0xFFFFFFFFu : (uint32_t)h;
+                else if (!blocked) {
                     uint32_t b1 = 1u << (c1 >> 2), b2 = 1u << (c2 >> 2);
                     int u1 = c1 & 3, u2 = c2 & 3;
                     int32_t r = prl_rank7_masks(s0 | (u1 == 0 ? b1 : 0u) | (u2 == 0 ? b2 : 0u), s1 | (u1 == 1 ? b1 : 0u) | (u2 == 1 ? b2 : 0u),
@@ -111,7 +119,8 @@ PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, in
         if (tid == 0) plan_nlive[b] = n;
         prl_sync();
         // records of the fused board pass (row16 order with 3 entries per lane: lists of 33..48 entries, at most 48 live cards)
-        const int n_t = T.n_cards - 1 - (has_board ? T.board_len : 0);
+        if (tid == 0) plan_ndealt[b] = n_dealt;
+        const int n_t = T.n_cards - 1 - n_dealt;
         if (plan_clx && has_board && T.n_cards - T.board_len <= PRL_CLX_SLOTS && n_t > 32 && n_t <= 48) {
             uint32_t* clx = plan_clx + (size_t)b * PRL_CLX_WORDS;
             const uint32_t inv = (uint32_t)PRL_CLX_ZERO_POS | PRL_CLX_HEAD | PRL_CLX_TAIL;
@@ -146,8 +155,9 @@ PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, in
 }
 
 void prl_launch_plan_build(const PrlDevTree& T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
-                           int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx, void* stream) {
+                           int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx, int32_t* plan_ndealt,
+                           void* stream) {
     int grid = n_plans < 32768 ? n_plans : 32768;
     PRL_LAUNCH(prl_k_plan_build, grid, 256, 2048 * sizeof(uint32_t) + 16, stream, T, n_plans, plan_sh, plan_pos, plan_gs, plan_ge, plan_cl,
-               plan_nlive, plan_hgs, plan_hge, plan_clx);
+               plan_nlive, plan_hgs, plan_hge, plan_clx, plan_ndealt);
 }

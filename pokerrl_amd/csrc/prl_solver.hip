@@ -389,7 +389,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     const PrlRules& r = full.rules;
     if (r.n_hole_cards == 1 && (r.range_size > 128 || full.board_len != 1)) { prl_set_error("1-card games: R <= 128, 1 board card"); return PRL_ERR_UNSUPPORTED; }
     if (r.n_hole_cards == 2 && (r.n_cards != 52 || r.n_suits != 4 || full.board_len != 5 || r.rank_rule != 2)) {
-        prl_set_error("2-card games: 52-card deck with 5-card boards (Flop5Holdem) only");
+        prl_set_error("2-card games: 52-card deck with 5-card run-outs (Flop5Holdem; hold'em games dealing 3 + 1 + 1) only");
         return PRL_ERR_UNSUPPORTED;
     }
     for (int i = 0; i < full.n_nodes; ++i)
@@ -461,7 +461,23 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     int n_chance_children = full.n_boards;
     for (int i = 0; i < full.n_nodes; ++i)
         if (full.kind[i] == PRL_NODE_CHANCE) { n_chance_children = full.n_children[i]; break; }
-    T.chance_prob = chance_prob_f32(n_chance_children * world, r.n_cards, r.n_hole_cards, full.board_len);  // global number of boards
+    {   // per chance node: the weight of each of its outcomes for a hand the outcome does not block. Generalised StrategyFiller.py:166
+        // (SURVEY Appendix C): 1 / (n_children * C(N' - 2H, k) / C(N', k)), N' = cards not on the board yet, k = cards dealt here
+        auto dealt = [&](int row) { int n = 0; if (row >= 0) for (int c = 0; c < full.board_len; ++c) n += full.boards[(size_t)row * full.board_len + c] >= 0; return n; };
+        std::vector<float> w(ft.n_nodes, 0.f);
+        bool first = true;
+        for (int i = 0; i < full.n_nodes; ++i) {
+            if (full.kind[i] != PRL_NODE_CHANCE) continue;
+            const int before = dealt(full.board_id[i]);
+            const int child = full.child_list[full.child_start[i]];
+            const int k = dealt(full.board_id[child]) - before;
+            const float p = chance_prob_f32(full.n_children[i] * world, r.n_cards - before, r.n_hole_cards, k);  // world: global number of boards
+            if (first) { T.chance_prob = p; first = false; }
+            if (!fused && i < ft.n_nodes) w[i] = p;
+        }
+        if (first) T.chance_prob = chance_prob_f32(n_chance_children * world, r.n_cards, r.n_hole_cards, full.board_len);
+        FAIL_IF(dev_upload(s, &T.chance_w, w));
+    }
     T.eq_const = eq_const_f32(r.n_cards, r.n_hole_cards);
 
     std::vector<int32_t> term, np[2];
@@ -483,24 +499,25 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         T.cl_stride = T.n_cards * (T.n_cards - 1);
         int16_t *sh, *pos, *gs, *ge, *cl, *hgs, *hge;
         uint32_t* clx = nullptr;
-        int32_t* nl;
+        int32_t *nl, *nd;
         FAIL_IF(dev_alloc(s, &sh, (size_t)n_plans * T.plan_stride));
         FAIL_IF(dev_alloc(s, &pos, (size_t)n_plans * T.plan_stride));
         FAIL_IF(dev_alloc(s, &gs, (size_t)n_plans * T.plan_stride));
         FAIL_IF(dev_alloc(s, &ge, (size_t)n_plans * T.plan_stride));
         FAIL_IF(dev_alloc(s, &cl, (size_t)n_plans * T.cl_stride));
         FAIL_IF(dev_alloc(s, &nl, (size_t)n_plans));
+        FAIL_IF(dev_alloc(s, &nd, (size_t)n_plans));
         FAIL_IF(dev_alloc(s, &hgs, (size_t)n_plans * T.plan_stride));
         FAIL_IF(dev_alloc(s, &hge, (size_t)n_plans * T.plan_stride));
         if (fused) FAIL_IF(dev_alloc(s, &clx, (size_t)n_plans * PRL_CLX_WORDS));
         PrlDevTree Tb = T;
         Tb.n_boards = full.n_boards;
-        prl_launch_plan_build(Tb, n_plans, sh, pos, gs, ge, cl, nl, hgs, hge, clx, s->stream);
+        prl_launch_plan_build(Tb, n_plans, sh, pos, gs, ge, cl, nl, hgs, hge, clx, nd, s->stream);
         // the LEVELS kernels address plan `board_id`, or plan index T.n_boards for "no board"; in the FUSED engine the
         // trunk tree has n_boards == 0, so its plan pointers are based at the last (no-board) plan
         const size_t off = fused ? (size_t)full.n_boards : 0;
         T.plan_sh = sh + off * T.plan_stride; T.plan_pos = pos + off * T.plan_stride; T.plan_gs = gs + off * T.plan_stride;
-        T.plan_ge = ge + off * T.plan_stride; T.plan_cl = cl + off * T.cl_stride; T.plan_nlive = nl + off;
+        T.plan_ge = ge + off * T.plan_stride; T.plan_cl = cl + off * T.cl_stride; T.plan_nlive = nl + off; T.plan_ndealt = nd + off;
         T.plan_hgs = hgs + off * T.plan_stride; T.plan_hge = hge + off * T.plan_stride; T.plan_clx = clx ? clx + off * PRL_CLX_WORDS : nullptr;
         if (fused) {
             PrlFhpParams& fp = s->fp;

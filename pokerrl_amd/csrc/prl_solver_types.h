@@ -38,7 +38,8 @@ struct PrlDevTree {
         *child_start, *child_list, *level_nodes;
     const int8_t* boards;   // [n_boards][board_len]
     const int16_t* hole;    // [R][2] 1d cards of every hand (second = -1 for 1-card games)
-    float chance_prob;      // generalised StrategyFiller.py:166 constant
+    float chance_prob;      // generalised StrategyFiller.py:166 constant of the FIRST chance node (what the fused engine's one level uses)
+    const float* chance_w;  // [n_nodes] the same per chance node (trees that deal on several streets: fewer cards left, other k); 0 elsewhere
     float eq_const;         // generalised ValueFiller.py:19 constant
     // showdown plans of 2-card games, one per board + one "no board" plan at index n_boards (see prl_plan_kernels.hip)
     int32_t plan_stride;         // = R
@@ -49,6 +50,7 @@ struct PrlDevTree {
     const int16_t* plan_ge;      // [n_plans][R]   one past the last position of the tie group
     const int16_t* plan_cl;      // [n_plans][n_cards][n_cards-1] positions of the hands containing card c, ascending; -1 pad
     const int32_t* plan_nlive;   // [n_plans]
+    const int32_t* plan_ndealt;  // [n_plans]   board cards of the plan's row (0 for the no-board plan): its card lists hold n_cards - 1 - that many hands
     // hand-domain / flagged copies used by the fused board kernels (prl_fhp_kernels.hip)
     const int16_t* plan_hgs;     // [n_plans][R]   gs[pos[h]] (0 for blocked hands)
     const int16_t* plan_hge;     // [n_plans][R]   ge[pos[h]]

@@ -2,6 +2,7 @@
 #include "prl_tree.h"
 
 #include <algorithm>
+#include <map>
 
 namespace {
 
@@ -11,6 +12,28 @@ struct Builder {
     int n_boards, board_len;
     int stop_at_round;  // nodes of a round >= this are left unexpanded (PublicTree.py:173: stop_at_street); INT_MAX = full tree
     int err = 0;
+    // chance outcomes: the caller's run-outs cut into per-street prefixes (prl_tree.h). kids[(round, parent row)] = the rows of the
+    // distinct extensions dealt in the transition to `round`, in order of first appearance
+    std::map<std::pair<int, int>, std::vector<int>> kids;
+    int n_deal_levels = 0;
+    bool is_last_round(int r) const { return r == t->game.n_rounds - 1; }
+
+    // an all-in before the last street on a 2-hole-card tree: the reference pays the run-out average (ValueFiller.py:160-175, 1-card
+    // only). Here the remaining streets are dealt as a chain of chance nodes without decisions, showdown leaves at the end: the same
+    // expectation under the same chance weights a checked-down hand would see, and no special equity kernel.
+    void expand_runout(int parent, int child_idx, int action, int acted_last, int round_now, int row, int pot, int depth) {
+        if (err) return;
+        if (is_last_round(round_now)) {
+            new_node(PRL_NODE_TERM_SHOWDOWN, -1, parent, child_idx, action, acted_last, round_now, row, pot, depth);
+            return;
+        }
+        const int ch = new_node(PRL_NODE_CHANCE, -1, parent, child_idx, action, acted_last, round_now, row, pot, depth);
+        auto it = kids.find({round_now + 1, row});
+        if (it == kids.end() || it->second.empty()) { err = PRL_ERR_ARG; t->error = "no run-out listed below a board prefix"; return; }
+        t->n_children[ch] = (int)it->second.size();
+        for (size_t k = 0; k < it->second.size(); ++k) expand_runout(ch, (int)k, -1, -2, round_now + 1, it->second[k], pot, depth + 1);
+        t->subtree_size[ch] = t->n_nodes - ch;
+    }
 
     int new_node(int kind, int actor, int parent, int child_idx, int action, int acted_last, int round, int board_id,
                  int main_pot, int depth) {
@@ -71,35 +94,28 @@ struct Builder {
             if (info.is_terminal) {
                 // state before payouts; round / board stay the parent's (PublicTree.py:244-251)
                 int kind = (legal[i] == PRL_FOLD) ? PRL_NODE_TERM_FOLD : PRL_NODE_TERM_SHOWDOWN;
-                if (kind == PRL_NODE_TERM_SHOWDOWN && t->board_id[id] < 0 && t->rules.n_hole_cards != 1) {
-                    // all-in before the deal: the reference averages the showdown over every run-out (ValueFiller.py:160-175,
-                    // 1-card ranges only); for 2-card ranges that needs run-out equity tables, which this engine does not have.
-                    // Refuse the tree instead of valuing the terminal at 0.
-                    err = PRL_ERR_UNSUPPORTED;
-                    t->error = "showdown terminal before the deal (all-in run-out) on a 2-hole-card tree is not supported";
-                    return;
+                if (kind == PRL_NODE_TERM_SHOWDOWN && !is_last_round(t->round[id]) && t->rules.n_hole_cards != 1) {
+                    expand_runout(id, i, legal[i], actor, t->round[id], t->board_id[id], info.pot_before_payout, depth + 1);
+                    if (err) return;
+                    continue;
                 }
                 new_node(kind, -1, id, i, legal[i], actor, t->round[id], t->board_id[id], info.pot_before_payout, depth + 1);
             } else if (info.chance_acts) {
-                if (t->game.n_rounds != 2 || s2.round != 1) {
-                    err = PRL_ERR_UNSUPPORTED;
-                    t->error = "public trees with more than one chance level are not supported yet";
-                    return;
-                }
+                auto it = kids.find({(int)s2.round, t->board_id[id]});
+                if (it == kids.end() || it->second.empty()) { err = PRL_ERR_ARG; t->error = "no run-out listed below a board prefix"; return; }
+                const std::vector<int>& rows = it->second;
                 int ch = new_node(PRL_NODE_CHANCE, -1, id, i, legal[i], actor, t->round[id], t->board_id[id], st.main_pot, depth + 1);
-                t->n_children[ch] = n_boards;
+                t->n_children[ch] = (int)rows.size();
                 int s = -1, e = -1, col_s = -1, col_e = -1;
-                for (int b = 0; b < n_boards; ++b) {
-                    if (b == 0) {
-                        s = t->n_nodes;
-                        col_s = t->n_cols;
-                        int c = new_node(PRL_NODE_DECISION, s2.cur, ch, 0, -1, -2, s2.round, 0, s2.main_pot, depth + 2);
+                for (size_t b = 0; b < rows.size(); ++b) {
+                    if (b == 0 || n_deal_levels > 1) {  // with deeper chance levels the subtree depends on the row: expand every one
+                        if (b == 0) { s = t->n_nodes; col_s = t->n_cols; }
+                        int c = new_node(PRL_NODE_DECISION, s2.cur, ch, (int)b, -1, -2, s2.round, rows[b], s2.main_pot, depth + 2);
                         expand(c, s2);
                         if (err) return;
-                        e = t->n_nodes;
-                        col_e = t->n_cols;
+                        if (b == 0) { e = t->n_nodes; col_e = t->n_cols; }
                     } else {
-                        replicate(s, e, col_s, col_e, ch, b, b);
+                        replicate(s, e, col_s, col_e, ch, rows[b], (int)b);  // betting never looks at the cards: copy the first subtree
                     }
                 }
                 t->subtree_size[ch] = t->n_nodes - ch;
@@ -123,11 +139,44 @@ int prl_build_flat_tree(const PrlGame& game, const PrlRules& rules, const int8_t
     t.game = game;
     if (n_boards <= 0 || board_len <= 0 || board_len > PRL_MAX_BOARD_CARDS) { t.error = "bad board table"; return PRL_ERR_ARG; }
     if (rules.n_hole_cards != 1 && rules.n_hole_cards != 2) { t.error = "n_hole_cards must be 1 or 2"; return PRL_ERR_UNSUPPORTED; }
-    t.n_boards = n_boards;
+    // The caller lists RUN-OUTS: one row of board_len cards per run-out, in deal order. The chance outcomes of the transition to
+    // round r are the distinct prefixes of length (cards out after r) below the current prefix. Every prefix of every dealing round
+    // gets a row of the board table (cards not dealt yet = -1); with one dealing round the rows are the caller's rows, in order.
     t.board_len = board_len;
-    t.boards.assign(boards, boards + (size_t)n_boards * board_len);
-
+    t.n_runouts = n_boards;
     Builder b{&t, boards, n_boards, board_len, stop_at_round < 0 ? 0x7FFFFFFF : stop_at_round};
+    {
+        int out = 0, prev_len = 0;
+        std::map<std::vector<int8_t>, int> row_of;  // prefix -> row
+        std::vector<int> parent_row(n_boards, -1);  // per run-out: the row of its prefix at the previous dealing round
+        for (int r = 1; r < game.n_rounds; ++r) {
+            const int k = rules.board_cards_in_round[r];
+            if (k <= 0) continue;
+            out += k;
+            if (out > board_len) { t.error = "run-outs are shorter than the cards the game deals"; return PRL_ERR_ARG; }
+            b.n_deal_levels++;
+            for (int i = 0; i < n_boards; ++i) {
+                std::vector<int8_t> key(boards + (size_t)i * board_len, boards + (size_t)i * board_len + out);
+                key.push_back((int8_t)r);
+                auto it = row_of.find(key);
+                int row;
+                if (it == row_of.end()) {
+                    row = (int)(t.boards.size() / board_len);
+                    row_of.emplace(key, row);
+                    for (int c = 0; c < board_len; ++c) t.boards.push_back(c < out ? boards[(size_t)i * board_len + c] : (int8_t)-1);
+                    b.kids[{r, parent_row[i]}].push_back(row);
+                } else {
+                    row = it->second;
+                }
+                parent_row[i] = row;
+            }
+            prev_len = out;
+        }
+        (void)prev_len;
+        if (out != board_len) { t.error = "run-outs are longer than the cards the game deals"; return PRL_ERR_ARG; }
+        t.n_boards = (int)(t.boards.size() / board_len);
+        if (b.n_deal_levels == 1 && t.n_boards != n_boards) { t.error = "duplicate boards"; return PRL_ERR_ARG; }
+    }
     PrlEnvState st;
     prl_env_reset(game, st);
     // the root is the first actor's decision node (PublicTree.py:111-124); its `action` is the reference's "CHANCE"

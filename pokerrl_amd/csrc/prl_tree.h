@@ -21,7 +21,8 @@ struct PrlFlatTree {
     PrlGame game;
     int32_t n_nodes = 0;
     int32_t n_cols = 0;       // sum over decision nodes of their number of actions ("action columns")
-    int32_t n_boards = 0;     // rows of the board table
+    int32_t n_boards = 0;     // rows of the board table: one per board PREFIX of every dealing round (cards not dealt yet = -1)
+    int32_t n_runouts = 0;    // the caller's rows (complete run-outs); == n_boards when the game deals once
     int32_t board_len = 0;    // cards per board row
     int32_t n_levels = 0;
     // per node
@@ -38,7 +39,10 @@ struct PrlFlatTree {
     std::string error;
 };
 
-// Builds the full public tree of a 2-round game (one chance level: Leduc family, Flop5Holdem). Returns 0 or PRL_ERR_*.
+// Builds the public tree. `boards` lists run-outs (board_len cards each, in deal order); a game that deals on several streets
+// (LimitHoldem: 3 + 1 + 1) gets one chance level per street whose children are the distinct prefixes of the listed run-outs.
+// An all-in before the last street of a 2-hole-card game becomes a chain of chance nodes down to showdown leaves.
+// Returns 0 or PRL_ERR_*.
 // stop_at_round >= 0: nodes whose betting round is >= stop_at_round are not expanded (PublicTree's stop_at_street,
 // PublicTree.py:72,173,185); such a partial tree carries structure and states only -- the solver refuses it.
 int prl_build_flat_tree(const PrlGame& game, const PrlRules& rules, const int8_t* boards, int n_boards, int board_len,

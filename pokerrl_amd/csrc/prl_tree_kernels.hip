@@ -118,7 +118,7 @@ PRL_DEV PRL_INLINE void prl_reach_level_body(const PrlDevTree& T, const PrlDevSt
             rc[(size_t)a * T.R + h] = v;
             rc[(size_t)(1 - a) * T.R + h] = rp[(size_t)(1 - a) * T.R + h];
         } else {  // chance: both seats' reach is scaled by the board probability, 0 for blocked hands
-            const float w = prl_hand_blocked(T, h, T.board_id[node]) ? 0.f : T.chance_prob;
+            const float w = prl_hand_blocked(T, h, T.board_id[node]) ? 0.f : T.chance_w[par];
             rc[h] = rp[h] * w;
             rc[(size_t)T.R + h] = rp[(size_t)T.R + h] * w;
         }
@@ -196,7 +196,7 @@ PRL_DEV PRL_INLINE void prl_terminal_equity_2card(const PrlDevTree& T, const flo
     const int16_t* ge = T.plan_ge + (size_t)plan * T.plan_stride;
     const int16_t* cl = T.plan_cl + (size_t)plan * T.cl_stride;
     const int n = T.plan_nlive[plan];
-    const int n_t = T.n_cards - 1 - (plan < T.n_boards ? T.board_len : 0);
+    const int n_t = T.n_cards - 1 - T.plan_ndealt[plan];
     const int tid = (int)prl_tid(), nt = (int)prl_nthreads();
     for (int i = tid; i < n; i += nt) y[i] = x[sh[i]];
     prl_sync();

@@ -380,7 +380,8 @@ class PublicTree:
             before = self._env_state_of(int(self._parent[pending]))
             env.load_state_dict(copy.deepcopy(before))
             env.step(int(self._action[pending]))  # sweeps the bets and opens the next round (its random deal is replaced below)
-            board_1d = np.asarray(self._native_tree.boards[self._board_id[idx]])
+            board_1d = np.asarray(self._native_tree.board_rows[self._board_id[idx]])
+            board_1d = board_1d[board_1d >= 0]  # a row of the board table is a prefix: the cards dealt so far
             env.board[:] = before[EnvDictIdxs.board_2d]
             env.board[:len(board_1d)] = self._env_bldr.lut_holder.get_2d_cards(board_1d)
             env.deck.load_state_dict(copy.deepcopy(before[EnvDictIdxs.deck]))

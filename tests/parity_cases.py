@@ -18,13 +18,17 @@ STATE_FIELDS = ("reach", "ev", "ev_br", "strategy", "strat_f64", "regret", "avg"
 RANK_RULE = {"StandardLeduc": 0, "BigLeduc": 1, "DiscretizedNLLeduc_POT": 0, "DiscretizedNLLeduc_B3_short": 0}
 
 
-def make_pair(L, game_cls, stack, bets, boards, variant, delay=0):
+def make_pair(L, game_cls, stack, bets, boards, variant, delay=0, max_raises=None):
     """(NativeTree, NativeSolver, Oracle) on the same flat tree (the product's builder feeds the oracle)."""
     args = env_args(game_cls, stack, bets)
-    t = _native.NativeTree(game_cls.native_game(args), game_cls.native_rules(), boards, _lib=L)
+    game = game_cls.native_game(args)
+    if max_raises is not None:  # a smaller betting tree than MAX_N_RAISES_PER_ROUND gives
+        for i, v in enumerate(max_raises):
+            game.max_raises[i] = v
+    t = _native.NativeTree(game, game_cls.native_rules(), boards, _lib=L)
     s = _native.NativeSolver(t, variant, delay, engine="levels", _lib=L)  # every per-node vector is compared below
     r = game_cls.RULES
-    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS,
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS,
                       r._RANK_RULE)
     o.cfr_reset(_native.VARIANTS[variant], delay)
     c = s.get("constants")
@@ -113,6 +117,50 @@ def check_fhp_vs_oracle(L, n_boards, variant, n_iters, check_fields=STATE_FIELDS
     return s, o
 
 
+def multistreet_runouts(n_flops, n_turns, n_rivers, seed=9):
+    """run-outs of a hold'em game that deals 3 + 1 + 1: n_flops flops, below each n_turns turn cards, below each n_rivers river cards
+    (deal order = row order, no card twice in a row)"""
+    rng = np.random.RandomState(seed)
+    rows = []
+    for _ in range(n_flops):
+        flop = rng.choice(52, 3, replace=False)
+        rest = [c for c in rng.permutation(52) if c not in flop]
+        for t in rest[:n_turns]:
+            rest2 = [c for c in rng.permutation(52) if c not in flop and c != t]
+            for r in rest2[:n_rivers]:
+                rows.append(list(flop) + [t, r])
+    return np.array(rows, np.int8)
+
+
+def check_multistreet_vs_oracle(L, game_cls, stack, bets, runouts, variant, n_iters, expect_runout_chain=False, max_raises=None):
+    """public trees of games that deal on several streets (one chance level per street, children = the distinct prefixes
+    of the listed run-outs), incl. all-in run-outs dealt as chance chains: every per-node vector, regrets, averages and the
+    exploitability of the level-synchronous engine against the oracle, bit for bit, plus the structural invariants."""
+    t, s, o = make_pair(L, game_cls, stack, bets, runouts, variant, max_raises=max_raises)
+    kind, bid, rnd, par = t.field("kind"), t.field("board_id"), t.field("round"), t.field("parent")
+    n_chance_levels = len({int(np.sum(t.board_rows[bid[c]] >= 0)) for c in np.where(par >= 0)[0] if kind[par[c]] == 1})
+    assert n_chance_levels == sum(1 for k in game_cls.native_rules().board_cards_in_round[1:game_cls.native_rules().n_rounds] if k > 0)
+    assert t.n_boards > len(runouts) or n_chance_levels == 1          # prefix rows of every street
+    sd = np.where(kind == 3)[0]
+    assert np.all(np.sum(t.board_rows[bid[sd]] >= 0, axis=1) == t.board_len)  # every showdown sits on a complete board
+    if expect_runout_chain:
+        assert np.any((kind == 1) & (kind[np.maximum(par, 0)] == 1))      # a chance node below a chance node: the all-in run-out
+    assert s.engine == "levels"
+    assert_state_equal(s, o, "multistreet it0")
+    for it in range(1, n_iters + 1):
+        s.iteration()
+        o.cfr_iteration()
+        assert_state_equal(s, o, "multistreet it%d" % it)
+        assert np.array_equal(s.eval_avg(), o.eval_avg())
+    # ValueFiller.py:98: zero-sum at every node (float64 accumulation of the float32 products)
+    ev, reach = s.get("ev"), s.get("reach")
+    zs = np.sum(ev.astype(np.float64) * reach.astype(np.float64), axis=(1, 2))
+    assert np.max(np.abs(zs)) < 1e-3
+    e = s.exploitability()
+    assert np.all(e >= -1e-3)
+    return t, s, o
+
+
 def check_br_of_given_strategy(L, gkey, seed, f64):
     """LocalBRMaster semantics (LocalBRMaster.py:67-80): fill an arbitrary strategy, reach, EV + best response."""
     cls, stack, bets = GAMES[gkey]
@@ -183,7 +231,7 @@ def check_fused_vs_oracle(L, n_boards, n_iters, delay=0, variant="plus", stack=2
     assert t.n_nodes == 5 + nodes_per_board * n_boards
     s = _native.NativeSolver(t, variant, delay, engine="auto", _lib=L)  # AUTO must pick the fused engine for a registered shape
     assert s.engine == "fused"
-    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, 2, 52, 4, 2)
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, 2, 52, 4, 2)
     o.cfr_reset(VARIANT_ID[variant], delay)
     assert np.array_equal(s.exploitability(), o.exploitability)
     fields = FUSED_FIELDS + ("strategy",) + (() if variant == "plus" else ("avg_sum",))
@@ -223,7 +271,7 @@ def check_fused_br_vs_oracle(L, n_boards, seed=3):
     args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
     t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
     s = _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
-    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, 2, 52, 4, 2)
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, 2, 52, 4, 2)
     o.cfr_reset(1, 0)
     nt = t.n_cols - 14 * n_boards
     for f64 in (False, True):
@@ -251,7 +299,7 @@ def check_fused_batched_vs_oracle(L, n_boards, n_iters, delay=0, variant="plus")
     args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
     t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
     s = _native.NativeSolver(t, variant, delay, engine="fused", _lib=L)
-    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, 2, 52, 4, 2)
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, 2, 52, 4, 2)
     o.cfr_reset(VARIANT_ID[variant], delay)
     want = [np.array(o.exploitability, np.float32)]
     for _ in range(n_iters):

@@ -117,6 +117,26 @@ def test_emu_br_of_random_strategy(L):
     pc.check_br_of_given_strategy(L, "StandardLeduc", 1, f64=False)
 
 
+def test_emu_multistreet_limit_holdem_tree(L):
+    """LimitHoldem (pre-flop, flop, turn, river; games.py:134-167) over 2 flops x 2 turns x 1 river: three chance levels"""
+    from pokerrl_amd.game import games as G
+    pc.check_multistreet_vs_oracle(L, G.LimitHoldem, 48, None, pc.multistreet_runouts(2, 2, 2), "plus", 1, max_raises=(1, 1, 0, 0))  # 130 nodes
+
+
+def test_emu_multistreet_short_stack_run_outs(L):
+    """4-chip stacks: all-ins on every street, each dealt out as a chain of chance nodes down to showdown leaves (41 chance nodes)"""
+    from pokerrl_amd.game import games as G
+    pc.check_multistreet_vs_oracle(L, G.LimitHoldem, 4, None, pc.multistreet_runouts(2, 2, 1), "vanilla", 1, expect_runout_chain=True)
+
+
+def test_emu_all_in_before_the_deal_is_dealt_out_as_a_chance_chain(L):
+    """Flop5Holdem with 250-chip stacks: the pot-sized pre-flop raise is all-in, the hand is dealt out (ValueFiller.py:160-175's
+    case for 2-card ranges): a run-out chance node with showdown leaves next to the ordinary one"""
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    pc.check_multistreet_vs_oracle(L, G.Flop5Holdem, 250, bet_sets.POT_ONLY, pc.fhp_boards(3), "linear", 2, expect_runout_chain=False)
+
+
 def test_emu_hand_rank_kernel(L):
     pc.check_hand_rank_golden(L)
     assert pc.check_hand_rank_checksums(L, n_chunks=2) == 2

@@ -163,6 +163,48 @@ def test_gpu_fused_other_registered_shapes_vs_oracle(L, stack, flop_raises, node
     pc.check_fused_vs_oracle(L, n_boards, 3, variant=variant, stack=stack, flop_raises=flop_raises, nodes_per_board=nodes)
 
 
+# ---- trees that deal on several streets, all-in run-outs -------------------------------------------------------
+def test_gpu_multistreet_limit_holdem_full_betting_vs_oracle(L):
+    """LimitHoldem with its full betting structure (8 / 70 / 630 / 5670 decision nodes per street) over 2 flops x 2 turns x 1 river:
+    ~52 k nodes, three chance levels; every per-node vector against the oracle"""
+    from pokerrl_amd.game import games as G
+    t, s, o = pc.check_multistreet_vs_oracle(L, G.LimitHoldem, 48, None, pc.multistreet_runouts(2, 2, 1), "plus", 2)
+    assert t.n_nodes > 40000
+
+
+@pytest.mark.parametrize("variant", ["vanilla", "linear"])
+def test_gpu_multistreet_short_stack_run_outs_vs_oracle(L, variant):
+    from pokerrl_amd.game import games as G
+    pc.check_multistreet_vs_oracle(L, G.LimitHoldem, 6, None, pc.multistreet_runouts(3, 2, 2), variant, 3, expect_runout_chain=True)
+
+
+def test_gpu_all_in_before_the_deal_run_out_vs_oracle(L):
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    pc.check_multistreet_vs_oracle(L, G.Flop5Holdem, 250, bet_sets.POT_ONLY, pc.fhp_boards(300), "plus", 4)
+
+
+def test_gpu_cfr_plus_on_limit_holdem_through_the_python_surface(L):
+    """CFRPlus(game_cls=LimitHoldem, boards=run-outs): the reference's class, a game its tree code cannot build; exploitability falls"""
+    from pokerrl_amd.cfr.CFRPlus import CFRPlus
+    from pokerrl_amd.game import games as G
+    from pokerrl_amd.rl.base_cls.workers.ChiefBase import ChiefBase
+    chief = ChiefBase(t_prof=None)
+    cfr = CFRPlus(name="lh", chief_handle=chief, game_cls=G.LimitHoldem, agent_bet_set=None, delay=0, boards=pc.multistreet_runouts(2, 1, 1),
+                  starting_stack_sizes=[8])
+    cfr.iterations(8)
+    vals, _ = chief.get_new_values()
+    curr = [v for k, v in vals.items() if "_Curr_S" in k][0]["Evaluation/" + G.LimitHoldem.WIN_METRIC]
+    assert len(curr) == 9 and curr[-1][1] < curr[0][1] and curr[-1][1] >= 0
+    root = cfr._trees[0].root
+    flop_chance = [n for n in cfr._trees[0].nodes() if n.p_id_acting_next == "Ch"][0]
+    cs = flop_chance.strategy
+    assert cs.shape == (1326, 2) and set(np.unique(cs).tolist()) <= {0.0, float(cs.max())}
+    st = flop_chance.children[0].env_state
+    assert st["current_round"] == 1 and int(np.sum(st["board_2d"][:, 0] >= 0)) == 3
+    assert root.exploitability.shape == (2,)
+
+
 @pytest.mark.parametrize("n_boards", [40, 2048])
 def test_gpu_fused_best_response_only_pass_vs_oracle(L, n_boards):
     """BASELINE config 4: exact best response of an explicit strategy; float32 strategies go through the best-response-only pass"""

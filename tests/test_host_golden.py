@@ -226,23 +226,48 @@ def test_tree_flop5holdem_structure():
     assert np.all(bid[first_board_child + T:first_board_child + 2 * T] == 1)
 
 
-def test_tree_rejects_multi_street_games():
+def test_tree_rejects_runouts_shorter_than_the_deal():
     with pytest.raises(_native.NativeError):
         native_tree(G.LimitHoldem, 48, [0.0], np.array([[0, 1, 2]], np.int8))
 
 
-def test_tree_rejects_all_in_before_the_deal_on_two_card_ranges():
-    """ValueFiller.py:160-175 averages an all-in-before-the-deal showdown over every run-out, for 1-card ranges only. On a
-    2-card tree neither the oracle nor the kernels restate that: the builder must refuse the tree (PRL_ERR_UNSUPPORTED),
-    not value the terminal at 0. A 250-chip stack puts the pot-sized pre-flop raise all-in."""
+def test_tree_deals_out_an_all_in_before_the_deal_on_two_card_ranges():
+    """ValueFiller.py:160-175 averages an all-in-before-the-deal showdown over every run-out, for 1-card ranges only. On a 2-card tree
+    the builder deals the hand out instead: a chance node without decisions whose children are showdown leaves on the listed boards (the
+    same expectation under the same chance weights; round 1 valued such a terminal at 0). A 250-chip stack puts the pot-sized
+    pre-flop raise all-in."""
     boards = np.array([[0, 5, 10, 15, 20], [1, 2, 3, 50, 51]], np.int8)
-    with pytest.raises(_native.NativeError, match="before the deal"):
-        native_tree(G.Flop5Holdem, 250, bet_sets.POT_ONLY, boards)
+    t = native_tree(G.Flop5Holdem, 250, bet_sets.POT_ONLY, boards)
+    k, bid, par, pot = t.field("kind"), t.field("board_id"), t.field("parent"), t.field("main_pot")
+    assert not np.any((k == 3) & (bid < 0))                      # no showdown without a board
+    run = [i for i in np.where(k == 1)[0] if all(k[c] == 3 for c in np.where(par == i)[0])]
+    assert len(run) == 1 and sorted(bid[np.where(par == run[0])[0]]) == [0, 1] and np.all(pot[np.where(par == run[0])[0]] == 500)
     t = native_tree(G.Flop5Holdem, 2000, bet_sets.POT_ONLY, boards)  # deep enough: every showdown is after the deal
-    k, bid = t.field("kind"), t.field("board_id")
-    assert not np.any((k == 3) & (bid < 0))
-    # the same short stack on a 1-card game is the reference's V6 case and stays supported (pinned by the B3_short goldens)
-    native_tree(G.DiscretizedNLLeduc, 1500, bet_sets.B_3, np.arange(6, dtype=np.int8).reshape(-1, 1))
+    assert int(np.sum(t.field("kind") == 1)) == 1
+    # a 1-card game keeps the reference's run-out TERMINAL (V6, pinned by the B3_short goldens)
+    t = native_tree(G.DiscretizedNLLeduc, 1500, bet_sets.B_3, np.arange(6, dtype=np.int8).reshape(-1, 1))
+    assert np.any((t.field("kind") == 3) & (t.field("board_id") < 0))
+
+
+def test_multi_street_tree_structure():
+    """LimitHoldem deals 3 + 1 + 1 (games.py:134-167). The caller lists run-outs; every street gets a chance level whose
+    children are the distinct prefixes. [probe] of the survey: 8 / 70 / 630 / 5670 decision nodes per street for one run-out."""
+    runouts = np.array([[0, 1, 2, 3, 4], [0, 1, 2, 3, 5], [0, 1, 2, 6, 7], [8, 9, 10, 11, 12]], np.int8)  # 2 flops; 2 turns below the first
+    t = native_tree(G.LimitHoldem, 48, None, runouts)
+    k, bid, rnd, par, nch = t.field("kind"), t.field("board_id"), t.field("round"), t.field("parent"), t.field("n_children")
+    rows = t.board_rows
+    assert rows.shape == (2 + 3 + 4, 5)                           # prefix rows: 2 flops, 3 (flop, turn), 4 run-outs
+    assert rows[:2].tolist() == [[0, 1, 2, -1, -1], [8, 9, 10, -1, -1]]
+    n_dealt = np.where(bid >= 0, np.sum(rows[np.maximum(bid, 0)] >= 0, axis=1), 0)
+    assert np.array_equal(n_dealt[k != 1], np.array([0, 3, 4, 5])[rnd[k != 1]])   # a node of round r sees the board of round r
+    ch = np.where(k == 1)[0]
+    assert set(nch[ch][rnd[ch] == 0].tolist()) == {2}             # pre-flop chance nodes: two flops
+    assert set(nch[ch][rnd[ch] == 1].tolist()) == {1, 2}          # flop chance nodes: two turns below flop 0, one below flop 1
+    one = native_tree(G.LimitHoldem, 48, None, runouts[:1])
+    dec = one.field("kind") == 0
+    assert [int(np.sum(dec & (one.field("round") == r))) for r in range(4)] == [8, 70, 630, 5670]
+    with pytest.raises(_native.NativeError, match="run-outs"):    # 3-card rows for a game that deals 5
+        native_tree(G.LimitHoldem, 48, None, runouts[:, :3])
 
 
 def test_c_abi_exports_every_declared_symbol():
