@@ -348,10 +348,18 @@ class PublicTree:
     def _chance_strategy(self, idx):
         """[R, n_boards] float32: board probability for hands not blocked by the board (StrategyFiller.py:148-169)"""
         t, lut = self._native_tree, self._env_bldr.lut_holder.LUT_IDX_2_HOLE_CARDS
-        p = self.solver.get("constants")[0]
-        out = np.zeros((t.range_size, t.n_boards), np.float32)
-        for b in range(t.n_boards):
-            blocked = np.isin(lut, t.boards[b]).any(axis=1)
+        kids = self.node(idx).children
+        before = t.board_rows[self._board_id[idx]] if self._board_id[idx] >= 0 else np.zeros(0, np.int8)
+        n_before = int(np.sum(before >= 0))
+        rows = [t.board_rows[self._board_id[c._i]] for c in kids]
+        k = int(np.sum(rows[0] >= 0)) - n_before
+        from math import comb
+        n = self._env_bldr.rules.N_CARDS_IN_DECK - n_before
+        h = self._env_bldr.rules.N_HOLE_CARDS
+        p = np.float32(1.0 / (float(len(kids)) * float(comb(n - 2 * h, k)) / float(comb(n, k))))  # generalised StrategyFiller.py:166
+        out = np.zeros((t.range_size, len(kids)), np.float32)
+        for b, row in enumerate(rows):
+            blocked = np.isin(lut, row[row >= 0]).any(axis=1)
             out[~blocked, b] = p
         return out
 
