@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 for rep in 1 2; do
   for nv in "$@"; do
     n=${nv%%=*}; l=${nv#*=}
-    POKERRL_AMD_LIB=$PWD/$l python bench.py --steps 10 --warmup 2 --boards $B --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/ab_${n}_$rep.json
+    POKERRL_AMD_LIB=$PWD/$l python bench.py --steps 30 --warmup 5 --boards $B --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/ab_${n}_$rep.json
     python - <<PY
 import json
 j=json.loads(open("gpurun_out/ab_${n}_$rep.json").read())
