@@ -182,6 +182,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # the reference's iteration() also evaluates the AVERAGE strategy every time (_CFRBase.py:134,218-262); timed separately
+    # (outside the K steps) as one best-response-style evaluation per iteration
+    t1 = time.perf_counter()
+    n_avg = 3
+    for _ in range(n_avg):
+        avg_expl = solver.eval_avg()
+    barrier()
+    avg_eval_ms = (time.perf_counter() - t1) * 1e3 / n_avg
+
     n_board_nodes = args.boards * 15
     n_nodes_total = (tree.n_nodes - n_board_nodes) + n_board_nodes * world  # one trunk + every rank's board subtrees
     value = n_nodes_total * args.steps / dt
@@ -205,6 +214,8 @@ def main():
             "nodes_whole_tree": n_nodes_total, "exchanges": exchange.calls if exchange else 0,
             "exchange_ms_mean": (exchange.seconds * 1e3 / max(exchange.calls, 1)) if exchange else None,
             "iterations_done": solver.iter, "exploitability_mbb_per_g": float(np.mean(expl) * 10.0),
+            "avg_strategy_exploitability_mbb_per_g": float(np.mean(avg_expl) * 10.0), "avg_strategy_evaluation_ms": avg_eval_ms,
+            "ms_per_step_with_avg_strategy_evaluation": dt * 1e3 / args.steps + avg_eval_ms,
             "hbm_bytes_allocated": int(solver.get("bytes_allocated")[0]),
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
