@@ -97,6 +97,18 @@ def free_port():
         return sk.getsockname()[1]
 
 
+def shard_geometry(total, world, rank):
+    """(boards of every rank before the last, boards of this rank) for ONE list of `total` boards: shards of whole canonical summation
+    units -- 1024-board groups if that leaves the last rank something to do, else 32-board blocks, else single boards
+    (prl_solver_create_sharded_ragged)."""
+    for unit in (1024, 32, 1):
+        per = -(-(-(-total // unit)) // world) * unit
+        if (world - 1) * per < total:
+            break
+    mine = per if rank < world - 1 else total - (world - 1) * per
+    return per, mine
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` outside a launcher: start the N ranks (one process per GPU) the way the driver would."""
     import subprocess
@@ -113,6 +125,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--boards", type=int, default=int(os.environ.get("PRL_BENCH_BOARDS", "262144")), help="boards per GPU")
+    ap.add_argument("--total-boards", type=int, default=0,
+                    help="solve ONE board list of this many boards split over the GPUs (strong scaling, ragged shards: every rank but the last "
+                         "holds the same whole number of canonical summation units, the last one the rest); overrides --boards")
+    ap.add_argument("--all-boards", action="store_true", help="--total-boards 2598960: every flop of Flop5Holdem, the whole game (about 88 GB "
+                    "of HBM per GPU on 8 GPUs; does not fit fewer than 4)")
     ap.add_argument("--engine", default=os.environ.get("PRL_BENCH_ENGINE", "auto"))
     ap.add_argument("--variant", default="plus", choices=["plus", "linear", "vanilla"],
                     help="CFR variant (the metric is quoted on CFR+; BASELINE config 3 also names LinearCFR)")
@@ -148,10 +165,18 @@ def main():
         _native.require_device()
         _native.set_device(local_rank if world > 1 else 0)  # the library allocates on this process's GPU, like torch above
     # every rank owns a contiguous block of the global board list (weak scaling: fixed boards per GPU)
-    boards = seeded_boards(args.boards, 0, offset=rank * args.boards)
+    total = 2598960 if args.all_boards else args.total_boards
+    shard_boards = args.boards
+    if total:
+        shard_boards, args.boards = shard_geometry(total, world, rank)
+    boards = seeded_boards(args.boards, 0, offset=rank * shard_boards)
     tree = fhp_tree(boards, lib)
     exchange = None
-    if world > 1 or os.environ.get("PRL_BENCH_FORCE_EXCHANGE"):  # the env knob runs the all-gather path on one GPU (tests)
+    if total and world > 1:
+        from pokerrl_amd.dist import TorchExchange
+        exchange = TorchExchange("cpu" if emu_lib else "cuda")
+        solver = _native.NativeSolver(tree, args.variant, 0, shard=(world, rank, exchange, shard_boards, total), _lib=lib)
+    elif world > 1 or os.environ.get("PRL_BENCH_FORCE_EXCHANGE"):  # the env knob runs the all-gather path on one GPU (tests)
         if dist is None:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -192,7 +217,7 @@ def main():
     avg_eval_ms = (time.perf_counter() - t1) * 1e3 / n_avg
 
     n_board_nodes = args.boards * 15
-    n_nodes_total = (tree.n_nodes - n_board_nodes) + n_board_nodes * world  # one trunk + every rank's board subtrees
+    n_nodes_total = (tree.n_nodes - n_board_nodes) + (total * 15 if total else n_board_nodes * world)  # one trunk + every rank's board subtrees
     value = n_nodes_total * args.steps / dt
     R, sum_a = tree.range_size, tree.n_cols
     bytes_iter = 20.0 * R * sum_a + 8.0 * R * args.boards  # per GPU
@@ -202,12 +227,12 @@ def main():
     out = {
         "metric": "CFR+ node-updates/sec on FHP public tree" if args.variant == "plus" else "%s CFR node-updates/sec on FHP public tree" % args.variant,
         "value": value, "unit": "node-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if total else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": {"plus": "CFR+ (delay 0)", "linear": "Linear CFR", "vanilla": "vanilla CFR"}[args.variant] +
                         " full-width iterations on the Flop5Holdem public tree (blinds 50/100, stacks 20000, "
-                        "pot-size raises), %d seeded boards per GPU, 1326-hand ranges" % args.boards,
+                        "pot-size raises), %s, 1326-hand ranges" % ("%d boards in all (%d on rank 0)" % (total, args.boards) if total else "%d seeded boards per GPU" % args.boards),
             "boards_per_gpu": args.boards, "nodes_per_gpu": tree.n_nodes, "action_columns_per_gpu": sum_a,
             "engine": solver.engine,
             "parallelism": "boards sharded over %d GPU(s), trunk replicated, 1 all-gather of chance-node partial sums per EV pass" % world,

@@ -270,7 +270,7 @@ int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay
 enum { PRL_ENGINE_AUTO = 0, PRL_ENGINE_LEVELS = 1, PRL_ENGINE_FUSED = 2 };
 int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out_solver);
 /* Sharded solve over `world_size` GPUs, one process per GPU: the tree handed to rank r holds the
- * r-th contiguous block of the global board list (every rank the same number of boards); the pre-chance trunk is
+ * r-th contiguous block of the global board list (every rank the same number of boards; see _ragged below); the pre-chance trunk is
  * replicated; regrets / averages of a board live on its owner only. The one exchange per EV pass is the pull-up of the
  * chance node's values (ValueFiller.py:76-78 is a plain sum over the chance children): every rank reduces its boards to
  * whole canonical summation units, `exchange` all-gathers them (rank-major), and every rank finishes the sum over all
@@ -282,6 +282,14 @@ int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t de
 typedef int32_t (*prl_exchange_fn)(void* user, const void* local_dev, void* gathered_dev, uint64_t bytes_per_rank);
 int32_t prl_solver_create_sharded(const prl_tree_t* local_tree, int32_t variant, int32_t delay, int32_t world_size, int32_t rank,
                                   prl_exchange_fn exchange, void* user, prl_solver_t** out_solver);
+/* Ragged shards (a board list that does not divide by the world size, e.g. all C(52,5) = 2 598 960 flops of Flop5Holdem on 8 GPUs):
+ * every rank before the last holds `shard_boards` boards, the last one the remaining total_boards - (world_size-1)*shard_boards
+ * (> 0, <= shard_boards). The exchange moves whole canonical summation units of the highest level shard_boards is a multiple of
+ * (1024-board groups, 32-board blocks, else single boards), bytes_per_rank is the same on every rank (the last rank pads with
+ * zeros that are never summed), and the result is still bit-identical to the single-GPU solve of the whole list. */
+int32_t prl_solver_create_sharded_ragged(const prl_tree_t* local_tree, int32_t variant, int32_t delay, int32_t world_size, int32_t rank,
+                                         int64_t shard_boards, int64_t total_boards, prl_exchange_fn exchange, void* user,
+                                         prl_solver_t** out_solver);
 /* Checkpoint / resume (the reference's CFR has none): the solver's persistent state -- iteration
  * counter, regrets, average strategy (+ sum), current trunk strategy with its dtype flags, exploitability history -- as one
  * opaque host blob. load_state needs a solver created on the same tree with the same variant / delay / engine; a resumed
@@ -299,6 +307,8 @@ int32_t prl_solver_set_exchange_async(prl_solver_t* solver, int32_t stream_order
  * out [2][R]. world_size > 1 replays the sharded path on one device (every rank's partial units at the level the shard
  * size allows, rank-major gather, finish); the result must not depend on world_size. n_boards % world_size == 0. */
 int32_t prl_chance_sum_host(const float* board_values, int32_t n_boards, int32_t R, int32_t world_size, float* out);
+/* the same with ragged shards: ranks before the last hold shard_boards boards, the last one the rest */
+int32_t prl_chance_sum_host_ragged(const float* board_values, int32_t n_boards, int32_t R, int32_t world_size, int32_t shard_boards, float* out);
 void prl_solver_destroy(prl_solver_t* solver);
 int32_t prl_solver_reset(prl_solver_t* solver);                        /* _CFRBase.reset            :110-120 */
 int32_t prl_solver_iteration(prl_solver_t* solver);                    /* _CFRBase.iteration        :122-134 (w/o avg eval) */

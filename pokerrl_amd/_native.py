@@ -154,6 +154,8 @@ def _bind_solver(L):
     L.prl_solver_create_ex.restype = i32
     L.prl_solver_create_sharded.argtypes = [vp, i32, i32, i32, i32, EXCHANGE_FN, vp, ctypes.POINTER(vp)]
     L.prl_solver_create_sharded.restype = i32
+    L.prl_solver_create_sharded_ragged.argtypes = [vp, i32, i32, i32, i32, ctypes.c_int64, ctypes.c_int64, EXCHANGE_FN, vp, ctypes.POINTER(vp)]
+    L.prl_solver_create_sharded_ragged.restype = i32
     L.prl_solver_time_iterations_ex.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i32)]
     L.prl_solver_time_iterations_ex.restype = i32
     L.prl_solver_time_evaluations.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i32)]
@@ -194,6 +196,8 @@ def _bind_solver(L):
     L.prl_solver_set_exchange_async.restype = i32
     L.prl_chance_sum_host.argtypes = [vp, i32, i32, i32, vp]
     L.prl_chance_sum_host.restype = i32
+    L.prl_chance_sum_host_ragged.argtypes = [vp, i32, i32, i32, i32, vp]
+    L.prl_chance_sum_host_ragged.restype = i32
     L.prl_solver_get.argtypes = [vp, i32, vp]
     L.prl_solver_get.restype = i32
     L.prl_solver_create.restype = i32
@@ -440,7 +444,9 @@ class NativeSolver:
 
     shard=(world_size, rank, exchange): sharded solve, `tree` holds this rank's contiguous block of the global board list
     and `exchange(local_ptr, gathered_ptr, bytes_per_rank)` all-gathers device buffers (pokerrl_amd.dist.TorchExchange);
-    every call that evaluates the tree is then collective. Results are bit-identical to the unsharded solve."""
+    every call that evaluates the tree is then collective. Results are bit-identical to the unsharded solve.
+    shard=(world_size, rank, exchange, shard_boards, total_boards): ragged shards -- every rank before the last holds shard_boards
+    boards, the last one the rest (prl_solver_create_sharded_ragged)."""
 
     def __init__(self, tree, variant, delay=0, engine="auto", _lib=None, shard=None):
         self._L = _lib or tree._L
@@ -452,7 +458,7 @@ class NativeSolver:
         e = ENGINES[engine] if isinstance(engine, str) else int(engine)
         self._exchange_cb = None
         if shard is not None:
-            world, rank, exchange = shard
+            world, rank, exchange = shard[:3]
 
             def _cb(_user, local_ptr, gathered_ptr, nbytes):
                 try:
@@ -464,8 +470,12 @@ class NativeSolver:
                     return 1
 
             self._exchange_cb = EXCHANGE_FN(_cb)  # kept alive with the solver
-            check(self._L.prl_solver_create_sharded(tree.handle, v, int(delay), int(world), int(rank), self._exchange_cb, None,
-                                                    ctypes.byref(self._h)), self._L)
+            if len(shard) == 5:
+                check(self._L.prl_solver_create_sharded_ragged(tree.handle, v, int(delay), int(world), int(rank), int(shard[3]), int(shard[4]),
+                                                               self._exchange_cb, None, ctypes.byref(self._h)), self._L)
+            else:
+                check(self._L.prl_solver_create_sharded(tree.handle, v, int(delay), int(world), int(rank), self._exchange_cb, None,
+                                                        ctypes.byref(self._h)), self._L)
         else:
             check(self._L.prl_solver_create_ex(tree.handle, v, int(delay), e, ctypes.byref(self._h)), self._L)
         if shard is not None and hasattr(shard[2], "bind_stream"):

@@ -48,7 +48,8 @@ struct prl_solver {
     // ---- FUSED engine ----
     bool fused = false;
     // sharded solve (prl_solver_create_sharded)
-    int world = 1, rank = 0, xlevel = 0, n_units = 0;  // summation level exchanged, units per rank
+    int world = 1, rank = 0, xlevel = 0, n_units = 0;  // summation level exchanged, units per rank (the exchange's fixed stride)
+    int n_units_all = 0;                               // units over all ranks: (world - 1) * n_units + the last rank's (ragged shards)
     uint64_t fingerprint = 0;  // boards + game + rules + (world, rank): what a checkpoint must match besides the array shapes
     prl_exchange_fn exchange = nullptr;
     bool exchange_async = false;  // the callback enqueues on s->stream: no host synchronisation around it
@@ -210,7 +211,8 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
             return PRL_ERR_STATE;
         }
         // rank-major blocks of whole units = global unit order already
-        prl_launch_fhp_chance_finish(s->d_xgather, s->world * s->n_units, s->xlevel, W, s->d_sum_scratch, summed, s->stream);
+        // (a shorter last shard: its units end before the zero padding of its block, which is therefore never read)
+        prl_launch_fhp_chance_finish(s->d_xgather, s->n_units_all, s->xlevel, W, s->d_sum_scratch, summed, s->stream);
     }
     const size_t vec = (size_t)p.R * sizeof(float);
     float* ch_ev = st.ev + prl_vidx(s->T, s->chance_trunk, 0);
@@ -380,7 +382,7 @@ int prl_fhp_match_shape(const PrlFlatTree& t, int* chance_node, int* first_board
 extern "C" {
 
 static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t world, int32_t rank,
-                                  prl_exchange_fn exchange, void* exchange_user, prl_solver_t** out) {
+                                  prl_exchange_fn exchange, void* exchange_user, prl_solver_t** out, int64_t shard_boards = 0, int64_t total_boards = 0) {
     if (!tree || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
     if (variant < 0 || variant > 2 || delay < 0 || engine < 0 || engine > 2) { prl_set_error("bad variant / delay / engine"); return PRL_ERR_ARG; }
     if (!prl_device_available()) { prl_set_error("no HIP device: the solver has no CPU fallback"); return PRL_ERR_NO_DEVICE; }
@@ -404,6 +406,16 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         fused = true;
     } else if (engine == PRL_ENGINE_AUTO) fused = shape_ok;
     if (exchange && !fused) { prl_set_error("sharded solve: FUSED engine only (a board subtree of a registered shape, prl_fhp.h)"); return PRL_ERR_UNSUPPORTED; }
+    // shard geometry: equal shards unless told otherwise; ragged = every rank but the last holds shard_boards (whole canonical
+    // units of the level exchanged), the last one the rest of total_boards
+    if (shard_boards <= 0) { shard_boards = full.n_boards; total_boards = (int64_t)full.n_boards * world; }
+    {
+        const int64_t mine = rank == world - 1 ? total_boards - (int64_t)(world - 1) * shard_boards : shard_boards;
+        if (mine <= 0 || mine > shard_boards || mine != full.n_boards || total_boards > 0x7fffffffll) {
+            prl_set_error("sharded solve: this rank's tree does not hold its share of the board list (ranks before the last: shard_boards; the last: the rest)");
+            return PRL_ERR_ARG;
+        }
+    }
 
     prl_solver* s = new prl_solver();
     s->world = world;
@@ -471,11 +483,12 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             const int before = dealt(full.board_id[i]);
             const int child = full.child_list[full.child_start[i]];
             const int k = dealt(full.board_id[child]) - before;
-            const float p = chance_prob_f32(full.n_children[i] * world, r.n_cards - before, r.n_hole_cards, k);  // world: global number of boards
+            // sharded (one chance node, fused engine): the GLOBAL number of boards
+            const float p = chance_prob_f32(exchange ? (int)total_boards : full.n_children[i], r.n_cards - before, r.n_hole_cards, k);
             if (first) { T.chance_prob = p; first = false; }
             if (!fused && i < ft.n_nodes) w[i] = p;
         }
-        if (first) T.chance_prob = chance_prob_f32(n_chance_children * world, r.n_cards, r.n_hole_cards, full.board_len);
+        if (first) T.chance_prob = chance_prob_f32(exchange ? (int)total_boards : n_chance_children, r.n_cards, r.n_hole_cards, full.board_len);
         FAIL_IF(dev_upload(s, &T.chance_w, w));
     }
     T.eq_const = eq_const_f32(r.n_cards, r.n_hole_cards);
@@ -556,16 +569,18 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         const size_t bv = (size_t)full.n_boards * 2 * T.R;
         FAIL_IF(dev_alloc(s, &s->d_board_out, 2 * bv));
         FAIL_IF(dev_alloc(s, &s->d_row_sum, (size_t)4 * T.R));
-        const size_t n_blk = ((size_t)full.n_boards * world + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;  // sized for the global board list
+        const size_t n_blk = ((size_t)total_boards + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK + world;  // sized for the global board list
         const size_t n_grp = (n_blk + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
         FAIL_IF(dev_alloc(s, &s->d_sum_scratch, (n_blk + n_grp + 1) * 4 * T.R));  // rows of up to 4 vectors
         if (exchange) {
             // exchange whole canonical units: the highest summation level the shard size is a multiple of
-            s->xlevel = full.n_boards % (PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK) == 0 ? 2 : full.n_boards % PRL_CHANCE_BLOCK == 0 ? 1 : 0;
-            s->n_units = prl_fhp_units_at_level(full.n_boards, s->xlevel);
+            s->xlevel = shard_boards % (PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK) == 0 ? 2 : shard_boards % PRL_CHANCE_BLOCK == 0 ? 1 : 0;
+            s->n_units = prl_fhp_units_at_level((int)shard_boards, s->xlevel);
+            s->n_units_all = (world - 1) * s->n_units + prl_fhp_units_at_level((int)(total_boards - (int64_t)(world - 1) * shard_boards), s->xlevel);
             const size_t per_rank = (size_t)s->n_units * 4 * T.R;  // [units][<= 4 vectors][R]
             FAIL_IF(dev_alloc(s, &s->d_xlocal, per_rank));
             FAIL_IF(dev_alloc(s, &s->d_xgather, per_rank * world));
+            FAIL_IF(hipMemsetAsync(s->d_xlocal, 0, per_rank * sizeof(float), s->stream) == hipSuccess ? PRL_OK : PRL_ERR_HIP);  // a shorter last shard sends zero padding
         }
         FAIL_IF(dev_alloc(s, &s->d_half, (size_t)2 * T.R + 4));
         s->fp.regret = s->d_regret;
@@ -583,6 +598,15 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
 #undef FAIL_IF
     *out = s;
     return prl_solver_reset(s);
+}
+
+int32_t prl_solver_create_sharded_ragged(const prl_tree_t* local_tree, int32_t variant, int32_t delay, int32_t world_size, int32_t rank,
+                                         int64_t shard_boards, int64_t total_boards, prl_exchange_fn exchange, void* user, prl_solver_t** out) {
+    if (world_size < 1 || rank < 0 || rank >= world_size || !exchange || shard_boards <= 0 || total_boards <= (int64_t)(world_size - 1) * shard_boards) {
+        prl_set_error("bad world_size / rank / shard_boards / total_boards, or no exchange callback");
+        return PRL_ERR_ARG;
+    }
+    return solver_create_impl(local_tree, variant, delay, PRL_ENGINE_FUSED, world_size, rank, exchange, user, out, shard_boards, total_boards);
 }
 
 int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out) {
@@ -698,28 +722,32 @@ int32_t prl_solver_set_exchange_async(prl_solver_t* s, int32_t on) {
     return PRL_OK;
 }
 
-int32_t prl_chance_sum_host(const float* board_values, int32_t n_boards, int32_t R, int32_t world, float* out) {
-    if (!board_values || !out || n_boards <= 0 || R <= 0 || world < 1 || n_boards % world) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+int32_t prl_chance_sum_host_ragged(const float* board_values, int32_t n_boards, int32_t R, int32_t world, int32_t shard_boards, float* out) {
+    if (!board_values || !out || n_boards <= 0 || R <= 0 || world < 1 || shard_boards <= 0 || (int64_t)(world - 1) * shard_boards >= n_boards ||
+        (int64_t)world * shard_boards < n_boards) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
     if (!prl_device_available()) { prl_set_error("no HIP device"); return PRL_ERR_NO_DEVICE; }
     const size_t R2 = (size_t)2 * R, nv = (size_t)n_boards * R2;
-    const int n_local = n_boards / world;
-    const int level = world == 1 ? 0 : n_local % (PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK) == 0 ? 2 : n_local % PRL_CHANCE_BLOCK == 0 ? 1 : 0;
-    const int n_units = prl_fhp_units_at_level(n_local, level);
+    const int n_last = n_boards - (world - 1) * shard_boards;
+    const int level = world == 1 ? 0 : shard_boards % (PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK) == 0 ? 2 : shard_boards % PRL_CHANCE_BLOCK == 0 ? 1 : 0;
+    const int n_units = prl_fhp_units_at_level(shard_boards, level);
+    const int n_units_all = (world - 1) * n_units + prl_fhp_units_at_level(n_last, level);
     float *d_vals = nullptr, *d_scratch = nullptr, *d_gather = nullptr, *d_compact = nullptr, *d_out = nullptr;
     int rc = PRL_OK;
 #define CS_TRY(x) do { if ((x) != hipSuccess) { prl_set_error("HIP error in prl_chance_sum_host"); rc = PRL_ERR_HIP; goto done; } } while (0)
     CS_TRY(hipMalloc((void**)&d_vals, nv * sizeof(float)));
-    CS_TRY(hipMalloc((void**)&d_scratch, ((size_t)n_boards / PRL_CHANCE_BLOCK + n_boards / (PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK) + 4) * R2 * sizeof(float)));
+    CS_TRY(hipMalloc((void**)&d_scratch, ((size_t)n_boards / PRL_CHANCE_BLOCK + n_boards / (PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK) + 4 + world) * R2 * sizeof(float)));
     CS_TRY(hipMalloc((void**)&d_gather, (size_t)world * n_units * R2 * sizeof(float)));
     CS_TRY(hipMalloc((void**)&d_compact, (size_t)world * n_units * R2 * sizeof(float)));
     CS_TRY(hipMalloc((void**)&d_out, R2 * sizeof(float)));
     CS_TRY(hipMemcpy(d_vals, board_values, nv * sizeof(float), hipMemcpyHostToDevice));
+    CS_TRY(hipMemset(d_gather, 0, (size_t)world * n_units * R2 * sizeof(float)));
     if (world == 1) prl_launch_fhp_chance_sum(d_vals, n_boards, 2 * R, d_scratch, d_out, nullptr);
     else {
         for (int r = 0; r < world; ++r)  // rank r's units land where the all-gather would put them
-            prl_launch_fhp_chance_partial(d_vals + (size_t)r * n_local * R2, n_local, level, 2 * R, d_scratch, d_gather + (size_t)r * n_units * R2, nullptr);
+            prl_launch_fhp_chance_partial(d_vals + (size_t)r * shard_boards * R2, r == world - 1 ? n_last : shard_boards, level, 2 * R, d_scratch,
+                                          d_gather + (size_t)r * n_units * R2, nullptr);
         prl_launch_fhp_compact_gathered(d_gather, world, 1, n_units, 2 * R, d_compact, nullptr);
-        prl_launch_fhp_chance_finish(d_compact, world * n_units, level, 2 * R, d_scratch, d_out, nullptr);
+        prl_launch_fhp_chance_finish(d_compact, n_units_all, level, 2 * R, d_scratch, d_out, nullptr);
     }
     CS_TRY(hipDeviceSynchronize());
     CS_TRY(hipMemcpy(out, d_out, R2 * sizeof(float), hipMemcpyDeviceToHost));
@@ -727,6 +755,11 @@ int32_t prl_chance_sum_host(const float* board_values, int32_t n_boards, int32_t
 done:
     (void)hipFree(d_vals); (void)hipFree(d_scratch); (void)hipFree(d_gather); (void)hipFree(d_compact); (void)hipFree(d_out);
     return rc;
+}
+
+int32_t prl_chance_sum_host(const float* board_values, int32_t n_boards, int32_t R, int32_t world, float* out) {
+    if (world < 1 || n_boards <= 0 || n_boards % world) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    return prl_chance_sum_host_ragged(board_values, n_boards, R, world, n_boards / world, out);
 }
 
 int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay, prl_solver_t** out) {

@@ -29,14 +29,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_sharded(lib_path, device, world, n_local, n_iters, delay, seed, timeout):
+def run_sharded(lib_path, device, world, n_local, n_iters, delay, seed, timeout, total=None):
     port = _free_port()
     with tempfile.TemporaryDirectory() as d:
         procs = []
         for r in range(world):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
             procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), lib_path, device, d,
-                                           str(n_local), str(n_iters), str(delay), str(seed)], env=env))
+                                           str(n_local), str(n_iters), str(delay), str(seed)] + ([str(total)] if total else []), env=env))
         try:
             for p in procs:
                 assert p.wait(timeout=timeout) == 0
@@ -47,14 +47,15 @@ def run_sharded(lib_path, device, world, n_local, n_iters, delay, seed, timeout)
         return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(world)]
 
 
-def check_against_union(L, ranks, world, n_local, n_iters, delay, seed):
-    boards = pc.fhp_boards(world * n_local, seed=seed, with_special=False)
+def check_against_union(L, ranks, world, n_local, n_iters, delay, seed, total=None):
+    total = total or world * n_local
+    boards = pc.fhp_boards(total, seed=seed, with_special=False)
     args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
     t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
     s = _native.NativeSolver(t, "plus", delay, engine="fused", _lib=L)
     s.iterations(n_iters)
     hist, regret, avg, ev_avg = s.get("expl_history"), s.get("regret"), s.get("avg"), s.eval_avg()
-    s.set_strategy(pc.seeded_strategy_for_sharding(t.n_cols - world * n_local * 14, world * n_local, t.range_size, seed + 1))
+    s.set_strategy(pc.seeded_strategy_for_sharding(t.n_cols - total * 14, total, t.range_size, seed + 1))
     s.compute_ev()
     br = s.exploitability()
     per = n_local * 14
@@ -65,7 +66,7 @@ def check_against_union(L, ranks, world, n_local, n_iters, delay, seed):
         assert np.array_equal(out["br_of_random"], br), "rank %d: best response of an explicit strategy" % r
         for name, full in (("regret", regret), ("avg", avg)):
             assert np.array_equal(out[name][:nt], full[:nt]), "rank %d: trunk %s" % (r, name)
-            assert np.array_equal(out[name][nt:], full[nt + r * per: nt + (r + 1) * per]), "rank %d: board %s" % (r, name)
+            assert np.array_equal(out[name][nt:], full[nt + r * per: nt + min((r + 1) * n_local, total) * 14]), "rank %d: board %s" % (r, name)
         # one exchange per EV pass: reset (1), iteration() = 3, every further batched iteration 2, the batch's closing
         # evaluation 1, eval_avg 1
         assert int(out["exchanges"]) == 1 + 3 + (2 * (n_iters - 1) + 1 if n_iters > 1 else 0) + 1, out["exchanges"]
@@ -99,6 +100,19 @@ def check_chance_sum(L, n_boards, worlds):
         assert np.array_equal(out, want), "world %d" % w
 
 
+def check_chance_sum_ragged(L, n_boards, world, shard_boards):
+    """every rank before the last holds shard_boards boards, the last one the rest: same bits as the one-rank sum"""
+    import ctypes
+    rng = np.random.RandomState(n_boards + world)
+    R = 6
+    vals = (rng.random_sample((n_boards, 2, R)) * np.exp(rng.uniform(-8, 8, (n_boards, 2, R)))).astype(np.float32)
+    want = chance_sum_reference(vals.reshape(n_boards, 2 * R)).reshape(2, R)
+    out = np.zeros((2, R), np.float32)
+    rc = L.prl_chance_sum_host_ragged(vals.ctypes.data_as(ctypes.c_void_p), n_boards, R, world, shard_boards, out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    assert np.array_equal(out, want), (n_boards, world, shard_boards)
+
+
 @pytest.fixture(scope="module")
 def EMU():
     sys.path.insert(0, os.path.join(HERE, "emu"))
@@ -111,6 +125,20 @@ def test_chance_sum_levels_do_not_depend_on_world_size_emu(EMU):
     check_chance_sum(L, 2048, (1, 2))       # shards of 1024 boards: whole groups are exchanged
     check_chance_sum(L, 2048 + 64, (1, 2, 3, 11))  # 1056 / 704 / 192 boards per rank: blocks
     check_chance_sum(L, 70, (1, 2, 5, 7))   # ragged: per-board values are exchanged
+    check_chance_sum_ragged(L, 2048 + 48, 3, 1024)   # whole groups + a last shard of 48 boards (a partial group)
+    check_chance_sum_ragged(L, 3 * 1024 + 1, 2, 2048)
+    check_chance_sum_ragged(L, 200, 3, 96)           # blocks; the last shard is 8 boards
+    check_chance_sum_ragged(L, 23, 4, 7)             # single boards
+    out = np.zeros((2, 6), np.float32)  # a last shard that would be empty or longer than the others is refused
+    import ctypes
+    for n, w, sb in ((64, 3, 32), (100, 2, 40)):
+        assert L.prl_chance_sum_host_ragged(out.ctypes.data_as(ctypes.c_void_p), n, 6, w, sb, out.ctypes.data_as(ctypes.c_void_p)) != 0
+
+
+def test_sharded_ragged_world2_gloo_emu(EMU):
+    """3 boards over 2 ranks (2 + 1): the all-boards configuration in small (`bench.py --all-boards`)"""
+    ranks = run_sharded(EMU, "cpu", 2, 2, 2, 0, 33, timeout=900, total=3)
+    check_against_union(_native.bind(EMU), ranks, 2, 2, 2, 0, 33, total=3)
 
 
 def test_sharded_world2_gloo_emu(EMU):
@@ -139,6 +167,24 @@ def test_bench_gpus_2_launches_two_ranks_gloo_emu(EMU):
     j1 = json.loads([x for x in one.splitlines() if x.startswith("{")][0])
     assert j1["n_gpus"] == 1 and j1["config"]["exchanges"] == 0
     assert j1["config"]["exploitability_mbb_per_g"] == j["config"]["exploitability_mbb_per_g"]
+    # ONE list of 3 boards over two ranks (2 + 1, `--all-boards` in small): strong scaling, same result as the one-rank solve of the 3
+    rag = subprocess.run(cmd[:2] + ["--gpus", "2", "--steps", "1", "--warmup", "1", "--total-boards", "3", "--no-cpu-baseline"], env=env,
+                         capture_output=True, text=True, timeout=900, check=True).stdout
+    j2 = json.loads([x for x in rag.splitlines() if x.startswith("{")][0])
+    one3 = subprocess.run(cmd[:2] + ["--gpus", "1", "--steps", "1", "--warmup", "1", "--boards", "3", "--no-cpu-baseline"], env=env,
+                          capture_output=True, text=True, timeout=900, check=True).stdout
+    j3 = json.loads([x for x in one3.splitlines() if x.startswith("{")][0])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and j2["config"]["nodes_whole_tree"] == 5 + 15 * 3 == j3["config"]["nodes_whole_tree"]
+    assert j2["config"]["exploitability_mbb_per_g"] == j3["config"]["exploitability_mbb_per_g"]
+    assert j2["config"]["avg_strategy_exploitability_mbb_per_g"] == j3["config"]["avg_strategy_exploitability_mbb_per_g"]
+
+
+def test_bench_shard_geometry():
+    import bench
+    for total, world in ((2598960, 8), (2598960, 4), (3, 2), (100, 3), (5000, 2), (7, 1), (2048, 2)):
+        g = [bench.shard_geometry(total, world, r) for r in range(world)]
+        assert sum(x[1] for x in g) == total and all(0 < x[1] <= x[0] for x in g) and len({x[0] for x in g}) == 1
+    assert bench.shard_geometry(2598960, 8, 0) == (325632, 325632) and bench.shard_geometry(2598960, 8, 7) == (325632, 319536)
 
 
 @pytest.mark.gpu
@@ -154,6 +200,21 @@ def test_gpu_chance_sum_levels_do_not_depend_on_world_size():
 def test_gpu_sharded_world2_matches_unsharded(n_local):
     ranks = run_sharded(_native.LIB_PATH, "cuda", 2, n_local, 4, 0, 33, timeout=600)
     check_against_union(_native.lib(), ranks, 2, n_local, 4, 0, 33)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_local,total", [(1024, 1024 + 48), (64, 100), (5, 8)])  # groups / blocks / boards, shorter last shard
+def test_gpu_sharded_ragged_world2_matches_unsharded(n_local, total):
+    ranks = run_sharded(_native.LIB_PATH, "cuda", 2, n_local, 3, 0, 34, timeout=600, total=total)
+    check_against_union(_native.lib(), ranks, 2, n_local, 3, 0, 34, total=total)
+
+
+@pytest.mark.gpu
+def test_gpu_chance_sum_ragged_shards():
+    L = _native.lib()
+    check_chance_sum_ragged(L, 8 * 1024 + 48, 8, 2048)   # the all-boards geometry in small: whole groups, a short last shard
+    check_chance_sum_ragged(L, 200, 3, 96)
+    check_chance_sum_ragged(L, 23, 4, 7)
 
 
 @pytest.mark.gpu
