@@ -544,6 +544,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
                 const char* g = getenv("PRL_FHP_GRID");
                 if (g && atoi(g) > 0) fp.max_grid = atoi(g);
             }
+            fp.no_steady = getenv("PRL_FHP_NO_STEADY") ? 1 : 0;  // tests: the generic pass in the steady state too
             fp.chance_prob = T.chance_prob; fp.eq_const = T.eq_const;
             const PrlFhpShapeDesc& sd = prl_fhp_shape_desc(shape_id);
             fp.shape = shape_id; fp.n_cols_board = sd.n_cols; fp.n_dec = sd.n_dec;

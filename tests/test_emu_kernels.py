@@ -107,6 +107,15 @@ def test_emu_fused_engine_batched_iterations(L):
     pc.check_fused_batched_vs_oracle(L, 3, 4, delay=1)
 
 
+@pytest.mark.parametrize("no_steady", [False, True])
+def test_emu_fused_engine_steady_state_specialisation(L, monkeypatch, no_steady):
+    """CFR+ delay 0, batched: iterations 2.. run the steady-state instantiation of the two update passes (prl_fhp_pass.inc, FhpCtxT);
+    PRL_FHP_NO_STEADY keeps the generic one -- both must equal the oracle bit for bit"""
+    if no_steady:
+        monkeypatch.setenv("PRL_FHP_NO_STEADY", "1")
+    pc.check_fused_batched_vs_oracle(L, 3, 4, delay=0)
+
+
 @pytest.mark.parametrize("fused,variant", [(False, "plus"), (False, "linear"), (True, "plus"), (True, "vanilla")])
 def test_emu_checkpoint_resume(L, fused, variant):
     pc.check_checkpoint_resume(L, fused, variant)

@@ -220,6 +220,15 @@ def test_gpu_fused_batched_iterations_vs_oracle(L):
     pc.check_fused_batched_vs_oracle(L, 40, 5, delay=1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_steady", [False, True])
+def test_gpu_fused_steady_state_specialisation_vs_oracle(L, monkeypatch, no_steady):
+    """the CFR+ steady-state instantiation of the update passes and the generic one (PRL_FHP_NO_STEADY) against the oracle"""
+    if no_steady:
+        monkeypatch.setenv("PRL_FHP_NO_STEADY", "1")
+    pc.check_fused_batched_vs_oracle(L, 300, 5, delay=0)
+
+
 def test_gpu_fused_vs_levels_2048_boards(L):
     """2048 boards = 64 canonical chance blocks = 2 groups: both engines of the library must agree bit for bit."""
     pc.check_fused_vs_levels(L, 2048, 6)
