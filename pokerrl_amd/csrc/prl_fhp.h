@@ -169,6 +169,7 @@ struct PrlFhpParams {
     // follows q's pass -- so it rides on the next pass that walks q's reach (phase B for seat q): bit q of avgsum_mask
     float* avg_sum;             // [n_cols][R] node.data["avg_strat_sum"] (VanillaCFR.py:40-55, LinearCFR.py:41-57)
     int32_t avgsum_mask, avgsum_iter[2];
+    int32_t exp;                // FHP_EXPERIMENT builds: run-time switch between two code paths (prl_debug_set_experiment)
     int32_t no_steady;          // tests: 1 = never take the CFR+ steady-state specialisation of the pass (prl_fhp_pass.inc, FhpCtxT)
     const double* strat_arr;    // explicit strategy (average strategy / caller-provided), [n_cols][R]
     float* board_out;           // [n_boards][prl_fhp_out_width(mode)][R] root vectors of every board subtree

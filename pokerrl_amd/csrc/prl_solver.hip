@@ -1093,11 +1093,14 @@ int32_t prl_solver_time_iterations_ex(prl_solver_t* s, int32_t n, float* out_ms,
         PRL_HIP_TRY(hipEventSynchronize(e1));
         PRL_HIP_TRY(hipEventElapsedTime(out_ms, e0, e1));
         float pass_ms = 0.f;
+        const bool dump = getenv("PRL_DUMP_PASS_MS") != nullptr;  // diagnostics: every board-pass launch's duration on stderr
         for (size_t i = 0; i + 1 < s->pass_events.size(); i += 2) {
             float t = 0.f;
             PRL_HIP_TRY(hipEventElapsedTime(&t, s->pass_events[i], s->pass_events[i + 1]));
             pass_ms += t;
+            if (dump) fprintf(stderr, "%.3f%s", t, (i / 2) % 16 == 15 ? "\n" : " ");
         }
+        if (dump) fprintf(stderr, "\n");
         if (out_pass_ms) *out_pass_ms = pass_ms;
         if (out_n_pass) *out_n_pass = (int32_t)(s->pass_events.size() / 2);
     }
@@ -1147,6 +1150,15 @@ int32_t prl_solver_time_evaluations(prl_solver_t* s, int32_t n, float* out_ms, f
 int32_t prl_solver_time_iterations(prl_solver_t* s, int32_t n, float* out_ms) {
     return prl_solver_time_iterations_ex(s, n, out_ms, nullptr, nullptr);
 }
+
+#ifdef FHP_EXPERIMENT
+// experiment builds (scripts/gpu_toggle.py): run-time switch between two code paths of the board pass
+extern "C" int32_t prl_debug_set_experiment(prl_solver_t* s, int32_t flags) {
+    if (!s) return PRL_ERR_ARG;
+    s->fp.exp = flags;
+    return PRL_OK;
+}
+#endif
 
 #ifdef PRL_FHP_TIMING
 // instrumented builds only (scripts/gpu_phases.sh): shader clocks wave 0 spent per phase, summed over boards and passes
