@@ -15,7 +15,7 @@ keep = []
 for i in range(n):
     s = _native.NativeSolver(tree, "plus", 0, engine="fused")
     out = []
-    for rep in range(3):
+    for rep in range(int(os.environ.get("PROBE_REPS", "3"))):
         s.reset()
         s.iterations(4)
         dev_ms, pass_ms, n_pass = s.time_iterations_ex(10)

@@ -16,18 +16,21 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 boards = bench.seeded_boards(int(sys.argv[2]) if len(sys.argv) > 2 else 262144, 0)
 tree = bench.fhp_tree(boards, L)
 L.prl_debug_set_experiment.argtypes = [ctypes.c_void_p, ctypes.c_int32]
-tot = {0: [], 1: []}
+flags = [int(x) for x in os.environ.get("TOGGLE_FLAGS", "0,1").split(",")]
+tot = {f: [] for f in flags}
 for i in range(n):
     s = _native.NativeSolver(tree, "plus", 0, engine="fused", _lib=L)
     s.iterations(4)
     row = []
     for rep in range(3):
-        for flag in (0, 1):
+        for flag in flags:
             L.prl_debug_set_experiment(s._h, flag)
             dev_ms, pass_ms, n_pass = s.time_iterations_ex(10)
-            row.append("%d:%.3f" % (flag, pass_ms / 10))
+            row.append("%d:%.2f" % (flag, pass_ms / 10))
             tot[flag].append(pass_ms / 10)
     print("solver %d: %s" % (i, " ".join(row)), flush=True)
     del s
-m0, m1 = sum(tot[0]) / len(tot[0]), sum(tot[1]) / len(tot[1])
-print("mean exp=0 %.3f ms, exp=1 %.3f ms  (%.2f %%)" % (m0, m1, 100 * (m1 - m0) / m0))
+m0 = sum(tot[flags[0]]) / len(tot[flags[0]])
+for f in flags:
+    m = sum(tot[f]) / len(tot[f])
+    print("mean exp=%d %.3f ms  (%+.2f %%)" % (f, m, 100 * (m - m0) / m0))
