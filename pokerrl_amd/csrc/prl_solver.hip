@@ -587,8 +587,8 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         s->fp.regret = s->d_regret;
         s->fp.board_out = s->d_board_out;
 #ifdef PRL_FHP_TIMING
-        FAIL_IF(dev_alloc(s, &s->fp.timing, (size_t)8));
-        PRL_HIP_TRY(hipMemsetAsync(s->fp.timing, 0, 8 * sizeof(unsigned long long), s->stream));
+        FAIL_IF(dev_alloc(s, &s->fp.timing, (size_t)72));
+        PRL_HIP_TRY(hipMemsetAsync(s->fp.timing, 0, 72 * sizeof(unsigned long long), s->stream));
 #endif
     }
     if (hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
@@ -1165,8 +1165,8 @@ extern "C" int32_t prl_debug_set_experiment(prl_solver_t* s, int32_t flags) {
 extern "C" int32_t prl_debug_fhp_timing(prl_solver_t* s, unsigned long long* out8, int32_t reset) {
     if (!s || !s->fp.timing) return PRL_ERR_ARG;
     PRL_HIP_TRY(hipStreamSynchronize(s->stream));
-    PRL_HIP_TRY(hipMemcpy(out8, s->fp.timing, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (reset) PRL_HIP_TRY(hipMemset(s->fp.timing, 0, 8 * sizeof(unsigned long long)));
+    PRL_HIP_TRY(hipMemcpy(out8, s->fp.timing, 72 * sizeof(unsigned long long), hipMemcpyDeviceToHost));  // [8] phases + [5][12] barrier waits
+    if (reset) PRL_HIP_TRY(hipMemset(s->fp.timing, 0, 72 * sizeof(unsigned long long)));
     return PRL_OK;
 }
 #endif

@@ -21,7 +21,7 @@ t = _native.NativeTree.for_game(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards,
 s = _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
 s.iterations(int(sys.argv[3]) if len(sys.argv) > 3 else 2)
 s.sync()
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 72)()
 L.prl_debug_fhp_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int32]
 L.prl_debug_fhp_timing(s._h, out, 1)
 ms = s.time_iterations(iters)
@@ -33,5 +33,9 @@ tot = v[:6].sum()
 print("ms/iter %.3f   clocks summed over wave-0 of every board pass: %.3e" % (ms / iters, tot))
 for n, x in zip(names, v[:6]):
     print("%-24s %6.2f %%   %10.0f clk per board-iteration" % (n, 100 * x / tot, x / n_boards / iters))
+print("waiting at the barriers, clk per board-iteration and wave (0 = board start, 1 = after B, 2 = inside C, 3 = after D, 4 = between the seats of a two-seat pass):")
+for bi in range(5):
+    w = v[8 + 12 * bi: 20 + 12 * bi] / n_boards / iters
+    print("barrier %d: %s   mean %.0f" % (bi, " ".join("%5.0f" % x for x in w), w.mean()))
 if v[7] > 0:
     print("waves with every loaded regret inside the fast-division box: %.2f %% of %d wave-boards" % (100 * v[6] / v[7], v[7]))
