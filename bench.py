@@ -38,8 +38,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # UPDATE1_EVAL1 2 * 20.93 GB read + 32.62 GB written, UPDATE0_BR 2 * 20.91 + 31.26 = 147.6 GB per iteration; every board subtree moves
 # the same bytes (563 KB per board and iteration: 14 regret columns + the plan in, 7 regret columns out, 7 float64 average columns in
 # and out -- the reference's float64 average is 53 % of it -- and the root vectors), so other sizes scale linearly.
-PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION = 147.56e9 / 262144
-PMC_TRAFFIC_SOURCE = "profiles/r02m_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION = 150.51e9 / 262144
+PMC_TRAFFIC_SOURCE = "profiles/r03n_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
 
 
 def seeded_boards(n, seed, offset=0):

@@ -212,7 +212,7 @@ def test_gpu_sharded_ragged_world2_matches_unsharded(n_local, total):
 @pytest.mark.gpu
 def test_gpu_chance_sum_ragged_shards():
     L = _native.lib()
-    check_chance_sum_ragged(L, 8 * 1024 + 48, 8, 2048)   # the all-boards geometry in small: whole groups, a short last shard
+    check_chance_sum_ragged(L, 7 * 2048 + 48, 8, 2048)   # the all-boards geometry in small: whole groups, a short last shard
     check_chance_sum_ragged(L, 200, 3, 96)
     check_chance_sum_ragged(L, 23, 4, 7)
 
