@@ -50,6 +50,16 @@ PRL_DEV PRL_INLINE void prl_lds_dma_x4(const void* gbase, uint32_t byte_off, voi
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(saved_m0) : "s"(la), "v"(byte_off), "s"(gbase) : "memory");
 }
+// the same with the LDS destination as a 32-bit LDS address (prl_lds_addr): scalar arithmetic on it stays scalar, and there is no
+// generic-to-LDS pointer conversion (with its null test) per instruction
+PRL_DEV PRL_INLINE uint32_t prl_lds_addr(const void* lds_ptr) {
+    return __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) const char*)lds_ptr);
+}
+PRL_DEV PRL_INLINE void prl_lds_dma_x4_a(const void* gbase, uint32_t byte_off, uint32_t lds_wave_addr) {
+    uint32_t saved_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved_m0) : "s"(lds_wave_addr), "v"(byte_off), "s"(gbase) : "memory");
+}
 PRL_DEV PRL_INLINE void prl_lds_dma_dword(const void* gbase, uint32_t byte_off, void* lds_wave_base) {
     const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
     uint32_t saved_m0;
@@ -57,6 +67,8 @@ PRL_DEV PRL_INLINE void prl_lds_dma_dword(const void* gbase, uint32_t byte_off, 
                  : "=&s"(saved_m0) : "s"(la), "v"(byte_off), "s"(gbase) : "memory");
 }
 PRL_DEV PRL_INLINE void prl_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+PRL_DEV PRL_INLINE int prl_opaque_scalar(int v) { asm volatile("" : "+s"(v)); return v; }  // hides a wave-uniform value's history from the optimiser
+PRL_DEV PRL_INLINE int prl_wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }  // v is the same in every lane: keep it scalar
 PRL_DEV PRL_INLINE char* prl_smem() {
     extern __shared__ __attribute__((aligned(16))) char prl_dyn_smem[];
     return prl_dyn_smem;

@@ -88,8 +88,9 @@ template <class T>
 int dev_alloc(prl_solver* s, T** p, size_t count) {
     void* q = nullptr;
     size_t bytes = (count ? count : 1) * sizeof(T);
-    // 16 spare bytes: the fused engine's 16-byte LDS-DMA prefetch rounds the end of a board's block up to a whole chunk
-    hipError_t e = hipMalloc(&q, bytes + 16);
+    // spare bytes at the far end: the fused engine's LDS-DMA prefetch fetches whole rows of 64 x 16 bytes, so the last board's
+    // last row reads up to ~1 KB past its block
+    hipError_t e = hipMalloc(&q, bytes + 4096);
     if (e != hipSuccess) {
         prl_set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
         return PRL_ERR_OOM;

@@ -47,7 +47,14 @@ inline void prl_lds_dma_dword(const void* gbase, uint32_t byte_off, void* lds_wa
 inline void prl_lds_dma_x4(const void* gbase, uint32_t byte_off, void* lds_wave_base) {
     memcpy((char*)lds_wave_base + 16 * (prl_emu::g_ctx->tid & 63u), (const char*)gbase + byte_off, 16);
 }
+// LDS addresses of the emulator: byte offsets into the workgroup's shared memory
+inline uint32_t prl_lds_addr(const void* lds_ptr) { return (uint32_t)((const char*)lds_ptr - prl_emu::g_ctx->smem); }
+inline void prl_lds_dma_x4_a(const void* gbase, uint32_t byte_off, uint32_t lds_wave_addr) {
+    memcpy(prl_emu::g_ctx->smem + lds_wave_addr + 16 * (prl_emu::g_ctx->tid & 63u), (const char*)gbase + byte_off, 16);
+}
 inline void prl_dma_wait() {}
+inline int prl_wave_uniform(int v) { return v; }
+inline int prl_opaque_scalar(int v) { return v; }
 inline char* prl_smem() { return prl_emu::g_ctx->smem; }
 
 inline float prl_shfl(float v, int src_lane) {
