@@ -169,6 +169,7 @@ struct PrlFhpParams {
     // follows q's pass -- so it rides on the next pass that walks q's reach (phase B for seat q): bit q of avgsum_mask
     float* avg_sum;             // [n_cols][R] node.data["avg_strat_sum"] (VanillaCFR.py:40-55, LinearCFR.py:41-57)
     int32_t avgsum_mask, avgsum_iter[2];
+    int32_t block_sum;          // 1: board_out holds one row per PRL_CHANCE_BLOCK boards (level 0 of the chance sum done by the pass)
     int32_t exp;                // FHP_EXPERIMENT builds: run-time switch between two code paths (prl_debug_set_experiment)
     int32_t no_steady;          // tests: 1 = never take the CFR+ steady-state specialisation of the pass (prl_fhp_pass.inc, FhpCtxT)
     const double* strat_arr;    // explicit strategy (average strategy / caller-provided), [n_cols][R]
@@ -194,5 +195,6 @@ void prl_launch_fhp_chance_sum(const float* d_board_vals, int n_boards, int W, f
 // sharded solve (prl_solver_create_sharded): local reduction up to `level`, all-gather, then the remaining levels
 int prl_fhp_units_at_level(int n_boards, int level);
 void prl_launch_fhp_chance_partial(const float* d_board_vals, int n_boards, int level, int W, float* d_scratch, float* d_units, void* stream);
+void prl_launch_fhp_chance_partial_from_blocks(const float* d_blocks, int n_blk, int level, int W, float* d_units, void* stream);
 void prl_launch_fhp_chance_finish(const float* d_units, int n_units, int level, int W, float* d_scratch, float* d_dest, void* stream);
 void prl_launch_fhp_compact_gathered(const float* d_in, int world, int n_which, int n_units, int W, float* d_out, void* stream);

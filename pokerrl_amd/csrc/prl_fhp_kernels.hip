@@ -198,6 +198,16 @@ void prl_launch_fhp_chance_partial(const float* d_board_vals, int n_boards, int 
     PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)n_grp * R2 / 2, 256), 256, 0, stream, (const float*)blk, n_blk, PRL_CHANCE_BLOCK, R2, d_units);
 }
 
+// the same when the board pass already summed its boards per block (PrlFhpParams::block_sum): d_blocks = level-1 units
+void prl_launch_fhp_chance_partial_from_blocks(const float* d_blocks, int n_blk, int level, int W, float* d_units, void* stream) {
+    if (level <= 1) {  // the blocks are the units
+        PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)n_blk * W / 2, 256), 256, 0, stream, d_blocks, n_blk, 1, W, d_units);
+        return;
+    }
+    const int n_grp = (n_blk + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
+    PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)n_grp * W / 2, 256), 256, 0, stream, d_blocks, n_blk, PRL_CHANCE_BLOCK, W, d_units);
+}
+
 // units of `level` (contiguous [n_units][2][R]) -> dest [2][R]; scratch >= (ceil(n/32) + ceil(n/1024) + 1) * 2R floats
 void prl_launch_fhp_chance_finish(const float* d_units, int n_units, int level, int W, float* d_scratch, float* d_dest, void* stream) {
     const int R2 = W;

@@ -53,6 +53,7 @@ struct prl_solver {
     uint64_t fingerprint = 0;  // boards + game + rules + (world, rank): what a checkpoint must match besides the array shapes
     prl_exchange_fn exchange = nullptr;
     bool exchange_async = false;  // the callback enqueues on s->stream: no host synchronisation around it
+    bool block_sum = true;        // the board pass sums its root vectors per 32-board block (PRL_FHP_NO_BLOCK_SUM: per-board rows, tests)
     void* exchange_user = nullptr;
     float *d_xlocal = nullptr, *d_xgather = nullptr;
     bool have_half = false;      // FUSED steady state: seat 1's half of the exploitability of the current iterate is in d_half
@@ -169,6 +170,9 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
     p.avg_sum = s->S.avg_sum;
     p.avg = s->d_avg;
     p.avgsum_mask = 0;
+    // level 0 of the canonical chance sum inside the pass (one row per 32-board block leaves the chip) whenever whole blocks are
+    // what comes next: always without an exchange, and with one when the units exchanged are blocks or groups of blocks
+    p.block_sum = (s->block_sum && (!s->exchange || s->xlevel >= 1)) ? 1 : 0;
     if (&st == &s->S && strat_arr == nullptr) {
         const bool walks[2] = {prl_fhp_runs_seat(mode, 1), prl_fhp_runs_seat(mode, 0)};  // seat q is the opponent of a batch of 1 - q
         for (int q = 0; q < 2; ++q)
@@ -200,12 +204,15 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
     const bool with_br = prl_fhp_with_br(mode);
     const int W = prl_fhp_out_width(mode) * p.R;
     float* summed = s->d_row_sum;
+    const int n_blk = (p.n_boards + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
     if (!s->exchange) {
-        prl_launch_fhp_chance_sum(s->d_board_out, p.n_boards, W, s->d_sum_scratch, summed, s->stream);
+        if (p.block_sum) prl_launch_fhp_chance_finish(s->d_board_out, n_blk, 1, W, s->d_sum_scratch, summed, s->stream);
+        else prl_launch_fhp_chance_sum(s->d_board_out, p.n_boards, W, s->d_sum_scratch, summed, s->stream);
     } else {
         // local units -> all-gather -> remaining levels over all units in global order (header: prl_solver_create_sharded)
         const size_t per_rank = (size_t)s->n_units * W;
-        prl_launch_fhp_chance_partial(s->d_board_out, p.n_boards, s->xlevel, W, s->d_sum_scratch, s->d_xlocal, s->stream);
+        if (p.block_sum) prl_launch_fhp_chance_partial_from_blocks(s->d_board_out, n_blk, s->xlevel, W, s->d_xlocal, s->stream);
+        else prl_launch_fhp_chance_partial(s->d_board_out, p.n_boards, s->xlevel, W, s->d_sum_scratch, s->d_xlocal, s->stream);
         if (!s->exchange_async) PRL_HIP_TRY(hipStreamSynchronize(s->stream));
         if (s->exchange(s->exchange_user, s->d_xlocal, s->d_xgather, (uint64_t)(per_rank * sizeof(float))) != 0) {
             prl_set_error("sharded solve: the exchange callback failed");
@@ -545,6 +552,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
                 const char* g = getenv("PRL_FHP_GRID");
                 if (g && atoi(g) > 0) fp.max_grid = atoi(g);
             }
+            s->block_sum = getenv("PRL_FHP_NO_BLOCK_SUM") == nullptr;
             fp.no_steady = getenv("PRL_FHP_NO_STEADY") ? 1 : 0;  // tests: the generic pass in the steady state too
             fp.chance_prob = T.chance_prob; fp.eq_const = T.eq_const;
             const PrlFhpShapeDesc& sd = prl_fhp_shape_desc(shape_id);

@@ -9,18 +9,19 @@ import bench  # noqa: E402
 from pokerrl_amd import _native  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+_L = _native.bind(os.environ["PROBE_LIB"]) if os.environ.get("PROBE_LIB") else None  # another build of the library
 boards = bench.seeded_boards(int(os.environ.get("PROBE_BOARDS", "262144")), 0)
-tree = bench.fhp_tree(boards)
+tree = bench.fhp_tree(boards, _L)
 keep = []
 for i in range(n):
-    s = _native.NativeSolver(tree, "plus", 0, engine="fused")
+    s = _native.NativeSolver(tree, "plus", 0, engine="fused", _lib=_L)
     out = []
     for rep in range(int(os.environ.get("PROBE_REPS", "3"))):
         s.reset()
         s.iterations(4)
         dev_ms, pass_ms, n_pass = s.time_iterations_ex(10)
         out.append(pass_ms / 10)
-    print("solver %d: board pass %s ms per iteration" % (i, " ".join("%.3f" % x for x in out)), flush=True)
+    print("solver %d: board pass %s ms per iteration, whole iteration %.3f" % (i, " ".join("%.3f" % x for x in out), dev_ms / 10), flush=True)
     if os.environ.get("PROBE_KEEP"):
         keep.append(s)  # the next solver lands in other memory
     else:

@@ -107,6 +107,13 @@ def test_emu_fused_engine_batched_iterations(L):
     pc.check_fused_batched_vs_oracle(L, 3, 4, delay=1)
 
 
+def test_emu_fused_engine_block_sums_across_a_block_boundary(L, monkeypatch):
+    """33 boards on two workgroups: the pass sums its root vectors per 32-board block (one full block + a block of one), the sum
+    kernels start a level higher -- against the oracle's board-by-board canonical sum"""
+    monkeypatch.setenv("PRL_FHP_GRID", "2")
+    pc.check_fused_batched_vs_oracle(L, 33, 2, delay=0)
+
+
 @pytest.mark.parametrize("no_steady", [False, True])
 def test_emu_fused_engine_steady_state_specialisation(L, monkeypatch, no_steady):
     """CFR+ delay 0, batched: iterations 2.. run the steady-state instantiation of the two update passes (prl_fhp_pass.inc, FhpCtxT);

@@ -221,6 +221,13 @@ def test_gpu_fused_batched_iterations_vs_oracle(L):
 
 
 @pytest.mark.gpu
+def test_gpu_fused_per_board_rows_vs_oracle(L, monkeypatch):
+    """PRL_FHP_NO_BLOCK_SUM: the pass writes one row per board and the sum kernels do level 0 (the path of shards that are not whole blocks)"""
+    monkeypatch.setenv("PRL_FHP_NO_BLOCK_SUM", "1")
+    pc.check_fused_batched_vs_oracle(L, 70, 3, delay=0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("no_steady", [False, True])
 def test_gpu_fused_steady_state_specialisation_vs_oracle(L, monkeypatch, no_steady):
     """the CFR+ steady-state instantiation of the update passes and the generic one (PRL_FHP_NO_STEADY) against the oracle"""
