@@ -576,8 +576,10 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     if (variant != PRL_CFR_PLUS) FAIL_IF(dev_alloc(s, &s->S.avg_sum, nc_full));
     FAIL_IF(alloc_node_vectors(s, &s->S, true));
     if (fused) {
-        const size_t bv = (size_t)full.n_boards * 2 * T.R;
-        FAIL_IF(dev_alloc(s, &s->d_board_out, 2 * bv));
+        // root-vector rows of a pass: one per board, or one per 32-board block when the pass sums its blocks itself (fused_board_pass)
+        const bool rows_are_blocks = s->block_sum && (!exchange || shard_boards % PRL_CHANCE_BLOCK == 0);
+        const size_t n_rows = rows_are_blocks ? ((size_t)full.n_boards + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK : (size_t)full.n_boards;
+        FAIL_IF(dev_alloc(s, &s->d_board_out, n_rows * 4 * T.R));
         FAIL_IF(dev_alloc(s, &s->d_row_sum, (size_t)4 * T.R));
         const size_t n_blk = ((size_t)total_boards + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK + world;  // sized for the global board list
         const size_t n_grp = (n_blk + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
