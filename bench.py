@@ -34,12 +34,12 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per CFR+ iteration of the board-pass kernels, from the PMC passes (FETCH_SIZE / WRITE_SIZE in their own rocprofv3 runs,
-# FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads). Measured at 262144 boards (profiles/r03n_pmc.txt):
-# UPDATE0_BR 2 * 21.04 GB read + 33.91 GB written, UPDATE1_EVAL1 2 * 21.00 + 32.52 = 150.5 GB per iteration; every board subtree moves
-# the same bytes (574 KB per board and iteration: 14 regret columns + the plan in, 7 regret columns out, 7 float64 average columns in
+# FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads). Measured at 262144 boards (profiles/r03v_pmc.txt):
+# UPDATE0_BR 2 * 21.00 GB read + 29.82 GB written, UPDATE1_EVAL1 2 * 21.04 + 29.88 = 143.8 GB per iteration; every board subtree moves
+# the same bytes (548 KB per board and iteration: 14 regret columns + the plan in, 7 regret columns out, 7 float64 average columns in
 # and out -- the reference's float64 average is 53 % of it -- and the root vectors), so other sizes scale linearly.
-PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION = 150.51e9 / 262144
-PMC_TRAFFIC_SOURCE = "profiles/r03n_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION = 143.78e9 / 262144
+PMC_TRAFFIC_SOURCE = "profiles/r03v_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
 
 
 def seeded_boards(n, seed, offset=0):
