@@ -250,6 +250,11 @@ def main():
                      "launches_per_iteration": n_pass / float(args.steps) if n_pass else None,
                      "kernel_ms_per_iteration": kernel_ms / args.steps, "device_ms_per_iteration": dev_ms / args.steps,
                      "bytes_per_iteration_algorithmic": bytes_iter,
+                     # the PMC-measured bytes over the same kernel time: what the kernel actually pulls through HBM (float64 averages
+                     # included), against the ~6.3 TB/s MI355X_MICROARCH.md gives as sustained
+                     "traffic_rate_gbps": (PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION * args.boards * args.steps / (kernel_ms * 1e-3) / 1e9)
+                     if (solver.engine == "fused" and args.variant == "plus") else None,
+                     "sustained_hbm_gbps": 6300.0,
                      "achieved_whole_iteration": bytes_iter * args.steps / (dev_ms * 1e-3) / 1e9},
     }
     if rank == 0:
