@@ -30,6 +30,13 @@ class _GameBase:
     EV_NORMALIZER = None
     WIN_METRIC = None
 
+    def __new__(cls, env_args, lut_holder=None, is_evaluating=True):
+        """`game_cls(env_args=..., lut_holder=..., is_evaluating=...)` is how the reference builds an env (a game class IS a PokerEnv
+        subclass there, PokerEnv.py:53): here it returns the native-backed PokerEnv facade of that game."""
+        from pokerrl_amd.game.poker_env import PokerEnv
+        return PokerEnv(env_cls=cls, env_args=env_args, lut_holder=lut_holder if lut_holder is not None else cls.get_lut_holder(),
+                        is_evaluating=is_evaluating)
+
     @classmethod
     def get_lut_holder(cls):
         return cls.RULES.get_lut_holder()
