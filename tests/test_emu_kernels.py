@@ -99,8 +99,12 @@ def test_emu_fused_engine_vanilla_linear(L, variant):
     pc.check_fused_vs_oracle(L, 3, 3, variant=variant)
 
 
-def test_emu_fused_engine_linear_batched_iterations(L):
-    pc.check_fused_batched_vs_oracle(L, 3, 3, variant="linear")
+@pytest.mark.parametrize("variant,no_steady", [("linear", False), ("linear", True), ("vanilla", False)])
+def test_emu_fused_engine_linear_batched_iterations(L, monkeypatch, variant, no_steady):
+    """Linear / vanilla CFR, batched: iterations 2.. run their steady-state instantiation of the update passes (PRL_FHP_NO_STEADY: the generic one)"""
+    if no_steady:
+        monkeypatch.setenv("PRL_FHP_NO_STEADY", "1")
+    pc.check_fused_batched_vs_oracle(L, 3, 3, variant=variant)
 
 
 def test_emu_fused_engine_batched_iterations(L):

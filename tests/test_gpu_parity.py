@@ -136,6 +136,7 @@ def test_gpu_fused_vanilla_linear_vs_oracle(L, variant):
 
 def test_gpu_fused_linear_batched_vs_oracle_and_levels(L):
     pc.check_fused_batched_vs_oracle(L, 35, 5, variant="linear")
+    pc.check_fused_batched_vs_oracle(L, 35, 4, variant="vanilla")
     pc.check_fused_vs_levels(L, 2048, 5, variant="linear")
 
 
