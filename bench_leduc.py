@@ -14,7 +14,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
@@ -65,7 +64,7 @@ def main():
         # a Leduc-sized tree occupies ONE CU: the GPU is filled by solving many trees at once -- here the same game at
         # args.solves different stack sizes (different trees), one workgroup each, all advanced by one launch per call
         stacks = [stack + i for i in range(args.solves)]
-        trees = [native_tree(game_cls, st, bets, boards) for st in stacks]
+        trees = [_native.NativeTree.for_game(game_cls, st, bets, boards) for st in stacks]
         solvers = [_native.NativeSolver(t, args.variant, 0, engine="levels") for t in trees]
         try:
             _native.NativeSolver.iterations_many(solvers, args.warmup)
