@@ -33,6 +33,7 @@ struct prl_solver {
     bool eval_ready = false;
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;
+    std::vector<void*> vmm;  // large arrays: shuffled virtual-memory-management ranges (PrlVmmRange*, dev_alloc)
     int32_t* d_term_nodes = nullptr;
     int n_term = 0;
     int32_t* d_nodes_p[2] = {nullptr, nullptr};
@@ -85,10 +86,79 @@ struct prl_solver {
 
 namespace {
 
+#if !defined(PRL_EMU)
+// A large array as ONE virtual range backed by 2 MB physical chunks mapped in a SHUFFLED order (HIP virtual memory management).
+// Why: the board pass streams ~5.6 TB/s, within 10 % of what the part sustains, and how fast it runs depends on where its 66 GB land
+// physically -- a plain hipMalloc object is sometimes up to 15 % slower than another one at the same virtual addresses, physically
+// contiguous backing (hipDeviceMallocContiguous) is ALWAYS the slow case, and this scattered backing is always the fast one (12 of
+// 12 solver objects within 0.2 %, profiles/r02_experiments.txt). The permutation has a fixed seed. PRL_VMM_SHUFFLE_MB=0 turns it off,
+// another value changes the chunk size (8 and 64 MB chunks already show some of the spread). Returns nullptr when anything fails
+// (the caller falls back to hipMalloc).
+struct PrlVmmRange { void* va; size_t size, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
+static void* vmm_alloc_shuffled(size_t bytes, size_t chunk, PrlVmmRange* out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) return nullptr;
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t n = (bytes + chunk - 1) / chunk, size = n * chunk;
+    void* va = nullptr;
+    if (hipMemAddressReserve(&va, size, chunk, nullptr, 0) != hipSuccess) return nullptr;
+    out->va = va; out->size = size; out->chunk = chunk;
+    std::vector<size_t> slot(n);
+    for (size_t i = 0; i < n; ++i) slot[i] = i;
+    unsigned long long x = 0x9E3779B97F4A7C15ull;  // fixed seed: the same mapping every run
+    for (size_t i = n; i > 1; --i) { x = x * 6364136223846793005ull + 1442695040888963407ull; std::swap(slot[i - 1], slot[(size_t)((x >> 33) % i)]); }
+    bool ok = true;
+    for (size_t i = 0; i < n && ok; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { ok = false; break; }
+        out->handles.push_back(h);
+        if (hipMemMap((char*)va + slot[i] * chunk, chunk, 0, h, 0) != hipSuccess) ok = false;
+    }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (ok && hipMemSetAccess(va, size, &acc, 1) != hipSuccess) ok = false;
+    if (!ok) {
+        (void)hipGetLastError();
+        (void)hipMemUnmap(va, size);
+        for (auto h : out->handles) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(va, size);
+        out->handles.clear();
+        return nullptr;
+    }
+    return va;
+}
+static void vmm_free(PrlVmmRange& r) {
+    (void)hipMemUnmap(r.va, r.size);
+    for (auto h : r.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(r.va, r.size);
+}
+#endif
+
 template <class T>
-int dev_alloc(prl_solver* s, T** p, size_t count) {
+int dev_alloc(prl_solver* s, T** p, size_t count, bool plain = false) {  // plain: buffers handed to the exchange callback (RCCL)
     void* q = nullptr;
     size_t bytes = (count ? count : 1) * sizeof(T);
+#if !defined(PRL_EMU)
+    static const long vmm_mb = getenv("PRL_VMM_SHUFFLE_MB") ? atol(getenv("PRL_VMM_SHUFFLE_MB")) : 2;
+    if (!plain && vmm_mb > 0 && bytes >= ((size_t)32 << 20)) {
+        PrlVmmRange* r = new PrlVmmRange();
+        q = vmm_alloc_shuffled(bytes + 4096, (size_t)vmm_mb << 20, r);
+        if (q) {
+            s->vmm.push_back(r);
+            s->bytes_allocated += bytes;
+            *p = (T*)q;
+            return PRL_OK;
+        }
+        delete r;  // (no message: plain hipMalloc is a correct fallback, only the run-to-run spread comes back)
+    }
+#endif
     // spare bytes at the far end: the fused engine's LDS-DMA prefetch fetches whole rows of 64 x 16 bytes, so the last board's
     // last row reads up to ~1 KB past its block
     hipError_t e = hipMalloc(&q, bytes + 4096);
@@ -590,8 +660,8 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             s->n_units = prl_fhp_units_at_level((int)shard_boards, s->xlevel);
             s->n_units_all = (world - 1) * s->n_units + prl_fhp_units_at_level((int)(total_boards - (int64_t)(world - 1) * shard_boards), s->xlevel);
             const size_t per_rank = (size_t)s->n_units * 4 * T.R;  // [units][<= 4 vectors][R]
-            FAIL_IF(dev_alloc(s, &s->d_xlocal, per_rank));
-            FAIL_IF(dev_alloc(s, &s->d_xgather, per_rank * world));
+            FAIL_IF(dev_alloc(s, &s->d_xlocal, per_rank, true));
+            FAIL_IF(dev_alloc(s, &s->d_xgather, per_rank * world, true));
             FAIL_IF(hipMemsetAsync(s->d_xlocal, 0, per_rank * sizeof(float), s->stream) == hipSuccess ? PRL_OK : PRL_ERR_HIP);  // a shorter last shard sends zero padding
         }
         FAIL_IF(dev_alloc(s, &s->d_half, (size_t)2 * T.R + 4));
@@ -785,6 +855,9 @@ void prl_solver_destroy(prl_solver_t* s) {
     if (s->levels_graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)s->levels_graph_exec);
 #endif
     for (void* p : s->allocs) (void)hipFree(p);
+#if !defined(PRL_EMU)
+    for (void* r : s->vmm) { vmm_free(*(PrlVmmRange*)r); delete (PrlVmmRange*)r; }
+#endif
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }

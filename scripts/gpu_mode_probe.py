@@ -14,14 +14,18 @@ boards = bench.seeded_boards(int(os.environ.get("PROBE_BOARDS", "262144")), 0)
 tree = bench.fhp_tree(boards, _L)
 keep = []
 for i in range(n):
+    import time
+    t0 = time.perf_counter()
     s = _native.NativeSolver(tree, "plus", 0, engine="fused", _lib=_L)
+    s.sync()
+    t_create = time.perf_counter() - t0
     out = []
     for rep in range(int(os.environ.get("PROBE_REPS", "3"))):
         s.reset()
         s.iterations(4)
         dev_ms, pass_ms, n_pass = s.time_iterations_ex(10)
         out.append(pass_ms / 10)
-    print("solver %d: board pass %s ms per iteration, whole iteration %.3f" % (i, " ".join("%.3f" % x for x in out), dev_ms / 10), flush=True)
+    print("solver %d: board pass %s ms per iteration, whole iteration %.3f (solver created in %.1f s)" % (i, " ".join("%.3f" % x for x in out), dev_ms / 10, t_create), flush=True)
     if os.environ.get("PROBE_KEEP"):
         keep.append(s)  # the next solver lands in other memory
     else:
