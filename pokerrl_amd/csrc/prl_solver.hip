@@ -33,7 +33,7 @@ struct prl_solver {
     bool eval_ready = false;
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;
-    std::vector<void*> vmm;  // large arrays: shuffled virtual-memory-management ranges (PrlVmmRange*, dev_alloc)
+    std::vector<void*> vmm;  // PRL_VMM_SHUFFLE_MB: shuffled virtual-memory-management ranges (PrlVmmRange*, dev_alloc)
     int32_t* d_term_nodes = nullptr;
     int n_term = 0;
     int32_t* d_nodes_p[2] = {nullptr, nullptr};
@@ -87,13 +87,13 @@ struct prl_solver {
 namespace {
 
 #if !defined(PRL_EMU)
-// A large array as ONE virtual range backed by 2 MB physical chunks mapped in a SHUFFLED order (HIP virtual memory management).
-// Why: the board pass streams ~5.6 TB/s, within 10 % of what the part sustains, and how fast it runs depends on where its 66 GB land
-// physically -- a plain hipMalloc object is sometimes up to 15 % slower than another one at the same virtual addresses, physically
-// contiguous backing (hipDeviceMallocContiguous) is ALWAYS the slow case, and this scattered backing is always the fast one (12 of
-// 12 solver objects within 0.2 %, profiles/r02_experiments.txt). The permutation has a fixed seed. PRL_VMM_SHUFFLE_MB=0 turns it off,
-// another value changes the chunk size (8 and 64 MB chunks already show some of the spread). Returns nullptr when anything fails
-// (the caller falls back to hipMalloc).
+// Opt-in experiment (PRL_VMM_SHUFFLE_MB=c): a large array as ONE virtual range backed by c MB physical chunks mapped in a SHUFFLED
+// order (HIP virtual memory management). The board pass streams within 10 % of what the part sustains and its speed depends on where
+// its 66 GB land physically: plain hipMalloc objects of one process differ by up to 15 %, physically contiguous backing
+// (hipDeviceMallocContiguous) is always the slow case. Shuffled 2 MB chunks remove the object-to-object spread on a box (12 of 12
+// objects within 0.2 %) -- but at a level that is itself box-dependent: equal to the best plain objects on one box (26.1 ms), 7 %
+// behind them on another (27.6 vs 25.8 ms), so it is not the default (profiles/r02_experiments.txt). Returns nullptr when anything
+// fails (the caller falls back to hipMalloc).
 struct PrlVmmRange { void* va; size_t size, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
 static void* vmm_alloc_shuffled(size_t bytes, size_t chunk, PrlVmmRange* out) {
     int dev = 0;
@@ -146,7 +146,7 @@ int dev_alloc(prl_solver* s, T** p, size_t count, bool plain = false) {  // plai
     void* q = nullptr;
     size_t bytes = (count ? count : 1) * sizeof(T);
 #if !defined(PRL_EMU)
-    static const long vmm_mb = getenv("PRL_VMM_SHUFFLE_MB") ? atol(getenv("PRL_VMM_SHUFFLE_MB")) : 2;
+    static const long vmm_mb = getenv("PRL_VMM_SHUFFLE_MB") ? atol(getenv("PRL_VMM_SHUFFLE_MB")) : 0;
     if (!plain && vmm_mb > 0 && bytes >= ((size_t)32 << 20)) {
         PrlVmmRange* r = new PrlVmmRange();
         q = vmm_alloc_shuffled(bytes + 4096, (size_t)vmm_mb << 20, r);
