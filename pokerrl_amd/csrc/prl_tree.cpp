@@ -142,6 +142,14 @@ int prl_build_flat_tree(const PrlGame& game, const PrlRules& rules, const int8_t
     // The caller lists RUN-OUTS: one row of board_len cards per run-out, in deal order. The chance outcomes of the transition to
     // round r are the distinct prefixes of length (cards out after r) below the current prefix. Every prefix of every dealing round
     // gets a row of the board table (cards not dealt yet = -1); with one dealing round the rows are the caller's rows, in order.
+    for (int i = 0; i < n_boards; ++i) {  // every run-out: cards of this deck, no card twice (the kernels count on C(n - len, 2) live hands)
+        unsigned long long seen = 0;
+        for (int c = 0; c < board_len; ++c) {
+            const int card = boards[(size_t)i * board_len + c];
+            if (card < 0 || card >= rules.n_cards || card >= 64 || (seen >> card & 1ull)) { t.error = "a run-out holds a card outside the deck, or the same card twice"; return PRL_ERR_ARG; }
+            seen |= 1ull << card;
+        }
+    }
     t.board_len = board_len;
     t.n_runouts = n_boards;
     Builder b{&t, boards, n_boards, board_len, stop_at_round < 0 ? 0x7FFFFFFF : stop_at_round};

@@ -231,6 +231,15 @@ def test_tree_rejects_runouts_shorter_than_the_deal():
         native_tree(G.LimitHoldem, 48, [0.0], np.array([[0, 1, 2]], np.int8))
 
 
+def test_tree_rejects_runouts_with_repeated_or_foreign_cards():
+    """the board-pass kernels count on C(47, 2) live hands per 5-card board: a card twice (or outside the deck) is refused at build"""
+    for bad in ([3, 3, 10, 20, 30], [0, 1, 2, 3, 52], [0, 1, 2, 3, -1]):
+        with pytest.raises(_native.NativeError, match="card"):
+            native_tree(G.Flop5Holdem, 20000, [1.0], np.array([[4, 9, 14, 19, 24], bad], np.int8))
+    with pytest.raises(_native.NativeError, match="card"):
+        native_tree(G.StandardLeduc, 13, None, np.array([[0], [6]], np.int8))   # 6-card deck: cards 0..5
+
+
 def test_tree_deals_out_an_all_in_before_the_deal_on_two_card_ranges():
     """ValueFiller.py:160-175 averages an all-in-before-the-deal showdown over every run-out, for 1-card ranges only. On a 2-card tree
     the builder deals the hand out instead: a chance node without decisions whose children are showdown leaves on the listed boards (the
