@@ -4,10 +4,15 @@ TrainingProfileBase + ChiefBase) driven the way the reference's own scripts and 
 (examples/run_cfrp_example.py:27-37, test/cfr/test_cfr.py:15-62, test/game/test_tree.py:78-131), with results compared to
 logs captured from the reference (tests/golden/cfr_*.npz, SURVEY.md section 8a BR values).
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
 from helpers import golden
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 from pokerrl_amd.game import bet_sets
 from pokerrl_amd.game.games import DiscretizedNLLeduc, StandardLeduc
 from pokerrl_amd.rl.base_cls.workers.ChiefBase import ChiefBase
@@ -63,6 +68,30 @@ def test_run_cfrp_example_configuration():
     assert np.array_equal(np.array(vals[curr]["Evaluation/MBB_per_G"], dtype=np.float64), g["curr_series"])
     avg = [k for k in vals if "_Avg_total_S20000_" in k][0]
     assert vals[avg]["Evaluation/MBB_per_G"][-1] == [10, g["avg_series"][-1, 1]]
+
+
+def test_example_scripts_run(capsys):
+    """examples/run_cfrp_example.py / run_cfr_example.py / run_lcfr_example.py: their shared body for 3 iterations each; the CFR+ one
+    prints the reference's first exploitabilities (tests/golden/cfr_DiscretizedNLLeduc_POT_CFRPlus.npz)"""
+    import importlib
+    ex = os.path.join(os.path.dirname(HERE), "examples")
+    sys.path.insert(0, ex)
+    try:
+        common = importlib.import_module("_common")
+        from pokerrl_amd.cfr.CFRPlus import CFRPlus
+        from pokerrl_amd.cfr.LinearCFR import LinearCFR
+        from pokerrl_amd.cfr.VanillaCFR import VanillaCFR
+        g = golden("cfr_DiscretizedNLLeduc_POT_CFRPlus.npz")
+        common.run(CFRPlus, "CFRp_EXAMPLE", n_iterations=3, delay=0)
+        out = capsys.readouterr().out
+        lines = [x for x in out.splitlines() if x.startswith("Iteration:")]
+        assert len(lines) == 3
+        assert ("current %.3f" % g["curr_series"][3, 1]) in lines[2]  # after the third iteration
+        common.run(VanillaCFR, "CFR_EXAMPLE", n_iterations=2)
+        common.run(LinearCFR, "LCFR_EXAMPLE", n_iterations=2)
+        assert capsys.readouterr().out.count("Iteration:") == 4
+    finally:
+        sys.path.remove(ex)
 
 
 def _uniform_agent_cls():
