@@ -87,13 +87,13 @@ struct prl_solver {
 namespace {
 
 #if !defined(PRL_EMU)
-// Opt-in experiment (PRL_VMM_SHUFFLE_MB=c): a large array as ONE virtual range backed by c MB physical chunks mapped in a SHUFFLED
+// PRL_VMM_SHUFFLE_MB=c (default: 2 for sharded solves, 0 = off otherwise): a large array as ONE virtual range backed by c MB physical chunks mapped in a SHUFFLED
 // order (HIP virtual memory management). The board pass streams within 10 % of what the part sustains and its speed depends on where
 // its 66 GB land physically: plain hipMalloc objects of one process differ by up to 15 %, physically contiguous backing
 // (hipDeviceMallocContiguous) is always the slow case. Shuffled 2 MB chunks remove the object-to-object spread on a box (12 of 12
 // objects within 0.2 %) -- but at a level that is itself box-dependent: equal to the best plain objects on one box (26.1 ms), 7 %
-// behind them on another (27.6 vs 25.8 ms), so it is not the default (profiles/r02_experiments.txt). Returns nullptr when anything
-// fails (the caller falls back to hipMalloc).
+// behind them on another (27.6 vs 25.8 ms), so it is the default only where the slowest of several objects sets the pace (sharded
+// solves; profiles/r02_experiments.txt). Returns nullptr when anything fails (the caller falls back to hipMalloc).
 struct PrlVmmRange { void* va; size_t size, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
 static void* vmm_alloc_shuffled(size_t bytes, size_t chunk, PrlVmmRange* out) {
     int dev = 0;
@@ -146,7 +146,10 @@ int dev_alloc(prl_solver* s, T** p, size_t count, bool plain = false) {  // plai
     void* q = nullptr;
     size_t bytes = (count ? count : 1) * sizeof(T);
 #if !defined(PRL_EMU)
-    static const long vmm_mb = getenv("PRL_VMM_SHUFFLE_MB") ? atol(getenv("PRL_VMM_SHUFFLE_MB")) : 0;
+    // default: on (2 MB chunks) for sharded solves -- a multi-GPU step lasts as long as its SLOWEST rank, and with plain allocations
+    // one rank in three is a slow one -- off for a single GPU, where a well-placed plain allocation is the fastest case
+    static const long vmm_env = getenv("PRL_VMM_SHUFFLE_MB") ? atol(getenv("PRL_VMM_SHUFFLE_MB")) : -1;
+    const long vmm_mb = vmm_env >= 0 ? vmm_env : (s->world > 1 ? 2 : 0);
     if (!plain && vmm_mb > 0 && bytes >= ((size_t)32 << 20)) {
         PrlVmmRange* r = new PrlVmmRange();
         q = vmm_alloc_shuffled(bytes + 4096, (size_t)vmm_mb << 20, r);
