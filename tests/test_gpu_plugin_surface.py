@@ -196,6 +196,34 @@ def test_public_tree_api_like_test_tree():
     assert st["current_player"] == 1 and st["main_pot"] == 2
 
 
+def test_fill_random_random_like_reference():
+    """S2 (StrategyFiller.py:67-86): the same np.random seed gives the reference's float64 strategies node for node (DFS pre-order
+    draws), and compute_ev on them the reference's exploitability / root values / reach (tests/golden/make_randomfill_golden.py)"""
+    import hashlib
+    from pokerrl_amd.game.PublicTree import PublicTree
+    from pokerrl_amd.game.wrappers import HistoryEnvBuilder
+    g = golden("randomfill.npz")
+    args = StandardLeduc.ARGS_CLS(n_seats=2, starting_stack_sizes_list=[13, 13])
+    tree = PublicTree(env_bldr=HistoryEnvBuilder(env_cls=StandardLeduc, env_args=args), stack_size=[13, 13], stop_at_street=None)
+    tree.build_tree()
+    np.random.seed(7)
+    tree.fill_random_random()
+    tree.compute_ev()
+    nodes = list(tree.nodes())
+    dec = [n for n in nodes if not n.is_terminal and n.p_id_acting_next != "Ch"]
+    assert len(dec) == int(g["n_decision"])
+    h = hashlib.sha256()
+    for n in dec:
+        st = np.ascontiguousarray(n.strategy)
+        assert st.dtype == np.float64
+        h.update(st.tobytes())
+    assert np.array_equal(dec[0].strategy, g["first"]) and np.array_equal(dec[-1].strategy, g["last"])
+    assert h.hexdigest() == str(g["sha256"])
+    assert np.array_equal(tree.root.exploitability, g["exploitability"])
+    assert np.array_equal(tree.root.ev, g["root_ev"]) and np.array_equal(tree.root.ev_br, g["root_ev_br"])
+    assert np.array_equal(nodes[25].reach_probs, g["reach_25"]) and np.array_equal(nodes[25].ev, g["ev_25"])
+
+
 @pytest.mark.parametrize("tag", ["StandardLeduc", "DiscretizedNLLeduc"])
 def test_tree_export_like_reference(tag, tmp_path):
     """PublicTree.get_tree_as_dict / export_to_file (PublicTree.py:143-149,313-420) -- the reference's PokerViz
