@@ -301,6 +301,34 @@ class PokerEnv:
             rew = np.zeros(2, dtype=np.float32)
         return obs, rew, is_terminal, info
 
+    @property
+    def obs_idx_dict(self):
+        """name -> index of every entry of the heads-up observation, in the reference's naming (PokerEnv.py:199-261)"""
+        from pokerrl_amd.game.Poker import Poker as _P
+        names = ["ante", "small_blind", "big_blind", "min_raise", "pot_amt", "total_to_call", "last_action_how_much"]
+        names += ["last_action_what_%d" % i for i in range(3)] + ["last_action_who_%d" % i for i in range(2)]
+        names += ["p%d_acts_next" % i for i in range(2)] + ["round_" + _P.INT2STRING_ROUND[i] for i in range(self.ALL_ROUNDS_LIST[-1] + 1)]
+        for p in range(2):
+            names += ["stack_p%d" % p, "curr_bet_p%d" % p, "is_allin_p%d" % p]
+        for c in range(self.N_TOTAL_BOARD_CARDS):
+            names += ["%dth_board_card_rank_%d" % (c, j) for j in range(self.N_RANKS)] + ["%dth_board_card_suit_%d" % (c, j) for j in range(self.N_SUITS)]
+        return {n: i for i, n in enumerate(names)}
+
+    @property
+    def obs_parts_idxs_dict(self):
+        n_table = 7 + 3 + 2 + 2 + self.ALL_ROUNDS_LIST[-1] + 1
+        b0 = n_table + 6
+        return {"board": list(range(b0, b0 + self.N_TOTAL_BOARD_CARDS * (self.N_RANKS + self.N_SUITS))),
+                "players": [list(range(n_table + 3 * p, n_table + 3 * p + 3)) for p in range(2)], "table_state": list(range(n_table))}
+
+    def print_obs(self, obs):
+        """one line per observation entry, name then value (PokerEnv.py:1273-1279)"""
+        d = self.obs_idx_dict
+        width = max(len(n) for n in d) + 3
+        print("______________________________________ Printing _Observation _________________________________________")
+        for name, i in d.items():
+            print((name + ":  ").rjust(width), obs[i])
+
     def get_current_obs(self, is_terminal):
         """Heads-up "simple" observation layout (PokerEnv.py:199-261, :989-1031, :1253-1271)."""
         if is_terminal:
