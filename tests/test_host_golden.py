@@ -374,6 +374,26 @@ def test_agent_tournament_vs_reference(tag, tmp_path, capsys):
     assert isinstance(env, PokerEnv) and env.N_SEATS == 2
 
 
+def test_file_util_formats(tmp_path):
+    """pokerrl_amd.util.file_util: the reference's names and formats (file_util.py:13-56); files of one package load in the other"""
+    import json
+    import pickle
+    from pokerrl_amd.util import file_util as fu
+    d = {"a": [1, 2.5, "x"], "b": {"c": None}}
+    sub = os.path.join(str(tmp_path), "new", "dir")
+    fu.write_dict_to_file_json(sub, "tree", d)
+    fu.write_dict_to_file_js(sub, 7, d)
+    fu.do_pickle(d, sub, "state")
+    assert json.load(open(os.path.join(sub, "tree.json"))) == d
+    assert open(os.path.join(sub, "7.js")).read() == "const data=" + json.dumps(d)
+    assert pickle.load(open(os.path.join(sub, "state.pkl"), "rb")) == d
+    assert fu.load_pickle(sub, "state") == d and fu.load_pickle(os.path.join(sub, "state.pkl")) == d
+    assert sorted(fu.get_all_files_in_dir(sub)) == ["7.js", "state.pkl", "tree.json"]
+    assert fu.get_all_dirs_in_dir(os.path.join(str(tmp_path), "new")) == ["dir"]
+    assert fu.get_file_name_without_ending_and_path_from_path(os.path.join(sub, "state.pkl")) == "state"
+    fu.create_dir_if_not_exist(sub)  # exists already: no error
+
+
 def test_product_fails_loudly_without_a_device():
     """No CPU fallback: in a GPU-less container every device entry point of the PRODUCT library reports PRL_ERR_NO_DEVICE (or
     a bad-argument error first) with a message, and the Python host raises instead of computing anything on the CPU."""
