@@ -377,6 +377,7 @@ def test_agent_tournament_vs_reference(tag, tmp_path, capsys):
 def test_file_util_formats(tmp_path):
     """pokerrl_amd.util.file_util: the reference's names and formats (file_util.py:13-56); files of one package load in the other"""
     import json
+    import os
     import pickle
     from pokerrl_amd.util import file_util as fu
     d = {"a": [1, 2.5, "x"], "b": {"c": None}}
