@@ -224,7 +224,10 @@ PRL_DEV PRL_INLINE void lbrb_normalize(float* rg, int R, LbrbLeaves& Lf, LbrbSha
 #if defined(PRL_EMU)
 #define LBRB_LB
 #else
-#define LBRB_LB __launch_bounds__(LBRB_THREADS, 5)
+#ifndef LBRB_WAVES_PER_SIMD
+#define LBRB_WAVES_PER_SIMD 5
+#endif
+#define LBRB_LB __launch_bounds__(LBRB_THREADS, LBRB_WAVES_PER_SIMD)
 #endif
 PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
     char* lbrb_smem = prl_smem();
