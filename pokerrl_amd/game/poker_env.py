@@ -66,8 +66,10 @@ class _SeatView:
         self.side_pot_rank = -1
         self._award = 0  # chips paid out at showdown (may be x.5 on ties: PokerEnv.py:478-480 true division)
 
-    stack = property(lambda s: s._env._st.stack[s.seat_id] + s._award)
-    current_bet = property(lambda s: s._env._st.bet[s.seat_id])
+    # before the first reset() a seat shows its untouched starting stack, as the reference's freshly constructed players do
+    # (_PokerPlayer.py:18-34); the native state underneath already holds a dealt hand with the blinds posted
+    stack = property(lambda s: s.starting_stack_this_episode if s._env._pristine else s._env._st.stack[s.seat_id] + s._award)
+    current_bet = property(lambda s: 0 if s._env._pristine else s._env._st.bet[s.seat_id])
     is_allin = property(lambda s: bool(s._env._st.allin[s.seat_id]))
     folded_this_episode = property(lambda s: bool(s._env._st.folded[s.seat_id]))
     has_acted_this_round = property(lambda s: bool(s._env._st.acted[s.seat_id]))
@@ -95,12 +97,14 @@ class PokerEnv:
         self.deck = _Deck(self.N_RANKS, self.N_SUITS)
         self.board = None
         self.side_pots = [0, 0]
+        self._pristine = False
         self._init_from_args(env_args)
         # The reference constructor leaves the episode state to the first reset() and draws from np.random exactly once (the
         # deck's initial shuffle, PokerEnv.py:143): give the views a valid state without consuming any further randomness.
         rng_state = np.random.get_state()
         self.reset()
         np.random.set_state(rng_state)
+        self._pristine = True
 
     # ---- configuration -------------------------------------------------------------------------------------------------
     def _init_from_args(self, env_args):
@@ -135,7 +139,7 @@ class PokerEnv:
 
     # ---- public state views -------------------------------------------------------------------------------------------
     current_round = property(lambda s: s._st.round)
-    main_pot = property(lambda s: s._st.main_pot if not s._paid_out else 0)
+    main_pot = property(lambda s: s._st.main_pot if not (s._paid_out or s._pristine) else 0)
     current_player = property(lambda s: s.seats[s._st.cur])
     n_actions_this_episode = property(lambda s: s._st.n_actions_ep)
     n_raises_this_round = property(lambda s: s._st.n_raises_round)
@@ -151,6 +155,7 @@ class PokerEnv:
 
     # ---- episode control --------------------------------------------------------------------------------------------
     def reset(self, deck_state_dict=None):
+        self._pristine = False
         g = self._game
         for p in range(2):
             base = self._base_stacks[p]
@@ -269,6 +274,12 @@ class PokerEnv:
 
     def get_fraction_of_pot_raise(self, fraction, player_that_bets):
         seat = player_that_bets if isinstance(player_that_bets, int) else player_that_bets.seat_id
+        if getattr(self, "_paid_out", False):
+            # after the pots were paid out the reference computes on the swept table (PokerEnv.py:1389-1396: pots and bets are 0);
+            # the native state still holds the pre-payout pot
+            bets = [s.current_bet for s in self.seats]
+            to_call = max(bets) - bets[seat]
+            return int(to_call + (self.main_pot + sum(self.side_pots) + sum(bets) + to_call) * fraction) + bets[seat]
         out = ctypes.c_int32()
         _native.check(self._L.prl_env_fraction_of_pot_raise_host(ctypes.byref(self._st), float(fraction), int(seat), ctypes.byref(out)))
         return int(out.value)
@@ -289,8 +300,22 @@ class PokerEnv:
         return self.main_pot + self.seats[0].current_bet + self.seats[1].current_bet
 
     def get_random_action(self):
+        if self._game.game_type == 2:
+            # NoLimit envs act with (type, chips) tuples: a random type and a chip amount around half the pot, the draws the reference
+            # makes (PokerEnv.py:1345-1350); the env clips the amount to what is legal when it steps
+            a = np.random.randint(low=0, high=3)
+            pot_sum = sum(self.side_pots) + self.main_pot
+            return a, int(np.random.normal(loc=pot_sum / 2, scale=pot_sum / 5))
         legal = self.get_legal_actions()
         return legal[np.random.randint(len(legal))]
+
+    def get_frac_from_chip_amt(self, amt, player_that_bets):
+        """inverse of get_fraction_of_pot_raise (PokerEnv.py:1398-1418): the pot fraction a TOTAL bet of `amt` chips amounts to"""
+        seat = player_that_bets if isinstance(player_that_bets, int) else player_that_bets.seat_id
+        bets = [s.current_bet for s in self.seats]
+        to_call = max(bets) - bets[seat]
+        pot_after_call = self.main_pot + sum(self.side_pots) + sum(bets) + to_call
+        return float(amt - bets[seat] - to_call) / float(pot_after_call)
 
     # ---- outputs ------------------------------------------------------------------------------------------------------
     def _returns(self, is_terminal, info):
@@ -397,6 +422,7 @@ class PokerEnv:
         return d
 
     def load_state_dict(self, env_state_dict, blank_private_info=False):
+        self._pristine = False
         d = env_state_dict
         self.IS_EVALUATING = d[EnvDictIdxs.is_evaluating]
         st = self._st
