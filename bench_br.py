@@ -81,31 +81,39 @@ def main():
         sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PRL_BENCH_EMU_LIB (CPU test-suite only, tests/test_sharded.py): the ranks drive the emulator build of the library over gloo
+    emu_lib = os.environ.get("PRL_BENCH_EMU_LIB")
     import torch
-    torch.cuda.set_device(local_rank)
     from pokerrl_amd import _native
-    _native.require_device()
-    _native.set_device(local_rank)  # the library allocates on this process's GPU
+    lib = _native.bind(emu_lib) if emu_lib else None
+    if not emu_lib:
+        torch.cuda.set_device(local_rank)
+        _native.require_device()
+        _native.set_device(local_rank)  # the library allocates on this process's GPU
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if emu_lib:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     boards = bench.seeded_boards(args.boards, 0, offset=rank * args.boards)
-    tree = bench.fhp_tree(boards)
+    tree = bench.fhp_tree(boards, lib)
     exchange = None
     if world > 1:
         from pokerrl_amd.dist import TorchExchange
-        exchange = TorchExchange("cuda")
-        s = _native.NativeSolver(tree, "plus", 0, shard=(world, rank, exchange))
+        exchange = TorchExchange("cpu" if emu_lib else "cuda")
+        s = _native.NativeSolver(tree, "plus", 0, shard=(world, rank, exchange), _lib=lib)
     else:
-        s = _native.NativeSolver(tree, "plus", 0, engine="fused")
+        s = _native.NativeSolver(tree, "plus", 0, engine="fused", _lib=lib)
     nt = tree.n_cols - args.boards * 14
     s.set_strategy(seeded_strategy(nt, args.boards, tree.range_size, 1 + rank))  # any valid strategy; float32 columns
     s.time_evaluations(args.warmup)
 
     def barrier():
-        torch.cuda.synchronize()
+        if not emu_lib:
+            torch.cuda.synchronize()
         s.sync()
         if dist is not None:
             dist.barrier()
@@ -117,7 +125,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if emu_lib else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     n_nodes = (tree.n_nodes - args.boards * 15) + args.boards * 15 * world

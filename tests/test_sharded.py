@@ -179,6 +179,23 @@ def test_bench_gpus_2_launches_two_ranks_gloo_emu(EMU):
     assert j2["config"]["avg_strategy_exploitability_mbb_per_g"] == j3["config"]["avg_strategy_exploitability_mbb_per_g"]
 
 
+def test_bench_br_gpus_2_launches_two_ranks_gloo_emu(EMU):
+    """`python bench_br.py --gpus 2` (BASELINE config 4: exact best response with the boards sharded over the GPUs) starts its two ranks,
+    shards the boards and reports n_gpus = 2 with a non-zero exchange count; here over gloo on the emulator build"""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PRL_BENCH_EMU_LIB"] = EMU
+    cmd = [sys.executable, os.path.join(root, "bench_br.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--boards", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, check=True).stdout
+    line = [x for x in out.splitlines() if x.startswith("{")]
+    assert len(line) == 1, out
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["exchanges"] > 0
+    assert j["config"]["nodes_whole_tree"] == 5 + 15 * 4 and j["config"]["engine"] == "fused"
+    assert j["roofline"]["kernel"].startswith("prl_k_fhp_pass") and j["config"]["exploitability_mbb_per_g"] > 0
+
+
 def test_bench_shard_geometry():
     import bench
     for total, world in ((2598960, 8), (2598960, 4), (3, 2), (100, 3), (5000, 2), (7, 1), (2048, 2)):
