@@ -20,7 +20,8 @@
 #include "prl_solver_types.h"
 
 PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
-                                 int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx, int32_t* plan_ndealt) {
+                                 int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx, int32_t* plan_ndealt,
+                                 uint8_t* plan_klh) {
     uint32_t* keys = (uint32_t*)prl_smem();  // [2048]
     int* n_live_s = (int*)(keys + 2048);
     const int tid = (int)prl_tid(), nt = (int)prl_nthreads();
@@ -118,9 +119,31 @@ PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, in
         }
         if (tid == 0) plan_nlive[b] = n;
         prl_sync();
-        // records of the fused board pass (row16 order with 3 entries per lane: lists of 33..48 entries, at most 48 live cards)
         if (tid == 0) plan_ndealt[b] = n_dealt;
         const int n_t = T.n_cards - 1 - n_dealt;
+        // LEVELS engine: the bounds of every hand's tie group inside the lists of its two cards, found once here instead of by a
+        // linear search per hand, terminal and pass (prl_terminal_equity_2card)
+        if (plan_klh) {
+            uint8_t* klh = plan_klh + (size_t)b * T.R * 4;
+            for (int h = tid; h < T.R; h += nt) {
+                const int i = pos[h];
+                uint8_t out[4] = {0, 0, 0, 0};
+                if (i >= 0 && has_board) {
+                    const int g0 = gs[i], g1 = ge[i];
+                    for (int k = 0; k < 2; ++k) {
+                        const int16_t* row = cl + (size_t)T.hole[2 * h + k] * (T.n_cards - 1);
+                        int lo = 0;
+                        while (lo < n_t && row[lo] < g0) lo++;
+                        int hi = lo;
+                        while (hi < n_t && row[hi] < g1) hi++;
+                        out[2 * k] = (uint8_t)lo;
+                        out[2 * k + 1] = (uint8_t)hi;
+                    }
+                }
+                for (int k = 0; k < 4; ++k) klh[4 * h + k] = out[k];
+            }
+        }
+        // records of the fused board pass (row16 order with 3 entries per lane: lists of 33..48 entries, at most 48 live cards)
         if (plan_clx && has_board && T.n_cards - T.board_len <= PRL_CLX_SLOTS && n_t > 32 && n_t <= 48) {
             uint32_t* clx = plan_clx + (size_t)b * PRL_CLX_WORDS;
             const uint32_t inv = (uint32_t)PRL_CLX_ZERO_POS | PRL_CLX_HEAD | PRL_CLX_TAIL;
@@ -156,8 +179,8 @@ PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, in
 
 void prl_launch_plan_build(const PrlDevTree& T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
                            int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx, int32_t* plan_ndealt,
-                           void* stream) {
+                           uint8_t* plan_klh, void* stream) {
     int grid = n_plans < 32768 ? n_plans : 32768;
     PRL_LAUNCH(prl_k_plan_build, grid, 256, 2048 * sizeof(uint32_t) + 16, stream, T, n_plans, plan_sh, plan_pos, plan_gs, plan_ge, plan_cl,
-               plan_nlive, plan_hgs, plan_hge, plan_clx, plan_ndealt);
+               plan_nlive, plan_hgs, plan_hge, plan_clx, plan_ndealt, plan_klh);
 }

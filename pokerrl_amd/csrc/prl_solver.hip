@@ -604,15 +604,18 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         FAIL_IF(dev_alloc(s, &hgs, (size_t)n_plans * T.plan_stride));
         FAIL_IF(dev_alloc(s, &hge, (size_t)n_plans * T.plan_stride));
         if (fused) FAIL_IF(dev_alloc(s, &clx, (size_t)n_plans * PRL_CLX_WORDS));
+        uint8_t* klh = nullptr;  // the LEVELS engine's showdown terminals (a fused solver's trunk has none)
+        if (!fused) FAIL_IF(dev_alloc(s, &klh, (size_t)n_plans * T.R * 4));
         PrlDevTree Tb = T;
         Tb.n_boards = full.n_boards;
-        prl_launch_plan_build(Tb, n_plans, sh, pos, gs, ge, cl, nl, hgs, hge, clx, nd, s->stream);
+        prl_launch_plan_build(Tb, n_plans, sh, pos, gs, ge, cl, nl, hgs, hge, clx, nd, klh, s->stream);
         // the LEVELS kernels address plan `board_id`, or plan index T.n_boards for "no board"; in the FUSED engine the
         // trunk tree has n_boards == 0, so its plan pointers are based at the last (no-board) plan
         const size_t off = fused ? (size_t)full.n_boards : 0;
         T.plan_sh = sh + off * T.plan_stride; T.plan_pos = pos + off * T.plan_stride; T.plan_gs = gs + off * T.plan_stride;
         T.plan_ge = ge + off * T.plan_stride; T.plan_cl = cl + off * T.cl_stride; T.plan_nlive = nl + off; T.plan_ndealt = nd + off;
         T.plan_hgs = hgs + off * T.plan_stride; T.plan_hge = hge + off * T.plan_stride; T.plan_clx = clx ? clx + off * PRL_CLX_WORDS : nullptr;
+        T.plan_klh = klh;
         if (fused) {
             PrlFhpParams& fp = s->fp;
             fp.n_boards = full.n_boards; fp.R = T.R; fp.col_base = col_base;

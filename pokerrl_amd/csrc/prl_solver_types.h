@@ -49,6 +49,8 @@ struct PrlDevTree {
     const int16_t* plan_gs;      // [n_plans][R]   first position of the tie group
     const int16_t* plan_ge;      // [n_plans][R]   one past the last position of the tie group
     const int16_t* plan_cl;      // [n_plans][n_cards][n_cards-1] positions of the hands containing card c, ascending; -1 pad
+    const uint8_t* plan_klh;     // [n_plans][R][4] LEVELS engine (nullptr otherwise): per hand and for each of its two cards, how many
+                                 // entries of that card's list lie before the hand's tie group / before its end (lo1, hi1, lo2, hi2)
     const int32_t* plan_nlive;   // [n_plans]
     const int32_t* plan_ndealt;  // [n_plans]   board cards of the plan's row (0 for the no-board plan): its card lists hold n_cards - 1 - that many hands
     // hand-domain / flagged copies used by the fused board kernels (prl_fhp_kernels.hip)

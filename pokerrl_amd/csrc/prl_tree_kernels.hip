@@ -195,6 +195,7 @@ PRL_DEV PRL_INLINE void prl_terminal_equity_2card(const PrlDevTree& T, const flo
     const int16_t* gs = T.plan_gs + (size_t)plan * T.plan_stride;
     const int16_t* ge = T.plan_ge + (size_t)plan * T.plan_stride;
     const int16_t* cl = T.plan_cl + (size_t)plan * T.cl_stride;
+    const uint8_t* klh = T.plan_klh ? T.plan_klh + (size_t)plan * T.R * 4 : nullptr;
     const int n = T.plan_nlive[plan];
     const int n_t = T.n_cards - 1 - T.plan_ndealt[plan];
     const int tid = (int)prl_tid(), nt = (int)prl_nthreads();
@@ -241,11 +242,17 @@ PRL_DEV PRL_INLINE void prl_terminal_equity_2card(const PrlDevTree& T, const flo
                 float K[2];
                 for (int k = 0; k < 2; ++k) {
                     const int c = k == 0 ? c1 : c2;
-                    const int16_t* row = cl + (size_t)c * (T.n_cards - 1);
-                    int lo = 0;
-                    while (lo < n_t && row[lo] < g0) lo++;
-                    int hi = lo;
-                    while (hi < n_t && row[hi] < g1) hi++;
+                    int lo, hi;
+                    if (klh) {  // precomputed with the plan (prl_k_plan_build)
+                        lo = klh[4 * h + 2 * k];
+                        hi = klh[4 * h + 2 * k + 1];
+                    } else {
+                        const int16_t* row = cl + (size_t)c * (T.n_cards - 1);
+                        lo = 0;
+                        while (lo < n_t && row[lo] < g0) lo++;
+                        hi = lo;
+                        while (hi < n_t && row[hi] < g1) hi++;
+                    }
                     K[k] = Q[c * 65 + lo] - (Q[c * 65 + n_t] - Q[c * 65 + hi]);
                 }
                 e = G - (K[0] + K[1]);
