@@ -229,6 +229,8 @@ def main():
         "value": value, "unit": "node-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if total else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        # "hip-gfx950" = the product library; anything else (the SIMT emulator of the CPU test-suite, PRL_BENCH_EMU_LIB) is not a measurement
+        "build_flavor": (lib or _native.lib()).prl_build_flavor().decode(),
         "config": {
             "workload": {"plus": "CFR+ (delay 0)", "linear": "Linear CFR", "vanilla": "vanilla CFR"}[args.variant] +
                         " full-width iterations on the Flop5Holdem public tree (blinds 50/100, stacks 20000, "

@@ -353,7 +353,9 @@ enum {
     PRL_SF_CONSTANTS = 12,   /* float32 [2]              chance probability, equity constant   */
     PRL_SF_BYTES_ALLOCATED = 13, /* int64                HBM bytes held by the solver          */
     PRL_SF_ENGINE = 14,      /* int32                    PRL_ENGINE_LEVELS or PRL_ENGINE_FUSED  */
-    PRL_SF_GRAPH_REPLAY = 15 /* int32                    1 if iterations are replays of a captured hipGraph (LEVELS engine) */
+    PRL_SF_GRAPH_REPLAY = 15, /* int32                   1 if iterations are replays of a captured hipGraph (LEVELS engine) */
+    PRL_SF_EXPLICIT_STRATEGY = 16 /* int32               fused engines: -1 strategy follows regrets / uniform fill, 0 an explicit float32
+                                                         strategy is loaded (prl_solver_set_strategy), 1 an explicit float64 one; LEVELS: -1 */
 };
 int32_t prl_solver_get(prl_solver_t* solver, int32_t field, void* out);
 

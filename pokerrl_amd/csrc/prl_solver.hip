@@ -628,7 +628,17 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
                 const char* g = getenv("PRL_FHP_GRID");
                 if (g && atoi(g) > 0) fp.max_grid = atoi(g);
             }
-            s->block_sum = getenv("PRL_FHP_NO_BLOCK_SUM") == nullptr;
+            {   // level 0 of the chance sum inside the pass rounds a workgroup's board range up to whole 32-board blocks: with few
+                // boards per workgroup that idles CUs (4096 boards on 256 CUs: 16 per workgroup -> 32 -> half the chip), so the
+                // pass keeps per-board rows unless the rounding costs < ~6 %. PRL_FHP_BLOCK_SUM=0/1 forces either path (tests).
+                const int g = full.n_boards < fp.max_grid ? full.n_boards : fp.max_grid;
+                const int raw = (full.n_boards + g - 1) / g;
+                const int rounded = (raw + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK;
+                s->block_sum = raw >= PRL_CHANCE_BLOCK && (long long)rounded * 16 <= (long long)raw * 17;
+                const char* f = getenv("PRL_FHP_BLOCK_SUM");
+                if (f) s->block_sum = atoi(f) != 0;
+                if (getenv("PRL_FHP_NO_BLOCK_SUM")) s->block_sum = false;
+            }
             fp.no_steady = getenv("PRL_FHP_NO_STEADY") ? 1 : 0;  // tests: the generic pass in the steady state too
             fp.chance_prob = T.chance_prob; fp.eq_const = T.eq_const;
             const PrlFhpShapeDesc& sd = prl_fhp_shape_desc(shape_id);
@@ -1350,6 +1360,7 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
         case PRL_SF_BYTES_ALLOCATED: *(int64_t*)out = (int64_t)s->bytes_allocated; return PRL_OK;
         case PRL_SF_ENGINE: *(int32_t*)out = s->fused ? PRL_ENGINE_FUSED : PRL_ENGINE_LEVELS; return PRL_OK;
         case PRL_SF_GRAPH_REPLAY: *(int32_t*)out = s->levels_graph_exec != nullptr; return PRL_OK;
+        case PRL_SF_EXPLICIT_STRATEGY: *(int32_t*)out = s->fused ? s->user_strategy_f64 : -1; return PRL_OK;
         default: prl_set_error("unknown solver field"); return PRL_ERR_ARG;
     }
     if (!src) { prl_set_error("field not available for this variant"); return PRL_ERR_STATE; }

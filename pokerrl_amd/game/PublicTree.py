@@ -284,9 +284,11 @@ class PublicTree:
         self._invalidate()
 
     def copy(self):
-        c = PublicTree(self._env_bldr, self._stack_size, None, self._put_out_new_round_after_limit, self._is_debugging, self._boards,
-                       self._engine)
+        c = PublicTree(self._env_bldr, self._stack_size, self._stop_at_street if self._is_partial else None,
+                       self._put_out_new_round_after_limit, self._is_debugging, self._boards, self._engine)
         c.build_tree(variant=getattr(self, "_variant", "vanilla"), delay=getattr(self, "_delay", 0))
+        if self._is_partial:  # structure and states only: there is no solver state to move over
+            return c
         self._flush()
         try:  # a solver in a CFR run: the whole persistent state (regrets, averages, iteration counter) moves over
             c._solver.load_state(self.solver.save_state())
@@ -294,7 +296,10 @@ class PublicTree:
             if e.status != _native.ERR_STATE:  # ERR_STATE = an explicit strategy is loaded (fill_with_agent_policy ...): copy that
                 raise
             strat = self._vec("strategy")
-            f64 = bool(self.solver.get("strat_f64").any())
+            if self.solver.engine == "fused":  # ONE explicit strategy array whose dtype the solver remembers (no per-node flags)
+                f64 = int(self.solver.get("explicit_strategy")[0]) == 1
+            else:
+                f64 = bool(self.solver.get("strat_f64").any())
             c._solver.set_strategy(strat if f64 else strat.astype(np.float32))
         c._invalidate()
         return c

@@ -115,6 +115,7 @@ def test_emu_fused_engine_block_sums_across_a_block_boundary(L, monkeypatch):
     """33 boards on two workgroups: the pass sums its root vectors per 32-board block (one full block + a block of one), the sum
     kernels start a level higher -- against the oracle's board-by-board canonical sum"""
     monkeypatch.setenv("PRL_FHP_GRID", "2")
+    monkeypatch.setenv("PRL_FHP_BLOCK_SUM", "1")  # (the default keeps per-board rows below ~32 boards per workgroup)
     pc.check_fused_batched_vs_oracle(L, 33, 2, delay=0)
 
 

@@ -231,7 +231,9 @@ def test_gpu_fused_per_board_rows_vs_oracle(L, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("no_steady", [False, True])
 def test_gpu_fused_steady_state_specialisation_vs_oracle(L, monkeypatch, no_steady):
-    """the CFR+ steady-state instantiation of the update passes and the generic one (PRL_FHP_NO_STEADY) against the oracle"""
+    """the CFR+ steady-state instantiation of the update passes and the generic one (PRL_FHP_NO_STEADY) against the oracle;
+    block sums forced on (at 300 boards the default keeps per-board rows, which test_gpu_fused_batched_iterations_vs_oracle covers)"""
+    monkeypatch.setenv("PRL_FHP_BLOCK_SUM", "1")
     if no_steady:
         monkeypatch.setenv("PRL_FHP_NO_STEADY", "1")
     pc.check_fused_batched_vs_oracle(L, 300, 5, delay=0)

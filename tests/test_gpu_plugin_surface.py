@@ -281,3 +281,50 @@ def test_cfr_multi_stack_batched_equals_sequential():
     for ta, tb in zip(a._trees, b._trees):
         assert np.array_equal(ta.solver.get("regret"), tb.solver.get("regret"))
         assert np.array_equal(ta.solver.get("avg"), tb.solver.get("avg"))
+
+
+def test_public_tree_copy():
+    """PublicTree.copy(): a tree in a CFR run moves its whole solver state over; a tree holding an explicit strategy (random fill,
+    agent policy) moves that strategy with its dtype -- on the LEVELS engine and on the fused engine (which keeps one dtype flag for
+    the whole array); a partial tree copies its structure."""
+    from pokerrl_amd.game.PublicTree import PublicTree
+    from pokerrl_amd.game.games import Flop5Holdem
+    from pokerrl_amd.game.wrappers import HistoryEnvBuilder
+    args = StandardLeduc.ARGS_CLS(n_seats=2, starting_stack_sizes_list=[13, 13])
+    bldr = HistoryEnvBuilder(env_cls=StandardLeduc, env_args=args)
+    tree = PublicTree(env_bldr=bldr, stack_size=[13, 13], stop_at_street=None)
+    tree.build_tree(variant="plus")
+    tree.solver.iterations(3)
+    c = tree.copy()
+    tree.solver.iterations(2)
+    c.solver.iterations(2)
+    assert np.array_equal(tree.solver.get("regret"), c.solver.get("regret")) and np.array_equal(tree.solver.get("avg"), c.solver.get("avg"))
+    np.random.seed(3)
+    tree.fill_random_random()
+    tree.compute_ev()
+    c = tree.copy()
+    c.compute_ev()
+    assert np.array_equal(tree.root.exploitability, c.root.exploitability) and np.array_equal(tree.root.ev, c.root.ev)
+    part = PublicTree(env_bldr=bldr, stack_size=[13, 13], stop_at_street=1)
+    part.build_tree()
+    pc_ = part.copy()
+    assert pc_.n_nodes == part.n_nodes and pc_.stop_at_street == 1
+    # fused engine, explicit float64 and float32 strategies
+    fargs = Flop5Holdem.ARGS_CLS(n_seats=2, starting_stack_sizes_list=[20000, 20000])
+    boards = np.array([[0, 5, 10, 15, 20], [1, 6, 11, 16, 21], [30, 31, 32, 33, 50]], np.int8)
+    ft = PublicTree(env_bldr=HistoryEnvBuilder(env_cls=Flop5Holdem, env_args=fargs), stack_size=[20000, 20000], stop_at_street=None,
+                    boards=boards, engine="fused")
+    ft.build_tree()
+    assert ft.solver.engine == "fused"
+    np.random.seed(4)
+    ft.fill_random_random()
+    ft.compute_ev()
+    for as_f32 in (False, True):
+        if as_f32:
+            ft.solver.set_strategy(ft.solver.get("strategy").astype(np.float32))
+            ft._invalidate()
+            ft.compute_ev()
+        fc = ft.copy()
+        fc.compute_ev()
+        assert int(fc.solver.get("explicit_strategy")[0]) == (0 if as_f32 else 1)
+        assert np.array_equal(ft.root.exploitability, fc.root.exploitability)

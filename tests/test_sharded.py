@@ -213,8 +213,10 @@ def test_gpu_chance_sum_levels_do_not_depend_on_world_size():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_local", [3, 32, 1024])  # boards / blocks / groups are exchanged
-def test_gpu_sharded_world2_matches_unsharded(n_local):
+@pytest.mark.parametrize("n_local,block_sum", [(3, None), (32, None), (32, "1"), (1024, None), (1024, "1")])  # boards / blocks / groups are exchanged
+def test_gpu_sharded_world2_matches_unsharded(n_local, block_sum, monkeypatch):
+    if block_sum:  # the pass sums its 32-board blocks itself (the default at >= ~32 boards per workgroup; forced here on small shards)
+        monkeypatch.setenv("PRL_FHP_BLOCK_SUM", block_sum)
     ranks = run_sharded(_native.LIB_PATH, "cuda", 2, n_local, 4, 0, 33, timeout=600)
     check_against_union(_native.lib(), ranks, 2, n_local, 4, 0, 33)
 
