@@ -73,6 +73,15 @@ struct PrlFhpSpec21 {
     static constexpr int C(int n) { constexpr int t[N_NODES] = {2, 2, 0, 3, 0, 0, 3, 0, 0, 2, 0, 0, 3, 0, 0, 3, 0, 0, 2, 0, 0}; return t[n]; }
 };
 
+// four raises per round (LimitHoldem's MAX_N_RAISES_PER_ROUND, games.py:134-167): the betting subtree of every post-flop street of
+// a full-limit game. Used by the per-street engine (prl_st.h), whose non-final streets read the kind-3 leaves as "the street goes on"
+// (a chance node in the flat tree) instead of showdowns.
+struct PrlFhpSpec27 {
+    static constexpr int N_NODES = 27;
+    static constexpr int K(int n) { constexpr int t[N_NODES] = {0, 0, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3}; return t[n]; }
+    static constexpr int A(int n) { constexpr int t[N_NODES] = {1, 0, -1, 1, -1, -1, 0, -1, -1, 1, -1, -1, 0, -1, -1, 0, -1, -1, 1, -1, -1, 0, -1, -1, 1, -1, -1}; return t[n]; }
+    static constexpr int C(int n) { constexpr int t[N_NODES] = {2, 2, 0, 3, 0, 0, 3, 0, 0, 3, 0, 0, 2, 0, 0, 3, 0, 0, 3, 0, 0, 3, 0, 0, 2, 0, 0}; return t[n]; }
+};
 // everything the walk needs, derived from a spec (all constexpr: evaluated by the compiler for the template recursion)
 template <class S>
 struct PrlFhpDerive {

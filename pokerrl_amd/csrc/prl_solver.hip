@@ -22,6 +22,7 @@
 #include "prl_kernels.h"
 #include "prl_rt.h"
 #include "prl_solver_types.h"
+#include "prl_st.h"
 
 #define PRL_NODE_LEAF 4  // trunk view of the chance node in the FUSED engine: values are written by the chance sum
 
@@ -82,6 +83,15 @@ struct prl_solver {
     bool board_avg_stale = false;  // FUSED Vanilla / Linear: avg_sum moved on, the avg columns of the boards have not been recomputed yet
     float* d_regret = nullptr;  // [full_cols][R]
     double* d_avg = nullptr;    // [full_cols][R]
+    // ---- per-street fused engine (prl_st.h): `fused` with the board pass replaced by a sweep over the streets ----
+    bool streets = false;
+    PrlStPlanHost st;
+    PrlStParams sp{};                  // what every street launch shares (plans, sizes)
+    struct StLevelDev { PrlStInst* inst = nullptr; float* leaf_reach = nullptr; float* val = nullptr; } st_dev[PRL_ST_MAX_LEVELS];
+    int32_t* d_trunk_leaves = nullptr; // trunk ids of the trunk's chance leaves
+    float* d_trunk_reach = nullptr;    // [n_leaves][2][R] their reach, gathered for the street-1 kernels
+    int n_trunk_leaves = 1;
+    std::vector<int32_t> col_dfs;      // internal column -> flat-tree (DFS) column; empty = identity (every other engine)
 };
 
 namespace {
@@ -222,6 +232,16 @@ int do_update_reach(prl_solver* s, const PrlDevState& st) {
 // FUSED Vanilla / Linear: the board pass maintains avg_sum only; readers of the average call this first
 static int ensure_board_avg(prl_solver* s) {
     if (!s->fused || !s->board_avg_stale) return PRL_OK;
+    if (s->streets) {
+        for (int lv = 0; lv < s->st.n_levels; ++lv) {
+            PrlStParams q = s->sp;
+            q.n_inst = s->st.level[lv].n_inst; q.col_base = s->st.level[lv].col_base; q.avg_sum = s->S.avg_sum; q.avg = s->d_avg;
+            prl_launch_st_avg_from_sum(q, s->st.level[lv].spec, s->stream);
+        }
+        PRL_HIP_TRY(hipGetLastError());
+        s->board_avg_stale = false;
+        return PRL_OK;
+    }
     PrlFhpParams p = s->fp;
     p.avg_sum = s->S.avg_sum;
     p.avg = s->d_avg;
@@ -231,8 +251,104 @@ static int ensure_board_avg(prl_solver* s) {
     return PRL_OK;
 }
 
+// STREETS (prl_st.h): the sweep over the streets that takes the place of the board pass: reach down street by street, the last
+// street's pass, the other streets' passes bottom-up, the canonical sum over the first deal's outcomes into the trunk's chance leaves
+int street_sweep(prl_solver* s, const PrlDevState& st, int mode, int src0, int src1, const double* strat_arr, const float* strat32) {
+    PrlStParams p = s->sp;
+    p.regret = strat32 ? const_cast<float*>(strat32) : s->d_regret;
+    p.avg = s->d_avg;
+    p.avg_sum = s->S.avg_sum;
+    p.strat_arr = strat_arr;
+    p.variant = s->variant;
+    p.iter = s->iter;
+    p.avg_mode = s->fp.avg_mode; p.m_old = s->fp.m_old; p.m_new = s->fp.m_new;  // set by iteration_core for the update passes
+    p.avgsum_mask = 0;
+    if (&st == &s->S && strat_arr == nullptr) {  // pending Vanilla / Linear average updates ride on the reach walk of that seat
+        const bool walks[2] = {prl_fhp_runs_seat(mode, 1), prl_fhp_runs_seat(mode, 0)};
+        for (int q = 0; q < 2; ++q)
+            if (walks[q] && s->avg_pending[q] >= 0) {
+                p.avgsum_mask |= 1 << q;
+                p.avgsum_iter[q] = s->avg_pending[q];
+                s->avg_pending[q] = -1;
+                s->board_avg_f64 = true;
+                s->board_avg_stale = true;
+            }
+    }
+    const int L = s->st.n_levels, R = p.R, NL0 = s->n_trunk_leaves;
+    const int width = prl_fhp_out_width(mode);
+    prl_launch_st_gather_trunk_reach(st.reach, s->d_trunk_leaves, NL0, R, s->d_trunk_reach, s->stream);
+    auto level_params = [&](int lv) {
+        PrlStParams q = p;
+        const PrlStLevelHost& H = s->st.level[lv];
+        q.n_inst = H.n_inst; q.col_base = H.col_base; q.inst = s->st_dev[lv].inst;
+        q.parent_reach = lv == 0 ? s->d_trunk_reach : s->st_dev[lv - 1].leaf_reach;
+        q.leaf_reach = s->st_dev[lv].leaf_reach;
+        q.child_val = lv + 1 < L ? s->st_dev[lv + 1].val : nullptr;
+        q.child_w = width;
+        q.val = s->st_dev[lv].val;
+        return q;
+    };
+    for (int lv = 0; lv + 1 < L; ++lv) {
+        const int e = prl_launch_st_down(s->st.level[lv].spec, level_params(lv), src0, src1, s->stream);
+        if (e) { prl_set_error("street engine: unsupported strategy-source combination"); return e; }
+    }
+    for (int lv = L - 1; lv >= 0; --lv) {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        const bool timed = s->time_passes && lv == L - 1;  // the last street's pass is the dominant kernel
+        if (timed) {
+            PRL_HIP_TRY(hipEventCreate(&ev0));
+            PRL_HIP_TRY(hipEventCreate(&ev1));
+            PRL_HIP_TRY(hipEventRecord(ev0, s->stream));
+        }
+        const int e = prl_launch_st_pass(s->st.level[lv].spec, s->st.level[lv].last, level_params(lv), mode, src0, src1, s->stream);
+        if (e) { prl_set_error("street engine: unsupported pass mode / strategy-source combination"); return e; }
+        if (timed) {
+            PRL_HIP_TRY(hipEventRecord(ev1, s->stream));
+            s->pass_events.push_back(ev0);
+            s->pass_events.push_back(ev1);
+        }
+    }
+    // street-1 rows are outcome-major: [n_top][n_leaves][width][R] -> one canonical sum over the outcomes for all leaves at once
+    const int W = NL0 * width * R, n_top = s->st.n_top;
+    float* summed = s->d_row_sum;
+    const float* rows = s->st_dev[0].val;
+    if (!s->exchange) prl_launch_fhp_chance_sum(rows, n_top, W, s->d_sum_scratch, summed, s->stream);
+    else {
+        const size_t per_rank = (size_t)s->n_units * W;
+        prl_launch_fhp_chance_partial(rows, n_top, s->xlevel, W, s->d_sum_scratch, s->d_xlocal, s->stream);
+        if (!s->exchange_async) PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+        if (s->exchange(s->exchange_user, s->d_xlocal, s->d_xgather, (uint64_t)(per_rank * sizeof(float))) != 0) {
+            prl_set_error("sharded solve: the exchange callback failed");
+            return PRL_ERR_STATE;
+        }
+        prl_launch_fhp_chance_finish(s->d_xgather, s->n_units_all, s->xlevel, W, s->d_sum_scratch, summed, s->stream);
+    }
+    // the pieces go to their places in the trunk's chance leaves (as fused_board_pass does for its one chance node)
+    const bool both = prl_fhp_runs_seat(mode, 0) && prl_fhp_runs_seat(mode, 1);
+    const int seat = prl_fhp_runs_seat(mode, 0) ? 0 : 1;
+    const bool with_br = prl_fhp_with_br(mode);
+    PrlStScatter sc = {};
+    sc.n_vec = width;
+    auto add = [&](int src, int arr, int dst_seat) { sc.src_vec[sc.n_dst] = src; sc.dst_arr[sc.n_dst] = arr; sc.dst_seat[sc.n_dst] = dst_seat; ++sc.n_dst; };
+    if (both) {
+        add(0, 0, 0); add(1, 0, 1);
+        add(with_br ? 2 : 0, 1, 0); add(with_br ? 3 : 1, 1, 1);
+    } else if (mode == PRL_FHP_UPDATE1_EVAL1) {
+        add(0, 0, 1); add(0, 1, 1);
+        add(1, 2, 0); add(2, 2, 1);  // (seat 1 value under the new strategy, its best response): applied after the trunk update
+    } else {
+        add(0, 0, seat); add(with_br ? 1 : 0, 1, seat);
+    }
+    prl_launch_st_scatter_trunk(summed, s->d_trunk_leaves, NL0, R, sc, st.ev, st.ev_br, s->d_half, s->stream);
+    if (!both && mode != PRL_FHP_UPDATE1_EVAL1 && seat == 0 && with_br && s->have_half && &st == &s->S)
+        prl_launch_st_half_to_trunk(s->d_half, s->d_trunk_leaves, NL0, R, st.ev, st.ev_br, s->stream);
+    PRL_HIP_TRY(hipGetLastError());
+    return PRL_OK;
+}
+
 // FUSED: board pass + canonical chance sum into the trunk's chance node (st = trunk state to read reach from / write to)
 int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, int src1, const double* strat_arr, const float* strat32 = nullptr) {
+    if (s->streets) return street_sweep(s, st, mode, src0, src1, strat_arr, strat32);
     PrlFhpParams p = s->fp;
     if (strat32) p.regret = const_cast<float*>(strat32);  // PRL_SRC_STRAT32: float32 strategy columns in the regret array's layout (read only)
     p.iter = s->iter;
@@ -415,6 +531,54 @@ void make_trunk(const PrlFlatTree& t, int chance_node, int first_board_node, int
     for (int i = 0; i < u.n_nodes; ++i) u.level_nodes[fill[u.depth[i]]++] = i;
 }
 
+// trunk view of a multi-street tree (STREETS engine): the nodes above every chance node, the chance nodes as leaves, action
+// columns renumbered to the engine's internal order (trunk columns first)
+void make_trunk_streets(const PrlFlatTree& t, const PrlStPlanHost& P, PrlFlatTree* out, std::vector<int32_t>* leaf_trunk_ids) {
+    PrlFlatTree& u = *out;
+    u = PrlFlatTree();
+    u.rules = t.rules;
+    u.game = t.game;
+    std::vector<int> map(t.n_nodes, -1);
+    for (int i = 0; i < t.n_nodes;) {
+        map[i] = u.n_nodes++;
+        const bool is_ch = t.kind[i] == PRL_NODE_CHANCE;
+        u.kind.push_back(is_ch ? PRL_NODE_LEAF : t.kind[i]);
+        u.actor.push_back(t.actor[i]);
+        u.parent.push_back(t.parent[i] < 0 ? -1 : map[t.parent[i]]);
+        u.child_idx.push_back(t.child_idx[i]);
+        u.action.push_back(t.action[i]);
+        u.acted_last.push_back(t.acted_last[i]);
+        u.round.push_back(t.round[i]);
+        u.board_id.push_back(-1);
+        u.main_pot.push_back(t.main_pot[i]);
+        u.depth.push_back(t.depth[i]);
+        u.n_children.push_back(is_ch ? 0 : t.n_children[i]);
+        u.first_col.push_back(P.trunk_col_of_node[i]);
+        u.subtree_size.push_back(1);
+        if (is_ch) { leaf_trunk_ids->push_back(map[i]); i += t.subtree_size[i]; }
+        else ++i;
+    }
+    u.n_cols = P.n_trunk_cols;
+    for (int c = 0; c < u.n_cols; ++c) { u.col_action.push_back(t.col_action[P.col_dfs[c]]); u.col_node.push_back(map[t.col_node[P.col_dfs[c]]]); }
+    u.n_boards = 0;
+    u.board_len = t.board_len;
+    u.child_start.assign(u.n_nodes + 1, 0);
+    for (int i = 0; i < u.n_nodes; ++i) u.child_start[i + 1] = u.child_start[i] + u.n_children[i];
+    u.child_list.assign(u.child_start[u.n_nodes], -1);
+    int max_depth = 0;
+    for (int i = 1; i < u.n_nodes; ++i) {
+        u.child_list[u.child_start[u.parent[i]] + u.child_idx[i]] = i;
+        max_depth = max_depth > u.depth[i] ? max_depth : u.depth[i];
+    }
+    u.n_levels = max_depth + 1;
+    u.level_start.assign(u.n_levels + 1, 0);
+    for (int i = 0; i < u.n_nodes; ++i) u.level_start[u.depth[i] + 1]++;
+    for (int d = 0; d < u.n_levels; ++d) u.level_start[d + 1] += u.level_start[d];
+    u.level_nodes.assign(u.n_nodes, 0);
+    std::vector<int32_t> fill(u.level_start.begin(), u.level_start.end() - 1);
+    for (int i = 0; i < u.n_nodes; ++i) u.level_nodes[fill[u.depth[i]]++] = i;
+}
+
 }  // namespace
 
 bool prl_fhp_shape_compiled(int shape_id);  // prl_fhp_kernels.hip
@@ -481,18 +645,31 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     float pots[PRL_FHP_MAX_NODES];
     const int shape_id = prl_fhp_match_shape(full, &ch_node, &first_board, &col_base, pots);
     const bool shape_ok = shape_id >= 0;
-    bool fused = false;
+    bool fused = false, streets = false;
+    // trees that deal on several streets (or whose one deal hangs below several chance nodes): the per-street fused engine (prl_st.h).
+    // Its street-1 chance weight counts the GLOBAL number of first-deal outcomes in a sharded solve, known only below: the plan is
+    // built here to see whether the engine applies and once more with that count.
+    PrlStPlanHost st_plan;
+    std::string st_why;
+    const bool st_ok = !shape_ok && engine != PRL_ENGINE_LEVELS && r.n_hole_cards == 2 && prl_st_build(full, 0, &st_plan, &st_why) == PRL_OK;
     if (engine == PRL_ENGINE_FUSED) {
-        if (!shape_ok) { prl_set_error("fused engine: the board subtree of this tree is not one of the registered shapes (prl_fhp.h)"); return PRL_ERR_UNSUPPORTED; }
+        if (!shape_ok && !st_ok) {
+            prl_set_error("fused engine: neither a single-deal tree whose board subtree is a registered shape (prl_fhp.h) nor a multi-street tree of registered street shapes (prl_st.h)" +
+                          (st_why.empty() ? std::string() : ": " + st_why));
+            return PRL_ERR_UNSUPPORTED;
+        }
         fused = true;
-    } else if (engine == PRL_ENGINE_AUTO) fused = shape_ok;
-    if (exchange && !fused) { prl_set_error("sharded solve: FUSED engine only (a board subtree of a registered shape, prl_fhp.h)"); return PRL_ERR_UNSUPPORTED; }
+    } else if (engine == PRL_ENGINE_AUTO) fused = shape_ok || st_ok;
+    streets = fused && !shape_ok;
+    if (exchange && !fused) { prl_set_error("sharded solve: FUSED engine only (board / street subtrees of registered shapes, prl_fhp.h, prl_st.h)"); return PRL_ERR_UNSUPPORTED; }
+    // the unit a sharded solve splits: the outcomes of the first deal (boards of a single-deal tree, flops of a multi-street one)
+    const int n_top = streets ? st_plan.n_top : full.n_boards;
     // shard geometry: equal shards unless told otherwise; ragged = every rank but the last holds shard_boards (whole canonical
     // units of the level exchanged), the last one the rest of total_boards
-    if (shard_boards <= 0) { shard_boards = full.n_boards; total_boards = (int64_t)full.n_boards * world; }
+    if (shard_boards <= 0) { shard_boards = n_top; total_boards = (int64_t)n_top * world; }
     {
         const int64_t mine = rank == world - 1 ? total_boards - (int64_t)(world - 1) * shard_boards : shard_boards;
-        if (mine <= 0 || mine > shard_boards || mine != full.n_boards || total_boards > 0x7fffffffll) {
+        if (mine <= 0 || mine > shard_boards || mine != n_top || total_boards > 0x7fffffffll) {
             prl_set_error("sharded solve: this rank's tree does not hold its share of the board list (ranks before the last: shard_boards; the last: the rest)");
             return PRL_ERR_ARG;
         }
@@ -516,11 +693,22 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     s->variant = variant;
     s->delay = delay;
     s->fused = fused;
+    s->streets = streets;
+    if (streets) {
+        if (exchange && prl_st_build(full, total_boards, &st_plan, &st_why) != PRL_OK) { prl_set_error("street engine: " + st_why); delete s; return PRL_ERR_UNSUPPORTED; }
+        s->st = st_plan;
+        s->col_dfs = st_plan.col_dfs;
+        bool identity = true;
+        for (size_t c = 0; c < s->col_dfs.size() && identity; ++c) identity = s->col_dfs[c] == (int32_t)c;
+        if (identity) s->col_dfs.clear();
+    }
     s->small_tree = !fused && r.n_hole_cards == 1 && (long long)full.n_nodes * r.range_size <= 32768 && !getenv("PRL_NO_SMALL_TREE");
     s->full_nodes = full.n_nodes;
     s->full_cols = full.n_cols;
     s->R = r.range_size;
-    if (fused) make_trunk(full, ch_node, first_board, full.n_boards * prl_fhp_shape_desc(shape_id).n_nodes, &s->ft, &s->chance_trunk);
+    std::vector<int32_t> st_leaf_ids;
+    if (streets) make_trunk_streets(full, s->st, &s->ft, &st_leaf_ids);
+    else if (fused) make_trunk(full, ch_node, first_board, full.n_boards * prl_fhp_shape_desc(shape_id).n_nodes, &s->ft, &s->chance_trunk);
     else s->ft = full;
     const PrlFlatTree& ft = s->ft;
 #define FAIL_IF(x) do { int e_ = (x); if (e_) { prl_solver_destroy(s); return e_; } } while (0)
@@ -616,7 +804,18 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         T.plan_ge = ge + off * T.plan_stride; T.plan_cl = cl + off * T.cl_stride; T.plan_nlive = nl + off; T.plan_ndealt = nd + off;
         T.plan_hgs = hgs + off * T.plan_stride; T.plan_hge = hge + off * T.plan_stride; T.plan_clx = clx ? clx + off * PRL_CLX_WORDS : nullptr;
         T.plan_klh = klh;
-        if (fused) {
+        if (streets) {
+            PrlStParams& sp = s->sp;
+            sp.R = T.R; sp.eq_const = T.eq_const; sp.n_cards = T.n_cards;
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            sp.max_grid = cus > 0 ? cus : 256;
+            const char* g = getenv("PRL_FHP_GRID");
+            if (g && atoi(g) > 0) sp.max_grid = atoi(g);
+            sp.plan_stride = T.plan_stride; sp.cl_stride = T.cl_stride;
+            sp.plan_pos = pos; sp.plan_hgs = hgs; sp.plan_hge = hge; sp.plan_cl = cl; sp.plan_clx = clx; sp.plan_nlive = nl; sp.plan_ndealt = nd;
+            FAIL_IF(dev_upload(s, &sp.hole_packed, hole_packed));
+        } else if (fused) {
             PrlFhpParams& fp = s->fp;
             fp.n_boards = full.n_boards; fp.R = T.R; fp.col_base = col_base;
             {   // persistent workgroups, one per CU (LDS-bound occupancy): each walks its boards with the next one prefetching
@@ -661,26 +860,41 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     FAIL_IF(dev_alloc(s, &s->S.avg_f64, (size_t)T.n_nodes));
     if (variant != PRL_CFR_PLUS) FAIL_IF(dev_alloc(s, &s->S.avg_sum, nc_full));
     FAIL_IF(alloc_node_vectors(s, &s->S, true));
+    if (streets) {  // per street: instance table, leaf reach (not on the last street), one row of <= 4 root vectors per instance
+        s->n_trunk_leaves = (int)st_leaf_ids.size();
+        FAIL_IF(dev_upload(s, (const int32_t**)&s->d_trunk_leaves, st_leaf_ids));
+        FAIL_IF(dev_alloc(s, &s->d_trunk_reach, (size_t)s->n_trunk_leaves * 2 * T.R));
+        for (int lv = 0; lv < s->st.n_levels; ++lv) {
+            const PrlStLevelHost& H = s->st.level[lv];
+            FAIL_IF(dev_upload(s, (const PrlStInst**)&s->st_dev[lv].inst, H.inst));
+            if (!H.last) FAIL_IF(dev_alloc(s, &s->st_dev[lv].leaf_reach, (size_t)H.n_inst * H.n_leaves * 2 * T.R));
+            FAIL_IF(dev_alloc(s, &s->st_dev[lv].val, (size_t)H.n_inst * 4 * T.R));
+        }
+    }
     if (fused) {
-        // root-vector rows of a pass: one per board, or one per 32-board block when the pass sums its blocks itself (fused_board_pass)
-        const bool rows_are_blocks = s->block_sum && (!exchange || shard_boards % PRL_CHANCE_BLOCK == 0);
-        const size_t n_rows = rows_are_blocks ? ((size_t)full.n_boards + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK : (size_t)full.n_boards;
-        FAIL_IF(dev_alloc(s, &s->d_board_out, n_rows * 4 * T.R));
-        FAIL_IF(dev_alloc(s, &s->d_row_sum, (size_t)4 * T.R));
+        // a row = what one first-deal outcome contributes to the chance sum: <= 4 root vectors per chance leaf of the trunk
+        const size_t row_w = (size_t)(streets ? s->n_trunk_leaves : 1) * 4 * T.R;
+        if (!streets) {
+            // root-vector rows of a pass: one per board, or one per 32-board block when the pass sums its blocks itself (fused_board_pass)
+            const bool rows_are_blocks = s->block_sum && (!exchange || shard_boards % PRL_CHANCE_BLOCK == 0);
+            const size_t n_rows = rows_are_blocks ? ((size_t)full.n_boards + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK : (size_t)full.n_boards;
+            FAIL_IF(dev_alloc(s, &s->d_board_out, n_rows * 4 * T.R));
+        }
+        FAIL_IF(dev_alloc(s, &s->d_row_sum, row_w));
         const size_t n_blk = ((size_t)total_boards + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK + world;  // sized for the global board list
         const size_t n_grp = (n_blk + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
-        FAIL_IF(dev_alloc(s, &s->d_sum_scratch, (n_blk + n_grp + 1) * 4 * T.R));  // rows of up to 4 vectors
+        FAIL_IF(dev_alloc(s, &s->d_sum_scratch, (n_blk + n_grp + 1) * row_w));  // rows of up to 4 vectors (per trunk leaf)
         if (exchange) {
             // exchange whole canonical units: the highest summation level the shard size is a multiple of
             s->xlevel = shard_boards % (PRL_CHANCE_BLOCK * PRL_CHANCE_BLOCK) == 0 ? 2 : shard_boards % PRL_CHANCE_BLOCK == 0 ? 1 : 0;
             s->n_units = prl_fhp_units_at_level((int)shard_boards, s->xlevel);
             s->n_units_all = (world - 1) * s->n_units + prl_fhp_units_at_level((int)(total_boards - (int64_t)(world - 1) * shard_boards), s->xlevel);
-            const size_t per_rank = (size_t)s->n_units * 4 * T.R;  // [units][<= 4 vectors][R]
+            const size_t per_rank = (size_t)s->n_units * row_w;  // [units][<= 4 vectors (per trunk leaf)][R]
             FAIL_IF(dev_alloc(s, &s->d_xlocal, per_rank, true));
             FAIL_IF(dev_alloc(s, &s->d_xgather, per_rank * world, true));
             FAIL_IF(hipMemsetAsync(s->d_xlocal, 0, per_rank * sizeof(float), s->stream) == hipSuccess ? PRL_OK : PRL_ERR_HIP);  // a shorter last shard sends zero padding
         }
-        FAIL_IF(dev_alloc(s, &s->d_half, (size_t)2 * T.R + 4));
+        FAIL_IF(dev_alloc(s, &s->d_half, (size_t)(streets ? s->n_trunk_leaves : 1) * 2 * T.R + 4));
         s->fp.regret = s->d_regret;
         s->fp.board_out = s->d_board_out;
 #ifdef PRL_FHP_TIMING
@@ -921,6 +1135,13 @@ int32_t prl_solver_set_strategy_mixed(prl_solver_t* s, const void* strat, int32_
     if (node_is_f64 && (!is_f64 || s->fused)) { prl_set_error("per-node strategy dtypes: float64 data, LEVELS engine"); return PRL_ERR_ARG; }
     const size_t nc = (size_t)s->full_cols * s->R;
     std::vector<double> tmp;
+    std::vector<char> perm;  // the caller's columns (flat-tree DFS order) in the engine's internal column order
+    if (!s->col_dfs.empty()) {
+        const size_t cb = (size_t)s->R * (is_f64 ? sizeof(double) : sizeof(float));
+        perm.resize((size_t)s->full_cols * cb);
+        for (int c = 0; c < s->full_cols; ++c) memcpy(perm.data() + (size_t)c * cb, (const char*)strat + (size_t)s->col_dfs[c] * cb, cb);
+        strat = perm.data();
+    }
     const double* src = (const double*)strat;
     if (!is_f64) {
         tmp.resize(nc);
@@ -1332,7 +1553,10 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
                     PRL_HIP_TRY(hipStreamSynchronize(s->stream));
                     PRL_HIP_TRY(hipMemcpy(f.data(), s->d_user_strategy32, nc * 4, hipMemcpyDeviceToHost));
                     double* o = (double*)out;
-                    for (size_t i = 0; i < nc; ++i) o[i] = (double)f[i];
+                    if (s->col_dfs.empty()) for (size_t i = 0; i < nc; ++i) o[i] = (double)f[i];
+                    else
+                        for (int c = 0; c < s->full_cols; ++c)
+                            for (int h = 0; h < s->R; ++h) o[(size_t)s->col_dfs[c] * s->R + h] = (double)f[(size_t)c * s->R + h];
                     return PRL_OK;
                 }
                 if (s->src[0] != PRL_SRC_REGRET || s->src[1] != PRL_SRC_REGRET) {  // uniform float64 fill
@@ -1341,9 +1565,17 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
                 }
                 if (!s->d_user_strategy) TRY(dev_alloc(s, &s->d_user_strategy, nc));
                 PRL_HIP_TRY(hipMemcpyAsync(s->d_user_strategy, s->S.strategy, (size_t)s->T.n_cols * s->R * 8, hipMemcpyDeviceToDevice, s->stream));
-                PrlFhpParams fp = s->fp;
-                fp.variant = s->variant;
-                prl_launch_fhp_strategy_from_regret(fp, s->d_user_strategy, s->stream);
+                if (s->streets) {
+                    for (int lv = 0; lv < s->st.n_levels; ++lv) {
+                        PrlStParams q = s->sp;
+                        q.n_inst = s->st.level[lv].n_inst; q.col_base = s->st.level[lv].col_base; q.regret = s->d_regret; q.variant = s->variant;
+                        prl_launch_st_strategy_from_regret(q, s->st.level[lv].spec, s->d_user_strategy, s->stream);
+                    }
+                } else {
+                    PrlFhpParams fp = s->fp;
+                    fp.variant = s->variant;
+                    prl_launch_fhp_strategy_from_regret(fp, s->d_user_strategy, s->stream);
+                }
                 src = s->d_user_strategy; bytes = nc * 8;
                 break;
             }
@@ -1364,6 +1596,15 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
         default: prl_set_error("unknown solver field"); return PRL_ERR_ARG;
     }
     if (!src) { prl_set_error("field not available for this variant"); return PRL_ERR_STATE; }
+    const bool col_field = field == PRL_SF_STRATEGY || field == PRL_SF_REGRET || field == PRL_SF_AVG || field == PRL_SF_AVG_SUM;
+    if (col_field && !s->col_dfs.empty()) {  // internal column order -> the flat tree's DFS column order
+        std::vector<char> tmp(bytes);
+        PRL_HIP_TRY(hipMemcpyAsync(tmp.data(), src, bytes, hipMemcpyDeviceToHost, s->stream));
+        TRY(prl_solver_sync(s));
+        const size_t cb = bytes / (size_t)s->full_cols;
+        for (int c = 0; c < s->full_cols; ++c) memcpy((char*)out + (size_t)s->col_dfs[c] * cb, tmp.data() + (size_t)c * cb, cb);
+        return PRL_OK;
+    }
     PRL_HIP_TRY(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, s->stream));
     return prl_solver_sync(s);
 }

@@ -406,3 +406,52 @@ def check_iterations_many(L, n_iters=5):
     s.iterations(2)
     o.cfr_iteration(); o.cfr_iteration()
     assert_state_equal(s, o, "many[0] + 2")
+
+
+def make_streets_pair(L, game_cls, stack, runouts, variant, delay=0, max_raises=None):
+    """(tree, fused solver on the per-street engine, oracle) on one multi-street flat tree (csrc/prl_st.h)"""
+    args = env_args(game_cls, stack, None)
+    game = game_cls.native_game(args)
+    if max_raises is not None:
+        for i, v in enumerate(max_raises):
+            game.max_raises[i] = v
+    t = _native.NativeTree(game, game_cls.native_rules(), runouts, _lib=L)
+    s = _native.NativeSolver(t, variant, delay, engine="auto", _lib=L)
+    assert s.engine == "fused", "engine=auto must take the per-street fused engine for a multi-street tree of registered street shapes"
+    r = game_cls.RULES
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS, r._RANK_RULE)
+    o.cfr_reset(_native.VARIANTS[variant], delay)
+    return t, s, o
+
+
+def check_streets_vs_oracle(L, game_cls, stack, runouts, variant, n_iters, delay=0, max_raises=None, batched=False):
+    """SURVEY 8f-4 on the per-street fused engine (csrc/prl_st.h): regrets, averages, the strategy implied by the regrets, current- and
+    average-strategy exploitability after every iteration (batched: the exploitability history of prl_solver_iterations(n) and the
+    final state), bit for bit against the oracle -- in the flat tree's DFS column order, which the engine does not use internally."""
+    t, s, o = make_streets_pair(L, game_cls, stack, runouts, variant, delay, max_raises)
+    assert np.array_equal(s.exploitability(), o.exploitability), (s.exploitability(), o.exploitability)
+    fields = FUSED_FIELDS + ("strategy",) + (() if variant == "plus" else ("avg_sum",))
+
+    def same_state(tag):
+        for k in fields:
+            a, b = s.get(k), np.asarray(getattr(o, k))
+            assert np.array_equal(a, b), "streets %s: %s differs in %d entries, first %s" % (tag, k, int(np.sum(a != b)), np.argwhere(a != b)[:3].tolist())
+    if batched:
+        want = [np.array(o.exploitability, np.float32)]
+        for _ in range(n_iters):
+            o.cfr_iteration()
+            want.append(np.array(o.exploitability, np.float32))
+        s.iterations(n_iters - 1)
+        s.iterations(1)
+        assert np.array_equal(s.get("expl_history"), np.stack(want)), (s.get("expl_history"), np.stack(want))
+        same_state("batched")
+        assert np.array_equal(s.eval_avg(), o.eval_avg())
+    else:
+        for it in range(1, n_iters + 1):
+            s.iteration()
+            o.cfr_iteration()
+            same_state("it%d" % it)
+            assert np.array_equal(s.exploitability(), o.exploitability), (it, s.exploitability(), o.exploitability)
+            if it > delay:
+                assert np.array_equal(s.eval_avg(), o.eval_avg()), it
+    return t, s, o
