@@ -1,9 +1,14 @@
 """
 bench_multistreet.py -- CFR+ on a multi-street public tree (secondary to bench.py): LimitHoldem (3 + 1 + 1 board
-cards, full betting tree) over F flops x T turns x R rivers of seeded run-outs, 1326-hand ranges, on the level-synchronous (LEVELS)
-engine -- the engine multi-street trees run on today; the number is the baseline the per-street fused pass of DESIGN.md section 8 has to beat.
+cards, full betting tree) over F flops x T turns x R rivers of seeded run-outs, 1326-hand ranges. engine=auto runs it on the per-street
+fused engine (csrc/prl_st.h); --engine levels is the level-synchronous engine these trees ran on before (10.3 M node-updates/s on the default
+tree, profiles/r04p_bench_multistreet.json).
 
-    python bench_multistreet.py [--flops F] [--turns T] [--rivers R] [--steps K] [--warmup W]
+    python bench_multistreet.py [--flops F] [--turns T] [--rivers R] [--steps K] [--warmup W] [--engine auto|levels] [--no-cpu-baseline]
+
+roofline: algorithmic bytes per iteration 20 R sum(A) + 8 R N_rows of the LAST street (the dominant kernel: 94 % of the
+nodes) over that kernel's summed launch time (HIP events on the solver's stream inside the timed region); the whole tree over the whole
+iteration beside it. cpu_baseline: the oracle (1 thread) on one flop x one turn x one river of the same game.
 """
 import argparse
 import json
@@ -15,6 +20,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def runouts(n_flops, n_turns, n_rivers, seed=9):
@@ -29,13 +36,34 @@ def runouts(n_flops, n_turns, n_rivers, seed=9):
     return np.array(rows, np.int8)
 
 
+def cpu_baseline(n_iters):
+    """CFR+ on the same game with the CPU oracle (1 thread): one flop x one turn x one river, full betting"""
+    import oracle
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import games as G
+    oracle.set_threads(1)
+    t = _native.NativeTree.for_game(G.LimitHoldem, 48, None, runouts(1, 1, 1))
+    r = G.LimitHoldem.RULES
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS, r._RANK_RULE)
+    o.cfr_reset(1, 0)
+    t0 = time.perf_counter()
+    for _ in range(n_iters):
+        o.cfr_iteration()
+    dt = time.perf_counter() - t0
+    return {"value": t.n_nodes * n_iters / dt, "unit": "node-updates/s", "cores": 1, "kind": "port",
+            "sample": "CFR+ delay 0, LimitHoldem 1 flop x 1 turn x 1 river (%d nodes), %d iterations, oracle/prl_oracle.c, 1 thread, %.1f s" % (t.n_nodes, n_iters, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flops", type=int, default=4)
     ap.add_argument("--turns", type=int, default=2)
     ap.add_argument("--rivers", type=int, default=2)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--engine", default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
     args = ap.parse_args()
     import torch
     torch.cuda.set_device(0)
@@ -45,22 +73,44 @@ def main():
     t0 = time.perf_counter()
     tree = _native.NativeTree.for_game(G.LimitHoldem, 48, None, runouts(args.flops, args.turns, args.rivers))
     t_tree = time.perf_counter() - t0
-    s = _native.NativeSolver(tree, "plus", 0, engine="auto")
+    s = _native.NativeSolver(tree, "plus", 0, engine=args.engine)
     s.iterations(args.warmup)
     s.sync()
     t0 = time.perf_counter()
-    dev_ms = s.time_iterations(args.steps)
+    dev_ms, pass_ms, n_pass = s.time_iterations_ex(args.steps)
     s.sync()
     dt = time.perf_counter() - t0
     expl = s.exploitability()
-    print(json.dumps({
+    R = tree.range_size
+    kind, rnd, nch = tree.field("kind"), tree.field("round"), tree.field("n_children")
+    last = int(rnd.max())
+    cols_last = int(np.sum(nch[(kind == 0) & (rnd == last)]))
+    n_rows_last = int(np.sum(np.sum(tree.board_rows >= 0, axis=1) == tree.board_len))
+    bytes_iter = 20.0 * R * tree.n_cols + 8.0 * R * int(tree.n_boards)
+    bytes_last = 20.0 * R * cols_last + 8.0 * R * n_rows_last
+    fused = s.engine == "fused" and n_pass > 0
+    achieved = (bytes_last * args.steps / (pass_ms * 1e-3) if fused else bytes_iter * args.steps / (dev_ms * 1e-3)) / 1e9
+    out = {
         "metric": "CFR+ node-updates/sec on a multi-street LimitHoldem public tree", "value": tree.n_nodes * args.steps / dt, "unit": "node-updates/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "build_flavor": _native.build_flavor(),
         "config": {"workload": "CFR+ (delay 0) on LimitHoldem, %d flops x %d turns x %d rivers of seeded run-outs, 1326-hand ranges" % (args.flops, args.turns, args.rivers),
-                   "engine": s.engine, "nodes": tree.n_nodes, "action_columns": tree.n_cols, "board_rows": int(tree.n_boards), "tree_build_s": t_tree,
-                   "device_ms_per_iteration": dev_ms / args.steps, "exploitability_chips": float(np.mean(expl)),
-                   "hbm_bytes_allocated": int(s.get("bytes_allocated")[0])}}), flush=True)
+                   "engine": s.engine + (" (per-street)" if s.engine == "fused" else ""), "nodes": tree.n_nodes, "action_columns": tree.n_cols,
+                   "action_columns_last_street": cols_last, "board_rows": int(tree.n_boards), "tree_build_s": t_tree,
+                   "device_ms_per_iteration": dev_ms / args.steps, "exploitability_chips": float(np.mean(expl)), "iterations_done": s.iter,
+                   "hbm_bytes_allocated": int(s.get("bytes_allocated")[0])},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "prl_k_st_pass<last street>" if fused else "all kernels of the iteration",
+                     "launches_per_iteration": n_pass / float(args.steps) if fused else None,
+                     "kernel_ms_per_iteration": (pass_ms if fused else dev_ms) / args.steps,
+                     "bytes_per_iteration_algorithmic": bytes_last if fused else bytes_iter,
+                     "bytes_per_iteration_algorithmic_whole_tree": bytes_iter,
+                     "achieved_whole_iteration": bytes_iter * args.steps / (dev_ms * 1e-3) / 1e9,
+                     "frac_whole_iteration": bytes_iter * args.steps / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_iters)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -144,6 +144,28 @@ def test_emu_multistreet_limit_holdem_tree(L):
     pc.check_multistreet_vs_oracle(L, G.LimitHoldem, 48, None, pc.multistreet_runouts(2, 2, 2), "plus", 1, max_raises=(1, 1, 0, 0))  # 130 nodes
 
 
+@pytest.mark.parametrize("variant,runouts,max_raises,batched", [("plus", (2, 2, 1), (1, 1, 1, 1), False), ("vanilla", (1, 2, 2), (1, 1, 1, 1), True),
+                                                                ("linear", (1, 1, 2), (1, 2, 1, 1), True)])
+def test_emu_streets_engine_limit_holdem(L, variant, runouts, max_raises, batched):
+    """the per-street fused engine (csrc/prl_st.h) on LimitHoldem trees with three dealing streets: engine=auto takes it, regrets /
+    averages / exploitability history / average-strategy exploitability equal the oracle's bit for bit -- single iterations and the
+    batched steady state, 9- and 15-node street subtrees, several outcomes per chance node"""
+    from pokerrl_amd.game import games as G
+    pc.check_streets_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(*runouts), variant, 3 if batched else 2, max_raises=max_raises, batched=batched)
+
+
+def test_emu_streets_engine_refuses_all_in_run_outs(L):
+    """4-chip stacks: all-ins dealt out as chance chains are not street instances -- engine=auto falls back to the level-synchronous engine,
+    engine=fused says why"""
+    from helpers import env_args
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import games as G
+    t = _native.NativeTree(G.LimitHoldem.native_game(env_args(G.LimitHoldem, 4, None)), G.LimitHoldem.native_rules(), pc.multistreet_runouts(1, 1, 1), _lib=L)
+    assert _native.NativeSolver(t, "plus", 0, engine="auto", _lib=L).engine == "levels"
+    with pytest.raises(_native.NativeError, match="run-out"):
+        _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
+
+
 def test_emu_multistreet_short_stack_run_outs(L):
     """4-chip stacks: all-ins on every street, each dealt out as a chain of chance nodes down to showdown leaves (41 chance nodes)"""
     from pokerrl_amd.game import games as G

@@ -173,6 +173,39 @@ def test_gpu_multistreet_limit_holdem_full_betting_vs_oracle(L):
     assert t.n_nodes > 40000
 
 
+@pytest.mark.parametrize("variant,batched", [("plus", False), ("plus", True), ("vanilla", True), ("linear", True)])
+def test_gpu_streets_engine_limit_holdem_full_betting_vs_oracle(L, variant, batched):
+    """the per-street fused engine (csrc/prl_st.h) on LimitHoldem with its full betting structure (27-node street subtrees, 7 / 14 / 252
+    / 2268 street instances over 2 flops x 2 turns x 1 river, ~68 k nodes): regrets, averages, strategies, exploitability history and
+    average-strategy exploitability against the oracle, bit for bit -- single iterations and the batched steady state, all variants"""
+    from pokerrl_amd.game import games as G
+    t, s, o = pc.check_streets_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(2, 2, 1), variant, 4 if batched else 2, batched=batched)
+    assert t.n_nodes > 60000
+
+
+def test_gpu_streets_engine_vs_levels_engine_bench_tree(L):
+    """bench_multistreet.py's tree (4 flops x 2 turns x 2 rivers, 259 330 nodes) on both engines of the library: the same exploitability
+    history, regrets and averages; the per-street engine in < 1/3 of the level-synchronous engine's HBM"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench_multistreet
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import games as G
+    t = _native.NativeTree.for_game(G.LimitHoldem, 48, None, bench_multistreet.runouts(4, 2, 2), _lib=L)
+    a = _native.NativeSolver(t, "plus", 0, engine="auto", _lib=L)
+    assert a.engine == "fused"
+    a.iterations(3)
+    hist, regret, avg, ev_avg, mem_a = a.get("expl_history"), a.get("regret"), a.get("avg"), a.eval_avg(), int(a.get("bytes_allocated")[0])
+    del a
+    b = _native.NativeSolver(t, "plus", 0, engine="levels", _lib=L)
+    b.iterations(3)
+    assert np.array_equal(hist, b.get("expl_history"))
+    assert np.array_equal(regret, b.get("regret")) and np.array_equal(avg, b.get("avg"))
+    assert np.array_equal(ev_avg, b.eval_avg())
+    assert mem_a * 3 < int(b.get("bytes_allocated")[0])
+
+
 @pytest.mark.parametrize("variant", ["vanilla", "linear"])
 def test_gpu_multistreet_short_stack_run_outs_vs_oracle(L, variant):
     from pokerrl_amd.game import games as G

@@ -204,6 +204,88 @@ def test_bench_shard_geometry():
     assert bench.shard_geometry(2598960, 8, 0) == (325632, 325632) and bench.shard_geometry(2598960, 8, 7) == (325632, 319536)
 
 
+# ---- multi-street trees on the per-street fused engine: the flops (first-deal outcomes) are what the ranks split -----------------------
+def _top_blocks(t):
+    """column ranges of a multi-street flat tree: (trunk columns, {(trunk chance node index, outcome k): columns of that subtree}), DFS order"""
+    kind, sub, fc, nch = t.field("kind"), t.field("subtree_size"), t.field("first_col"), t.field("n_children")
+    cs, cl = t.field("child_start"), t.field("child_list")
+    ncols_below = lambda n: int(np.sum(nch[n:n + sub[n]][kind[n:n + sub[n]] == 0]))
+    trunk, blocks, n, j = [], {}, 0, 0
+    while n < t.n_nodes:
+        if kind[n] == 1:
+            for k in range(nch[n]):
+                root = int(cl[cs[n] + k])
+                blocks[(j, k)] = np.arange(fc[root], fc[root] + ncols_below(root))
+            j += 1
+            n += int(sub[n])
+            continue
+        if kind[n] == 0:
+            trunk.extend(range(fc[n], fc[n] + nch[n]))
+        n += 1
+    return np.array(trunk, np.int64), blocks
+
+
+def run_sharded_streets(lib_path, device, world, cfg, timeout):
+    import json
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_streets_worker.py"), lib_path, device, d, json.dumps(cfg)], env=env))
+        try:
+            for p in procs:
+                assert p.wait(timeout=timeout) == 0
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(world)]
+
+
+def check_streets_against_union(L, ranks, world, cfg):
+    """every rank's state = its flops' part of the one-rank solve of all flops, bit for bit (regrets, averages: the trunk's columns
+    and every street instance's; exploitability history; average-strategy exploitability)"""
+    n_local, per_flop = cfg["n_local"], cfg["n_turns"] * cfg["n_rivers"]
+    runouts = pc.multistreet_runouts(world * n_local, cfg["n_turns"], cfg["n_rivers"], seed=cfg["seed"])
+    game = G.LimitHoldem.native_game(env_args(G.LimitHoldem, 48, None))
+    for i, v in enumerate(cfg.get("max_raises") or []):
+        game.max_raises[i] = v
+    t = _native.NativeTree(game, G.LimitHoldem.native_rules(), runouts, _lib=L)
+    s = _native.NativeSolver(t, cfg.get("variant", "plus"), 0, engine="fused", _lib=L)
+    s.iterations(cfg["n_iters"])
+    hist, regret, avg, ev_avg = s.get("expl_history"), s.get("regret"), s.get("avg"), s.eval_avg()
+    trunk_u, blocks_u = _top_blocks(t)
+    for r, out in enumerate(ranks):
+        tl = _native.NativeTree(game, G.LimitHoldem.native_rules(), runouts[r * n_local * per_flop:(r + 1) * n_local * per_flop], _lib=L)
+        trunk_l, blocks_l = _top_blocks(tl)
+        assert np.array_equal(out["expl_history"], hist), "rank %d: exploitability history" % r
+        assert np.array_equal(out["eval_avg"], ev_avg), "rank %d: average-strategy exploitability" % r
+        for name, full in (("regret", regret), ("avg", avg)):
+            assert np.array_equal(out[name][trunk_l], full[trunk_u]), "rank %d: trunk %s" % (r, name)
+            for (j, k), cols in blocks_l.items():
+                assert np.array_equal(out[name][cols], full[blocks_u[(j, r * n_local + k)]]), "rank %d: %s of flop %d below trunk leaf %d" % (r, name, k, j)
+        assert int(out["exchanges"]) == 1 + 3 + (2 * (cfg["n_iters"] - 1) + 1 if cfg["n_iters"] > 1 else 0) + 1, out["exchanges"]
+
+
+def test_streets_sharded_world2_gloo_emu(EMU):
+    """LimitHoldem (one raise per round), 2 flops x 2 turns x 1 river, one flop per rank: the sharded per-street solve over gloo on the
+    emulator build equals the one-rank solve of both flops"""
+    cfg = dict(n_local=1, n_turns=2, n_rivers=1, n_iters=2, seed=13, max_raises=[1, 1, 1, 1])
+    ranks = run_sharded_streets(EMU, "cpu", 2, cfg, timeout=1500)
+    check_streets_against_union(_native.bind(EMU), ranks, 2, cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_local,max_raises", [(1, None), (32, [1, 1, 1, 1])])  # flops / blocks of 32 flops are exchanged
+def test_gpu_streets_sharded_world2_matches_unsharded(n_local, max_raises):
+    """two processes on the one GPU: LimitHoldem with its full betting (27-node street subtrees) one flop per rank; a 9-node betting tree
+    with 32 flops per rank (whole 32-flop blocks are what the ranks exchange)"""
+    cfg = dict(n_local=n_local, n_turns=2, n_rivers=2 if n_local == 1 else 1, n_iters=3, seed=17, max_raises=max_raises)
+    ranks = run_sharded_streets(_native.LIB_PATH, "cuda", 2, cfg, timeout=900)
+    check_streets_against_union(_native.lib(), ranks, 2, cfg)
+
+
 @pytest.mark.gpu
 def test_gpu_chance_sum_levels_do_not_depend_on_world_size():
     L = _native.lib()
