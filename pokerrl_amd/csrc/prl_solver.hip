@@ -286,6 +286,7 @@ int street_sweep(prl_solver* s, const PrlDevState& st, int mode, int src0, int s
         q.child_val = lv + 1 < L ? s->st_dev[lv + 1].val : nullptr;
         q.child_w = width;
         q.val = s->st_dev[lv].val;
+        if (!H.last) q.timing = nullptr;  // (PRL_ST_TIMING builds clock the last street's pass)
         return q;
     };
     for (int lv = 0; lv + 1 < L; ++lv) {
@@ -870,6 +871,10 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             if (!H.last) FAIL_IF(dev_alloc(s, &s->st_dev[lv].leaf_reach, (size_t)H.n_inst * H.n_leaves * 2 * T.R));
             FAIL_IF(dev_alloc(s, &s->st_dev[lv].val, (size_t)H.n_inst * 4 * T.R));
         }
+#ifdef PRL_ST_TIMING
+        FAIL_IF(dev_alloc(s, &s->sp.timing, (size_t)8));
+        PRL_HIP_TRY(hipMemsetAsync(s->sp.timing, 0, 8 * sizeof(unsigned long long), s->stream));
+#endif
     }
     if (fused) {
         // a row = what one first-deal outcome contributes to the chance sum: <= 4 root vectors per chance leaf of the trunk
@@ -1477,6 +1482,17 @@ int32_t prl_solver_time_iterations(prl_solver_t* s, int32_t n, float* out_ms) {
 extern "C" int32_t prl_debug_set_experiment(prl_solver_t* s, int32_t flags) {
     if (!s) return PRL_ERR_ARG;
     s->fp.exp = flags;
+    return PRL_OK;
+}
+#endif
+
+#ifdef PRL_ST_TIMING
+// instrumented builds only (scripts/st_phase_timing.py): shader clocks wave 0 of every workgroup spent per phase of the last street's pass
+extern "C" int32_t prl_debug_st_timing(prl_solver_t* s, unsigned long long* out8, int32_t reset) {
+    if (!s || !s->sp.timing) return PRL_ERR_ARG;
+    PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+    PRL_HIP_TRY(hipMemcpy(out8, s->sp.timing, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) PRL_HIP_TRY(hipMemset(s->sp.timing, 0, 8 * sizeof(unsigned long long)));
     return PRL_OK;
 }
 #endif

@@ -68,6 +68,7 @@ struct PrlStParams {
     const int16_t *plan_pos, *plan_hgs, *plan_hge, *plan_cl;
     const uint32_t* plan_clx;
     const int32_t *plan_nlive, *plan_ndealt;
+    unsigned long long* timing;  // PRL_ST_TIMING builds (scripts/gpu_st_phases.sh): [8] shader-clock accumulators per phase of the pass; else unused
 };
 
 // host description of one street (prl_st_build)
