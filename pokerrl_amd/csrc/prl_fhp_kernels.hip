@@ -15,6 +15,8 @@
 //     bit-identical to engine G (prl_tree_kernels.hip) and to the CPU oracle;
 //   * the chance-node sum over boards is done afterwards in the canonical nested order (blocks of 32, groups of 32).
 // No MFMA anywhere: nothing here is a contraction; measured, the kernel is bound by VALU issue.
+#include <type_traits>
+
 #include "prl_device.h"
 #include "prl_fhp.h"
 #include "prl_kernels.h"
