@@ -133,6 +133,11 @@ def main():
     ap.add_argument("--engine", default=os.environ.get("PRL_BENCH_ENGINE", "auto"))
     ap.add_argument("--variant", default="plus", choices=["plus", "linear", "vanilla"],
                     help="CFR variant (the metric is quoted on CFR+; BASELINE config 3 also names LinearCFR)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "torch"],
+                    help="the all-gather of a sharded run: rccl = ncclAllGather inside the library on the solver's stream (default on GPUs), "
+                         "torch = torch.distributed through the C ABI's callback")
+    ap.add_argument("--no-placement-probe", dest="placement_probe", action="store_false",
+                    help="one GPU: do not build a second set of arrays to keep the faster-placed one (DESIGN.md section 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-boards", type=int, default=384)
     ap.add_argument("--cpu-iters", type=int, default=24)
@@ -172,21 +177,52 @@ def main():
     boards = seeded_boards(args.boards, 0, offset=rank * shard_boards)
     tree = fhp_tree(boards, lib)
     exchange = None
-    if total and world > 1:
+    sharded = world > 1 or bool(os.environ.get("PRL_BENCH_FORCE_EXCHANGE"))  # the env knob runs the all-gather path on one GPU (tests)
+    # the exchange: "rccl" = inside the library (ncclAllGather on the solver's stream, no Python in the iteration loop; the default on
+    # GPUs), "torch" = torch.distributed through the C ABI's callback (the CPU test-suite's gloo runs; a fallback)
+    how = args.exchange if args.exchange != "auto" else ("torch" if emu_lib else "rccl")
+    if sharded and dist is None:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    if sharded and how == "rccl":
+        from pokerrl_amd.dist import rccl_shard
+        try:
+            solver = _native.NativeSolver(tree, args.variant, 0, shard=rccl_shard(world, rank, shard_boards if total else None, total or None, lib=lib), _lib=lib)
+        except _native.NativeError as e:  # no librccl.so to bind (the same on every rank): the callback path still works
+            if e.status != _native.ERR_UNSUPPORTED:
+                raise
+            sys.stderr.write("bench.py: the library's RCCL exchange is not available (%s); using torch.distributed\n" % e)
+            how = "torch"
+    if sharded and how == "torch":
         from pokerrl_amd.dist import TorchExchange
         exchange = TorchExchange("cpu" if emu_lib else "cuda")
-        solver = _native.NativeSolver(tree, args.variant, 0, shard=(world, rank, exchange, shard_boards, total), _lib=lib)
-    elif world > 1 or os.environ.get("PRL_BENCH_FORCE_EXCHANGE"):  # the env knob runs the all-gather path on one GPU (tests)
-        if dist is None:
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29531")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-        from pokerrl_amd.dist import TorchExchange
-        exchange = TorchExchange("cpu" if emu_lib else "cuda")
-        solver = _native.NativeSolver(tree, args.variant, 0, shard=(world, rank, exchange), _lib=lib)
-    else:
+        solver = _native.NativeSolver(tree, args.variant, 0, shard=(world, rank, exchange, shard_boards, total) if total else (world, rank, exchange), _lib=lib)
+    placement = None
+    if not sharded:
         solver = _native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib)
+        if args.placement_probe and not emu_lib and solver.engine == "fused":
+            # The board pass streams within ~10 % of what HBM sustains and its speed depends on WHERE its arrays land physically: solver
+            # objects of one process differ by up to 15 %, alternating between two levels ("Spread"). One GPU has room
+            # for two sets of arrays at this size, so: build a second solver while the first is alive, time both, keep the faster one.
+            # Both timings are reported (config.placement_probe_ms_per_iteration); --no-placement-probe measures the first allocation as is.
+            def probe(sv):
+                sv.iterations(3)  # past the first iterations (uniform strategies, first averages): the steady-state passes are what is compared
+                sv.sync()
+                return sv.time_iterations(4) / 4.0
+            try:
+                ms_a = probe(solver)
+                other = _native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib)
+                ms_b = probe(other)
+                placement = [ms_a, ms_b]
+                if ms_b < ms_a:
+                    solver, other = other, solver
+                del other
+                solver.reset()
+            except _native.NativeError as e:  # not enough HBM for two sets: measure the one there is
+                sys.stderr.write("bench.py: placement probe skipped (%s)\n" % e)
+                solver.reset()
     solver.sync()
 
     def barrier():
@@ -238,12 +274,13 @@ def main():
             "boards_per_gpu": args.boards, "nodes_per_gpu": tree.n_nodes, "action_columns_per_gpu": sum_a,
             "engine": solver.engine,
             "parallelism": "boards sharded over %d GPU(s), trunk replicated, 1 all-gather of chance-node partial sums per EV pass" % world,
-            "nodes_whole_tree": n_nodes_total, "exchanges": exchange.calls if exchange else 0,
+            "nodes_whole_tree": n_nodes_total, "exchanges": int(solver.get("exchanges")[0]), "exchange": (how if sharded else None),
             "exchange_ms_mean": (exchange.seconds * 1e3 / max(exchange.calls, 1)) if exchange else None,
             "iterations_done": solver.iter, "exploitability_mbb_per_g": float(np.mean(expl) * 10.0),
             "avg_strategy_exploitability_mbb_per_g": float(np.mean(avg_expl) * 10.0), "avg_strategy_evaluation_ms": avg_eval_ms,
             "ms_per_step_with_avg_strategy_evaluation": dt * 1e3 / args.steps + avg_eval_ms,
             "hbm_bytes_allocated": int(solver.get("bytes_allocated")[0]),
+            "placement_probe_ms_per_iteration": placement,  # [first allocation, second allocation]: the faster one was kept (None: not probed)
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION * args.boards if (solver.engine == "fused" and args.variant == "plus") else None,

@@ -290,6 +290,15 @@ int32_t prl_solver_create_sharded(const prl_tree_t* local_tree, int32_t variant,
 int32_t prl_solver_create_sharded_ragged(const prl_tree_t* local_tree, int32_t variant, int32_t delay, int32_t world_size, int32_t rank,
                                          int64_t shard_boards, int64_t total_boards, prl_exchange_fn exchange, void* user,
                                          prl_solver_t** out_solver);
+/* The same sharded solve with the exchange inside the library: ncclAllGather (RCCL over xGMI) enqueued on the solver's own HIP stream,
+ * no callback, no host synchronisation per pass. Rank 0 draws a 128-byte communicator id (prl_rccl_unique_id = ncclGetUniqueId) and
+ * hands it to every rank by any means (a file, MPI, torch.distributed.broadcast ...); every rank then calls this with the device of its
+ * GPU current (prl_set_device). Collective: returns once all ranks have joined. shard_boards = 0: equal shards (every rank's tree holds
+ * the same number of first-deal outcomes); else the ragged geometry of prl_solver_create_sharded_ragged. RCCL is bound at run time
+ * (dlopen; the one already in the process if PyTorch-ROCm is loaded): single-GPU users never load it. */
+int32_t prl_rccl_unique_id(void* out_id128);
+int32_t prl_solver_create_sharded_rccl(const prl_tree_t* local_tree, int32_t variant, int32_t delay, int32_t world_size, int32_t rank,
+                                       const void* unique_id128, int64_t shard_boards, int64_t total_boards, prl_solver_t** out_solver);
 /* Checkpoint / resume (the reference's CFR has none): the solver's persistent state -- iteration
  * counter, regrets, average strategy (+ sum), current trunk strategy with its dtype flags, exploitability history -- as one
  * opaque host blob. load_state needs a solver created on the same tree with the same variant / delay / engine; a resumed
@@ -354,10 +363,15 @@ enum {
     PRL_SF_BYTES_ALLOCATED = 13, /* int64                HBM bytes held by the solver          */
     PRL_SF_ENGINE = 14,      /* int32                    PRL_ENGINE_LEVELS or PRL_ENGINE_FUSED  */
     PRL_SF_GRAPH_REPLAY = 15, /* int32                   1 if iterations are replays of a captured hipGraph (LEVELS engine) */
+    PRL_SF_EXCHANGES = 17,   /* int64                    all-gathers of a sharded solve so far (0 for an unsharded one) */
     PRL_SF_EXPLICIT_STRATEGY = 16 /* int32               fused engines: -1 strategy follows regrets / uniform fill, 0 an explicit float32
                                                          strategy is loaded (prl_solver_set_strategy), 1 an explicit float64 one; LEVELS: -1 */
 };
 int32_t prl_solver_get(prl_solver_t* solver, int32_t field, void* out);
+/* n_cols action columns of a per-action-column field (REGRET, AVG, AVG_SUM) starting at flat-tree column col_begin: what lets a caller
+ * stream a 20-60 GB array through a small host buffer (hashing, checkpoints to disk). Trees on the per-street engine keep their columns
+ * in another order internally and refuse this call (use prl_solver_get). */
+int32_t prl_solver_get_cols(prl_solver_t* solver, int32_t field, int64_t col_begin, int64_t n_cols, void* out);
 
 /* ---------------------------------------------------------------------------------------------------------------- */
 /* 6. Local best response (LBR): the check-down equity of LBR's hand against agent ranges.                           */

@@ -34,6 +34,7 @@ def lib():
             getattr(L, n).restype = None
         L.orc_set_strategy.argtypes = [vp, vp, i32]
         L.orc_cfr_reset.argtypes = [vp, i32, i32]
+        L.orc_cfr_configure.argtypes = [vp, i32, i32]
         L.orc_eval_avg.argtypes = [vp, vp]
         L.orc_rank7.argtypes = [vp, i32, i32]
         L.orc_rank7.restype = i32
@@ -52,6 +53,11 @@ def lib():
         L.orc_set_chance_weights.argtypes = [vp, vp]
         L.orc_unsupported.argtypes = [vp]
         L.orc_unsupported.restype = i32
+        for n in ("orc_compute_regrets", "orc_compute_new_strategy", "orc_add_strategy_to_average", "orc_set_iter"):
+            getattr(L, n).argtypes = [vp, i32]
+            getattr(L, n).restype = None
+        L.orc_set_override.argtypes = [vp, i32, vp, vp]
+        L.orc_set_override.restype = None
         L.orc_set_threads.argtypes = [i32]
         L.orc_max_threads.restype = i32
         _lib = L
@@ -189,8 +195,35 @@ class Oracle:
     def cfr_reset(self, variant, delay=0):
         lib().orc_cfr_reset(self._h, int(variant), int(delay))
 
+    def cfr_configure(self, variant, delay=0):
+        """cfr_reset without the evaluation"""
+        lib().orc_cfr_configure(self._h, int(variant), int(delay))
+
     def cfr_iteration(self):
         lib().orc_cfr_iteration(self._h)
+
+    # pieces of cfr_iteration, for runs that evaluate a big tree chunk by chunk (tests/golden/make_fhp_golden_chunked.py)
+    def compute_regrets(self, p):
+        lib().orc_compute_regrets(self._h, int(p))
+
+    def compute_new_strategy(self, p):
+        lib().orc_compute_new_strategy(self._h, int(p))
+
+    def add_strategy_to_average(self, p):
+        lib().orc_add_strategy_to_average(self._h, int(p))
+
+    def set_iter(self, it):
+        lib().orc_set_iter(self._h, int(it))
+
+    def set_override(self, node, ev, ev_br):
+        """compute_ev takes `node`'s values ([2][R] each) from these arrays and skips its subtree; None clears it"""
+        if ev is None:
+            self._ov = None
+            lib().orc_set_override(self._h, -1, None, None)
+            return
+        self._ov = (np.ascontiguousarray(ev, np.float32), np.ascontiguousarray(ev_br, np.float32))
+        assert self._ov[0].shape == (2, self.R) and self._ov[1].shape == (2, self.R)
+        lib().orc_set_override(self._h, int(node), _p(self._ov[0]), _p(self._ov[1]))
 
     def eval_avg(self):
         out = np.zeros(2, dtype=np.float32)

@@ -227,6 +227,10 @@ typedef struct {
     float expl[2];
     int variant, delay, iter;
     int unsupported;      /* tree holds a terminal this restatement does not cover */
+    /* chunked runs of trees too big for one oracle instance (tests/golden/make_fhp_golden_chunked.py): the values of ONE node given from
+     * outside, its subtree skipped -- the chance node of a Flop5Holdem tree whose boards are evaluated chunk by chunk */
+    int ov_node;
+    const float *ov_ev, *ov_ev_br;
     Plan* plans;          /* [n_boards + 1], last = "no board" identity plan; built lazily */
     uint8_t* plan_ready;
     int32_t* tmp_ranks;
@@ -590,6 +594,11 @@ static void update_reach(Orc* o, int node) {
 static void compute_ev(Orc* o, int node) {
     const int R = o->R;
     const int A = o->n_children[node];
+    if (o->ov_ev && node == o->ov_node) {
+        memcpy(V2(o, ev, node, 0), o->ov_ev, sizeof(float) * 2 * (size_t)R);
+        memcpy(V2(o, ev_br, node, 0), o->ov_ev_br, sizeof(float) * 2 * (size_t)R);
+        return;
+    }
     if (o->kind[node] >= K_FOLD) { terminal_values(o, node); return; }
     if (o->kind[node] == K_CHANCE && A >= 64) {
         if (o->n_hole == 2) ensure_plans(o);
@@ -726,6 +735,18 @@ void orc_cfr_reset(Orc* o, int variant, int delay) { /* _CFRBase.reset (_CFRBase
     orc_compute_ev(o);
 }
 
+/* orc_cfr_reset without the evaluation (chunked runs set a chunk up and evaluate it themselves) */
+void orc_cfr_configure(Orc* o, int variant, int delay) {
+    o->variant = variant;
+    o->delay = delay;
+    o->iter = 0;
+    memset(o->regret, 0, sizeof(float) * (size_t)o->n_cols * o->R);
+    memset(o->avg_sum, 0, sizeof(float) * (size_t)o->n_cols * o->R);
+    memset(o->avg, 0, sizeof(double) * (size_t)o->n_cols * o->R);
+    memset(o->avg_f64, 0, o->n_nodes);
+    orc_fill_uniform(o);
+}
+
 static void compute_regrets(Orc* o, int p) { /* _CFRBase._compute_regrets (_CFRBase.py:146-185) */
     const int R = o->R;
 #pragma omp parallel for schedule(static, 64) if (o->n_nodes >= 1024)
@@ -849,6 +870,12 @@ void orc_eval_avg(Orc* o, float out_expl[2]) {
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* accessors                                                                                                           */
 /* ------------------------------------------------------------------------------------------------------------------ */
+/* pieces of orc_cfr_iteration, for runs that evaluate a tree chunk by chunk (tests/golden/make_fhp_golden_chunked.py) */
+void orc_compute_regrets(Orc* o, int p) { compute_regrets(o, p); }
+void orc_compute_new_strategy(Orc* o, int p) { compute_new_strategy(o, p); }
+void orc_add_strategy_to_average(Orc* o, int p) { add_strategy_to_average(o, p); }
+void orc_set_iter(Orc* o, int it) { o->iter = it; }
+void orc_set_override(Orc* o, int node, const float* ev2R, const float* ev_br2R) { o->ov_node = node; o->ov_ev = ev2R; o->ov_ev_br = ev_br2R; }
 float* orc_reach(Orc* o) { return o->reach; }
 float* orc_ev(Orc* o) { return o->ev; }
 float* orc_ev_br(Orc* o) { return o->ev_br; }

@@ -434,7 +434,7 @@ class NativeTree:
 
 # solver field ids (include/pokerrl_hip.h)
 SF = dict(reach=0, ev=1, ev_br=2, strategy=3, strat_f64=4, regret=5, avg=6, avg_f64=7, avg_sum=8, br_idx=9,
-          expl_history=10, iter=11, constants=12, bytes_allocated=13, engine=14, graph_replay=15, explicit_strategy=16)
+          expl_history=10, iter=11, constants=12, bytes_allocated=13, engine=14, graph_replay=15, explicit_strategy=16, exchanges=17)
 VARIANTS = {"vanilla": 0, "plus": 1, "linear": 2}
 ENGINES = {"auto": 0, "levels": 1, "fused": 2}
 
@@ -457,7 +457,20 @@ class NativeSolver:
         v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
         e = ENGINES[engine] if isinstance(engine, str) else int(engine)
         self._exchange_cb = None
-        if shard is not None:
+        if shard is not None and isinstance(shard[0], str):
+            # ("rccl", world, rank, unique_id bytes[, shard_boards, total_boards]): the exchange lives in the library (ncclAllGather on
+            # the solver's stream, prl_solver_create_sharded_rccl) -- no Python in the iteration loop. pokerrl_amd.dist.rccl_shard builds it.
+            assert shard[0] == "rccl"
+            world, rank, uid = shard[1:4]
+            uid = (ctypes.c_char * 128).from_buffer_copy(bytes(uid))
+            sb, tb = (int(shard[4]), int(shard[5])) if len(shard) == 6 else (0, 0)
+            self._L.prl_solver_create_sharded_rccl.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                                               ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]
+            self._L.prl_solver_create_sharded_rccl.restype = ctypes.c_int32
+            check(self._L.prl_solver_create_sharded_rccl(tree.handle, v, int(delay), int(world), int(rank), ctypes.cast(uid, ctypes.c_void_p), sb, tb,
+                                                         ctypes.byref(self._h)), self._L)
+            shard = None
+        elif shard is not None:
             world, rank, exchange = shard[:3]
 
             def _cb(_user, local_ptr, gathered_ptr, nbytes):
@@ -476,7 +489,7 @@ class NativeSolver:
             else:
                 check(self._L.prl_solver_create_sharded(tree.handle, v, int(delay), int(world), int(rank), self._exchange_cb, None,
                                                         ctypes.byref(self._h)), self._L)
-        else:
+        elif not self._h:
             check(self._L.prl_solver_create_ex(tree.handle, v, int(delay), e, ctypes.byref(self._h)), self._L)
         if shard is not None and hasattr(shard[2], "bind_stream"):
             # a stream-ordered exchange (RCCL under the solver's own stream): no host synchronisation per pass
@@ -601,6 +614,23 @@ class NativeSolver:
         self._call("prl_solver_get", SF["iter"], _ptr(out))
         return int(out[0])
 
+    def get_cols(self, name, col_begin, n_cols):
+        """columns [col_begin, col_begin + n_cols) of "regret" / "avg" / "avg_sum": streams a big array through a small host buffer"""
+        out = np.zeros((int(n_cols), self.R), np.float64 if name == "avg" else np.float32)
+        self._L.prl_solver_get_cols.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+        self._L.prl_solver_get_cols.restype = ctypes.c_int32
+        self._call("prl_solver_get_cols", SF[name], int(col_begin), int(n_cols), _ptr(out))
+        return out
+
+    def sha256_of(self, name, cols_per_piece=65536):
+        """SHA-256 of a per-action-column array in the flat tree's column order (-0.0 folded into +0.0 like tests/helpers.h32), streamed"""
+        import hashlib
+        h = hashlib.sha256()
+        for c0 in range(0, self.n_cols, cols_per_piece):
+            a = self.get_cols(name, c0, min(cols_per_piece, self.n_cols - c0))
+            h.update(np.ascontiguousarray(a + a.dtype.type(0)).tobytes())
+        return h.hexdigest()
+
     def get(self, name):
         n, c, R = self.n_nodes, self.n_cols, self.R
         shape, dtype = {
@@ -608,7 +638,7 @@ class NativeSolver:
             "strategy": ((c, R), np.float64), "strat_f64": ((n,), np.uint8), "regret": ((c, R), np.float32),
             "avg": ((c, R), np.float64), "avg_f64": ((n,), np.uint8), "avg_sum": ((c, R), np.float32),
             "br_idx": ((n, R), np.int32), "constants": ((2,), np.float32), "bytes_allocated": ((1,), np.int64),
-            "explicit_strategy": ((1,), np.int32),
+            "explicit_strategy": ((1,), np.int32), "exchanges": ((1,), np.int64),
         }.get(name, (None, None))
         if name == "expl_history":
             shape, dtype = (self.iter + 1, 2), np.float32

@@ -11,6 +11,10 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#if !defined(PRL_EMU)
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is bound at run time (prl_rccl_api), so that single-GPU users never load it
+#endif
 
 #include <string>
 #include <vector>
@@ -83,6 +87,8 @@ struct prl_solver {
     bool board_avg_stale = false;  // FUSED Vanilla / Linear: avg_sum moved on, the avg columns of the boards have not been recomputed yet
     float* d_regret = nullptr;  // [full_cols][R]
     double* d_avg = nullptr;    // [full_cols][R]
+    long long n_exchanges = 0;  // all-gathers done so far (PRL_SF_EXCHANGES)
+    void* rccl_comm = nullptr;  // sharded solve with the library's own exchange (prl_solver_create_sharded_rccl): ncclComm_t
     // ---- per-street fused engine (prl_st.h): `fused` with the board pass replaced by a sweep over the streets ----
     bool streets = false;
     PrlStPlanHost st;
@@ -148,6 +154,45 @@ static void vmm_free(PrlVmmRange& r) {
     (void)hipMemUnmap(r.va, r.size);
     for (auto h : r.handles) (void)hipMemRelease(h);
     (void)hipMemAddressFree(r.va, r.size);
+}
+#endif
+
+#if !defined(PRL_EMU)
+// RCCL bound at run time. A process that has PyTorch-ROCm loaded already has an RCCL (and ONE HIP runtime, see pokerrl_amd/_native.py):
+// that one is taken; otherwise the ROCm installation's.
+struct PrlRcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+static const PrlRcclApi& prl_rccl_api() {
+    static PrlRcclApi api = [] {
+        PrlRcclApi a;
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return a;
+        a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+        a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+        a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+        a.ok = a.GetUniqueId && a.CommInitRank && a.AllGather && a.CommDestroy && a.GetErrorString;
+        return a;
+    }();
+    return api;
+}
+// the exchange of a solver created with prl_solver_create_sharded_rccl: one ncclAllGather on the solver's own stream -- stream-ordered
+// after the partial sums, before the finishing sum; no host synchronisation, no callback into the host language
+static int32_t prl_rccl_exchange(void* user, const void* local_dev, void* gathered_dev, uint64_t bytes_per_rank) {
+    prl_solver* s = (prl_solver*)user;
+    const ncclResult_t r = prl_rccl_api().AllGather(local_dev, gathered_dev, (size_t)bytes_per_rank, ncclInt8, (ncclComm_t)s->rccl_comm, s->stream);
+    if (r != ncclSuccess) { prl_set_error(std::string("ncclAllGather: ") + prl_rccl_api().GetErrorString(r)); return 1; }
+    return 0;
 }
 #endif
 
@@ -318,6 +363,7 @@ int street_sweep(prl_solver* s, const PrlDevState& st, int mode, int src0, int s
         const size_t per_rank = (size_t)s->n_units * W;
         prl_launch_fhp_chance_partial(rows, n_top, s->xlevel, W, s->d_sum_scratch, s->d_xlocal, s->stream);
         if (!s->exchange_async) PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+        ++s->n_exchanges;
         if (s->exchange(s->exchange_user, s->d_xlocal, s->d_xgather, (uint64_t)(per_rank * sizeof(float))) != 0) {
             prl_set_error("sharded solve: the exchange callback failed");
             return PRL_ERR_STATE;
@@ -404,6 +450,7 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
         if (p.block_sum) prl_launch_fhp_chance_partial_from_blocks(s->d_board_out, n_blk, s->xlevel, W, s->d_xlocal, s->stream);
         else prl_launch_fhp_chance_partial(s->d_board_out, p.n_boards, s->xlevel, W, s->d_sum_scratch, s->d_xlocal, s->stream);
         if (!s->exchange_async) PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+        ++s->n_exchanges;
         if (s->exchange(s->exchange_user, s->d_xlocal, s->d_xgather, (uint64_t)(per_rank * sizeof(float))) != 0) {
             prl_set_error("sharded solve: the exchange callback failed");
             return PRL_ERR_STATE;
@@ -628,7 +675,8 @@ int prl_fhp_match_shape(const PrlFlatTree& t, int* chance_node, int* first_board
 extern "C" {
 
 static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t world, int32_t rank,
-                                  prl_exchange_fn exchange, void* exchange_user, prl_solver_t** out, int64_t shard_boards = 0, int64_t total_boards = 0) {
+                                  prl_exchange_fn exchange, void* exchange_user, prl_solver_t** out, int64_t shard_boards = 0, int64_t total_boards = 0,
+                                  const void* rccl_uid = nullptr) {
     if (!tree || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
     if (variant < 0 || variant > 2 || delay < 0 || engine < 0 || engine > 2) { prl_set_error("bad variant / delay / engine"); return PRL_ERR_ARG; }
     if (!prl_device_available()) { prl_set_error("no HIP device: the solver has no CPU fallback"); return PRL_ERR_NO_DEVICE; }
@@ -714,6 +762,24 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     const PrlFlatTree& ft = s->ft;
 #define FAIL_IF(x) do { int e_ = (x); if (e_) { prl_solver_destroy(s); return e_; } } while (0)
     if (hipStreamCreate(&s->stream) != hipSuccess) { prl_set_error("hipStreamCreate failed"); delete s; return PRL_ERR_HIP; }
+#if !defined(PRL_EMU)
+    if (rccl_uid) {  // the library's own exchange: this rank joins the communicator of the solve (collective: every rank is here)
+        ncclUniqueId id;
+        memcpy(&id, rccl_uid, sizeof(id));
+        ncclComm_t comm = nullptr;
+        const ncclResult_t r = prl_rccl_api().CommInitRank(&comm, world, id, rank);
+        if (r != ncclSuccess) {
+            prl_set_error(std::string("ncclCommInitRank: ") + prl_rccl_api().GetErrorString(r));
+            (void)hipStreamDestroy(s->stream);
+            delete s;
+            return PRL_ERR_HIP;
+        }
+        s->rccl_comm = comm;
+        s->exchange = prl_rccl_exchange;
+        s->exchange_user = s;
+        s->exchange_async = true;
+    }
+#endif
     PrlDevTree& T = s->T;
     T.n_nodes = ft.n_nodes; T.n_cols = ft.n_cols; T.R = r.range_size; T.n_hole = r.n_hole_cards; T.n_cards = r.n_cards;
     T.n_suits = r.n_suits; T.rank_rule = r.rank_rule; T.n_boards = ft.n_boards; T.board_len = ft.board_len; T.n_levels = ft.n_levels;
@@ -926,6 +992,40 @@ int32_t prl_solver_create_sharded_ragged(const prl_tree_t* local_tree, int32_t v
     return solver_create_impl(local_tree, variant, delay, PRL_ENGINE_FUSED, world_size, rank, exchange, user, out, shard_boards, total_boards);
 }
 
+// dummy non-null callback slot for the creation checks; replaced by prl_rccl_exchange once the communicator exists
+static int32_t prl_exchange_placeholder(void*, const void*, void*, uint64_t) { return 1; }
+
+int32_t prl_rccl_unique_id(void* out128) {
+#if defined(PRL_EMU)
+    (void)out128;
+    prl_set_error("no RCCL in this build");
+    return PRL_ERR_UNSUPPORTED;
+#else
+    if (!out128) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
+    if (!prl_rccl_api().ok) { prl_set_error("librccl.so could not be loaded"); return PRL_ERR_UNSUPPORTED; }
+    ncclUniqueId id;
+    const ncclResult_t r = prl_rccl_api().GetUniqueId(&id);
+    if (r != ncclSuccess) { prl_set_error(std::string("ncclGetUniqueId: ") + prl_rccl_api().GetErrorString(r)); return PRL_ERR_HIP; }
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(out128, &id, sizeof(id));
+    return PRL_OK;
+#endif
+}
+
+int32_t prl_solver_create_sharded_rccl(const prl_tree_t* local_tree, int32_t variant, int32_t delay, int32_t world_size, int32_t rank,
+                                       const void* unique_id128, int64_t shard_boards, int64_t total_boards, prl_solver_t** out) {
+#if defined(PRL_EMU)
+    prl_set_error("no RCCL in this build");
+    return PRL_ERR_UNSUPPORTED;
+#else
+    if (world_size < 1 || rank < 0 || rank >= world_size || !unique_id128) { prl_set_error("bad world_size / rank / unique id"); return PRL_ERR_ARG; }
+    if (shard_boards > 0 && total_boards <= (int64_t)(world_size - 1) * shard_boards) { prl_set_error("bad shard_boards / total_boards"); return PRL_ERR_ARG; }
+    if (!prl_rccl_api().ok) { prl_set_error("librccl.so could not be loaded"); return PRL_ERR_UNSUPPORTED; }
+    return solver_create_impl(local_tree, variant, delay, PRL_ENGINE_FUSED, world_size, rank, prl_exchange_placeholder, nullptr, out,
+                              shard_boards > 0 ? shard_boards : 0, shard_boards > 0 ? total_boards : 0, unique_id128);
+#endif
+}
+
 int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out) {
     return solver_create_impl(tree, variant, delay, engine, 1, 0, nullptr, nullptr, out);
 }
@@ -1088,6 +1188,9 @@ void prl_solver_destroy(prl_solver_t* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
 #if !defined(PRL_EMU)
     if (s->levels_graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)s->levels_graph_exec);
+#endif
+#if !defined(PRL_EMU)
+    if (s->rccl_comm) (void)prl_rccl_api().CommDestroy((ncclComm_t)s->rccl_comm);
 #endif
     for (void* p : s->allocs) (void)hipFree(p);
 #if !defined(PRL_EMU)
@@ -1546,6 +1649,23 @@ int32_t prl_solver_eval_avg(prl_solver_t* s, float* out2) {
     return prl_solver_sync(s);
 }
 
+int32_t prl_solver_get_cols(prl_solver_t* s, int32_t field, int64_t col_begin, int64_t n_cols, void* out) {
+    if (!s || !out || col_begin < 0 || n_cols < 0 || col_begin + n_cols > s->full_cols) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    if (!s->col_dfs.empty()) { prl_set_error("get_cols: this engine keeps its columns in an internal order; use prl_solver_get"); return PRL_ERR_UNSUPPORTED; }
+    const char* src = nullptr;
+    size_t elem = 0;
+    switch (field) {
+        case PRL_SF_REGRET: src = (const char*)s->d_regret; elem = 4; break;
+        case PRL_SF_AVG: TRY(ensure_board_avg(s)); src = (const char*)s->d_avg; elem = 8; break;
+        case PRL_SF_AVG_SUM: src = (const char*)s->S.avg_sum; elem = 4; break;
+        default: prl_set_error("get_cols: REGRET, AVG or AVG_SUM"); return PRL_ERR_ARG;
+    }
+    if (!src) { prl_set_error("field not available for this variant"); return PRL_ERR_STATE;}
+    const size_t cb = (size_t)s->R * elem;
+    PRL_HIP_TRY(hipMemcpyAsync(out, src + (size_t)col_begin * cb, (size_t)n_cols * cb, hipMemcpyDeviceToHost, s->stream));
+    return prl_solver_sync(s);
+}
+
 int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
     if (!s || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
     const size_t nv = (size_t)s->T.n_nodes * 2 * s->T.R, nc = (size_t)s->full_cols * s->R;
@@ -1608,6 +1728,7 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
         case PRL_SF_BYTES_ALLOCATED: *(int64_t*)out = (int64_t)s->bytes_allocated; return PRL_OK;
         case PRL_SF_ENGINE: *(int32_t*)out = s->fused ? PRL_ENGINE_FUSED : PRL_ENGINE_LEVELS; return PRL_OK;
         case PRL_SF_GRAPH_REPLAY: *(int32_t*)out = s->levels_graph_exec != nullptr; return PRL_OK;
+        case PRL_SF_EXCHANGES: *(int64_t*)out = (int64_t)s->n_exchanges; return PRL_OK;
         case PRL_SF_EXPLICIT_STRATEGY: *(int32_t*)out = s->fused ? s->user_strategy_f64 : -1; return PRL_OK;
         default: prl_set_error("unknown solver field"); return PRL_ERR_ARG;
     }

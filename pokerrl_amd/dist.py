@@ -77,3 +77,26 @@ class TorchExchange:
         self.calls += 1
         self.bytes += nbytes * self.world
         self.seconds += time.perf_counter() - t0
+
+
+def rccl_shard(world, rank, shard_boards=None, total_boards=None, group=None, lib=None):
+    """The `shard=` argument of NativeSolver for the library's OWN exchange (prl_solver_create_sharded_rccl): rank 0 draws the
+    communicator id (ncclGetUniqueId), torch.distributed broadcasts its 128 bytes, every rank joins inside the library; from then on the
+    all-gather of every EV pass is one ncclAllGather on the solver's stream -- no Python, no callback in the iteration loop.
+    torch.distributed is used for this one broadcast only (any other channel would do: the C ABI takes the raw bytes)."""
+    import ctypes
+    from pokerrl_amd import _native
+    L = lib or _native.lib()
+    buf = (ctypes.c_char * 128)()
+    if rank == 0:
+        _native.check(L.prl_rccl_unique_id(ctypes.cast(buf, ctypes.c_void_p)), L)
+    if world > 1:
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone().to(dev)
+        dist.broadcast(t, src=0, group=group)
+        uid = bytes(t.cpu().numpy().tobytes())
+    else:
+        uid = bytes(buf)
+    if shard_boards is None:
+        return ("rccl", world, rank, uid)
+    return ("rccl", world, rank, uid, int(shard_boards), int(total_boards))

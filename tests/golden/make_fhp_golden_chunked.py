@@ -1,0 +1,203 @@
+"""
+Generates tests/golden/fhp_<n>_<variant>_chunked.npz with the CPU ORACLE for board sets too big for one oracle instance (262144 boards =
+bench.py's default size: ~290 GB of oracle state in one piece): the boards are evaluated CHUNK BY CHUNK, the trunk in a second small
+instance whose chance node takes the canonical sum of all chunks' board values from outside (oracle: orc_set_override).
+
+    python tests/golden/make_fhp_golden_chunked.py [n_boards] [n_iters] [chunk] [workdir]      (CFR+ delay 0)
+
+Per half-iteration of _CFRBase.iteration (_CFRBase.py:122-134) -- EVs, regrets + strategy of seat p, reach, average of seat p --:
+  every chunk instance: trunk strategy from the trunk instance, its own boards' state from disk; update_reach; compute_ev (the board values
+      depend on the reach at the chance node only); the 1024-board group sums of the board roots' ev / ev_br (canonical order: blocks of
+      32, groups of 32 blocks); regrets / strategy / average of seat p's BOARD nodes; state back to disk
+  trunk instance: chance node := running sum of all groups in global order; compute_ev; regrets / strategy / reach / average of seat p's
+      trunk nodes.
+The evaluation that closes iteration t is the one iteration t + 1 starts with. The chunked run is checked against the one-piece oracle at
+a size both can do (`--selftest`: 2048 boards in chunks of 1024, every array bit for bit).
+Needs no GPU, ~60 GB of scratch disk and about an hour on 8 cores for 262144 boards x 2 iterations.
+"""
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+sys.path.insert(0, os.path.join(HERE, ".."))
+
+import oracle  # noqa: E402
+import parity_cases as pc  # noqa: E402
+from helpers import env_args, h32  # noqa: E402
+from pokerrl_amd import _native  # noqa: E402
+from pokerrl_amd.game import bet_sets  # noqa: E402
+from pokerrl_amd.game import games as G  # noqa: E402
+
+NB = 15  # nodes per board subtree (FHP15)
+NC = 14  # action columns per board subtree
+
+
+def make(boards, chance_prob=None):
+    args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
+    t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards)
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, boards, 2, 52, 4, 2, chance_prob=chance_prob)
+    return t, o
+
+
+def group_sums(vals):
+    """[n_boards][4][R] float32 (ev seat 0 / 1, ev_br seat 0 / 1 of the board roots) -> [n_boards / 1024][4][R]: running adds over blocks of 32
+    boards, then over the 32 blocks of a group (the canonical chance sum of DESIGN.md, levels 0 and 1)"""
+    n = vals.shape[0]
+    assert n % 1024 == 0
+    v = vals.reshape(n // 32, 32, *vals.shape[1:])
+    blk = v[:, 0].copy()
+    for i in range(1, 32):
+        blk = blk + v[:, i]
+    g = blk.reshape(n // 1024, 32, *vals.shape[1:])
+    out = g[:, 0].copy()
+    for i in range(1, 32):
+        out = out + g[:, i]
+    return out
+
+
+class Chunked:
+    def __init__(self, boards, chunk, workdir):
+        self.boards, self.chunk, self.workdir = boards, chunk, workdir
+        self.n = len(boards)
+        assert self.n % chunk == 0 and chunk % 1024 == 0
+        self.n_chunks = self.n // chunk
+        self.cp = oracle.chance_prob_f32(self.n, 52, 2, 5)
+        self.tt, self.T = make(boards[:32], chance_prob=self.cp)       # trunk instance (its own boards are never looked at)
+        self.ct, self.O = make(boards[:chunk], chance_prob=self.cp)    # chunk instance, re-used for every chunk (same tree shape; boards swapped below)
+        self.nt = self.ct.n_cols - chunk * NC                          # trunk columns come first
+        kind = self.ct.field("kind")
+        self.chance = int(np.where(kind == 1)[0][0])
+        self.first_board = self.chance + 1
+        assert self.ct.n_nodes == self.first_board + chunk * NB and int(np.where(self.tt.field("kind") == 1)[0][0]) == self.chance
+        self.updated = [False, False]  # seats whose strategy comes from regret matching (else the uniform fill)
+        self.T.cfr_reset(1, 0)
+        self.hist = []
+
+    def _path(self, c, name):
+        return os.path.join(self.workdir, "chunk%03d_%s.npy" % (c, name))
+
+    def _chunk_instance(self, c):
+        """a fresh oracle on chunk c's boards (the showdown plans belong to the boards) with its state from disk"""
+        del self.O
+        _, self.O = make(self.boards[c * self.chunk:(c + 1) * self.chunk], chance_prob=self.cp)
+        O = self.O
+        O.cfr_configure(1, 0)  # uniform strategy, zero regrets / averages (no evaluation yet)
+        if os.path.exists(self._path(c, "regret")):
+            O.regret[self.nt:] = np.load(self._path(c, "regret"))
+            O.avg[self.nt:] = np.load(self._path(c, "avg"))
+            O.avg_f64[self.first_board:] = np.load(self._path(c, "avg_f64"))
+        for p in (0, 1):
+            if self.updated[p]:
+                O.compute_new_strategy(p)  # a pure function of the regrets (CFRPlus.py:43-63)
+        # the trunk's strategy (and dtype flags) come from the trunk instance
+        O.strategy[:self.nt] = self.T.strategy[:self.nt]
+        O.strat_f64[:self.first_board] = self.T.strat_f64[:self.first_board]
+        return O
+
+    def sweep(self, it, p):
+        """evaluation of the current strategies (-> exploitability) and, if p is not None, seat p's half of iteration `it`"""
+        groups = []
+        for c in range(self.n_chunks):
+            t0 = time.time()
+            O = self._chunk_instance(c)
+            O.set_iter(it)
+            O.update_reach()
+            O.compute_ev()
+            roots = self.first_board + NB * np.arange(self.chunk)
+            vals = np.concatenate([O.ev[roots], O.ev_br[roots]], axis=1)  # [chunk][4][R]
+            groups.append(group_sums(vals))
+            if p is not None:
+                O.compute_regrets(p)
+                O.compute_new_strategy(p)
+                O.add_strategy_to_average(p)
+                np.save(self._path(c, "regret"), O.regret[self.nt:])
+                np.save(self._path(c, "avg"), O.avg[self.nt:])
+                np.save(self._path(c, "avg_f64"), O.avg_f64[self.first_board:])
+            print("  it %d seat %s chunk %d/%d  %.0f s" % (it, p, c + 1, self.n_chunks, time.time() - t0), flush=True)
+        g = np.concatenate(groups)  # all groups in global order
+        total = g[0].copy()
+        for i in range(1, len(g)):
+            total = total + g[i]
+        T = self.T
+        T.set_override(self.chance, total[0:2], total[2:4])
+        T.set_iter(it)
+        T.compute_ev()
+        expl = np.array(T.exploitability, np.float32)
+        if p is not None:
+            T.compute_regrets(p)
+            T.compute_new_strategy(p)
+            T.update_reach()
+            T.add_strategy_to_average(p)
+            self.updated[p] = True
+        return expl
+
+    def run(self, n_iters):
+        self.hist = []
+        for it in range(n_iters):
+            self.hist.append(self.sweep(it, 0))   # closes iteration it - 1 (or the reset) and does seat 0's half
+            self.sweep(it, 1)
+        self.hist.append(self.sweep(n_iters, None))
+        return np.stack(self.hist)
+
+    def state_hashes(self):
+        """sha-256 of regret / avg in the flat tree's column order: trunk columns, then every board's, chunk after chunk"""
+        out = {}
+        for name, arr in (("regret", self.T.regret), ("avg", self.T.avg)):
+            h = hashlib.sha256()
+            fold = lambda a: np.ascontiguousarray(a + a.dtype.type(0)).tobytes()  # "+ 0" folds -0.0 into +0.0, as helpers.h32
+            h.update(fold(np.asarray(arr[:self.nt])))
+            for c in range(self.n_chunks):
+                h.update(fold(np.load(self._path(c, name))))
+            out[name] = h.hexdigest()
+        return out
+
+    def full_arrays(self):
+        return {name: np.concatenate([np.asarray(getattr(self.T, name))[:self.nt]] + [np.load(self._path(c, name)) for c in range(self.n_chunks)])
+                for name in ("regret", "avg")}
+
+
+def selftest(workdir):
+    boards = pc.fhp_boards(2048, seed=5)
+    ch = Chunked(boards, 1024, workdir)
+    hist = ch.run(2)
+    t, o = make(boards)
+    o.cfr_reset(1, 0)
+    want = [np.array(o.exploitability, np.float32)]
+    for _ in range(2):
+        o.cfr_iteration()
+        want.append(np.array(o.exploitability, np.float32))
+    assert np.array_equal(hist, np.stack(want)), (hist, want)
+    full = ch.full_arrays()
+    assert np.array_equal(full["regret"], np.asarray(o.regret)) and np.array_equal(full["avg"], np.asarray(o.avg))
+    hs = ch.state_hashes()
+    assert hs["regret"] == h32(np.asarray(o.regret)) and hs["avg"] == h32(np.asarray(o.avg))
+    print("selftest ok: the chunked run equals the one-piece oracle (2048 boards, 2 iterations)")
+
+
+def main(n_boards, n_iters, chunk, workdir, seed=0):
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import bench
+    boards = bench.seeded_boards(n_boards, seed)  # bench.py's rank-0 board list
+    ch = Chunked(boards, chunk, workdir)
+    hist = ch.run(n_iters)
+    hs = ch.state_hashes()
+    out = os.path.join(HERE, "fhp_%d_plus_chunked.npz" % n_boards)
+    np.savez(out, n_boards=n_boards, seed=seed, variant="plus", n_iters=n_iters, chunk=chunk, boards_sha256=h32(boards), expl_history=hist,
+             regret_sha256=hs["regret"], avg_sha256=hs["avg"], numpy=np.__version__)
+    print("wrote", out, hist)
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    if a and a[0] == "--selftest":
+        os.makedirs(a[1] if len(a) > 1 else "/tmp/prl_chunked_selftest", exist_ok=True)
+        selftest(a[1] if len(a) > 1 else "/tmp/prl_chunked_selftest")
+    else:
+        wd = a[3] if len(a) > 3 else "/tmp/prl_chunked"
+        os.makedirs(wd, exist_ok=True)
+        main(int(a[0]) if a else 262144, int(a[1]) if len(a) > 1 else 2, int(a[2]) if len(a) > 2 else 16384, wd)
