@@ -45,23 +45,11 @@ PMC_TRAFFIC_SOURCE = "profiles/r03v_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_
 def seeded_boards(n, seed, offset=0):
     """Boards offset .. offset+n-1 of a seeded shuffle of ALL C(52,5) = 2 598 960 five-card boards (distinct
     sorted boards from numpy.random.RandomState(seed)): rank r of a sharded run takes offset = r * n, so the shards are disjoint by
-    construction and every rank is ready in about a second whatever its offset. int8 [n, 5], cards ascending."""
-    n_all = 2598960
-    assert 0 <= offset and offset + n <= n_all, "at most C(52,5) distinct boards"
-    ranks = np.random.RandomState(seed).permutation(n_all)[offset:offset + n].astype(np.int64)
-    # unrank in the combinatorial number system: rank = C(c4,5) + C(c3,4) + C(c2,3) + C(c1,2) + C(c0,1), c0 < c1 < ... < c4
-    binom = np.zeros((53, 6), np.int64)
-    binom[:, 0] = 1
-    for m in range(1, 53):
-        for k in range(1, 6):
-            binom[m, k] = binom[m - 1, k - 1] + binom[m - 1, k]
-    out = np.zeros((n, 5), np.int8)
-    rem = ranks.copy()
-    for k in range(5, 0, -1):
-        c = np.searchsorted(binom[:, k], rem, side="right") - 1  # the largest c with C(c, k) <= rem
-        out[:, k - 1] = c
-        rem -= binom[c, k]
-    return out
+    construction and every rank is ready in about a second whatever its offset. int8 [n, 5], cards ascending. The tree builder's own
+    enumeration (pokerrl_amd.game.board_enum: what PublicTree(Flop5Holdem) builds from when it is not handed boards)."""
+    from pokerrl_amd.game import board_enum
+    from pokerrl_amd.game import games as G
+    return board_enum.single_deal_boards(G.Flop5Holdem, n_boards=n, seed=seed, offset=offset)
 
 
 def fhp_tree(boards, lib=None):

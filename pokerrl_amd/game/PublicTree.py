@@ -142,7 +142,11 @@ class PublicTree:
     CHANCE_ID = "Ch"
 
     def __init__(self, env_bldr, stack_size, stop_at_street, put_out_new_round_after_limit=False, is_debugging=False, boards=None,
-                 engine="levels"):
+                 engine="levels", n_boards=None, max_outcomes=None, board_seed=None):
+        """boards=None: the builder deals the chance outcomes from the deck itself as the reference does (PublicTree.py:188-210) -- every board
+        of the game (Leduc: the 6 cards; Flop5Holdem: all C(52,5) five-card boards), or a subset: n_boards= (games that deal once) /
+        max_outcomes=(flops, turns, rivers) (games that deal on several streets), the first ones in combinatorial order or, with board_seed=,
+        a seeded choice (pokerrl_amd/game/board_enum.py). boards=[[c1..c5], ...] lists them explicitly (run-outs in deal order)."""
         self._env_bldr = env_bldr
         self._stack_size = stack_size
         self._is_debugging = is_debugging
@@ -152,6 +156,7 @@ class PublicTree:
         self._stop_at_street = max(env_bldr.rules.ALL_ROUNDS_LIST) + 1 if stop_at_street is None else int(stop_at_street)
         self._is_partial = self._stop_at_street <= max(env_bldr.rules.ALL_ROUNDS_LIST)
         self._boards = boards
+        self._board_caps = (n_boards, max_outcomes, board_seed)
         self._engine = engine
         self._n_seats = env_bldr.N_SEATS
         self.dir_tree_vis_data = None
@@ -188,10 +193,10 @@ class PublicTree:
         args = copy.deepcopy(self._env_bldr.env_args)
         args.starting_stack_sizes_list = copy.deepcopy(self._stack_size)
         boards = self._boards
-        if boards is None:
-            if rules.N_HOLE_CARDS != 1:
-                raise ValueError("2-hole-card public trees need an explicit list of boards (boards=[[c1..c5], ...])")
-            boards = np.arange(rules.N_CARDS_IN_DECK, dtype=np.int8).reshape(-1, 1)  # PublicTree.py:193-203: cards ascending
+        if boards is None:  # PublicTree.py:188-210: the chance outcomes come from the deck, cards ascending
+            from pokerrl_amd.game import board_enum
+            n_boards, max_outcomes, seed = self._board_caps
+            boards = self._boards = board_enum.default_boards(env_cls, n_boards=n_boards, max_outcomes=max_outcomes, seed=seed)
         self._native_tree = _native.NativeTree(env_cls.native_game(args), env_cls.native_rules(), boards,
                                                stop_at_round=self._stop_at_street if self._is_partial else None)
         t = self._native_tree

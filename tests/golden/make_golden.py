@@ -2,7 +2,7 @@
 Generates the golden fixtures under tests/golden/ by RUNNING THE REFERENCE (/root/reference, read-only) in this
 container. The fixtures travel to the GPU box; the reference does not.
 
-    python tests/golden/make_golden.py [luts] [handrank] [handrank_exhaustive] [tree] [env] [cfr] [br]
+    python tests/golden/make_golden.py [luts] [handrank] [handrank_exhaustive] [tree] [tree_lh] [env] [cfr] [br]
 
 Everything is deterministic (fixed seeds); numpy version is recorded in every file because the reference's float32
 results depend on NumPy-2 promotion rules (SURVEY.md section 8a "dtype ledger").
@@ -236,6 +236,17 @@ def make_tree():
     flat = walk_env_tree(Flop5Holdem, stack=20000, bets=bet_sets.POT_ONLY)
     print("Flop5Holdem betting structure: nodes", len(flat["kind"]))
     save("tree_Flop5Holdem_1board.npz", **flat)
+    make_tree_limit_holdem()
+
+
+def make_tree_limit_holdem():
+    """LimitHoldem (pre-flop, flop, turn, river; full betting structure, 48-chip stacks): the betting tree of ONE run-out, walked through the
+    reference ENV street by street (the reference's PublicTree cannot deal several cards) -- what pins the
+    multi-street tree structure (csrc/prl_tree.cpp, the per-street engine's street instances) to the reference. 17 221 nodes."""
+    sys.setrecursionlimit(20000)
+    flat = walk_env_tree(LimitHoldem, stack=48, bets=None)
+    print("LimitHoldem betting structure (one run-out): nodes", len(flat["kind"]), "per round", np.bincount(flat["round"]).tolist())
+    save("tree_LimitHoldem_1runout.npz", **flat)
 
 
 def walk_env_tree(cls, stack, bets):
@@ -532,7 +543,7 @@ def make_env_obs():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["luts", "handrank", "tree", "env", "cfr"]
     fns = {"luts": make_luts, "handrank": make_handrank, "handrank_exhaustive": make_handrank_exhaustive,
-           "tree": make_tree, "env": make_env, "cfr": make_cfr, "env_obs": make_env_obs}
+           "tree": make_tree, "tree_lh": make_tree_limit_holdem, "env": make_env, "cfr": make_cfr, "env_obs": make_env_obs}
     i = 0
     while i < len(what):
         w = what[i]

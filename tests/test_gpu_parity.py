@@ -218,6 +218,38 @@ def test_gpu_all_in_before_the_deal_run_out_vs_oracle(L):
     pc.check_multistreet_vs_oracle(L, G.Flop5Holdem, 250, bet_sets.POT_ONLY, pc.fhp_boards(300), "plus", 4)
 
 
+def test_gpu_cfr_plus_on_limit_holdem_builder_dealt_run_outs_on_the_street_engine(L):
+    """CFRPlus(game_cls=LimitHoldem, max_outcomes=(2, 2, 1)): the builder deals the run-outs from the deck itself (board_enum.py), engine=auto
+    takes the per-street fused engine; the logged exploitability series equals the level-synchronous engine's on the same tree"""
+    from pokerrl_amd.cfr.CFRPlus import CFRPlus
+    from pokerrl_amd.game import games as G
+    from pokerrl_amd.rl.base_cls.workers.ChiefBase import ChiefBase
+    series = []
+    for engine in ("auto", "levels"):
+        chief = ChiefBase(t_prof=None)
+        cfr = CFRPlus(name="lh_" + engine, chief_handle=chief, game_cls=G.LimitHoldem, agent_bet_set=None, delay=0, max_outcomes=(2, 2, 1), engine=engine)
+        assert cfr._trees[0].solver.engine == ("fused" if engine == "auto" else "levels")
+        cfr.iterations(4)
+        vals, _ = chief.get_new_values()
+        series.append([v for k, v in vals.items() if "_Curr_S" in k][0]["Evaluation/" + G.LimitHoldem.WIN_METRIC])
+    assert series[0] == series[1] and len(series[0]) == 5 and series[0][-1][1] < series[0][0][1]
+
+
+def test_gpu_bench_total_boards_one_gpu_smoke():
+    """bench.py --total-boards T on one GPU: ONE board list (strong-scaling mode; the shape of --all-boards, which needs 4-8 GPUs), the
+    builder's own seeded enumeration; the JSON says so"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--total-boards", "3000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-placement-probe"], capture_output=True, text=True, timeout=600, check=True).stdout
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["scaling"] == "strong" and d["config"]["nodes_whole_tree"] == 5 + 3000 * 15 and d["config"]["boards_per_gpu"] == 3000
+    assert d["build_flavor"] == "hip-gfx950" and d["config"]["exploitability_mbb_per_g"] > 0
+
+
 def test_gpu_cfr_plus_on_limit_holdem_through_the_python_surface(L):
     """CFRPlus(game_cls=LimitHoldem, boards=run-outs): the reference's class, a game its tree code cannot build; exploitability falls"""
     from pokerrl_amd.cfr.CFRPlus import CFRPlus

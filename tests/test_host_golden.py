@@ -187,6 +187,22 @@ def test_tree_matches_reference(name):
     assert t.n_decision + t.n_terminal + int(np.sum(t.field("kind") == 1)) == t.n_nodes
 
 
+def test_tree_limit_holdem_multistreet_structure_like_reference_env():
+    """LimitHoldem, one run-out: the multi-street flat tree (three chance levels, 17 221 nodes) node for node against the betting tree walked
+    through the REFERENCE env street by street (tests/golden/make_golden.py tree_lh) -- kinds, actors, actions, pots, rounds, depths,
+    child counts, action columns; and the per-street engine's view of it: 7 / 63 / 567 street instances of the registered 27-node shape"""
+    ref = golden("tree_LimitHoldem_1runout.npz")
+    t = native_tree(G.LimitHoldem, 48, None, np.array([[3, 17, 40, 8, 51]], np.int8))
+    assert t.n_nodes == len(ref["kind"]) == 17221
+    for f in ("kind", "actor", "parent", "child_idx", "action", "acted_last", "round", "main_pot", "depth", "n_children", "first_col", "col_action"):
+        assert np.array_equal(t.field(f), ref[f]), f
+    kind, par, rnd = ref["kind"], ref["parent"], ref["round"]
+    roots = [i for i in range(len(kind)) if par[i] >= 0 and kind[par[i]] == 1]
+    assert np.bincount(rnd[roots]).tolist() == [0, 7, 63, 567]
+    sizes = {int(t.field("subtree_size")[r]) for r in roots if rnd[r] == 3}
+    assert sizes == {27}
+
+
 def test_tree_flop5holdem_structure():
     ref = golden("tree_Flop5Holdem_1board.npz")
     boards = np.array([[0, 5, 10, 15, 20], [1, 2, 3, 50, 51], [7, 8, 9, 30, 44]], np.int8)
@@ -472,3 +488,36 @@ def test_partial_tree_matches_reference(name, stop):
         tree.compute_ev()
     with pytest.raises(_native.NativeError):  # "partial tree" on a GPU box, "no usable HIP device" here
         _native.NativeSolver(t, "plus", 0)
+
+
+def test_board_enumeration_like_the_tree_builder_deals():
+    """pokerrl_amd/game/board_enum.py (PublicTree.py:188-210 for games that deal several cards): Leduc = the deck, cards ascending (the
+    reference's order); Flop5Holdem = all C(52,5) boards in combinatorial order / a seeded subset; LimitHoldem = run-outs street by street
+    with caps; the host tree builder accepts all of them and PublicTree builds from them when it is not handed boards"""
+    from math import comb
+    from pokerrl_amd.game import board_enum
+    from pokerrl_amd.game import games as G
+    assert board_enum.single_deal_boards(G.StandardLeduc).ravel().tolist() == [0, 1, 2, 3, 4, 5]
+    assert board_enum.single_deal_boards(G.BigLeduc).shape == (24, 1)
+    b = board_enum.single_deal_boards(G.Flop5Holdem, n_boards=5000, offset=comb(52, 5) - 5000)
+    assert b[-1].tolist() == [47, 48, 49, 50, 51] and np.all(np.diff(b.astype(int), axis=1) > 0) and len({tuple(x) for x in b.tolist()}) == 5000
+    s1, s2 = board_enum.single_deal_boards(G.Flop5Holdem, n_boards=300, seed=3), board_enum.single_deal_boards(G.Flop5Holdem, n_boards=300, seed=3, offset=300)
+    assert not ({tuple(x) for x in s1.tolist()} & {tuple(x) for x in s2.tolist()})
+    r = board_enum.runouts(G.LimitHoldem, (2, 3, 2))
+    assert r.shape == (12, 5) and r[0].tolist() == [0, 1, 2, 3, 4] and r[-1].tolist() == [0, 1, 3, 5, 4]
+    assert all(len(set(x)) == 5 for x in r.tolist())
+    rs = board_enum.runouts(G.LimitHoldem, (3, 2, 2), seed=1)
+    assert rs.shape == (12, 5) and np.array_equal(rs, board_enum.runouts(G.LimitHoldem, (3, 2, 2), seed=1)) and all(len(set(x)) == 5 for x in rs.tolist())
+    with pytest.raises(ValueError, match="cap the chance outcomes"):
+        board_enum.runouts(G.LimitHoldem)
+    # the tree builder takes them: 2 flops x 3 turns x 2 rivers -> 2 + 6 + 12 prefix rows, one chance level per street
+    t = _native.NativeTree.for_game(G.LimitHoldem, 48, None, r)
+    assert t.n_boards == 2 + 6 + 12
+    # PublicTree without boards: the builder's own enumeration (partial tree: structure only, no device needed)
+    from pokerrl_amd.game.PublicTree import PublicTree
+    from pokerrl_amd.game.wrappers import HistoryEnvBuilder
+    args = G.Flop5Holdem.ARGS_CLS(n_seats=2, starting_stack_sizes_list=[20000, 20000])
+    tree = PublicTree(env_bldr=HistoryEnvBuilder(env_cls=G.Flop5Holdem, env_args=args), stack_size=[20000, 20000], stop_at_street=1, n_boards=40, board_seed=0)
+    tree.build_tree()
+    import bench
+    assert np.array_equal(tree._boards, bench.seeded_boards(40, 0))
