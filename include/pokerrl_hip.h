@@ -248,6 +248,33 @@ int32_t prl_envbatch_random_rollout(prl_envbatch_t* batch, int32_t n_steps, uint
 /* the same play with the state in HBM between steps: n_launches launches of ONE step per env (13 words in, 13 out per env and step) */
 int32_t prl_envbatch_random_steps(prl_envbatch_t* batch, int32_t n_launches, uint32_t seed, uint64_t* out_stats3, float* out_device_ms);
 int32_t prl_env_random_rollout_host(const PrlGame* game, int32_t n_envs, int32_t n_steps, uint32_t seed, uint64_t* out_stats3);
+/* The WHOLE PokerEnv.step for n envs (PokerEnv.py:737-789: obs, reward, done, info; state incl. deck / board / hands :1161-1197): a batch
+ * created with cards also holds every env's hole cards and board (1-d cards [n][2 * n_hole + n_board]: seat 0's hand, seat 1's hand, the
+ * board in deal order), dealt from a counter-based deck keyed by (deck_seed, episode * n_envs + env) at every reset -- or set by the caller
+ * (prl_envbatch_set_cards: replays, an external dealer). step_full returns per env the observation vector of the reference's heads-up
+ * layout (PokerEnv.py:199-261, 1253-1271: float64 quotients rounded to float32; zeros once the episode is over), the two seats' rewards
+ * ((stack after the payout - starting stack) / reward_scalar, PokerEnv.py:468-481, 1069-1072; showdowns ranked on the device, a tie pays
+ * half the pot each), the done flag and the info words of prl_envbatch_step. Heads-up; 1-hole-card games and 52-card hold'em. */
+int32_t prl_envbatch_create_with_cards(const PrlGame* game, const PrlRules* rules, int32_t n_envs, uint64_t deck_seed, double reward_scalar,
+                                       prl_envbatch_t** out_batch);
+int32_t prl_envbatch_obs_dim(prl_envbatch_t* batch, int32_t* out_dim);
+int32_t prl_envbatch_reset_full(prl_envbatch_t* batch, const uint8_t* mask, float* out_obs /* [n][obs_dim], may be NULL */);
+int32_t prl_envbatch_set_cards(prl_envbatch_t* batch, const int8_t* cards);
+int32_t prl_envbatch_get_cards(prl_envbatch_t* batch, int8_t* out_cards);
+int32_t prl_envbatch_observe(prl_envbatch_t* batch, float* out_obs);
+int32_t prl_envbatch_step_full(prl_envbatch_t* batch, const int32_t* actions, const int32_t* amounts, float* out_obs, double* out_reward2,
+                               uint8_t* out_done, int32_t* out_info4);
+int32_t prl_envbatch_step_full_device(prl_envbatch_t* batch, const int32_t* d_actions, const int32_t* d_amounts, float* d_obs, double* d_reward2,
+                                      uint8_t* d_done, int32_t* d_info4);
+/* whole hands with the state in registers: deal, uniform-random legal betting, showdown ranks, payout, deal again; n_steps steps per env.
+ * out_stats4 = steps, finished hands, showdowns, sum over hands of (2 x seat 0's chip winnings + 2^20) (an integer checksum of the
+ * payouts); prl_env_random_rollout_full_host plays the same hands on the host */
+int32_t prl_envbatch_random_rollout_full(prl_envbatch_t* batch, int32_t n_steps, uint32_t seed, uint64_t* out_stats4, float* out_device_ms);
+/* the same play with the state in HBM between steps: n_launches launches of ONE whole step per env -- 13 state words in and out, the
+ * observation vector, two rewards and the done flag out per env and step (what an agent-driven rollout moves); out_stats3 as random_steps */
+int32_t prl_envbatch_random_steps_full(prl_envbatch_t* batch, int32_t n_launches, uint32_t seed, uint64_t* out_stats3, float* out_device_ms);
+int32_t prl_env_random_rollout_full_host(const PrlGame* game, const PrlRules* rules, int32_t n_envs, int32_t n_steps, uint32_t seed, uint64_t deck_seed,
+                                         double reward_scalar, uint64_t* out_stats4);
 
 /* ---------------------------------------------------------------------------------------------------------------- */
 /* 5. Device-resident tabular solver: public-tree CFR / CFR+ / Linear CFR and exact best response on one GPU.          */

@@ -357,6 +357,77 @@ class NativeEnvBatch:
         check(self._L.prl_envbatch_random_steps(self._h, int(n_launches), int(seed) & 0xFFFFFFFF, _ptr(st), ctypes.byref(ms)), self._L)
         return int(st[0]), int(st[1]), int(st[2]), float(ms.value)
 
+    # ---- the whole PokerEnv.step: cards, payouts, rewards, observations (prl_envbatch_create_with_cards) --------------------------
+    @classmethod
+    def with_cards(cls, game, rules, n_envs, deck_seed=0, reward_scalar=1.0, _lib=None):
+        """n envs that also hold their hole cards and board (dealt from a counter-based deck at every reset, or set by the caller):
+        step_full() returns (obs, reward, done, info) like n calls of PokerEnv.step (PokerEnv.py:737-789)."""
+        self = cls.__new__(cls)
+        self._L = _lib or lib()
+        self._h = ctypes.c_void_p()
+        self._game, self._rules = game, rules
+        self.n_envs = int(n_envs)
+        L = self._L
+        L.prl_envbatch_create_with_cards.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), ctypes.c_int32, ctypes.c_uint64, ctypes.c_double,
+                                                     ctypes.POINTER(ctypes.c_void_p)]
+        L.prl_envbatch_create_with_cards.restype = ctypes.c_int32
+        for name, args in (("prl_envbatch_obs_dim", [ctypes.c_void_p, ctypes.c_void_p]), ("prl_envbatch_reset_full", [ctypes.c_void_p] * 3),
+                           ("prl_envbatch_set_cards", [ctypes.c_void_p] * 2), ("prl_envbatch_get_cards", [ctypes.c_void_p] * 2),
+                           ("prl_envbatch_observe", [ctypes.c_void_p] * 2), ("prl_envbatch_step_full", [ctypes.c_void_p] * 7),
+                           ("prl_envbatch_random_rollout_full", [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p])):
+            getattr(L, name).argtypes = args
+            getattr(L, name).restype = ctypes.c_int32
+        check(L.prl_envbatch_create_with_cards(ctypes.byref(game), ctypes.byref(rules), self.n_envs, int(deck_seed), float(reward_scalar), ctypes.byref(self._h)), L)
+        d = ctypes.c_int32()
+        check(L.prl_envbatch_obs_dim(self._h, ctypes.byref(d)), L)
+        self.obs_dim = int(d.value)
+        self.n_deal = 2 * rules.n_hole_cards + rules.n_board_cards
+        return self
+
+    def reset_full(self, mask=None):
+        """reset the masked envs (all if None): public state, a fresh hand from the deck -> observations float32 [n_envs, obs_dim] of ALL envs' states"""
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        check(self._L.prl_envbatch_reset_full(self._h, None if m is None else _ptr(m), None), self._L)
+        return self.observe()
+
+    def set_cards(self, cards):
+        c = np.ascontiguousarray(cards, dtype=np.int8)
+        assert c.shape == (self.n_envs, self.n_deal)
+        check(self._L.prl_envbatch_set_cards(self._h, _ptr(c)), self._L)
+
+    def get_cards(self):
+        c = np.empty((self.n_envs, self.n_deal), np.int8)
+        check(self._L.prl_envbatch_get_cards(self._h, _ptr(c)), self._L)
+        return c
+
+    def observe(self):
+        o = np.empty((self.n_envs, self.obs_dim), np.float32)
+        check(self._L.prl_envbatch_observe(self._h, _ptr(o)), self._L)
+        return o
+
+    def step_full(self, actions, amounts=None):
+        """-> (obs float32 [n, obs_dim], reward float64 [n, 2], done uint8 [n], info int32 [4, n])"""
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        b = None if amounts is None else np.ascontiguousarray(amounts, dtype=np.int32)
+        obs, rew = np.empty((self.n_envs, self.obs_dim), np.float32), np.empty((self.n_envs, 2), np.float64)
+        done, info = np.empty(self.n_envs, np.uint8), np.empty((4, self.n_envs), np.int32)
+        check(self._L.prl_envbatch_step_full(self._h, _ptr(a), None if b is None else _ptr(b), _ptr(obs), _ptr(rew), _ptr(done), _ptr(info)), self._L)
+        return obs, rew, done, info
+
+    def random_steps_full(self, n_launches, seed):
+        """one WHOLE step (obs, rewards, done out) per env and launch, state in HBM between the launches -> (steps, hands, pots, device ms)"""
+        st, ms = np.zeros(3, np.uint64), ctypes.c_float()
+        self._L.prl_envbatch_random_steps_full.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        self._L.prl_envbatch_random_steps_full.restype = ctypes.c_int32
+        check(self._L.prl_envbatch_random_steps_full(self._h, int(n_launches), int(seed) & 0xFFFFFFFF, _ptr(st), ctypes.byref(ms)), self._L)
+        return int(st[0]), int(st[1]), int(st[2]), float(ms.value)
+
+    def random_rollout_full(self, n_steps, seed):
+        """whole hands in registers -> (steps, finished hands, showdowns, payout checksum, kernel ms)"""
+        st, ms = np.zeros(4, np.uint64), ctypes.c_float()
+        check(self._L.prl_envbatch_random_rollout_full(self._h, int(n_steps), int(seed) & 0xFFFFFFFF, _ptr(st), ctypes.byref(ms)), self._L)
+        return int(st[0]), int(st[1]), int(st[2]), int(st[3]), float(ms.value)
+
     def __del__(self):
         try:
             if self._h:
@@ -364,6 +435,17 @@ class NativeEnvBatch:
                 self._h = None
         except Exception:
             pass
+
+
+def env_random_rollout_full_host(game, rules, n_envs, n_steps, seed, deck_seed=0, reward_scalar=1.0, _lib=None):
+    L = _lib or lib()
+    st = np.zeros(4, np.uint64)
+    L.prl_env_random_rollout_full_host.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), ctypes.c_int32, ctypes.c_int32, ctypes.c_uint32,
+                                                   ctypes.c_uint64, ctypes.c_double, ctypes.c_void_p]
+    L.prl_env_random_rollout_full_host.restype = ctypes.c_int32
+    check(L.prl_env_random_rollout_full_host(ctypes.byref(game), ctypes.byref(rules), int(n_envs), int(n_steps), int(seed) & 0xFFFFFFFF, int(deck_seed),
+                                             float(reward_scalar), _ptr(st)), L)
+    return tuple(int(x) for x in st)
 
 
 def env_random_rollout_host(game, n_envs, n_steps, seed, _lib=None):

@@ -46,3 +46,25 @@ PRL_HD PRL_INLINE void prl_hand_cards(const PrlRules& r, int idx, int* c1, int* 
         prl_hole_cards_2(idx, r.n_cards, c1, c2);
     }
 }
+
+// Counter-based decks for the batched engines (no reference counterpart: the reference shuffles with np.random, one hand at a time): the
+// first n_deal cards of hand `hand_id` depend on (seed, hand_id) only. A partial Fisher-Yates shuffle of 0 .. n_cards-1 driven by a
+// SplitMix-style hash; the deck as a sparse permutation (only the touched positions are remembered). n_deal <= 16.
+PRL_HD PRL_INLINE void prl_deal_hand(int n_cards, int n_deal, unsigned long long seed, unsigned long long hand_id, int8_t* out) {
+    const unsigned long long idx = (hand_id + 1ull) * 0x9E3779B97F4A7C15ull + seed;
+    int pos[16], val[16];
+    int n_touched = 0;
+    for (int d = 0; d < n_deal; ++d) {
+        unsigned long long x = idx + (unsigned long long)(d + 1) * 0xBF58476D1CE4E5B9ull;
+        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+        x ^= x >> 27; x *= 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        const int j = d + (int)(x % (unsigned long long)(n_cards - d));
+        int a = d, b = j, ib = -1;
+        for (int k = 0; k < n_touched; ++k) { if (pos[k] == d) a = val[k]; if (pos[k] == j) { b = val[k]; ib = k; } }
+        // position d takes b (final: no later draw looks below d + 1, so it is not remembered), position j takes a: at most one new entry
+        // per card dealt -- 16 entries cover n_deal <= 16 (remembering position d as well overran the arrays from the 9th card on)
+        if (j != d) { if (ib >= 0) val[ib] = a; else { pos[n_touched] = j; val[n_touched] = a; ++n_touched; } }
+        out[d] = (int8_t)b;
+    }
+}

@@ -21,8 +21,10 @@
 #include <string>
 #include <vector>
 
+#include "prl_cards.h"
 #include "prl_device.h"
 #include "prl_env.h"
+#include "prl_lbr.h"
 #include "prl_rt.h"
 
 enum {
@@ -43,6 +45,17 @@ struct prl_envbatch {
     int32_t* d_count = nullptr;
     unsigned long long* d_stats = nullptr;  // [EB_STAT_SLOTS][3]
     hipStream_t stream = nullptr;
+    // ---- the whole PokerEnv.step (prl_envbatch_create_with_cards): cards, payouts, rewards, observations ----
+    bool with_cards = false;
+    PrlRules rules{};
+    int32_t n_deal = 0, obs_dim = 0;
+    uint64_t deck_seed = 0;
+    double reward_scalar = 1.0;
+    int8_t* d_cards = nullptr;      // [n][n_deal]: hole cards of seat 0, of seat 1, the board in deal order (1-d cards)
+    uint32_t* d_episode = nullptr;  // [n] episodes dealt so far (the deck counter of env i: episode * n + i)
+    float* d_obs = nullptr;         // [n][obs_dim] staging for the host-pointer entry points
+    double* d_rew = nullptr;        // [n][2]
+    uint8_t* d_done = nullptr;      // [n]
 };
 
 PRL_DEV PRL_INLINE void eb_load(const int32_t* st, int n, int i, PrlEnvState& s, bool* done) {
@@ -109,11 +122,12 @@ PRL_HD PRL_INLINE int eb_legal_mask(const PrlGame& g, const PrlEnvState& s, uint
 PRL_DEV PRL_INLINE void eb_stats_add(unsigned long long* stats, unsigned long long steps, unsigned long long hands, unsigned long long pots) {
     for (int d = 32; d > 0; d >>= 1) {
         const int src = (int)prl_lane() ^ d;
-        steps += (unsigned long long)(unsigned)prl_shfl_i((int)(unsigned)steps, src);
-        hands += (unsigned long long)(unsigned)prl_shfl_i((int)(unsigned)hands, src);
-        const unsigned lo = (unsigned)prl_shfl_i((int)(unsigned)(pots & 0xFFFFFFFFull), src);
-        const unsigned hi = (unsigned)prl_shfl_i((int)(unsigned)(pots >> 32), src);
-        pots += ((unsigned long long)hi << 32) | lo;
+        auto add64 = [&](unsigned long long& v) {  // 64-bit butterfly add through two 32-bit shuffles (no truncation of long rollouts)
+            const unsigned lo = (unsigned)prl_shfl_i((int)(unsigned)(v & 0xFFFFFFFFull), src);
+            const unsigned hi = (unsigned)prl_shfl_i((int)(unsigned)(v >> 32), src);
+            v += ((unsigned long long)hi << 32) | lo;
+        };
+        add64(steps); add64(hands); add64(pots);
     }
     if (prl_lane() == 0) {
         unsigned long long* s = stats + 3 * (((prl_bid() * prl_nthreads() + prl_tid()) >> 6) & (EB_STAT_SLOTS - 1));
@@ -238,6 +252,224 @@ PRL_GLOBAL void prl_k_eb_random_step(const PrlGame* g, int32_t* st, int n, int k
     eb_stats_add(stats, steps, hands, pots);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// the whole PokerEnv.step for n envs: cards, payout, rewards, observation vector
+// ---------------------------------------------------------------------------------------------------------------------
+struct EbFull {
+    PrlRules rules;
+    int32_t n_deal, obs_dim, suits_matter;
+    double reward_scalar;
+};
+PRL_HD PRL_INLINE int eb_obs_dim(const PrlRules& r) { return 7 + 3 + 2 + 2 + r.n_rounds + 3 * 2 + r.n_board_cards * (r.n_ranks + r.n_suits); }
+PRL_HD PRL_INLINE int eb_cards_out(const PrlRules& r, int round) {  // board cards on the table in `round`
+    int n = 0;
+    for (int k = 1; k <= round && k < 4; ++k) n += r.board_cards_in_round[k];
+    return n;
+}
+PRL_HD PRL_INLINE int eb_hand_idx(const PrlRules& r, const int8_t* hc) {
+    if (r.n_hole_cards == 1) return hc[0];
+    const int a = hc[0] < hc[1] ? hc[0] : hc[1], b = hc[0] < hc[1] ? hc[1] : hc[0];
+    return prl_range_idx_2(a, b, r.n_cards);
+}
+// PokerEnv._payout_pots, heads-up (PokerEnv.py:468-481) + the rewards of PokerEnv.py:1069-1072: (stack after - starting stack) / REWARD_SCALAR
+PRL_HD PRL_INLINE void eb_payout(const PrlGame& g, const EbFull& F, const PrlEnvState& s, const int8_t* cards, double rew[2], bool* showdown) {
+    const int pot = s.main_pot;
+    double award[2] = {0.0, 0.0};
+    *showdown = false;
+    if (s.folded[0] || s.folded[1]) award[s.folded[0] ? 1 : 0] = (double)pot;
+    else {
+        PrlLbrGame hg;
+        hg.n_hole = F.rules.n_hole_cards; hg.n_cards = F.rules.n_cards; hg.n_suits = F.rules.n_suits; hg.rank_rule = F.rules.rank_rule; hg.R = F.rules.range_size;
+        hg.n_board_total = F.rules.n_board_cards;
+        const int8_t* board = cards + 2 * F.rules.n_hole_cards;
+        const int32_t r0 = prl_lbr_rank(hg, eb_hand_idx(F.rules, cards), board), r1 = prl_lbr_rank(hg, eb_hand_idx(F.rules, cards + F.rules.n_hole_cards), board);
+        if (r0 > r1) award[0] = (double)pot;
+        else if (r0 < r1) award[1] = (double)pot;
+        else award[0] = award[1] = (double)pot / 2.0;
+        *showdown = true;
+    }
+    for (int p = 0; p < 2; ++p) rew[p] = ((double)s.stack[p] + award[p] - (double)g.start_stack[p]) / F.reward_scalar;
+}
+// the heads-up "simple" observation (PokerEnv.py:199-261, :989-1031, :1253-1271): float64 quotients rounded to float32 like the
+// reference's np.array(list of Python floats, dtype=float32)
+PRL_HD PRL_INLINE void eb_observation(const PrlGame& g, const EbFull& F, const PrlEnvState& s, const int8_t* cards, float* o, size_t stride) {
+    const double norm = (double)(g.start_stack[0] + g.start_stack[1]) / 2.0;
+    const int small = s.bet[0] < s.bet[1] ? s.bet[0] : s.bet[1], big = s.bet[0] < s.bet[1] ? s.bet[1] : s.bet[0];
+    const int min_raise = big + ((big - small) > g.big_blind ? (big - small) : g.big_blind);
+    const bool have_la = s.last_action[0] >= 0;
+    int k = 0;
+    auto put = [&](double v) { o[(size_t)k * stride] = (float)v; ++k; };
+    put((double)g.ante / norm); put((double)g.small_blind / norm); put((double)g.big_blind / norm); put((double)min_raise / norm);
+    put((double)s.main_pot / norm); put((double)big / norm); put(have_la ? (double)s.last_action[1] / norm : 0.0);
+    for (int a = 0; a < 3; ++a) put(have_la && s.last_action[0] == a ? 1.0 : 0.0);
+    for (int p = 0; p < 2; ++p) put(have_la && s.last_action[2] == p ? 1.0 : 0.0);
+    for (int p = 0; p < 2; ++p) put(s.cur == p ? 1.0 : 0.0);
+    for (int r = 0; r < F.rules.n_rounds; ++r) put(s.round == r ? 1.0 : 0.0);
+    for (int p = 0; p < 2; ++p) { put((double)s.stack[p] / norm); put((double)s.bet[p] / norm); put(s.allin[p] ? 1.0 : 0.0); }
+    const int n_out = eb_cards_out(F.rules, s.round);
+    const int8_t* board = cards + 2 * F.rules.n_hole_cards;
+    for (int i = 0; i < F.rules.n_board_cards; ++i) {
+        const int c = i < n_out ? board[i] : -1;
+        const int rank = c >= 0 ? c / F.rules.n_suits : -1, suit = c >= 0 ? c % F.rules.n_suits : -1;
+        for (int j = 0; j < F.rules.n_ranks; ++j) put(j == rank ? 1.0 : 0.0);
+        for (int j = 0; j < F.rules.n_suits; ++j) put(F.suits_matter && j == suit ? 1.0 : 0.0);
+    }
+}
+
+// reset of the masked envs: public state, a fresh hand from the env's counter-based deck, the observation of the new hand
+PRL_GLOBAL void prl_k_ebf_reset(const PrlGame* g, EbFull F, int32_t* st, int n, const uint8_t* mask, int8_t* cards, uint32_t* episode, uint64_t deck_seed,
+                                int deal, float* obs) {
+    for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) {
+        if (mask && !mask[i]) continue;
+        PrlEnvState s;
+        prl_env_reset(*g, s);
+        eb_store(st, n, i, s, false);
+        int8_t* c = cards + (size_t)i * F.n_deal;
+        if (deal) {
+            const uint32_t ep = episode[i];
+            episode[i] = ep + 1u;
+            prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, c);
+        }
+        if (obs) eb_observation(*g, F, s, c, obs + (size_t)i * F.obs_dim, 1);
+    }
+}
+
+// PokerEnv.step of every env: (obs, reward, done, info). An env whose episode is over, or whose action is < 0, is skipped
+// (done = 1, zero observation, zero reward, info -1 as prl_k_eb_step).
+PRL_GLOBAL void prl_k_ebf_step(const PrlGame* g, EbFull F, int32_t* st, int n, const int32_t* a0, const int32_t* a1, int processed, const int8_t* cards,
+                               float* obs, double* rew, uint8_t* done_out, int32_t* info) {
+    for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) {
+        PrlEnvState s;
+        bool done;
+        eb_load(st, n, i, s, &done);
+        const int act = a0[i];
+        int o0 = -1, o1 = 0, o2 = 0, o3 = 0;
+        double r[2] = {0.0, 0.0};
+        const int n_act = g->game_type == PRL_GAME_DISCRETIZED ? g->n_bet_sizes + 2 : 3;
+        float* o = obs + (size_t)i * F.obs_dim;
+        const bool stepped = !done && act >= 0 && act < (processed ? 3 : n_act);
+        if (stepped) {
+            PrlStepInfo si;
+            if (processed) prl_env_step_processed(*g, s, act, a1[i], &si);
+            else prl_env_step(*g, s, act, &si);
+            done = si.is_terminal != 0;
+            eb_store(st, n, i, s, done);
+            o0 = si.is_terminal; o1 = si.chance_acts; o2 = si.pot_before_payout;
+            o3 = si.is_terminal ? (si.terminal_is_fold ? 1 : (si.rundown ? 3 : 2)) : 0;
+            if (done) {
+                bool sd;
+                eb_payout(*g, F, s, cards + (size_t)i * F.n_deal, r, &sd);
+            }
+        }
+        if (stepped && !done) eb_observation(*g, F, s, cards + (size_t)i * F.n_deal, o, 1);
+        else for (int k = 0; k < F.obs_dim; ++k) o[k] = 0.f;  // PokerEnv.get_current_obs(is_terminal=True): zeros
+        rew[2 * (size_t)i] = r[0];
+        rew[2 * (size_t)i + 1] = r[1];
+        done_out[i] = done ? 1 : 0;
+        if (info) { info[i] = o0; info[(size_t)n + i] = o1; info[(size_t)2 * n + i] = o2; info[(size_t)3 * n + i] = o3; }
+    }
+}
+
+// the observation of every env's CURRENT state (PokerEnv.get_current_obs; zeros for a finished episode)
+PRL_GLOBAL void prl_k_ebf_observe(const PrlGame* g, EbFull F, const int32_t* st, int n, const int8_t* cards, float* obs) {
+    for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) {
+        PrlEnvState s;
+        bool done;
+        eb_load(st, n, i, s, &done);
+        float* o = obs + (size_t)i * F.obs_dim;
+        if (!done) eb_observation(*g, F, s, cards + (size_t)i * F.n_deal, o, 1);
+        else for (int k = 0; k < F.obs_dim; ++k) o[k] = 0.f;
+    }
+}
+
+// uniform-random legal play of WHOLE hands with the state in registers: deal, bet, show down, pay out, deal again. stats: steps, finished
+// hands, showdowns, sum over hands of 2 x seat 0's chip winnings + a large offset (an integer checksum of the payouts)
+PRL_HD PRL_INLINE void eb_play_full(const PrlGame& g, const EbFull& F, int n, int i, int n_steps, uint32_t seed, uint64_t deck_seed, unsigned long long acc[4]) {
+    PrlEnvState s;
+    prl_env_reset(g, s);
+    int8_t cards[16];
+    uint32_t ep = 0;
+    prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, cards);
+    for (int k = 0; k < n_steps; ++k) {
+        int32_t legal[PRL_MAX_BET_SIZES + 2];
+        const int nl = prl_legal_actions(g, s, legal);
+        const uint32_t r = eb_mix32(seed ^ eb_mix32((uint32_t)i * 0x9E3779B9u + (uint32_t)k));
+        PrlStepInfo si;
+        const int a = legal[r % (uint32_t)nl];
+        if (g.game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(g, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(s.stack[s.cur] + s.bet[s.cur] + 1)) : -1, &si);
+        else prl_env_step(g, s, a, &si);
+        acc[0] += 1;
+        if (si.is_terminal) {
+            double rew[2];
+            bool sd;
+            eb_payout(g, F, s, cards, rew, &sd);
+            acc[1] += 1;
+            acc[2] += sd ? 1 : 0;
+            acc[3] += (unsigned long long)(long long)(2.0 * rew[0] * F.reward_scalar) + (1ull << 20);
+            prl_env_reset(g, s);
+            ++ep;
+            prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, cards);
+        }
+    }
+}
+PRL_GLOBAL void prl_k_ebf_rollout(const PrlGame* g, EbFull F, int n, int n_steps, uint32_t seed, uint64_t deck_seed, unsigned long long* stats) {
+    unsigned long long acc[4] = {0, 0, 0, 0};
+    for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) eb_play_full(*g, F, n, i, n_steps, seed, deck_seed, acc);
+    // per wave: butterfly sums in 32-bit halves, one atomic per counter
+    for (int c = 0; c < 4; ++c) {
+        unsigned long long v = acc[c];
+        for (int d = 32; d > 0; d >>= 1) {
+            const int src = (int)prl_lane() ^ d;
+            const unsigned lo = (unsigned)prl_shfl_i((int)(unsigned)(v & 0xFFFFFFFFull), src);
+            const unsigned hi = (unsigned)prl_shfl_i((int)(unsigned)(v >> 32), src);
+            v += ((unsigned long long)hi << 32) | lo;
+        }
+        if (prl_lane() == 0) prl_atomic_add_u64(stats + 4 * (((prl_bid() * prl_nthreads() + prl_tid()) >> 6) & (EB_STAT_SLOTS - 1)) + c, v);
+    }
+}
+
+// one whole PokerEnv.step per env and launch with the state in HBM between the launches, driven by uniform-random legal actions: what an
+// agent-driven rollout costs per step -- 13 state words in and out, the observation vector, two rewards and the done flag out; a finished
+// hand is reset and dealt again at the next launch. Step k of env i draws the same number as step k of the other rollouts.
+PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* g, EbFull F, int32_t* st, int n, int k, uint32_t seed, int8_t* cards, uint32_t* episode, uint64_t deck_seed,
+                                      float* obs, double* rew, uint8_t* done_out, unsigned long long* stats) {
+    unsigned long long hands = 0, pots = 0, steps = 0;
+    for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) {
+        PrlEnvState s;
+        bool done;
+        eb_load(st, n, i, s, &done);
+        int8_t* c = cards + (size_t)i * F.n_deal;
+        if (done) {
+            prl_env_reset(*g, s);
+            const uint32_t ep = episode[i];
+            episode[i] = ep + 1u;
+            prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, c);
+        }
+        int32_t legal[PRL_MAX_BET_SIZES + 2];
+        const int nl = prl_legal_actions(*g, s, legal);
+        const uint32_t r = eb_mix32(seed ^ eb_mix32((uint32_t)i * 0x9E3779B9u + (uint32_t)k));
+        PrlStepInfo si;
+        const int a = legal[r % (uint32_t)nl];
+        if (g->game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(*g, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(s.stack[s.cur] + s.bet[s.cur] + 1)) : -1, &si);
+        else prl_env_step(*g, s, a, &si);
+        ++steps;
+        double rw[2] = {0.0, 0.0};
+        float* o = obs + (size_t)i * F.obs_dim;
+        if (si.is_terminal) {
+            bool sd;
+            eb_payout(*g, F, s, c, rw, &sd);
+            ++hands;
+            pots += (unsigned long long)si.pot_before_payout;
+            for (int j = 0; j < F.obs_dim; ++j) o[j] = 0.f;
+        } else eb_observation(*g, F, s, c, o, 1);
+        rew[2 * (size_t)i] = rw[0];
+        rew[2 * (size_t)i + 1] = rw[1];
+        done_out[i] = si.is_terminal ? 1 : 0;
+        eb_store(st, n, i, s, si.is_terminal != 0);
+    }
+    eb_stats_add(stats, steps, hands, pots);
+}
+
 static int eb_grid(int n) {
     int g = (n + 255) / 256;
     return g < 1 ? 1 : (g > 4096 ? 4096 : g);
@@ -261,16 +493,183 @@ int32_t prl_envbatch_create(const PrlGame* game, int32_t n_envs, prl_envbatch_t*
     if (hipMalloc((void**)&b->d_info, (size_t)4 * n_envs * sizeof(int32_t)) != hipSuccess) return fail("staging");
     if (hipMalloc((void**)&b->d_mask, (size_t)4 * n_envs * sizeof(uint32_t)) != hipSuccess) return fail("staging");
     if (hipMalloc((void**)&b->d_count, (size_t)(n_envs + 64) * sizeof(int32_t)) != hipSuccess) return fail("staging");
-    if (hipMalloc((void**)&b->d_stats, (size_t)3 * 256 * sizeof(unsigned long long)) != hipSuccess) return fail("stats");
-    PRL_HIP_TRY(hipMemcpy(b->d_game, game, sizeof(PrlGame), hipMemcpyHostToDevice));
+    if (hipMalloc((void**)&b->d_stats, (size_t)4 * EB_STAT_SLOTS * sizeof(unsigned long long)) != hipSuccess) return fail("stats");
+    if (hipMemcpy(b->d_game, game, sizeof(PrlGame), hipMemcpyHostToDevice) != hipSuccess) return fail("upload");
     *out = b;
     return prl_envbatch_reset(b, nullptr);
+}
+
+static EbFull eb_full(const prl_envbatch* b) {
+    EbFull F;
+    F.rules = b->rules; F.n_deal = b->n_deal; F.obs_dim = b->obs_dim; F.suits_matter = b->rules.rank_rule == 2 ? 1 : 0;  // game_rules.py: SUITS_MATTER
+    F.reward_scalar = b->reward_scalar;
+    return F;
+}
+
+int32_t prl_envbatch_create_with_cards(const PrlGame* game, const PrlRules* rules, int32_t n_envs, uint64_t deck_seed, double reward_scalar,
+                                       prl_envbatch_t** out) {
+    if (!rules || !(reward_scalar > 0.0)) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    const int nh = rules->n_hole_cards, nb = rules->n_board_cards;
+    if (nh < 1 || nh > 2 || nb < 1 || nb > 5 || rules->n_cards > PRL_LBR_MAX_CARDS || rules->n_rounds > 4 || (nh == 2 && (rules->n_cards != 52 || nb != 5))) {
+        prl_set_error("batched env with cards: 1-hole-card games or 52-card hold'em");
+        return PRL_ERR_UNSUPPORTED;
+    }
+    prl_envbatch* b = nullptr;
+    int rc = prl_envbatch_create(game, n_envs, &b);
+    if (rc) return rc;
+    b->with_cards = true;
+    b->rules = *rules;
+    b->n_deal = 2 * nh + nb;
+    b->obs_dim = eb_obs_dim(*rules);
+    b->deck_seed = deck_seed;
+    b->reward_scalar = reward_scalar;
+    auto fail = [&](const char* what) { prl_set_error(std::string("prl_envbatch_create_with_cards: ") + what); prl_envbatch_destroy(b); return PRL_ERR_OOM; };
+    if (hipMalloc((void**)&b->d_cards, (size_t)n_envs * b->n_deal) != hipSuccess) return fail("cards");
+    if (hipMalloc((void**)&b->d_episode, (size_t)n_envs * sizeof(uint32_t)) != hipSuccess) return fail("episode counters");
+    if (hipMalloc((void**)&b->d_obs, (size_t)n_envs * b->obs_dim * sizeof(float)) != hipSuccess) return fail("observations");
+    if (hipMalloc((void**)&b->d_rew, (size_t)n_envs * 2 * sizeof(double)) != hipSuccess) return fail("rewards");
+    if (hipMalloc((void**)&b->d_done, (size_t)n_envs) != hipSuccess) return fail("done flags");
+    if (hipMemset(b->d_episode, 0, (size_t)n_envs * sizeof(uint32_t)) != hipSuccess) return fail("memset");
+    *out = b;
+    return prl_envbatch_reset_full(b, nullptr, nullptr);
+}
+
+int32_t prl_envbatch_obs_dim(prl_envbatch_t* b, int32_t* out) {
+    if (!b || !out || !b->with_cards) { prl_set_error("not a batch with cards"); return PRL_ERR_ARG; }
+    *out = b->obs_dim;
+    return PRL_OK;
+}
+
+int32_t prl_envbatch_reset_full(prl_envbatch_t* b, const uint8_t* mask, float* out_obs) {
+    if (!b || !b->with_cards) { prl_set_error("not a batch with cards"); return PRL_ERR_ARG; }
+    uint8_t* d_m = nullptr;
+    if (mask) {
+        d_m = (uint8_t*)b->d_mask;
+        PRL_HIP_TRY(hipMemcpyAsync(d_m, mask, (size_t)b->n, hipMemcpyHostToDevice, b->stream));
+    }
+    PRL_LAUNCH(prl_k_ebf_reset, eb_grid(b->n), 256, 0, b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, (const uint8_t*)d_m, b->d_cards,
+               b->d_episode, b->deck_seed, 1, b->d_obs);
+    PRL_HIP_TRY(hipGetLastError());
+    if (out_obs) PRL_HIP_TRY(hipMemcpyAsync(out_obs, b->d_obs, (size_t)b->n * b->obs_dim * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    PRL_HIP_TRY(hipStreamSynchronize(b->stream));
+    return PRL_OK;
+}
+
+int32_t prl_envbatch_set_cards(prl_envbatch_t* b, const int8_t* cards) {
+    if (!b || !b->with_cards || !cards) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    PRL_HIP_TRY(hipMemcpyAsync(b->d_cards, cards, (size_t)b->n * b->n_deal, hipMemcpyHostToDevice, b->stream));
+    PRL_HIP_TRY(hipStreamSynchronize(b->stream));
+    return PRL_OK;
+}
+
+int32_t prl_envbatch_get_cards(prl_envbatch_t* b, int8_t* out_cards) {
+    if (!b || !b->with_cards || !out_cards) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    PRL_HIP_TRY(hipStreamSynchronize(b->stream));
+    PRL_HIP_TRY(hipMemcpy(out_cards, b->d_cards, (size_t)b->n * b->n_deal, hipMemcpyDeviceToHost));
+    return PRL_OK;
+}
+
+int32_t prl_envbatch_observe(prl_envbatch_t* b, float* out_obs) {
+    if (!b || !b->with_cards || !out_obs) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    PRL_LAUNCH(prl_k_ebf_observe, eb_grid(b->n), 256, 0, b->stream, (const PrlGame*)b->d_game, eb_full(b), (const int32_t*)b->d_state, b->n, (const int8_t*)b->d_cards, b->d_obs);
+    PRL_HIP_TRY(hipGetLastError());
+    PRL_HIP_TRY(hipMemcpyAsync(out_obs, b->d_obs, (size_t)b->n * b->obs_dim * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    PRL_HIP_TRY(hipStreamSynchronize(b->stream));
+    return PRL_OK;
+}
+
+int32_t prl_envbatch_step_full_device(prl_envbatch_t* b, const int32_t* d_actions, const int32_t* d_amounts, float* d_obs, double* d_reward2, uint8_t* d_done,
+                                      int32_t* d_info4) {
+    if (!b || !b->with_cards || !d_actions || !d_obs || !d_reward2 || !d_done) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    PRL_LAUNCH(prl_k_ebf_step, eb_grid(b->n), 256, 0, b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, d_actions, d_amounts, d_amounts ? 1 : 0,
+               (const int8_t*)b->d_cards, d_obs, d_reward2, d_done, d_info4);
+    PRL_HIP_TRY(hipGetLastError());
+    return PRL_OK;
+}
+
+int32_t prl_envbatch_step_full(prl_envbatch_t* b, const int32_t* actions, const int32_t* amounts, float* out_obs, double* out_reward2, uint8_t* out_done,
+                               int32_t* out_info4) {
+    if (!b || !b->with_cards || !actions || !out_obs || !out_reward2 || !out_done) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    PRL_HIP_TRY(hipMemcpyAsync(b->d_a, actions, (size_t)b->n * 4, hipMemcpyHostToDevice, b->stream));
+    if (amounts) PRL_HIP_TRY(hipMemcpyAsync(b->d_b, amounts, (size_t)b->n * 4, hipMemcpyHostToDevice, b->stream));
+    int rc = prl_envbatch_step_full_device(b, b->d_a, amounts ? b->d_b : nullptr, b->d_obs, b->d_rew, b->d_done, b->d_info);
+    if (rc) return rc;
+    PRL_HIP_TRY(hipMemcpyAsync(out_obs, b->d_obs, (size_t)b->n * b->obs_dim * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    PRL_HIP_TRY(hipMemcpyAsync(out_reward2, b->d_rew, (size_t)b->n * 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    PRL_HIP_TRY(hipMemcpyAsync(out_done, b->d_done, (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
+    if (out_info4) PRL_HIP_TRY(hipMemcpyAsync(out_info4, b->d_info, (size_t)4 * b->n * 4, hipMemcpyDeviceToHost, b->stream));
+    PRL_HIP_TRY(hipStreamSynchronize(b->stream));
+    return PRL_OK;
+}
+
+int32_t prl_envbatch_random_rollout_full(prl_envbatch_t* b, int32_t n_steps, uint32_t seed, uint64_t* out_stats4, float* out_device_ms) {
+    if (!b || !b->with_cards || n_steps < 0 || !out_stats4) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    unsigned long long* d_stats = b->d_stats;
+    PRL_HIP_TRY(hipMemsetAsync(d_stats, 0, 4 * EB_STAT_SLOTS * sizeof(unsigned long long), b->stream));
+    hipEvent_t e0, e1;
+    PRL_HIP_TRY(hipEventCreate(&e0));
+    PRL_HIP_TRY(hipEventCreate(&e1));
+    PRL_HIP_TRY(hipEventRecord(e0, b->stream));
+    PRL_LAUNCH(prl_k_ebf_rollout, eb_grid(b->n), 256, 0, b->stream, (const PrlGame*)b->d_game, eb_full(b), b->n, n_steps, seed, b->deck_seed, d_stats);
+    PRL_HIP_TRY(hipGetLastError());
+    PRL_HIP_TRY(hipEventRecord(e1, b->stream));
+    PRL_HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PRL_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (out_device_ms) *out_device_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    unsigned long long h[4 * EB_STAT_SLOTS];
+    PRL_HIP_TRY(hipMemcpy(h, d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) out_stats4[k] = 0;
+    for (int j = 0; j < EB_STAT_SLOTS; ++j)
+        for (int k = 0; k < 4; ++k) out_stats4[k] += (uint64_t)h[4 * j + k];
+    return PRL_OK;
+}
+
+int32_t prl_envbatch_random_steps_full(prl_envbatch_t* b, int32_t n_launches, uint32_t seed, uint64_t* out_stats3, float* out_device_ms) {
+    if (!b || !b->with_cards || n_launches < 0 || !out_stats3) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    unsigned long long* d_stats = b->d_stats;
+    PRL_HIP_TRY(hipMemsetAsync(d_stats, 0, 4 * EB_STAT_SLOTS * sizeof(unsigned long long), b->stream));
+    hipEvent_t e0, e1;
+    PRL_HIP_TRY(hipEventCreate(&e0));
+    PRL_HIP_TRY(hipEventCreate(&e1));
+    PRL_HIP_TRY(hipEventRecord(e0, b->stream));
+    for (int k = 0; k < n_launches; ++k)
+        PRL_LAUNCH(prl_k_ebf_random_step, eb_grid(b->n), 256, 0, b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, k, seed, b->d_cards, b->d_episode,
+                   b->deck_seed, b->d_obs, b->d_rew, b->d_done, d_stats);
+    PRL_HIP_TRY(hipGetLastError());
+    PRL_HIP_TRY(hipEventRecord(e1, b->stream));
+    PRL_HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PRL_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (out_device_ms) *out_device_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    unsigned long long h[3 * EB_STAT_SLOTS];
+    PRL_HIP_TRY(hipMemcpy(h, d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; ++k) out_stats3[k] = 0;
+    for (int j = 0; j < EB_STAT_SLOTS; ++j)
+        for (int k = 0; k < 3; ++k) out_stats3[k] += (uint64_t)h[3 * j + k];
+    return PRL_OK;
+}
+
+// the same hands on the host, one env after the other (the checker of prl_k_ebf_rollout and the CPU leg of bench_env.py --full)
+int32_t prl_env_random_rollout_full_host(const PrlGame* game, const PrlRules* rules, int32_t n_envs, int32_t n_steps, uint32_t seed, uint64_t deck_seed,
+                                         double reward_scalar, uint64_t* out_stats4) {
+    if (!game || !rules || n_envs < 0 || n_steps < 0 || !out_stats4 || !(reward_scalar > 0.0)) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    EbFull F;
+    F.rules = *rules; F.n_deal = 2 * rules->n_hole_cards + rules->n_board_cards; F.obs_dim = eb_obs_dim(*rules); F.suits_matter = rules->rank_rule == 2; F.reward_scalar = reward_scalar;
+    unsigned long long acc[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n_envs; ++i) eb_play_full(*game, F, n_envs, i, n_steps, seed, deck_seed, acc);
+    for (int k = 0; k < 4; ++k) out_stats4[k] = (uint64_t)acc[k];
+    return PRL_OK;
 }
 
 void prl_envbatch_destroy(prl_envbatch_t* b) {
     if (!b) return;
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    void* ptrs[] = {b->d_state, b->d_game, b->d_a, b->d_b, b->d_info, b->d_mask, b->d_count, b->d_stats};
+    void* ptrs[] = {b->d_state, b->d_game, b->d_a, b->d_b, b->d_info, b->d_mask, b->d_count, b->d_stats, b->d_cards, b->d_episode, b->d_obs, b->d_rew, b->d_done};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (b->stream) (void)hipStreamDestroy(b->stream);

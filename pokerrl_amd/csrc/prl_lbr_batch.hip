@@ -744,23 +744,7 @@ done:
 PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_deal_decks(int n_hands, int n_cards, int n_deal, unsigned long long seed, unsigned long long first_hand, int8_t* out) {
     const int i = (int)(prl_bid() * prl_nthreads() + prl_tid());
     if (i >= n_hands) return;
-    const unsigned long long idx = (first_hand + (unsigned long long)i + 1ull) * 0x9E3779B97F4A7C15ull + seed;
-    // the deck as a sparse permutation: only the (at most n_deal) touched positions are remembered
-    int pos[16], val[16];
-    int n_touched = 0;
-    auto get = [&](int p) { for (int k = 0; k < n_touched; ++k) if (pos[k] == p) return val[k]; return p; };
-    auto set = [&](int p, int v) { for (int k = 0; k < n_touched; ++k) if (pos[k] == p) { val[k] = v; return; } pos[n_touched] = p; val[n_touched] = v; ++n_touched; };
-    for (int d = 0; d < n_deal; ++d) {
-        unsigned long long x = idx + (unsigned long long)(d + 1) * 0xBF58476D1CE4E5B9ull;
-        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-        x ^= x >> 27; x *= 0x94D049BB133111EBull;
-        x ^= x >> 31;
-        const int j = d + (int)(x % (unsigned long long)(n_cards - d));
-        const int a = get(d), b = get(j);
-        set(d, b);
-        set(j, a);
-        out[(size_t)i * n_deal + d] = (int8_t)b;
-    }
+    prl_deal_hand(n_cards, n_deal, seed, first_hand + (unsigned long long)i, out + (size_t)i * n_deal);  // prl_cards.h
 }
 
 extern "C" int32_t prl_deal_decks(int32_t n_hands, int32_t n_cards_in_deck, int32_t n_deal, uint64_t seed, uint64_t first_hand, int8_t* out_cards) {

@@ -83,3 +83,73 @@ def check_rollout_matches_host(L, cls, stack, bets, n_envs, n_steps, seed=7):
     b2 = _native.NativeEnvBatch(game, n_envs, _lib=L)  # one step per launch, state through HBM: the same hands
     assert b2.random_steps(n_steps, seed)[:3] == (steps, hands, pots)
     return steps, hands
+
+
+# ---- the whole PokerEnv.step (cards, payouts, rewards, observations): tests/golden/env_obs.npz ------------------------------------------
+def check_full_env_vs_reference(L, name, n_envs):
+    """env i replays episode i % 40 of the reference's recorded full episodes with the reference's own cards: observation vectors after the
+    reset and after every step, the final rewards and the done flags -- bit for bit"""
+    g = golden("env_obs.npz")
+    obs_ref, meta = g[name + "_obs"], g[name + "_meta"]
+    cls, stack, bset = _env_obs_cfg()[name]
+    args = env_args(cls, stack, bset)
+    game, rules = cls.native_game(args), cls.native_rules()
+    nh, nb = rules.n_hole_cards, rules.n_board_cards
+    eps, cur = [], None
+    for row, o in zip(meta, obs_ref):  # meta rows: ep, action (-1 = reset), done, r0, r1 [, cards at the last row of the episode]
+        if int(row[1]) == -1:
+            cur = dict(rows=[], obs=[])
+            eps.append(cur)
+        cur["rows"].append(row)
+        cur["obs"].append(o)
+    reward_scalar = (float(stack + stack) / 2.0 / 5.0) if getattr(args, "scale_rewards", False) else 1.0
+    b = _native.NativeEnvBatch.with_cards(game, rules, n_envs, deck_seed=1, reward_scalar=reward_scalar, _lib=L)
+    assert b.obs_dim == obs_ref.shape[1]
+    which = np.arange(n_envs) % len(eps)
+    cards = np.zeros((len(eps), 2 * nh + nb), np.int8)
+    for e, ep in enumerate(eps):
+        last = ep["rows"][-1]
+        board = [int(c) for c in last[5:5 + nb]]
+        hands = [int(c) for c in last[5 + nb:5 + nb + 2 * nh]]
+        used = set(c for c in board + hands if c >= 0)
+        spare = [c for c in range(rules.n_cards) if c not in used]
+        board = [c if c >= 0 else spare.pop() for c in board]  # streets the episode never reached: any unused card (never looked at)
+        cards[e] = hands + board
+    b.reset_full()
+    b.set_cards(cards[which])
+    o = b.observe()
+    first = np.stack([ep["obs"][0] for ep in eps])
+    assert np.array_equal(o, first[which]), (name, "observation after the reset")
+    max_len = max(len(ep["rows"]) for ep in eps)
+    for k in range(1, max_len):
+        act = np.array([int(ep["rows"][k][1]) if k < len(ep["rows"]) else -1 for ep in eps], np.int32)
+        live = (act >= 0)[which]
+        obs, rew, done, info = b.step_full(act[which])
+        want_obs = np.stack([ep["obs"][k] if k < len(ep["rows"]) else np.zeros(b.obs_dim, np.float32) for ep in eps])
+        assert np.array_equal(obs[live], want_obs[which][live]), (name, k, "observation")
+        want_done = np.array([int(ep["rows"][k][2]) if k < len(ep["rows"]) else 1 for ep in eps])
+        assert np.array_equal(done[live].astype(int), want_done[which][live]), (name, k, "done")
+        want_rew = np.array([[ep["rows"][k][3], ep["rows"][k][4]] if k < len(ep["rows"]) else [0.0, 0.0] for ep in eps], np.float64)
+        assert np.array_equal(rew[live], want_rew[which][live]), (name, k, "rewards")
+        assert np.all(done[~live] == 1) and np.all(obs[~live] == 0)
+    return len(eps), max_len
+
+
+def _env_obs_cfg():
+    """fixture name -> (game class, stack, bet set): ENV_FUZZ of tests/golden/make_golden.py"""
+    from pokerrl_amd.game import bet_sets
+    return {"StandardLeduc": (G.StandardLeduc, 13, [0.0]), "BigLeduc_short": (G.BigLeduc, 9, [0.0]),
+            "DiscretizedNLLeduc_B5_short": (G.DiscretizedNLLeduc, 900, bet_sets.B_5), "LimitHoldem": (G.LimitHoldem, 48, [0.0]),
+            "DiscretizedNLHoldem_B5": (G.DiscretizedNLHoldem, 20000, bet_sets.B_5),
+            "DiscretizedNLHoldem_OT11_short": (G.DiscretizedNLHoldem, 2300, bet_sets.OFF_TREE_11), "Flop5Holdem": (G.Flop5Holdem, 20000, [0.0])}
+
+
+def check_full_rollout_matches_host(L, cls, stack, bets, n_envs, n_steps, seed=5):
+    """whole hands in registers on the device = the same hands on the host: steps, hands, showdowns and the payout checksum"""
+    args = env_args(cls, stack, bets)
+    game, rules = cls.native_game(args), cls.native_rules()
+    b = _native.NativeEnvBatch.with_cards(game, rules, n_envs, deck_seed=77, reward_scalar=1.0, _lib=L)
+    dev = b.random_rollout_full(n_steps, seed)[:4]
+    host = _native.env_random_rollout_full_host(game, rules, n_envs, n_steps, seed, deck_seed=77, reward_scalar=1.0, _lib=L)
+    assert dev == host and dev[0] == n_envs * n_steps and dev[1] > 0 and dev[2] > 0, (dev, host)
+    return dev
