@@ -98,6 +98,17 @@ def main():
                       "lbr_lookaheads_per_s_rank0": sum(s["lbr_lookaheads"] for s in stats) / dev_s,
                       "hand_evals_per_s_rank0": sum(s["range_board_equities"] for s in stats) * 1326 / dev_s,
                       "lbr_winnings_mbb_per_g": mean, "conf95_per_seat": [r[1] for r in res]}}
+    # The batch kernel keeps a hand's whole state in LDS / registers: HBM moves the decks in and the winnings out (bytes per hand in the
+    # tens), so neither the HBM nor the MFMA roofline says anything about it. Its arithmetic is the (range, board) equities of LBR's
+    # look-aheads (LocalLBRWorker.py:427-512): per equity and hand of the 1326-hand range one add into the normalising sum, one division,
+    # one add into the win / tie sums = 3 R float32 operations; the bound is the vector FP32 pipe (157.3 TFLOP/s spec, MI355X_MICROARCH.md).
+    flops_eq = 3.0 * 1326
+    achieved_tflops = sum(s["range_board_equities"] for s in stats) * flops_eq / dev_s / 1e12
+    out["roofline"] = {"bound": "valu-fp32", "achieved": achieved_tflops, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved_tflops / 157.3, "traffic": None,
+                       "kernel": "prl_k_lbr_batch", "flops_per_range_board_equity_algorithmic": flops_eq,
+                       "range_board_equities_per_hand": sum(s["range_board_equities"] for s in stats) / max(float(n), 1.0),
+                       "note": "not an HBM- or MFMA-bound kernel: state on chip, no contraction; the model counts 3 float32 operations per hand of a "
+                               "(range, board) equity, the kernel also spends integer work on blockers, the betting engine and the agent's draws"}
     if rank == 0 and args.cpu_hands > 0 and world == 1:
         from pokerrl_amd.rl import hash_agent as fx
         from pokerrl_amd.rl.base_cls.EvalAgentBase import EvalAgentBase
@@ -108,8 +119,9 @@ def main():
         dtc = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": args.cpu_hands / dtc, "unit": "hands/s", "cores": 1, "kind": "port",
                                "sample": "pokerrl_amd.eval.lbr.LocalLBRWorker (the reference's Python episode loop, equity queries on the GPU), "
-                                         "%d hands, same agent and bet sets, %.1f s; the reference's own worker: ~30 hands/s per core (BASELINE.md)"
-                                         % (args.cpu_hands, dtc)}
+                                         "%d hands, same agent and bet sets, %.1f s" % (args.cpu_hands, dtc),
+                               # the reference's own worker needs /root/reference, which does not travel to the GPU box: its timing is the survey box's
+                               "reference_python_hands_per_s_survey_box": 30.0, "reference_timing_source": "BASELINE.md section 2 (LocalLBRWorker, one core)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -407,7 +407,8 @@ int32_t prl_solver_get_cols(prl_solver_t* solver, int32_t field, int64_t col_beg
 /*              normalize (PokerRange.py:26-84) as they are used there. float32, NumPy's summation order: bit-exact.   */
 /*    board_dealt: the n_dealt board cards on the table (1d cards, deal order); lbr_hand: n_hole_cards 1d cards;       */
 /*    ranges: [n_q][R] candidate agent ranges (the current one, and the one after "agent does not fold" per raise);    */
-/*    out_wp[n_q]: P(LBR wins the check-down) per range. At most 2 board cards to come (lbr_check_to_round).            */
+/*    out_wp[n_q]: P(LBR wins the check-down) per range. Any number of board cards to come: hold'em before the flop     */
+/*    enumerates all C(50, 5) = 2 118 760 run-outs (LocalLBRWorker.py:388-425), about a second per decision.           */
 /* ---------------------------------------------------------------------------------------------------------------- */
 int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t* board_dealt, int32_t n_dealt, const int8_t* lbr_hand,
                                  const float* ranges, int32_t n_q, float* out_wp);

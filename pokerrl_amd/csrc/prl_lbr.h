@@ -8,7 +8,7 @@
 #include "prl_handeval.h"
 
 #define PRL_LBR_MAX_CARDS 52
-#define PRL_LBR_MAX_DEAL 2   // cards still to come when LBR evaluates (flop: 2, turn: 1, river / Leduc flop: 0, Leduc pre-flop: 1)
+#define PRL_LBR_MAX_DEAL 5   // cards still to come when LBR evaluates (hold'em pre-flop: 5, flop: 2, turn: 1, river / Leduc flop: 0, Leduc pre-flop: 1)
 
 // NumPy's pairwise sum (numpy/_core/src/umath/loops_utils.h.src) over a stream: `next()` yields the elements in order. The
 // algorithm visits a[0], a[1], ... exactly once and in order, so no random access is needed. The recursion (halve until a
@@ -157,7 +157,7 @@ PRL_HD PRL_INLINE int prl_lbr_possible_cards(const PrlLbrGame& g, int8_t* pc) {
 }
 PRL_HD PRL_INLINE int prl_lbr_n_boards(const PrlLbrGame& g) {
     const int n = g.n_cards - g.n_hole - g.n_dealt;
-    return g.n_to_deal == 0 ? 1 : (g.n_to_deal == 1 ? n : n * (n - 1) / 2);
+    return (int)prl_comb(n, g.n_to_deal);  // 1, n, n (n - 1) / 2 ...; hold'em pre-flop: C(50, 5) = 2 118 760
 }
 // b-th complete board in the reference's enumeration order (:408-417)
 PRL_HD PRL_INLINE void prl_lbr_board_at(const PrlLbrGame& g, const int8_t* pc, int n_pc, int b, int8_t* fb) {
@@ -223,14 +223,70 @@ PRL_HD PRL_INLINE float prl_lbr_reduce_range_cp(const PrlLbrGame& g, const float
     for (int m = 2; m <= g.n_to_deal; ++m) fact = fact * (float)m;
     return win * fact;  // :463-468
 }
+// the same for three to five cards to come (hold'em before the flop): _calc_eq's recursion (:470-512) as an odometer -- at depth l the
+// card probabilities of depth l - 1 with the card just dealt zeroed and re-normalised (NumPy sum over the deck, element-wise division),
+// the reach probability the float32 product of the dealt cards' probabilities in deal order, the boards in lexicographic order of the
+// ascending cards to come. cps: [n_to_deal][n_cards] work floats (level 0 = cp on entry, as prl_lbr_reduce_range_cp).
+PRL_HD PRL_INLINE float prl_lbr_reduce_range_deep(const PrlLbrGame& g, const float* e, float* cps, const int8_t* pc, int n_pc) {
+    const int k = g.n_to_deal, nc = g.n_cards;
+    float* cp = cps;
+    for (int i = 0; i < g.n_hole; ++i) cp[g.lbr_hand[i]] = 0.f;
+    for (int i = 0; i < g.n_dealt; ++i) cp[g.board[i]] = 0.f;
+    {
+        int j = 0;
+        auto nx = [&]() { return cp[j++]; };
+        const float s = prl_np_sum_stream<0>(nc, nx);
+        if (s > 0.f)
+            for (int c = 0; c < nc; ++c) cp[c] = cp[c] / s;
+    }
+    float win = 0.f, reach[PRL_LBR_MAX_DEAL + 1];
+    bool first = true;
+    int idx[PRL_LBR_MAX_DEAL], l = 0, b = 0;
+    idx[0] = 0;
+    reach[0] = 1.f;
+    while (l >= 0) {
+        if (idx[l] > n_pc - (k - l)) {  // this depth has dealt its last card: back up
+            if (--l >= 0) ++idx[l];
+            continue;
+        }
+        const float* cur = cps + (size_t)l * nc;
+        const int card = pc[idx[l]];
+        const float r = l == 0 ? cur[card] : reach[l] * cur[card];  // 1.0 * p at depth 0
+        if (l == k - 1) {
+            const float x = e[b++] * r;
+            win = first ? x : win + x;
+            first = false;
+            ++idx[l];
+            continue;
+        }
+        float* nxt = cps + (size_t)(l + 1) * nc;
+        for (int c = 0; c < nc; ++c) nxt[c] = cur[c];
+        nxt[card] = 0.f;
+        int j = 0;
+        auto nx = [&]() { return nxt[j++]; };
+        const float s = prl_np_sum_stream<0>(nc, nx);
+        for (int c = 0; c < nc; ++c) nxt[c] = nxt[c] / s;
+        reach[l + 1] = r;
+        idx[l + 1] = idx[l] + 1;
+        ++l;
+    }
+    float fact = 1.f;
+    for (int m = 2; m <= k; ++m) fact = fact * (float)m;
+    return win * fact;
+}
 PRL_HD PRL_INLINE float prl_lbr_reduce_range_w(const PrlLbrGame& g, const float* rg, const float* e /* [n_boards] */, float* cp, float* cp2,
                                                const int8_t* pc, int n_pc) {
     for (int c = 0; c < g.n_cards; ++c) cp[c] = prl_lbr_card_not_held(g, rg, c);
     return prl_lbr_reduce_range_cp(g, e, cp, cp2, pc, n_pc);
 }
 PRL_HD PRL_INLINE float prl_lbr_reduce_range(const PrlLbrGame& g, const float* rg, const float* e /* [n_boards] */) {
-    float cp[PRL_LBR_MAX_CARDS], cp2[PRL_LBR_MAX_CARDS];
     int8_t pc[PRL_LBR_MAX_CARDS];
     const int n_pc = prl_lbr_possible_cards(g, pc);
+    if (g.n_to_deal > 2) {
+        float cps[PRL_LBR_MAX_DEAL * PRL_LBR_MAX_CARDS];
+        for (int c = 0; c < g.n_cards; ++c) cps[c] = prl_lbr_card_not_held(g, rg, c);
+        return prl_lbr_reduce_range_deep(g, e, cps, pc, n_pc);
+    }
+    float cp[PRL_LBR_MAX_CARDS], cp2[PRL_LBR_MAX_CARDS];
     return prl_lbr_reduce_range_w(g, rg, e, cp, cp2, pc, n_pc);
 }

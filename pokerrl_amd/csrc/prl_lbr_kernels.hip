@@ -54,7 +54,7 @@ extern "C" int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t*
     if (g.n_hole < 1 || g.n_hole > 2 || g.n_cards > PRL_LBR_MAX_CARDS || g.n_board_total > 5 || (g.n_hole == 2 && (g.n_cards != 52 || g.n_board_total != 5))) {
         prl_set_error("LBR: 1-hole-card games or 52-card hold'em with 5 board cards"); return PRL_ERR_UNSUPPORTED;
     }
-    if (g.n_to_deal < 0 || g.n_to_deal > PRL_LBR_MAX_DEAL) { prl_set_error("LBR equity: at most 2 board cards to come (set lbr_check_to_round)"); return PRL_ERR_UNSUPPORTED; }
+    if (g.n_to_deal < 0 || g.n_to_deal > PRL_LBR_MAX_DEAL) { prl_set_error("LBR equity: at most 5 board cards to come"); return PRL_ERR_UNSUPPORTED; }
     for (int i = 0; i < n_dealt; ++i) g.board[i] = board_dealt[i];
     for (int i = 0; i < g.n_hole; ++i) g.lbr_hand[i] = lbr_hand[i];
     if (g.n_hole == 2 && g.lbr_hand[0] > g.lbr_hand[1]) { int8_t t = g.lbr_hand[0]; g.lbr_hand[0] = g.lbr_hand[1]; g.lbr_hand[1] = t; }
@@ -67,17 +67,24 @@ extern "C" int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t*
         if (!used) pc.push_back((int8_t)c);
     }
     std::vector<int8_t> boards;
-    auto push = [&](int a, int b) {
-        int8_t fb[5] = {0, 0, 0, 0, 0};
-        for (int i = 0; i < n_dealt; ++i) fb[i] = g.board[i];
-        if (a >= 0) fb[n_dealt] = (int8_t)a;
-        if (b >= 0) fb[n_dealt + 1] = (int8_t)b;
-        boards.insert(boards.end(), fb, fb + 5);
-    };
-    if (g.n_to_deal == 0) push(-1, -1);
-    else if (g.n_to_deal == 1) for (size_t i = 0; i < pc.size(); ++i) push(pc[i], -1);
-    else for (size_t i = 0; i + 1 < pc.size(); ++i) for (size_t j = i + 1; j < pc.size(); ++j) push(pc[i], pc[j]);
+    {   // every combination of n_to_deal of the possible cards, lexicographic (what the nested loops of :408-417 produce)
+        const int k = g.n_to_deal, m = (int)pc.size();
+        boards.reserve((size_t)prl_comb(m, k) * 5);
+        int idx[PRL_LBR_MAX_DEAL + 1];
+        for (int i = 0; i < k; ++i) idx[i] = i;
+        for (bool more = k <= m; more;) {
+            int8_t fb[5] = {0, 0, 0, 0, 0};
+            for (int i = 0; i < n_dealt; ++i) fb[i] = g.board[i];
+            for (int i = 0; i < k; ++i) fb[n_dealt + i] = pc[idx[i]];
+            boards.insert(boards.end(), fb, fb + 5);
+            int i = k - 1;
+            while (i >= 0 && idx[i] == m - k + i) --i;
+            if (i < 0) more = false;
+            else { ++idx[i]; for (int j = i + 1; j < k; ++j) idx[j] = idx[j - 1] + 1; }
+        }
+    }
     const int n_boards = (int)(boards.size() / 5);
+    if ((long long)n_q * n_boards > 0x7FFFFFFFll) { prl_set_error("LBR equity: too many (range, board) pairs in one call"); return PRL_ERR_ARG; }
     const uint16_t* hole_lut = nullptr;  // hold'em: the process-wide (c1, c2) table of the hand evaluator
     if (g.n_hole == 2 && prl_hole_lut_device(&hole_lut) != PRL_OK) return PRL_ERR_HIP;
     int8_t* d_boards = nullptr; uint8_t* d_cls = nullptr; float *d_rg = nullptr, *d_eq = nullptr, *d_out = nullptr;
@@ -93,7 +100,8 @@ extern "C" int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t*
     {
         const size_t items = (size_t)g.R;  // first board only
         PRL_LAUNCH(prl_k_lbr_classify, (int)((items + 255) / 256), 256, 0, nullptr, g, (const int8_t*)d_boards, 1, d_cls);
-        PRL_LAUNCH(prl_k_lbr_board_eq, (n_q * n_boards + 63) / 64, 64, 0, nullptr, g, (const int8_t*)d_boards, n_boards, (const uint8_t*)d_cls,
+        const long long items_eq = (long long)n_q * n_boards;
+        PRL_LAUNCH(prl_k_lbr_board_eq, (int)((items_eq + 63) / 64 < 262144 ? (items_eq + 63) / 64 : 262144), 64, 0, nullptr, g, (const int8_t*)d_boards, n_boards, (const uint8_t*)d_cls,
                    (const float*)d_rg, n_q, d_eq, hole_lut);
         PRL_LAUNCH(prl_k_lbr_reduce, (n_q + 63) / 64, 64, 0, nullptr, g, n_boards, (const float*)d_rg, n_q, (const float*)d_eq, d_out);
     }

@@ -124,6 +124,43 @@ def check_equity_kernel(L, tag, extra_random=0, max_to_deal=2):
             assert got[q] == want or (np.isnan(got[q]) and np.isnan(want)), (tag, q, got[q], want)
 
 
+def check_equity_many_cards_to_come(L, n_to_deal, n_ranges, seed=4):
+    """three to five board cards to come (hold'em before the flop = 5: all C(50, 5) run-outs, LocalLBRWorker.py:388-425): the equity
+    kernels' deep reduction against the oracle's restatement of the reference's recursion, on properly prepared agent ranges (LBR's cards
+    and the board removed, normalised -- what LocalLBRWorker hands over)"""
+    import ctypes
+    from oracle.lbr import checkdown_equity
+    from pokerrl_amd.game import games as G
+    rules = G.DiscretizedNLHoldem.native_rules()
+    rs = np.random.RandomState(seed + n_to_deal)
+    cards = rs.choice(52, 2 + 5 - n_to_deal, replace=False)
+    hand, board = np.sort(cards[:2]).astype(np.int8), cards[2:].astype(np.int8)
+    ranges = (rs.random_sample((n_ranges, 1326)) ** 3).astype(np.float32)
+    c1, c2 = np.triu_indices(52, 1)
+    dead = np.isin(c1, list(cards)) | np.isin(c2, list(cards))
+    ranges[:, dead] = 0
+    ranges /= ranges.sum(axis=1, keepdims=True)
+    out = np.zeros(n_ranges, np.float32)
+    assert L.prl_lbr_checkdown_equity(ctypes.byref(rules), board.ctypes.data_as(ctypes.c_void_p), int(board.shape[0]), hand.ctypes.data_as(ctypes.c_void_p),
+                                      ranges.ctypes.data_as(ctypes.c_void_p), n_ranges, out.ctypes.data_as(ctypes.c_void_p)) == 0
+    for q in range(n_ranges):
+        want = checkdown_equity(_rank_fn("DiscretizedNLHoldem"), 2, 52, 5, board, hand, ranges[q])
+        assert out[q] == want and 0.0 < float(out[q]) < 1.0, (n_to_deal, q, out[q], want)
+    return out
+
+
+def test_emu_lbr_equity_three_cards_to_come(emu_lib):
+    check_equity_many_cards_to_come(emu_lib, 3, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_to_deal,n_ranges", [(3, 3), (4, 2), (5, 1)])
+def test_gpu_lbr_equity_before_the_flop(n_to_deal, n_ranges):
+    """5 = a hold'em decision before the flop: 2 118 760 run-outs per range on the device against the oracle (about a minute of NumPy)"""
+    _native.require_device()
+    check_equity_many_cards_to_come(_native.lib(), n_to_deal, n_ranges)
+
+
 def test_lbr_equity_oracle_vs_reference_golden():
     check_equity_oracle_vs_golden("StandardLeduc")
     check_equity_oracle_vs_golden("DiscretizedNLHoldem", max_to_deal=1)  # the flop cases (990 boards) run in the GPU suite
