@@ -124,6 +124,10 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "torch"],
                     help="the all-gather of a sharded run: rccl = ncclAllGather inside the library on the solver's stream (default on GPUs), "
                          "torch = torch.distributed through the C ABI's callback")
+    ap.add_argument("--avg-f32", action="store_true",
+                    help="OPT-IN, not the reference's numerics: CFR+'s running average stored as float32 (PRL_SOLVER_AVG_F32; the float64 one is "
+                         "54 %% of the board pass's HBM traffic). A SECOND bench line beside the default one: config.avg_dtype says so, and "
+                         "config.avg_f32_check compares the average-strategy exploitability of both dtypes over 100 iterations on 4096 boards")
     ap.add_argument("--no-placement-probe", dest="placement_probe", action="store_false",
                     help="one GPU: do not build a second set of arrays to keep the faster-placed one (DESIGN.md section 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -189,7 +193,8 @@ def main():
         solver = _native.NativeSolver(tree, args.variant, 0, shard=(world, rank, exchange, shard_boards, total) if total else (world, rank, exchange), _lib=lib)
     placement = None
     if not sharded:
-        solver = _native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib)
+        avg_dtype = "f32" if args.avg_f32 else "f64"
+        solver = _native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib, avg_dtype=avg_dtype)
         if args.placement_probe and not emu_lib and solver.engine == "fused":
             # The board pass streams within ~10 % of what HBM sustains and its speed depends on WHERE its arrays land physically: solver
             # objects of one process differ by up to 15 %, alternating between two levels ("Spread"). One GPU has room
@@ -201,7 +206,7 @@ def main():
                 return sv.time_iterations(4) / 4.0
             try:
                 ms_a = probe(solver)
-                other = _native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib)
+                other = _native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib, avg_dtype=avg_dtype)
                 ms_b = probe(other)
                 placement = [ms_a, ms_b]
                 if ms_b < ms_a:
@@ -240,6 +245,18 @@ def main():
     barrier()
     avg_eval_ms = (time.perf_counter() - t1) * 1e3 / n_avg
 
+    avg_check = None
+    if args.avg_f32 and rank == 0:  # what the float32 storage costs in accuracy: both dtypes, the same 4096 boards, 100 iterations
+        small = fhp_tree(seeded_boards(4096, 0), lib)
+        ev = {}
+        for dt_ in ("f64", "f32"):
+            sv = _native.NativeSolver(small, "plus", 0, engine="fused", _lib=lib, avg_dtype=dt_)
+            sv.iterations(100)
+            ev[dt_] = float(np.mean(sv.eval_avg()) * 10.0)
+            cur = float(np.mean(sv.exploitability()) * 10.0)
+            del sv
+        avg_check = {"boards": 4096, "iterations": 100, "avg_strategy_exploitability_mbb_per_g_f64": ev["f64"], "avg_strategy_exploitability_mbb_per_g_f32": ev["f32"],
+                     "relative_difference": abs(ev["f32"] - ev["f64"]) / ev["f64"], "current_strategy_exploitability_mbb_per_g_both": cur}
     n_board_nodes = args.boards * 15
     n_nodes_total = (tree.n_nodes - n_board_nodes) + (total * 15 if total else n_board_nodes * world)  # one trunk + every rank's board subtrees
     value = n_nodes_total * args.steps / dt
@@ -260,7 +277,7 @@ def main():
                         " full-width iterations on the Flop5Holdem public tree (blinds 50/100, stacks 20000, "
                         "pot-size raises), %s, 1326-hand ranges" % ("%d boards in all (%d on rank 0)" % (total, args.boards) if total else "%d seeded boards per GPU" % args.boards),
             "boards_per_gpu": args.boards, "nodes_per_gpu": tree.n_nodes, "action_columns_per_gpu": sum_a,
-            "engine": solver.engine,
+            "engine": solver.engine, "avg_dtype": "f32 (opt-in: PRL_SOLVER_AVG_F32; the reference's average is float64)" if args.avg_f32 else "f64", "avg_f32_check": avg_check,
             "parallelism": "boards sharded over %d GPU(s), trunk replicated, 1 all-gather of chance-node partial sums per EV pass" % world,
             "nodes_whole_tree": n_nodes_total, "exchanges": int(solver.get("exchanges")[0]), "exchange": (how if sharded else None),
             "exchange_ms_mean": (exchange.seconds * 1e3 / max(exchange.calls, 1)) if exchange else None,
@@ -271,7 +288,7 @@ def main():
             "placement_probe_ms_per_iteration": placement,  # [first allocation, second allocation]: the faster one was kept (None: not probed)
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION * args.boards if (solver.engine == "fused" and args.variant == "plus") else None,
+                     "traffic": PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION * args.boards if (solver.engine == "fused" and args.variant == "plus" and not args.avg_f32) else None,
                      "traffic_source": PMC_TRAFFIC_SOURCE,
                      "kernel": "prl_k_fhp_pass" if n_pass else "all kernels of the iteration",
                      "launches_per_iteration": n_pass / float(args.steps) if n_pass else None,
@@ -280,7 +297,7 @@ def main():
                      # the PMC-measured bytes over the same kernel time: what the kernel actually pulls through HBM (float64 averages
                      # included), against the ~6.3 TB/s MI355X_MICROARCH.md gives as sustained
                      "traffic_rate_gbps": (PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION * args.boards * args.steps / (kernel_ms * 1e-3) / 1e9)
-                     if (solver.engine == "fused" and args.variant == "plus") else None,
+                     if (solver.engine == "fused" and args.variant == "plus" and not args.avg_f32) else None,
                      "sustained_hbm_gbps": 6300.0,
                      "achieved_whole_iteration": bytes_iter * args.steps / (dev_ms * 1e-3) / 1e9},
     }

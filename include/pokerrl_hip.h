@@ -296,6 +296,13 @@ int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay
  *   FUSED walks each board subtree on chip and only keeps regrets / averages / per-board root values in HBM. */
 enum { PRL_ENGINE_AUTO = 0, PRL_ENGINE_LEVELS = 1, PRL_ENGINE_FUSED = 2 };
 int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out_solver);
+/* Options. PRL_SOLVER_AVG_F32 (opt-in, NOT the reference's numerics): CFR+'s running average strategy of the board columns is STORED as
+ * float32 -- read, widened, blended in float64 with the reference's weights (CFRPlus.py:65-87), rounded on the store. The reference's average
+ * is float64 (a NumPy-2 promotion of its integer weights) and is 54 % of the board pass's HBM traffic; with float32 storage the average
+ * differs from the reference's by one rounding per iteration (bench.py --avg-f32 reports the average-strategy exploitability of both).
+ * Regrets, current strategies and the current-strategy exploitability history are unaffected. Single-deal fused engine, CFR+, no checkpoints. */
+enum { PRL_SOLVER_AVG_F32 = 1 };
+int32_t prl_solver_create_opts(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t flags, prl_solver_t** out_solver);
 /* Sharded solve over `world_size` GPUs, one process per GPU: the tree handed to rank r holds the
  * r-th contiguous block of the global board list (every rank the same number of boards; see _ragged below); the pre-chance trunk is
  * replicated; regrets / averages of a board live on its owner only. The one exchange per EV pass is the pull-up of the

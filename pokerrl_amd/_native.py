@@ -530,7 +530,7 @@ class NativeSolver:
     shard=(world_size, rank, exchange, shard_boards, total_boards): ragged shards -- every rank before the last holds shard_boards
     boards, the last one the rest (prl_solver_create_sharded_ragged)."""
 
-    def __init__(self, tree, variant, delay=0, engine="auto", _lib=None, shard=None):
+    def __init__(self, tree, variant, delay=0, engine="auto", _lib=None, shard=None, avg_dtype="f64"):
         self._L = _lib or tree._L
         if _lib is None and self._L is lib():
             require_device()
@@ -572,7 +572,13 @@ class NativeSolver:
                 check(self._L.prl_solver_create_sharded(tree.handle, v, int(delay), int(world), int(rank), self._exchange_cb, None,
                                                         ctypes.byref(self._h)), self._L)
         elif not self._h:
-            check(self._L.prl_solver_create_ex(tree.handle, v, int(delay), e, ctypes.byref(self._h)), self._L)
+            if avg_dtype == "f32":  # opt-in: the running average stored as float32 (prl_solver_create_opts: PRL_SOLVER_AVG_F32); not the reference's numerics
+                self._L.prl_solver_create_opts.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+                self._L.prl_solver_create_opts.restype = ctypes.c_int32
+                check(self._L.prl_solver_create_opts(tree.handle, v, int(delay), e, 1, ctypes.byref(self._h)), self._L)
+            else:
+                assert avg_dtype == "f64"
+                check(self._L.prl_solver_create_ex(tree.handle, v, int(delay), e, ctypes.byref(self._h)), self._L)
         if shard is not None and hasattr(shard[2], "bind_stream"):
             # a stream-ordered exchange (RCCL under the solver's own stream): no host synchronisation per pass
             sp = ctypes.c_void_p()

@@ -22,7 +22,8 @@
 #include "prl_tree.h"
 
 enum { PRL_SRC_REGRET = 0, PRL_SRC_UNIFORM64 = 1, PRL_SRC_ARR64 = 2, PRL_SRC_ARR32 = 3,
-       PRL_SRC_STRAT32 = 4 /* PrlFhpParams::regret points at float32 STRATEGY columns (regret layout): played as is */ };
+       PRL_SRC_STRAT32 = 4 /* PrlFhpParams::regret points at float32 STRATEGY columns (regret layout): played as is */,
+       PRL_SRC_AVGF32 = 5 /* PrlFhpParams::avg32: the opt-in float32 running average, widened and played with float64 arithmetic like ARR64 */ };
 // UPDATE0 / UPDATE1: that seat's values + regret / average update. EVAL: both seats + best response.
 // UPDATE0_EVAL: EVAL and UPDATE0 of the same strategy in one pass (the evaluation that closes iteration t and the first
 // half of iteration t + 1 read the same regrets).
@@ -172,6 +173,8 @@ struct PrlFhpParams {
     const float* chance_reach;  // [2][R] reach at the chance node (trunk state)
     float* regret;              // [n_cols][R] (global column ids)
     double* avg;                // [n_cols][R] average strategy, updated by the update passes when avg_mode != 0
+    float* avg32;               // opt-in (prl_solver_create_opts: PRL_SOLVER_AVG_F32): the same average STORED as float32 -- read, widened, blended in
+                                // float64 with the reference's weights, rounded on the store; `avg` is not touched by the board pass then
     int32_t avg_mode;           // 0: no update (before the delay), 1: avg = strategy, 2: avg = m_old * avg + m_new * strategy
     double m_old, m_new;        // CFRPlus.py:65-87 weights (float64)
     // Vanilla / Linear CFR: the reach-weighted average of seat q needs q's NEW reach, known only after the trunk update that

@@ -86,7 +86,9 @@ struct prl_solver {
     bool board_avg_f64 = false;
     bool board_avg_stale = false;  // FUSED Vanilla / Linear: avg_sum moved on, the avg columns of the boards have not been recomputed yet
     float* d_regret = nullptr;  // [full_cols][R]
-    double* d_avg = nullptr;    // [full_cols][R]
+    double* d_avg = nullptr;    // [full_cols][R] (avg_f32: the trunk's columns only)
+    float* d_avg32 = nullptr;   // opt-in (PRL_SOLVER_AVG_F32): the board columns' running average stored as float32, [full_cols][R]
+    bool avg_f32 = false;
     long long n_exchanges = 0;  // all-gathers done so far (PRL_SF_EXCHANGES)
     void* rccl_comm = nullptr;  // sharded solve with the library's own exchange (prl_solver_create_sharded_rccl): ncclComm_t
     // ---- per-street fused engine (prl_st.h): `fused` with the board pass replaced by a sweep over the streets ----
@@ -405,6 +407,7 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
     // pending Vanilla / Linear average updates ride on the phase-B walk of that seat (the training state only)
     p.avg_sum = s->S.avg_sum;
     p.avg = s->d_avg;
+    p.avg32 = s->d_avg32;
     p.avgsum_mask = 0;
     // level 0 of the canonical chance sum inside the pass (one row per 32-board block leaves the chip) whenever whole blocks are
     // what comes next: always without an exchange, and with one when the units exchanged are blocks or groups of blocks
@@ -676,7 +679,7 @@ extern "C" {
 
 static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t world, int32_t rank,
                                   prl_exchange_fn exchange, void* exchange_user, prl_solver_t** out, int64_t shard_boards = 0, int64_t total_boards = 0,
-                                  const void* rccl_uid = nullptr) {
+                                  const void* rccl_uid = nullptr, int32_t flags = 0) {
     if (!tree || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
     if (variant < 0 || variant > 2 || delay < 0 || engine < 0 || engine > 2) { prl_set_error("bad variant / delay / engine"); return PRL_ERR_ARG; }
     if (!prl_device_available()) { prl_set_error("no HIP device: the solver has no CPU fallback"); return PRL_ERR_NO_DEVICE; }
@@ -710,6 +713,10 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         fused = true;
     } else if (engine == PRL_ENGINE_AUTO) fused = shape_ok || st_ok;
     streets = fused && !shape_ok;
+    if ((flags & PRL_SOLVER_AVG_F32) && (!fused || streets || variant != PRL_CFR_PLUS)) {
+        prl_set_error("PRL_SOLVER_AVG_F32: the single-deal fused engine with CFR+ only (the variant whose running average the board pass blends)");
+        return PRL_ERR_UNSUPPORTED;
+    }
     if (exchange && !fused) { prl_set_error("sharded solve: FUSED engine only (board / street subtrees of registered shapes, prl_fhp.h, prl_st.h)"); return PRL_ERR_UNSUPPORTED; }
     // the unit a sharded solve splits: the outcomes of the first deal (boards of a single-deal tree, flops of a multi-street one)
     const int n_top = streets ? st_plan.n_top : full.n_boards;
@@ -919,7 +926,11 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
 
     const size_t nc_full = (size_t)full.n_cols * T.R;
     FAIL_IF(dev_alloc(s, &s->d_regret, nc_full));
-    FAIL_IF(dev_alloc(s, &s->d_avg, nc_full));
+    s->avg_f32 = (flags & PRL_SOLVER_AVG_F32) != 0;
+    if (s->avg_f32) {  // float64 for the trunk's few columns (the LEVELS kernels keep the reference's dtype), float32 for the boards'
+        FAIL_IF(dev_alloc(s, &s->d_avg, (size_t)T.n_cols * T.R));
+        FAIL_IF(dev_alloc(s, &s->d_avg32, nc_full));
+    } else FAIL_IF(dev_alloc(s, &s->d_avg, nc_full));
     s->S.regret = s->d_regret;
     s->S.avg = s->d_avg;
     FAIL_IF(dev_alloc(s, &s->S.strategy, (size_t)T.n_cols * T.R));  // FUSED: trunk columns only
@@ -1026,6 +1037,11 @@ int32_t prl_solver_create_sharded_rccl(const prl_tree_t* local_tree, int32_t var
 #endif
 }
 
+int32_t prl_solver_create_opts(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t flags, prl_solver_t** out) {
+    if (flags & ~PRL_SOLVER_AVG_F32) { prl_set_error("unknown solver flag"); return PRL_ERR_ARG; }
+    return solver_create_impl(tree, variant, delay, engine, 1, 0, nullptr, nullptr, out, 0, 0, nullptr, flags);
+}
+
 int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out) {
     return solver_create_impl(tree, variant, delay, engine, 1, 0, nullptr, nullptr, out);
 }
@@ -1062,12 +1078,14 @@ StateLayout state_layout(const prl_solver* s, int iter) {
 
 int32_t prl_solver_state_size(prl_solver_t* s, uint64_t* out) {
     if (!s || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
+    if (s->avg_f32) { prl_set_error("checkpoints: not for solvers with the float32 running average (PRL_SOLVER_AVG_F32)"); return PRL_ERR_UNSUPPORTED; }
     *out = (uint64_t)state_layout(s, s->iter).total;
     return PRL_OK;
 }
 
 int32_t prl_solver_save_state(prl_solver_t* s, void* out, uint64_t bytes) {
     if (!s || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
+    if (s->avg_f32) { prl_set_error("save_state: not for solvers with the float32 running average (PRL_SOLVER_AVG_F32)"); return PRL_ERR_UNSUPPORTED; }
     if (s->user_strategy_f64 >= 0) { prl_set_error("save_state: an explicit strategy is loaded (set_strategy); reset or fill_uniform first"); return PRL_ERR_STATE; }
     TRY(ensure_ev(s));  // closes a pending evaluation / pending average updates, so the blob is a clean iteration boundary
     const StateLayout L = state_layout(s, s->iter);
@@ -1097,6 +1115,7 @@ int32_t prl_solver_load_state(prl_solver_t* s, const void* in, uint64_t bytes) {
     if (!s || !in || bytes < sizeof(PrlStateHeader)) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
     PrlStateHeader h;
     memcpy(&h, in, sizeof(h));
+    if (s->avg_f32) { prl_set_error("load_state: not for solvers with the float32 running average (PRL_SOLVER_AVG_F32)"); return PRL_ERR_UNSUPPORTED; }
     if (h.magic != PRL_STATE_MAGIC || h.version != PRL_STATE_VERSION) { prl_set_error("load_state: not a solver state blob (or one of another library version)"); return PRL_ERR_ARG; }
     if (h.variant != s->variant || h.delay != s->delay || h.fused != (int32_t)s->fused || h.full_cols != s->full_cols || h.R != s->R ||
         h.trunk_cols != s->T.n_cols || h.trunk_nodes != s->T.n_nodes || h.has_avg_sum != (int32_t)(s->S.avg_sum != nullptr) || h.iter < 0) {
@@ -1209,7 +1228,8 @@ int32_t prl_solver_reset(prl_solver_t* s) {
     s->have_half = false;
     s->avg_pending[0] = s->avg_pending[1] = -1;
     PRL_HIP_TRY(hipMemsetAsync(s->d_regret, 0, nc * sizeof(float), s->stream));
-    PRL_HIP_TRY(hipMemsetAsync(s->d_avg, 0, nc * sizeof(double), s->stream));
+    PRL_HIP_TRY(hipMemsetAsync(s->d_avg, 0, (s->avg_f32 ? (size_t)s->T.n_cols * s->R : nc) * sizeof(double), s->stream));
+    if (s->avg_f32) PRL_HIP_TRY(hipMemsetAsync(s->d_avg32, 0, nc * sizeof(float), s->stream));
     PRL_HIP_TRY(hipMemsetAsync(s->S.avg_f64, 0, (size_t)s->T.n_nodes, s->stream));
     if (s->S.avg_sum) PRL_HIP_TRY(hipMemsetAsync(s->S.avg_sum, 0, nc * sizeof(float), s->stream));
     s->board_avg_f64 = false; s->board_avg_stale = false;
@@ -1640,8 +1660,15 @@ int32_t prl_solver_eval_avg(prl_solver_t* s, float* out2) {
     E.regret = nullptr; E.avg = nullptr; E.avg_sum = nullptr; E.avg_f64 = nullptr;
     TRY(do_update_reach(s, E));
     if (s->fused) {
-        const int src = s->board_avg_f64 ? PRL_SRC_ARR64 : PRL_SRC_ARR32;
-        TRY(fused_board_pass(s, E, PRL_FHP_EVAL, src, src, s->d_avg));
+        if (s->avg_f32) {
+            // float32 storage: a blended average is widened and played with float64 arithmetic (what ARR64 does with the float64 one); before
+            // the first blend the average IS a float32 strategy: played as is, float32 arithmetic (what ARR32 does)
+            const int src = s->board_avg_f64 ? PRL_SRC_AVGF32 : PRL_SRC_STRAT32;
+            TRY(fused_board_pass(s, E, PRL_FHP_EVAL, src, src, nullptr, s->board_avg_f64 ? nullptr : s->d_avg32));
+        } else {
+            const int src = s->board_avg_f64 ? PRL_SRC_ARR64 : PRL_SRC_ARR32;
+            TRY(fused_board_pass(s, E, PRL_FHP_EVAL, src, src, s->d_avg));
+        }
     }
     prl_launch_ev(s->T, E, s->ft.level_start.data(), s->d_term_nodes, s->n_term, s->stream);
     PRL_HIP_TRY(hipGetLastError());
@@ -1656,7 +1683,9 @@ int32_t prl_solver_get_cols(prl_solver_t* s, int32_t field, int64_t col_begin, i
     size_t elem = 0;
     switch (field) {
         case PRL_SF_REGRET: src = (const char*)s->d_regret; elem = 4; break;
-        case PRL_SF_AVG: TRY(ensure_board_avg(s)); src = (const char*)s->d_avg; elem = 8; break;
+        case PRL_SF_AVG:
+            if (s->avg_f32) { prl_set_error("get_cols(AVG): the average is stored as float32 in this solver; use prl_solver_get"); return PRL_ERR_UNSUPPORTED; }
+            TRY(ensure_board_avg(s)); src = (const char*)s->d_avg; elem = 8; break;
         case PRL_SF_AVG_SUM: src = (const char*)s->S.avg_sum; elem = 4; break;
         default: prl_set_error("get_cols: REGRET, AVG or AVG_SUM"); return PRL_ERR_ARG;
     }
@@ -1718,7 +1747,18 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
             src = s->S.strategy; bytes = nc * 8; break;
         case PRL_SF_STRAT_F64: src = s->S.strat_f64; bytes = (size_t)s->T.n_nodes; break;
         case PRL_SF_REGRET: src = s->d_regret; bytes = nc * 4; break;
-        case PRL_SF_AVG: TRY(ensure_board_avg(s)); src = s->d_avg; bytes = nc * 8; break;
+        case PRL_SF_AVG:
+            if (s->avg_f32) {  // trunk columns float64, board columns float32 widened (exact)
+                const size_t nt = (size_t)s->T.n_cols * s->R;
+                std::vector<float> f(nc - nt);
+                PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+                PRL_HIP_TRY(hipMemcpy(out, s->d_avg, nt * 8, hipMemcpyDeviceToHost));
+                PRL_HIP_TRY(hipMemcpy(f.data(), s->d_avg32 + nt, (nc - nt) * 4, hipMemcpyDeviceToHost));
+                double* o = (double*)out + nt;
+                for (size_t i = 0; i < nc - nt; ++i) o[i] = (double)f[i];
+                return PRL_OK;
+            }
+            TRY(ensure_board_avg(s)); src = s->d_avg; bytes = nc * 8; break;
         case PRL_SF_AVG_F64: src = s->S.avg_f64; bytes = (size_t)s->T.n_nodes; break;
         case PRL_SF_AVG_SUM: src = s->S.avg_sum; bytes = nc * 4; break;
         case PRL_SF_BR_IDX: TRY(ensure_ev(s)); src = s->S.br_idx; bytes = (size_t)s->T.n_nodes * s->T.R * 4; break;

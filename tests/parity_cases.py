@@ -455,3 +455,35 @@ def check_streets_vs_oracle(L, game_cls, stack, runouts, variant, n_iters, delay
             if it > delay:
                 assert np.array_equal(s.eval_avg(), o.eval_avg()), it
     return t, s, o
+
+
+def check_fused_avg_f32(L, n_boards, n_iters):
+    """PRL_SOLVER_AVG_F32 (opt-in): the board columns' running average stored as float32. Everything else -- regrets, strategies, the
+    current-strategy exploitability history -- stays bit-exact to the oracle; the average equals the reference's recurrence with one rounding
+    per iteration (restated here from the oracle's strategies: avg32 <- float32(m_old * float64(avg32) + m_new * strategy), CFRPlus.py:65-87);
+    the trunk's columns stay float64 = the oracle's; the average-strategy exploitability stays within 1e-5 relative of the float64 one."""
+    boards = fhp_boards(n_boards)
+    args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
+    t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
+    s = _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L, avg_dtype="f32")
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, 2, 52, 4, 2)
+    o.cfr_reset(1, 0)
+    nt = t.n_cols - 14 * n_boards
+    a32 = np.zeros((t.n_cols - nt, t.range_size), np.float32)
+    for it in range(n_iters):
+        s.iteration()
+        o.cfr_iteration()
+        strat = np.asarray(o.strategy)[nt:]
+        if it == 0:
+            a32 = strat.astype(np.float32)
+        else:
+            cw, nw = sum(range(1, it + 1)), it + 1
+            a32 = (cw / (cw + nw) * a32.astype(np.float64) + nw / (cw + nw) * strat).astype(np.float32)
+        assert np.array_equal(s.get("regret"), np.asarray(o.regret)), it
+        assert np.array_equal(s.exploitability(), o.exploitability), it
+        avg = s.get("avg")
+        assert np.array_equal(avg[:nt], np.asarray(o.avg)[:nt]), (it, "trunk average")
+        assert np.array_equal(avg[nt:], a32.astype(np.float64)), (it, "board average: float32 recurrence")
+        e32, e64 = s.eval_avg(), o.eval_avg()
+        assert np.allclose(e32, e64, rtol=1e-5, atol=0), (it, e32, e64)
+    return s.eval_avg(), o.eval_avg()

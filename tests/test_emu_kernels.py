@@ -119,6 +119,11 @@ def test_emu_fused_engine_block_sums_across_a_block_boundary(L, monkeypatch):
     pc.check_fused_batched_vs_oracle(L, 33, 2, delay=0)
 
 
+def test_emu_fused_engine_float32_running_average_opt_in(L):
+    """PRL_SOLVER_AVG_F32: generic and steady-state instantiations of the update passes with the average stored as float32"""
+    pc.check_fused_avg_f32(L, 3, 4)
+
+
 @pytest.mark.parametrize("no_steady", [False, True])
 def test_emu_fused_engine_steady_state_specialisation(L, monkeypatch, no_steady):
     """CFR+ delay 0, batched: iterations 2.. run the steady-state instantiation of the two update passes (prl_fhp_pass.inc, FhpCtxT);

@@ -304,6 +304,12 @@ def test_gpu_fused_steady_state_specialisation_vs_oracle(L, monkeypatch, no_stea
     pc.check_fused_batched_vs_oracle(L, 300, 5, delay=0)
 
 
+def test_gpu_fused_float32_running_average_opt_in(L):
+    """PRL_SOLVER_AVG_F32 (opt-in, bench.py --avg-f32): regrets / current exploitability bit-exact to the oracle, the average = the float32
+    recurrence, its exploitability within 1e-5 of the float64 one; 600 boards, 6 iterations (several boards per CU, the steady-state kernels)"""
+    pc.check_fused_avg_f32(L, 600, 6)
+
+
 def test_gpu_fused_vs_levels_2048_boards(L):
     """2048 boards = 64 canonical chance blocks = 2 groups: both engines of the library must agree bit for bit."""
     pc.check_fused_vs_levels(L, 2048, 6)
