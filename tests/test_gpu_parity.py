@@ -364,6 +364,34 @@ def test_gpu_fused_bench_size_vs_oracle_fixture(L):
     assert s.sha256_of("avg") == str(g["avg_sha256"])
 
 
+def test_gpu_fused_br_bench_size_vs_oracle_fixture(L):
+    """bench_br.py's workload at full size (65536 boards, rank 0's board list and seeded float32 strategy) against the ORACLE's chunked
+    evaluation (tests/golden/make_fhp_br_golden_chunked.py; equals the one-piece oracle at 2048 boards): both seats' exploitability."""
+    import os
+    import bench
+    import bench_br
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    from helpers import GOLDEN, h32, native_tree
+    path = os.path.join(GOLDEN, "fhp_br_65536_chunked.npz")
+    if not os.path.isfile(path):
+        pytest.skip("fixture not generated (tests/golden/make_fhp_br_golden_chunked.py)")
+    g = np.load(path)
+    n_boards = int(g["n_boards"])
+    boards = bench.seeded_boards(n_boards, int(g["board_seed"]))
+    assert h32(boards) == str(g["boards_sha256"])
+    t = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)
+    strat = bench_br.seeded_strategy(t.n_cols - 14 * n_boards, n_boards, t.range_size, int(g["strategy_seed"]))
+    assert h32(strat) == str(g["strategy_sha256"])
+    s = _native.NativeSolver(t, "plus", 0, engine="fused")
+    s.set_strategy(strat)
+    s.compute_ev()
+    assert np.array_equal(s.exploitability(), g["exploitability"]), (s.exploitability(), g["exploitability"])
+    s.time_evaluations(2)  # the timed entry point of bench_br.py runs the same pass
+    assert np.array_equal(s.exploitability(), g["exploitability"])
+
+
 def test_gpu_fused_properties_at_bench_size(L):
     """bench.py's workload at full size (262144 boards, 71 GB) on the fused engine: the size-independent properties the engine
     exposes at that size -- exploitability of the current and of the average strategy positive and falling, the closing
