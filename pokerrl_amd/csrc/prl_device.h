@@ -68,6 +68,10 @@ PRL_DEV PRL_INLINE void prl_lds_dma_dword(const void* gbase, uint32_t byte_off, 
 }
 PRL_DEV PRL_INLINE void prl_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 PRL_DEV PRL_INLINE int prl_opaque_scalar(int v) { asm volatile("" : "+s"(v)); return v; }  // hides a wave-uniform value's history from the optimiser
+// the same for a per-lane value: what is computed from the result cannot be hoisted out of a loop or shared with other uses (the compiler
+// otherwise precomputes every loop-invariant LDS address of the pass before the loop and SPILLS them: 24 scratch reloads per instance, each
+// with a full s_waitcnt vmcnt(0), on the 27-node shape; profiles/r05_experiments.txt)
+PRL_DEV PRL_INLINE int prl_opaque_lane(int v) { asm volatile("" : "+v"(v)); return v; }
 PRL_DEV PRL_INLINE int prl_wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }  // v is the same in every lane: keep it scalar
 PRL_DEV PRL_INLINE char* prl_smem() {
     extern __shared__ __attribute__((aligned(16))) char prl_dyn_smem[];

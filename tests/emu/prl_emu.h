@@ -55,6 +55,7 @@ inline void prl_lds_dma_x4_a(const void* gbase, uint32_t byte_off, uint32_t lds_
 inline void prl_dma_wait() {}
 inline int prl_wave_uniform(int v) { return v; }
 inline int prl_opaque_scalar(int v) { return v; }
+inline int prl_opaque_lane(int v) { return v; }
 inline char* prl_smem() { return prl_emu::g_ctx->smem; }
 
 inline float prl_shfl(float v, int src_lane) {
