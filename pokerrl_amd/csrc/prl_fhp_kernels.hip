@@ -217,6 +217,7 @@ void prl_launch_fhp_chance_finish(const float* d_units, int n_units, int level, 
     int n = n_units;
     float* next = d_scratch;
     for (int l = level; l < 2; ++l) {
+        if (n <= PRL_CHANCE_BLOCK) break;  // one block: the remaining levels would copy its sum (a multi-street tree with a handful of flops)
         const int n_out = (n + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
         PRL_LAUNCH(prl_k_fhp_sum_level, fhp_grid_for((size_t)n_out * R2, 256), 256, 0, stream, cur, n, PRL_CHANCE_BLOCK, R2, next);
         cur = next;

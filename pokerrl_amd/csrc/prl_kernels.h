@@ -9,9 +9,11 @@ void prl_launch_hand_rank_boards(const int8_t* d_boards, int n_boards, const uin
 struct PrlDevTree;
 struct PrlDevState;
 void prl_launch_fill_uniform(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_col_node, void* stream);
-void prl_launch_reach(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, void* stream);
+void prl_launch_reach(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, void* stream, bool root_is_set = false);
+void prl_launch_terminals(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_term_nodes, int n_term, void* stream);
+void prl_launch_ev_levels(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, void* stream, float* d_expl_copy = nullptr);
 void prl_launch_ev(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, const int32_t* d_term_nodes, int n_term,
-                   void* stream);
+                   void* stream, float* d_expl_copy = nullptr);
 void prl_launch_regret_strategy(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, int iter,
                                 void* stream);
 void prl_launch_average(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, int iter, int mode,

@@ -46,6 +46,8 @@ struct prl_solver {
     int32_t* d_col_node = nullptr;
     int variant = PRL_CFR_PLUS, delay = 0, iter = 0;
     bool ev_valid = false;    // S.ev / S.ev_br / S.expl correspond to the current strategy + reach
+    bool root_reach_set[2] = {false, false};  // the root's reach (a constant) is in place: S / any other state
+    float* expl_copy_dst = nullptr;  // where the next evaluation's exploitability goes besides S.expl (its slot of the history)
     float* d_expl_hist = nullptr;  // [cap][2] current-strategy exploitability after every iteration
     int hist_cap = 0;
     size_t bytes_allocated = 0;
@@ -97,7 +99,6 @@ struct prl_solver {
     PrlStParams sp{};                  // what every street launch shares (plans, sizes)
     struct StLevelDev { PrlStInst* inst = nullptr; float* leaf_reach = nullptr; float* val = nullptr; } st_dev[PRL_ST_MAX_LEVELS];
     int32_t* d_trunk_leaves = nullptr; // trunk ids of the trunk's chance leaves
-    float* d_trunk_reach = nullptr;    // [n_leaves][2][R] their reach, gathered for the street-1 kernels
     int n_trunk_leaves = 1;
     std::vector<int32_t> col_dfs;      // internal column -> flat-tree (DFS) column; empty = identity (every other engine)
 };
@@ -271,7 +272,9 @@ float eq_const_f32(int n_cards, int n_hole) {
 }
 
 int do_update_reach(prl_solver* s, const PrlDevState& st) {
-    prl_launch_reach(s->T, st, s->ft.level_start.data(), s->stream);
+    bool& root_set = &st == &s->S ? s->root_reach_set[0] : s->root_reach_set[1];  // (any other state: the scratch state of the average's evaluation)
+    prl_launch_reach(s->T, st, s->ft.level_start.data(), s->stream, root_set && &st == &s->S);
+    root_set = true;
     PRL_HIP_TRY(hipGetLastError());
     return PRL_OK;
 }
@@ -323,17 +326,16 @@ int street_sweep(prl_solver* s, const PrlDevState& st, int mode, int src0, int s
     }
     const int L = s->st.n_levels, R = p.R, NL0 = s->n_trunk_leaves;
     const int width = prl_fhp_out_width(mode);
-    prl_launch_st_gather_trunk_reach(st.reach, s->d_trunk_leaves, NL0, R, s->d_trunk_reach, s->stream);
     auto level_params = [&](int lv) {
         PrlStParams q = p;
         const PrlStLevelHost& H = s->st.level[lv];
         q.n_inst = H.n_inst; q.col_base = H.col_base; q.inst = s->st_dev[lv].inst;
-        q.parent_reach = lv == 0 ? s->d_trunk_reach : s->st_dev[lv - 1].leaf_reach;
+        q.parent_reach = lv == 0 ? st.reach : s->st_dev[lv - 1].leaf_reach;  // (node-major [n_nodes][2][R]: prl_vidx)
         q.leaf_reach = s->st_dev[lv].leaf_reach;
         q.child_val = lv + 1 < L ? s->st_dev[lv + 1].val : nullptr;
         q.child_w = width;
         q.val = s->st_dev[lv].val;
-        if (!H.last) q.timing = nullptr;  // (PRL_ST_TIMING builds clock the last street's pass)
+        if (H.last == (getenv("PRL_ST_TIMING_INNER") != nullptr)) q.timing = nullptr;  // (PRL_ST_TIMING builds clock the last street's pass, or the others')
         return q;
     };
     for (int lv = 0; lv + 1 < L; ++lv) {
@@ -503,7 +505,8 @@ int do_compute_ev(prl_solver* s, const PrlDevState& st, int fused_mode = PRL_FHP
         }
         TRY(fused_board_pass(s, st, fused_mode, s0, s1, arr, arr32));
     }
-    prl_launch_ev(s->T, st, s->ft.level_start.data(), s->d_term_nodes, s->n_term, s->stream);
+    prl_launch_ev(s->T, st, s->ft.level_start.data(), s->d_term_nodes, s->n_term, s->stream, &st == &s->S ? s->expl_copy_dst : nullptr);
+    if (&st == &s->S) s->expl_copy_dst = nullptr;
     PRL_HIP_TRY(hipGetLastError());
     return PRL_OK;
 }
@@ -524,6 +527,13 @@ int ensure_hist(prl_solver* s, int need) {
     if (s->d_expl_hist && s->hist_cap) PRL_HIP_TRY(hipMemcpyAsync(q, s->d_expl_hist, (size_t)s->hist_cap * 2 * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
     s->d_expl_hist = q;  // the old block stays in `allocs` and is released with the solver
     s->hist_cap = cap;
+    return PRL_OK;
+}
+
+// the evaluation that follows writes its exploitability into slot `iter` of the history itself (no separate copy)
+int expl_to_history(prl_solver* s) {
+    TRY(ensure_hist(s, s->iter + 1));
+    s->expl_copy_dst = s->d_expl_hist + (size_t)s->iter * 2;
     return PRL_OK;
 }
 
@@ -941,9 +951,14 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     if (streets) {  // per street: instance table, leaf reach (not on the last street), one row of <= 4 root vectors per instance
         s->n_trunk_leaves = (int)st_leaf_ids.size();
         FAIL_IF(dev_upload(s, (const int32_t**)&s->d_trunk_leaves, st_leaf_ids));
-        FAIL_IF(dev_alloc(s, &s->d_trunk_reach, (size_t)s->n_trunk_leaves * 2 * T.R));
         for (int lv = 0; lv < s->st.n_levels; ++lv) {
             const PrlStLevelHost& H = s->st.level[lv];
+            if (lv == 0) {
+                // first street: an instance's root reach is read straight from the trunk's reach array (row = the trunk id of its chance leaf)
+                std::vector<PrlStInst> inst0 = H.inst;
+                for (PrlStInst& in : inst0) in.parent_slot = st_leaf_ids[in.parent_slot];
+                FAIL_IF(dev_upload(s, (const PrlStInst**)&s->st_dev[lv].inst, inst0));
+            } else
             FAIL_IF(dev_upload(s, (const PrlStInst**)&s->st_dev[lv].inst, H.inst));
             if (!H.last) FAIL_IF(dev_alloc(s, &s->st_dev[lv].leaf_reach, (size_t)H.n_inst * H.n_leaves * 2 * T.R));
             FAIL_IF(dev_alloc(s, &s->st_dev[lv].val, (size_t)H.n_inst * 4 * T.R));
@@ -1338,13 +1353,13 @@ static int iteration_core(prl_solver* s, bool closing_eval) {
             if (p == 0 && s->expl_pending && s->have_half) {
                 // seat 0's half of the previous iterate's exploitability rides on this pass; seat 1's half was computed
                 // by the pass that updated seat 1
+                TRY(expl_to_history(s));
                 TRY(do_compute_ev(s, s->S, PRL_FHP_UPDATE0_BR));
-                TRY(record_expl(s));
                 s->expl_pending = false;
                 s->have_half = false;
             } else if (p == 0 && s->expl_pending) {  // the evaluation that closes the previous iteration rides on this pass
+                TRY(expl_to_history(s));
                 TRY(do_compute_ev(s, s->S, PRL_FHP_UPDATE0_EVAL));
-                TRY(record_expl(s));
                 s->expl_pending = false;
             } else if (p == 1 && steady) {
                 TRY(do_compute_ev(s, s->S, PRL_FHP_UPDATE1_EVAL1));

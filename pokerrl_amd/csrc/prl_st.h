@@ -98,7 +98,6 @@ int prl_st_build(const PrlFlatTree& t, long long top_weight_children, PrlStPlanH
 int prl_launch_st_down(int spec, const PrlStParams& prm, int src0, int src1, void* stream);
 int prl_launch_st_pass(int spec, bool last, const PrlStParams& prm, int mode, int src0, int src1, void* stream);
 // trunk glue: reach of the trunk's chance leaves -> [n_leaves][2][R]; summed street-1 rows -> the trunk's leaf nodes
-void prl_launch_st_gather_trunk_reach(const float* d_reach, const int32_t* d_leaf_nodes, int n_leaves, int R, float* d_out, void* stream);
 struct PrlStScatter {  // copies out of a summed row of n_vec vectors: vector src_vec[d] -> array dst_arr[d] (0 ev, 1 ev_br, 2 half buffer), seat / slot dst_seat[d]
     int32_t n_vec, n_dst;
     int32_t src_vec[6], dst_arr[6], dst_seat[6];

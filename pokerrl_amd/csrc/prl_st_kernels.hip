@@ -38,19 +38,6 @@ int prl_launch_st_pass(int spec, bool last, const PrlStParams& prm, int mode, in
 // ---------------------------------------------------------------------------------------------------------------------------------
 // trunk glue
 // ---------------------------------------------------------------------------------------------------------------------------------
-// reach of the trunk's chance leaves (LEVELS state, [n_nodes][2][R]) -> the street-1 kernels' parent_reach [n_leaves][2][R]
-PRL_GLOBAL void prl_k_st_gather_trunk_reach(const float* __restrict__ reach, const int32_t* __restrict__ leaf_nodes, int n_leaves, int R, float* __restrict__ out) {
-    const int total = n_leaves * 2 * R;
-    for (int t = (int)(prl_bid() * prl_nthreads() + prl_tid()); t < total; t += (int)(prl_nblocks() * prl_nthreads())) {
-        const int j = t / (2 * R), x = t % (2 * R);
-        out[t] = reach[(size_t)leaf_nodes[j] * 2 * R + x];
-    }
-}
-void prl_launch_st_gather_trunk_reach(const float* d_reach, const int32_t* d_leaf_nodes, int n_leaves, int R, float* d_out, void* stream) {
-    const int total = n_leaves * 2 * R;
-    PRL_LAUNCH(prl_k_st_gather_trunk_reach, (total + 255) / 256, 256, 0, stream, d_reach, d_leaf_nodes, n_leaves, R, d_out);
-}
-
 // the canonical sum over the first deal's outcomes, one row [n_leaves][n_vec][R], to where the trunk's kernels read a leaf's values:
 // copy d takes vector src_vec[d] of leaf j to ev / ev_br of that leaf's node (seat dst_seat[d]) or to the "half" buffer
 // [n_leaves][2][R] (slot dst_seat[d])

@@ -461,6 +461,12 @@ PRL_GLOBAL void prl_k_terminal_1card(PrlDevTree T, PrlDevState S, const int32_t*
 }
 PRL_GLOBAL void prl_k_ev_level(PrlDevTree T, PrlDevState S, int level_begin, int level_count) { prl_ev_level_body(T, S, level_begin, level_count); }
 PRL_GLOBAL void prl_k_exploitability(PrlDevTree T, PrlDevState S, float* out2) { prl_exploitability_body(T, S, out2); }
+// the same, the result also to a second place (the solver's history slot: no separate 8-byte copy on a launch-bound trunk)
+PRL_GLOBAL void prl_k_exploitability2(PrlDevTree T, PrlDevState S, float* out2, float* out2b) {
+    prl_exploitability_body(T, S, out2);
+    prl_sync();
+    if (prl_tid() < 2) out2b[prl_tid()] = out2[prl_tid()];
+}
 PRL_GLOBAL void prl_k_regret_strategy(PrlDevTree T, PrlDevState S, const int32_t* __restrict__ nodes, int n_nodes_p, int p, int variant, int iter) {
     prl_regret_strategy_body(T, S, nodes, n_nodes_p, p, variant, iter);
 }
@@ -626,16 +632,15 @@ void prl_launch_fill_uniform(const PrlDevTree& T, const PrlDevState& S, const in
     PRL_LAUNCH(prl_k_fill_uniform, prl_grid_for((size_t)T.n_cols * T.R, 256), 256, 0, stream, T, S, d_col_node);
 }
 
-void prl_launch_reach(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, void* stream) {
-    PRL_LAUNCH(prl_k_reach_root, 1, 256, 0, stream, T, S);
+void prl_launch_reach(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, void* stream, bool root_is_set) {
+    if (!root_is_set) PRL_LAUNCH(prl_k_reach_root, 1, 256, 0, stream, T, S);  // the root's reach is a constant: written once per state
     for (int d = 1; d < T.n_levels; ++d) {
         int cnt = h_level_start[d + 1] - h_level_start[d];
         if (cnt > 0) PRL_LAUNCH(prl_k_reach_level, prl_grid_for((size_t)cnt * T.R, 256), 256, 0, stream, T, S, h_level_start[d], cnt);
     }
 }
 
-void prl_launch_ev(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, const int32_t* d_term_nodes, int n_term,
-                   void* stream) {
+void prl_launch_terminals(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_term_nodes, int n_term, void* stream) {
     if (n_term > 0) {
         if (T.n_hole == 1) {
             PRL_LAUNCH(prl_k_terminal_1card, prl_grid_for((size_t)n_term * 2 * T.R, 256), 256, 0, stream, T, S, d_term_nodes, n_term);
@@ -644,12 +649,24 @@ void prl_launch_ev(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_l
             PRL_LAUNCH(prl_k_terminal_2card, 2 * n_term < 65536 ? 2 * n_term : 65536, 256, smem, stream, T, S, d_term_nodes, n_term);
         }
     }
+}
+
+// values bottom-up once the terminals (and a fused engine's chance leaves) hold theirs, and the root exploitability
+void prl_launch_ev_levels(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, void* stream, float* d_expl_copy) {
     for (int d = T.n_levels - 2; d >= 0; --d) {
         int cnt = h_level_start[d + 1] - h_level_start[d];
         if (cnt > 0) PRL_LAUNCH(prl_k_ev_level, prl_grid_for((size_t)cnt * T.R, 256), 256, 0, stream, T, S, h_level_start[d], cnt);
     }
+    // (the root's level inside the exploitability kernel was measured: 31 us for that launch against 6 + 10 for the two; profiles/r05_experiments.txt)
     size_t smem = T.n_hole == 1 ? 0 : ((size_t)PRL_T2_YPAD + (PRL_T2_YPAD + 8) + 64 + 64) * sizeof(float);
-    PRL_LAUNCH(prl_k_exploitability, 1, 256, smem, stream, T, S, S.expl);
+    if (d_expl_copy) PRL_LAUNCH(prl_k_exploitability2, 1, 256, smem, stream, T, S, S.expl, d_expl_copy);
+    else PRL_LAUNCH(prl_k_exploitability, 1, 256, smem, stream, T, S, S.expl);
+}
+
+void prl_launch_ev(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, const int32_t* d_term_nodes, int n_term,
+                   void* stream, float* d_expl_copy) {
+    prl_launch_terminals(T, S, d_term_nodes, n_term, stream);
+    prl_launch_ev_levels(T, S, h_level_start, stream, d_expl_copy);
 }
 
 void prl_launch_regret_strategy(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, int iter,

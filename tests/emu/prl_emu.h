@@ -134,6 +134,9 @@ struct prl_emu_event { double t; };
 double prl_emu_now_ms();
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new prl_emu_event{0}; return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+enum { hipEventDisableTiming = 2 };
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = prl_emu_now_ms(); return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }  // launches are synchronous here
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }

@@ -82,9 +82,12 @@ def test_emu_fused_engine_twentyone_node_board_subtree(L):
 
 
 def test_emu_unregistered_board_subtree_falls_back_to_levels(L):
+    """four post-flop raises = the 27-node shape, which only the per-street engine instantiates: a single-deal tree is one street to it;
+    five raises (with stacks that allow them) match no registered shape: level-synchronous engine, and asking for the fused one is an error"""
     from pokerrl_amd import _native
     from pokerrl_amd.game import games as G
-    t = _native.NativeTree(pc.fhp_game(20000, flop_raises=4), G.Flop5Holdem.native_rules(), pc.fhp_boards(3), _lib=L)
+    pc.check_fused_vs_oracle(L, 3, 2, flop_raises=4, nodes_per_board=27)
+    t = _native.NativeTree(pc.fhp_game(200000, flop_raises=5), G.Flop5Holdem.native_rules(), pc.fhp_boards(3), _lib=L)  # 33 nodes per board
     assert _native.NativeSolver(t, "plus", 0, engine="auto", _lib=L).engine == "levels"
     with pytest.raises(_native.NativeError):
         _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
