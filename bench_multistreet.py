@@ -22,6 +22,11 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# HBM bytes of the last street's two steady-state passes per CFR+ iteration and action column, from the PMC counters on the default tree (235 872
+# last-street columns): (2 x 1.267e6 + 2.047e6) + (2 x 1.496e6 + 2.042e6) KB per launch pair = 9.615 GB
+PMC_TRAFFIC_BYTES_PER_LAST_STREET_COLUMN = 9.615e9 / 235872
+PMC_TRAFFIC_SOURCE = ("profiles/r05k_multistreet_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per "
+                      "MI355X_MICROARCH.md), scaled by the last street's action columns")
 
 
 def runouts(n_flops, n_turns, n_rivers, seed=9):
@@ -99,7 +104,8 @@ def main():
                    "action_columns_last_street": cols_last, "board_rows": int(tree.n_boards), "tree_build_s": t_tree,
                    "device_ms_per_iteration": dev_ms / args.steps, "exploitability_chips": float(np.mean(expl)), "iterations_done": s.iter,
                    "hbm_bytes_allocated": int(s.get("bytes_allocated")[0])},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": PMC_TRAFFIC_BYTES_PER_LAST_STREET_COLUMN * cols_last if fused else None, "traffic_source": PMC_TRAFFIC_SOURCE,
                      "kernel": "prl_k_st_pass<last street>" if fused else "all kernels of the iteration",
                      "launches_per_iteration": n_pass / float(args.steps) if fused else None,
                      "kernel_ms_per_iteration": (pass_ms if fused else dev_ms) / args.steps,
