@@ -85,10 +85,14 @@ def lib():
         # PyTorch-ROCm ships its own HIP runtime. Whichever HIP runtime a process initialises first owns the GPU for that process:
         # with this library loaded first, a later `import torch` finds "No HIP GPUs" (seen on the MI355X box). Neural agents and
         # torch.distributed (RCCL) live in the same process as the solver, so torch goes first whenever it is installed.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        # (POKERRL_AMD_NO_TORCH_PRELOAD=1 skips this for purely tabular use; a torch that fails to import must not take this package down.)
+        if os.environ.get("POKERRL_AMD_NO_TORCH_PRELOAD", "0") in ("", "0"):
+            try:
+                import torch  # noqa: F401
+            except Exception as e:  # ImportError, or OSError / RuntimeError of a broken install
+                if not isinstance(e, ImportError):
+                    import warnings
+                    warnings.warn("pokerrl_amd: `import torch` failed (%s: %s); continuing without it" % (type(e).__name__, e))
         _lib = bind(LIB_PATH)
     return _lib
 

@@ -748,8 +748,16 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         uint64_t h = 1469598103934665603ull;
         auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
         mix(full.boards.data(), full.boards.size());
-        mix(&full.game, sizeof(full.game));
-        mix(&full.rules, sizeof(full.rules));
+        // the meaningful fields only: array tails past n_rounds / n_bet_sizes are whatever the caller's memory held (both structs are all
+        // 4- / 8-byte fields without padding); zero-initialised descriptions hash as before
+        PrlGame g = full.game;
+        PrlRules r = full.rules;
+        for (int i = g.n_rounds < 0 ? 0 : g.n_rounds; i < 4; ++i) g.max_raises[i] = 0;
+        for (int i = g.n_bet_sizes < 0 ? 0 : g.n_bet_sizes; i < PRL_MAX_BET_SIZES; ++i) g.bet_fracs[i] = 0.;
+        for (int i = r.n_rounds < 0 ? 0 : r.n_rounds; i < 4; ++i) r.board_cards_in_round[i] = 0;
+        static_assert(sizeof(PrlGame) == 18 * 4 + 8 * PRL_MAX_BET_SIZES && sizeof(PrlRules) == 13 * 4, "no padding in the hashed descriptions");
+        mix(&g, sizeof(g));
+        mix(&r, sizeof(r));
         const int32_t wr[2] = {world, rank};
         mix(wr, sizeof(wr));
         s->fingerprint = h;

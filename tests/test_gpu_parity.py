@@ -183,6 +183,14 @@ def test_gpu_streets_engine_limit_holdem_full_betting_vs_oracle(L, variant, batc
     assert t.n_nodes > 60000
 
 
+@pytest.mark.parametrize("variant,max_raises", [("plus", (1, 1, 1, 1)), ("linear", (2, 2, 2, 2)), ("plus", (3, 3, 3, 3)), ("vanilla", (1, 2, 3, 4))])
+def test_gpu_streets_engine_other_street_shapes_vs_oracle(L, variant, max_raises):
+    """the per-street engine's other registered street subtrees (9 / 15 / 21 nodes: one, two, three raises per round) and a game whose streets
+    differ in shape (1, 2, 3, 4 raises: 9-, 15-, 21- and 27-node streets in one tree), 2 flops x 2 turns x 2 rivers, batched iterations"""
+    from pokerrl_amd.game import games as G
+    pc.check_streets_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(2, 2, 2), variant, 3, max_raises=max_raises, batched=True)
+
+
 def test_gpu_streets_engine_vs_levels_engine_bench_tree(L):
     """bench_multistreet.py's tree (4 flops x 2 turns x 2 rivers, 259 330 nodes) on both engines of the library: the same exploitability
     history, regrets and averages; the per-street engine in < 1/3 of the level-synchronous engine's HBM"""

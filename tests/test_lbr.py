@@ -161,6 +161,35 @@ def test_gpu_lbr_equity_before_the_flop(n_to_deal, n_ranges):
     check_equity_many_cards_to_come(_native.lib(), n_to_deal, n_ranges)
 
 
+def _preflop_fixture():
+    path = os.path.join(HERE, "golden", "lbr_equity_preflop.npz")
+    if not os.path.isfile(path):
+        pytest.skip("fixture not generated (tests/golden/make_lbr_equity_preflop_golden.py: ~20 GB of RAM, the reference's rollout manager before the flop)")
+    return np.load(path)
+
+
+@pytest.mark.gpu
+def test_gpu_lbr_equity_before_the_flop_vs_reference():
+    """the REFERENCE's _LBRRolloutManager at hold'em's first decision (five cards to come, 1 712 304 run-outs; lbr_equity_preflop.npz):
+    prl_lbr_checkdown_equity returns its numbers bit for bit -- and so does the oracle's restatement of the recursion for the first range"""
+    import ctypes
+    from oracle.lbr import checkdown_equity
+    from pokerrl_amd.game import games as G
+    _native.require_device()
+    g = _preflop_fixture()
+    L = _native.lib()
+    rules = G.DiscretizedNLHoldem.native_rules()
+    hand = np.ascontiguousarray(g["hand"], dtype=np.int8)
+    ranges = np.ascontiguousarray(g["range"], dtype=np.float32)
+    board = np.zeros(0, np.int8)
+    out = np.zeros(ranges.shape[0], np.float32)
+    assert L.prl_lbr_checkdown_equity(ctypes.byref(rules), board.ctypes.data_as(ctypes.c_void_p), 0, hand.ctypes.data_as(ctypes.c_void_p),
+                                      ranges.ctypes.data_as(ctypes.c_void_p), int(ranges.shape[0]), out.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert np.array_equal(out, g["wp"]), (out, g["wp"])
+    want = checkdown_equity(_rank_fn("DiscretizedNLHoldem"), 2, 52, 5, board, hand, ranges[0])
+    assert want == g["wp"][0], (want, g["wp"][0])
+
+
 def test_lbr_equity_oracle_vs_reference_golden():
     check_equity_oracle_vs_golden("StandardLeduc")
     check_equity_oracle_vs_golden("DiscretizedNLHoldem", max_to_deal=1)  # the flop cases (990 boards) run in the GPU suite
