@@ -190,6 +190,16 @@ def test_gpu_lbr_equity_before_the_flop_vs_reference():
     assert want == g["wp"][0], (want, g["wp"][0])
 
 
+def test_lbr_equity_oracle_vs_reference_before_the_flop():
+    """oracle/lbr.py's recursion for any number of cards to come = the reference's rollout manager at hold'em's first decision (one of the
+    fixture's ranges here, ~1 minute of NumPy; the GPU suite checks the kernel against all of them)"""
+    from oracle.lbr import checkdown_equity
+    g = _preflop_fixture()
+    assert int(g["n_runouts"]) == 2118760  # C(50, 5): LBR's own cards are out, the agent's are not known
+    want = checkdown_equity(_rank_fn("DiscretizedNLHoldem"), 2, 52, 5, np.zeros(0, np.int8), g["hand"], g["range"][2])
+    assert want == g["wp"][2], (want, g["wp"][2])
+
+
 def test_lbr_equity_oracle_vs_reference_golden():
     check_equity_oracle_vs_golden("StandardLeduc")
     check_equity_oracle_vs_golden("DiscretizedNLHoldem", max_to_deal=1)  # the flop cases (990 boards) run in the GPU suite
