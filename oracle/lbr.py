@@ -4,7 +4,8 @@ TEST INFRASTRUCTURE ONLY (never imported by pokerrl_amd): NumPy restatement of L
 Follows PokerRL/eval/lbr/LocalLBRWorker.py:379-512 (_LBRRolloutManager.__init__ / _build_eq_vecs :381-425,
 get_lbr_checkdown_equity :427-468, _calc_eq :470-512) and the PokerRange operations it uses (PokerRange.py:26-84), written
 against plain arrays instead of env / range objects. Pinned to the reference by tests/golden/lbr_equity.npz (outputs of the
-reference's own rollout manager) and, end to end, by tests/golden/lbr_*.npz.
+reference's own rollout manager at every stage from the flop on), tests/golden/lbr_equity_preflop.npz (the same before the flop: five cards to
+come, 2 118 760 run-outs, three ranges) and, end to end, by tests/golden/lbr_*.npz.
 """
 import numpy as np
 
