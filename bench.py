@@ -39,7 +39,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # the same bytes (548 KB per board and iteration: 14 regret columns + the plan in, 7 regret columns out, 7 float64 average columns in
 # and out -- the reference's float64 average is 53 % of it -- and the root vectors), so other sizes scale linearly.
 PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION = 143.78e9 / 262144
-PMC_TRAFFIC_SOURCE = "profiles/r03v_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+PMC_TRAFFIC_SOURCE = "profiles/r05s_pmc.txt = r03v_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
 
 
 def seeded_boards(n, seed, offset=0):

@@ -335,7 +335,11 @@ int street_sweep(prl_solver* s, const PrlDevState& st, int mode, int src0, int s
         q.child_val = lv + 1 < L ? s->st_dev[lv + 1].val : nullptr;
         q.child_w = width;
         q.val = s->st_dev[lv].val;
-        if (H.last == (getenv("PRL_ST_TIMING_INNER") != nullptr)) q.timing = nullptr;  // (PRL_ST_TIMING builds clock the last street's pass, or the others')
+#ifdef PRL_ST_TIMING
+        if (H.last == (getenv("PRL_ST_TIMING_INNER") != nullptr)) q.timing = nullptr;  // instrumented builds clock the last street's pass, or the others'
+#else
+        q.timing = nullptr;
+#endif
         return q;
     };
     for (int lv = 0; lv + 1 < L; ++lv) {
