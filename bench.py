@@ -180,12 +180,17 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     if sharded and how == "rccl":
         from pokerrl_amd.dist import rccl_shard
+        solver, err = None, None
         try:
             solver = _native.NativeSolver(tree, args.variant, 0, shard=rccl_shard(world, rank, shard_boards if total else None, total or None, lib=lib), _lib=lib)
-        except _native.NativeError as e:  # no librccl.so to bind (the same on every rank): the callback path still works
-            if e.status != _native.ERR_UNSUPPORTED:
-                raise
-            sys.stderr.write("bench.py: the library's RCCL exchange is not available (%s); using torch.distributed\n" % e)
+        except _native.NativeError as e:  # no librccl.so to bind, or the communicator could not be set up: the callback path still works
+            err = e
+        ok = torch.tensor([0 if solver is None else 1], dtype=torch.int32, device="cpu" if emu_lib else "cuda")
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # the ranks take the same path: all inside the library, or all through the callback
+        if int(ok.item()) == 0:
+            sys.stderr.write("bench.py[rank %d]: the library's RCCL exchange is not available (%s); using torch.distributed\n" % (rank, err if err else "another rank failed"))
+            solver = None
             how = "torch"
     if sharded and how == "torch":
         from pokerrl_amd.dist import TorchExchange
