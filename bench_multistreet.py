@@ -4,7 +4,10 @@ cards, full betting tree) over F flops x T turns x R rivers of seeded run-outs, 
 fused engine (csrc/prl_st.h); --engine levels is the level-synchronous engine these trees ran on before (10.3 M node-updates/s on the default
 tree, profiles/r04p_bench_multistreet.json).
 
-    python bench_multistreet.py [--flops F] [--turns T] [--rivers R] [--steps K] [--warmup W] [--engine auto|levels] [--no-cpu-baseline]
+    python bench_multistreet.py [--gpus N] [--flops F] [--turns T] [--rivers R] [--steps K] [--warmup W] [--engine auto|levels] [--no-cpu-baseline]
+
+N > 1 GPUs: the flops (first-deal outcomes) are sharded, F per GPU (weak scaling: N x F flops in all), the betting before the flop replicated,
+one all-gather of the first street's root rows per EV pass (inside the library over RCCL; `--gpus N` starts the ranks itself as bench.py does).
 
 roofline: algorithmic bytes per iteration 20 R sum(A) + 8 R N_rows of the LAST street (the dominant kernel: 94 % of the
 nodes) over that kernel's summed launch time (HIP events on the solver's stream inside the timed region); the whole tree over the whole
@@ -69,22 +72,76 @@ def main():
     ap.add_argument("--engine", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--max-raises", default=None, help="raises per betting round, e.g. 1,1,1,1 (smaller street subtrees: the CPU test-suite's emulator runs); default: the game's 4")
     args = ap.parse_args()
+    import bench
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(bench.free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    emu_lib = os.environ.get("PRL_BENCH_EMU_LIB")  # CPU test-suite only: the ranks drive the emulator build of the library over gloo
     import torch
-    torch.cuda.set_device(0)
     from pokerrl_amd import _native
     from pokerrl_amd.game import games as G
-    _native.require_device()
+    lib = _native.bind(emu_lib) if emu_lib else None
+    if not emu_lib:
+        torch.cuda.set_device(local_rank)
+        _native.require_device()
+        _native.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if emu_lib:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     t0 = time.perf_counter()
-    tree = _native.NativeTree.for_game(G.LimitHoldem, 48, None, runouts(args.flops, args.turns, args.rivers))
+    per_flop = args.turns * args.rivers
+    all_runouts = runouts(world * args.flops, args.turns, args.rivers)
+    mine = all_runouts[rank * args.flops * per_flop:(rank + 1) * args.flops * per_flop]  # this rank's block of the flops, with their run-outs
+    if args.max_raises:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import env_args
+        game = G.LimitHoldem.native_game(env_args(G.LimitHoldem, 48, None))
+        for i, v in enumerate(int(x) for x in args.max_raises.split(",")):
+            game.max_raises[i] = v
+        tree = _native.NativeTree(game, G.LimitHoldem.native_rules(), mine, _lib=lib)
+    else:
+        tree = _native.NativeTree.for_game(G.LimitHoldem, 48, None, mine, _lib=lib)
     t_tree = time.perf_counter() - t0
-    s = _native.NativeSolver(tree, "plus", 0, engine=args.engine)
+    exchange = None
+    if world > 1:
+        if emu_lib:
+            from pokerrl_amd.dist import TorchExchange
+            exchange = TorchExchange("cpu")
+            s = _native.NativeSolver(tree, "plus", 0, shard=(world, rank, exchange), _lib=lib)
+        else:
+            from pokerrl_amd.dist import rccl_shard
+            s = _native.NativeSolver(tree, "plus", 0, shard=rccl_shard(world, rank))
+    else:
+        s = _native.NativeSolver(tree, "plus", 0, engine=args.engine, _lib=lib)
+
+    def barrier():
+        if not emu_lib:
+            torch.cuda.synchronize()
+        s.sync()
+        if dist is not None:
+            dist.barrier()
+
     s.iterations(args.warmup)
-    s.sync()
+    barrier()
     t0 = time.perf_counter()
     dev_ms, pass_ms, n_pass = s.time_iterations_ex(args.steps)
-    s.sync()
+    barrier()
     dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cpu" if emu_lib else "cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
     expl = s.exploitability()
     R = tree.range_size
     kind, rnd, nch = tree.field("kind"), tree.field("round"), tree.field("n_children")
@@ -94,13 +151,16 @@ def main():
     bytes_iter = 20.0 * R * tree.n_cols + 8.0 * R * int(tree.n_boards)
     bytes_last = 20.0 * R * cols_last + 8.0 * R * n_rows_last
     fused = s.engine == "fused" and n_pass > 0
+    n_trunk = int(np.sum(rnd == int(rnd.min())))  # the betting before the first deal: replicated on every rank, counted once
+    n_nodes_job = n_trunk + world * (tree.n_nodes - n_trunk)
     achieved = (bytes_last * args.steps / (pass_ms * 1e-3) if fused else bytes_iter * args.steps / (dev_ms * 1e-3)) / 1e9
     out = {
-        "metric": "CFR+ node-updates/sec on a multi-street LimitHoldem public tree", "value": tree.n_nodes * args.steps / dt, "unit": "node-updates/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "build_flavor": _native.build_flavor(),
-        "config": {"workload": "CFR+ (delay 0) on LimitHoldem, %d flops x %d turns x %d rivers of seeded run-outs, 1326-hand ranges" % (args.flops, args.turns, args.rivers),
-                   "engine": s.engine + (" (per-street)" if s.engine == "fused" else ""), "nodes": tree.n_nodes, "action_columns": tree.n_cols,
+        "metric": "CFR+ node-updates/sec on a multi-street LimitHoldem public tree", "value": n_nodes_job * args.steps / dt, "unit": "node-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "build_flavor": (lib or _native.lib()).prl_build_flavor().decode(),
+        "config": {"workload": "CFR+ (delay 0) on LimitHoldem, %d flops per GPU x %d turns x %d rivers of seeded run-outs, 1326-hand ranges" % (args.flops, args.turns, args.rivers),
+                   "engine": s.engine + (" (per-street)" if s.engine == "fused" else ""), "nodes": tree.n_nodes, "nodes_whole_job": n_nodes_job,
+                   "flops_per_gpu": args.flops, "exchanges": int(s.get("exchanges")[0]) if world > 1 else 0, "action_columns": tree.n_cols,
                    "action_columns_last_street": cols_last, "board_rows": int(tree.n_boards), "tree_build_s": t_tree,
                    "device_ms_per_iteration": dev_ms / args.steps, "exploitability_chips": float(np.mean(expl)), "iterations_done": s.iter,
                    "hbm_bytes_allocated": int(s.get("bytes_allocated")[0])},
@@ -114,9 +174,13 @@ def main():
                      "achieved_whole_iteration": bytes_iter * args.steps / (dev_ms * 1e-3) / 1e9,
                      "frac_whole_iteration": bytes_iter * args.steps / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
     }
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_iters)
-    print(json.dumps(out), flush=True)
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_iters)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

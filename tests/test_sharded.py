@@ -146,6 +146,27 @@ def test_sharded_world2_gloo_emu(EMU):
     check_against_union(_native.bind(EMU), ranks, 2, 2, 3, 1, 21)
 
 
+def test_bench_multistreet_gpus_2_gloo_emu(EMU):
+    """`python bench_multistreet.py --gpus 2`: two ranks, one flop each (with its turn / river run-outs), the per-street engine sharded over the
+    first deal's outcomes; the same exploitability as the one-rank solve of both flops, ONE JSON line from rank 0"""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PRL_BENCH_EMU_LIB"] = EMU
+    common = ["--turns", "2", "--rivers", "1", "--steps", "1", "--warmup", "1", "--max-raises", "1,1,1,1", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(root, "bench_multistreet.py")]
+    two = subprocess.run(cmd + ["--gpus", "2", "--flops", "1"] + common, env=env, capture_output=True, text=True, timeout=900, check=True).stdout
+    line = [x for x in two.splitlines() if x.startswith("{")]
+    assert len(line) == 1, two
+    j2 = json.loads(line[0])
+    one = subprocess.run(cmd + ["--gpus", "1", "--flops", "2"] + common, env=env, capture_output=True, text=True, timeout=900, check=True).stdout
+    j1 = json.loads([x for x in one.splitlines() if x.startswith("{")][0])
+    assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1 and j2["config"]["exchanges"] > 0 and j1["config"]["exchanges"] == 0
+    assert j2["config"]["engine"].startswith("fused") and j2["build_flavor"].startswith("emu")
+    assert j2["config"]["nodes_whole_job"] == j1["config"]["nodes_whole_job"] == j1["config"]["nodes"]
+    assert j2["config"]["exploitability_chips"] == j1["config"]["exploitability_chips"]
+
+
 def test_bench_gpus_2_launches_two_ranks_gloo_emu(EMU):
     """`python bench.py --gpus 2` with no launcher around it (the driver's form for N = 1; for N > 1 it wraps the same command in
     torch.distributed.run) must start two ranks itself, shard the boards, exchange once per EV pass and report n_gpus = 2. Here
