@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--placement-candidates", type=int, default=3, help="one GPU: solver objects built and timed before the run, the fastest is kept (1 = no probe)")
     ap.add_argument("--max-raises", default=None, help="raises per betting round, e.g. 1,1,1,1 (smaller street subtrees: the CPU test-suite's emulator runs); default: the game's 4")
     args = ap.parse_args()
     import bench
@@ -114,6 +115,7 @@ def main():
         tree = _native.NativeTree.for_game(G.LimitHoldem, 48, None, mine, _lib=lib)
     t_tree = time.perf_counter() - t0
     exchange = None
+    placement = None
     if world > 1:
         if emu_lib:
             from pokerrl_amd.dist import TorchExchange
@@ -124,6 +126,25 @@ def main():
             s = _native.NativeSolver(tree, "plus", 0, shard=rccl_shard(world, rank))
     else:
         s = _native.NativeSolver(tree, "plus", 0, engine=args.engine, _lib=lib)
+        if args.placement_candidates > 1 and not emu_lib and s.engine == "fused":
+            # as bench.py's placement probe: solver objects of one process differ by ~7 % on this tree, repeatably per object, with where their
+            # arrays land physically (scripts/ms_placement_probe.py: 2.38 .. 2.54 ms per iteration). 4 GB each: build a few, keep the fastest,
+            # report all (config.placement_probe_ms_per_iteration); --placement-candidates 1 measures the first allocation as it is.
+            def probe(sv):
+                sv.iterations(3)
+                sv.sync()
+                return sv.time_iterations(6) / 6.0
+            cands = [(probe(s), s)]
+            try:
+                for _ in range(args.placement_candidates - 1):
+                    c = _native.NativeSolver(tree, "plus", 0, engine=args.engine, _lib=lib)
+                    cands.append((probe(c), c))
+            except _native.NativeError as e:
+                sys.stderr.write("bench_multistreet.py: placement probe cut short (%s)\n" % e)
+            placement = [ms for ms, _ in cands]
+            s = min(cands, key=lambda x: x[0])[1]
+            cands = None
+            s.reset()
 
     def barrier():
         if not emu_lib:
@@ -160,7 +181,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "build_flavor": (lib or _native.lib()).prl_build_flavor().decode(),
         "config": {"workload": "CFR+ (delay 0) on LimitHoldem, %d flops per GPU x %d turns x %d rivers of seeded run-outs, 1326-hand ranges" % (args.flops, args.turns, args.rivers),
                    "engine": s.engine + (" (per-street)" if s.engine == "fused" else ""), "nodes": tree.n_nodes, "nodes_whole_job": n_nodes_job,
-                   "flops_per_gpu": args.flops, "exchanges": int(s.get("exchanges")[0]) if world > 1 else 0, "action_columns": tree.n_cols,
+                   "placement_probe_ms_per_iteration": placement, "flops_per_gpu": args.flops, "exchanges": int(s.get("exchanges")[0]) if world > 1 else 0, "action_columns": tree.n_cols,
                    "action_columns_last_street": cols_last, "board_rows": int(tree.n_boards), "tree_build_s": t_tree,
                    "device_ms_per_iteration": dev_ms / args.steps, "exploitability_chips": float(np.mean(expl)), "iterations_done": s.iter,
                    "hbm_bytes_allocated": int(s.get("bytes_allocated")[0])},
