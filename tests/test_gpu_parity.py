@@ -191,6 +191,14 @@ def test_gpu_streets_engine_other_street_shapes_vs_oracle(L, variant, max_raises
     pc.check_streets_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(2, 2, 2), variant, 3, max_raises=max_raises, batched=True)
 
 
+@pytest.mark.parametrize("variant,runouts", [("plus", (1, 34, 1)), ("linear", (1, 5, 2)), ("plus", (2, 33, 2))])
+def test_gpu_streets_engine_many_outcomes_per_deal_vs_oracle(L, variant, runouts):
+    """more outcomes below a chance node than one canonical block of 32 (34 turn cards: two blocks) and than one batch of child rows of the leaf
+    sums (5 > 4): the non-final streets' chance sums against the oracle, 9-node street subtrees, batched iterations"""
+    from pokerrl_amd.game import games as G
+    pc.check_streets_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(*runouts), variant, 3, max_raises=(1, 1, 1, 1), batched=True)
+
+
 def test_gpu_streets_engine_vs_levels_engine_bench_tree(L):
     """bench_multistreet.py's tree (4 flops x 2 turns x 2 rivers, 259 330 nodes) on both engines of the library: the same exploitability
     history, regrets and averages; the per-street engine in < 1/3 of the level-synchronous engine's HBM"""
