@@ -424,6 +424,33 @@ def make_streets_pair(L, game_cls, stack, runouts, variant, delay=0, max_raises=
     return t, s, o
 
 
+def check_streets_br_vs_oracle(L, game_cls, stack, runouts, max_raises=None, seed=5):
+    """Exact best response of an explicit strategy on a multi-street tree, per-street engine (LocalBRMaster.py:67-80): a seeded strategy given as
+    float32 (played as float32 from the engine's internal column order) and as float64 columns in the flat tree's DFS order; exploitability
+    against the oracle, the strategy read back unchanged; iterating again after reset()"""
+    t, s, o = make_streets_pair(L, game_cls, stack, runouts, "plus", 0, max_raises)
+    kind, nch, fc = t.field("kind"), t.field("n_children"), t.field("first_col")
+    rng = np.random.RandomState(seed)
+    strat = np.empty((t.n_cols, t.range_size), np.float32)
+    for n in np.where(kind == 0)[0]:
+        x = rng.random_sample((nch[n], t.range_size)).astype(np.float32)
+        strat[fc[n]:fc[n] + nch[n]] = x / x.sum(axis=0, keepdims=True)
+    for f64 in (False, True):
+        st = strat.astype(np.float64) * (1.0 + 1e-9 * rng.random_sample(strat.shape)) if f64 else strat
+        s.set_strategy(st)
+        o.set_strategy(np.asarray(st, dtype=np.float64), f64)
+        s.compute_ev()
+        o.compute_ev()
+        assert np.array_equal(s.exploitability(), o.exploitability), (f64, s.exploitability(), o.exploitability)
+        assert np.array_equal(s.get("strategy"), np.asarray(st, dtype=np.float64))
+    s.reset()
+    o.cfr_reset(1, 0)
+    s.iterations(2)
+    o.cfr_iteration(); o.cfr_iteration()
+    assert np.array_equal(s.exploitability(), o.exploitability)
+    return t
+
+
 def check_streets_vs_oracle(L, game_cls, stack, runouts, variant, n_iters, delay=0, max_raises=None, batched=False):
     """SURVEY 8f-4 on the per-street fused engine (csrc/prl_st.h): regrets, averages, the strategy implied by the regrets, current- and
     average-strategy exploitability after every iteration (batched: the exploitability history of prl_solver_iterations(n) and the

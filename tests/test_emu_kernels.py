@@ -162,6 +162,12 @@ def test_emu_streets_engine_limit_holdem(L, variant, runouts, max_raises, batche
     pc.check_streets_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(*runouts), variant, 3 if batched else 2, max_raises=max_raises, batched=batched)
 
 
+def test_emu_streets_engine_best_response_of_an_explicit_strategy(L):
+    """LocalBRMaster's evaluation on a multi-street tree: explicit float32 / float64 strategies on the per-street engine against the oracle"""
+    from pokerrl_amd.game import games as G
+    pc.check_streets_br_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(1, 2, 1), max_raises=(1, 2, 1, 1))
+
+
 def test_emu_streets_engine_refuses_all_in_run_outs(L):
     """4-chip stacks: all-ins dealt out as chance chains are not street instances -- engine=auto falls back to the level-synchronous engine,
     engine=fused says why"""

@@ -199,6 +199,14 @@ def test_gpu_streets_engine_many_outcomes_per_deal_vs_oracle(L, variant, runouts
     pc.check_streets_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(*runouts), variant, 3, max_raises=(1, 1, 1, 1), batched=True)
 
 
+def test_gpu_streets_engine_best_response_of_an_explicit_strategy_vs_oracle(L):
+    """LocalBRMaster's evaluation (LocalBRMaster.py:67-80) on LimitHoldem with its full betting, 2 flops x 2 turns x 1 river: explicit float32 /
+    float64 strategies on the per-street engine against the oracle; iterating again after reset()"""
+    from pokerrl_amd.game import games as G
+    t = pc.check_streets_br_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(2, 2, 1))
+    assert t.n_nodes > 60000
+
+
 def test_gpu_streets_engine_vs_levels_engine_bench_tree(L):
     """bench_multistreet.py's tree (4 flops x 2 turns x 2 rivers, 259 330 nodes) on both engines of the library: the same exploitability
     history, regrets and averages; the per-street engine in < 1/3 of the level-synchronous engine's HBM"""
