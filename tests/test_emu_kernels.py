@@ -168,6 +168,23 @@ def test_emu_streets_engine_best_response_of_an_explicit_strategy(L):
     pc.check_streets_br_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(1, 2, 1), max_raises=(1, 2, 1, 1))
 
 
+def test_emu_streets_engine_checkpoint_resume(L):
+    """prl_solver_save_state / load_state on the per-street engine: a resumed solve continues bit for bit"""
+    import numpy as np
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import games as G
+    t, s, _o = pc.make_streets_pair(L, G.LimitHoldem, 48, pc.multistreet_runouts(1, 2, 1), "plus", 0, (1, 1, 1, 1))
+    s.iterations(2)
+    blob = s.save_state()
+    s2 = _native.NativeSolver(t, "plus", 0, engine="auto", _lib=L)
+    s2.load_state(blob)
+    s.iterations(2)
+    s2.iterations(2)
+    for k in ("regret", "avg", "expl_history"):
+        assert np.array_equal(s.get(k), s2.get(k)), k
+    assert np.array_equal(s.eval_avg(), s2.eval_avg())
+
+
 def test_emu_streets_engine_refuses_all_in_run_outs(L):
     """4-chip stacks: all-ins dealt out as chance chains are not street instances -- engine=auto falls back to the level-synchronous engine,
     engine=fused says why"""
