@@ -199,6 +199,14 @@ def test_gpu_streets_engine_many_outcomes_per_deal_vs_oracle(L, variant, runouts
     pc.check_streets_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(*runouts), variant, 3, max_raises=(1, 1, 1, 1), batched=True)
 
 
+@pytest.mark.parametrize("batched", [False, True])
+def test_gpu_streets_engine_cfr_plus_with_averaging_delay_vs_oracle(L, batched):
+    """CFR+ with a linear-averaging delay of 2 (CFRPlus.py:65-87: no average before iteration 2, a copy at 2, blends after) on the per-street engine,
+    LimitHoldem with two raises per round, 2 flops x 2 turns x 2 rivers"""
+    from pokerrl_amd.game import games as G
+    pc.check_streets_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(2, 2, 2), "plus", 5, delay=2, max_raises=(2, 2, 2, 2), batched=batched)
+
+
 def test_gpu_streets_engine_best_response_of_an_explicit_strategy_vs_oracle(L):
     """LocalBRMaster's evaluation (LocalBRMaster.py:67-80) on LimitHoldem with its full betting, 2 flops x 2 turns x 1 river: explicit float32 /
     float64 strategies on the per-street engine against the oracle; iterating again after reset()"""
