@@ -60,6 +60,12 @@ def main():
         "metric": "head-to-head hands/s (DiscretizedNLHoldem, one GPU lane per hand)", "value": 2 * args.hands / dt, "unit": "hands/s", "n_gpus": 1,
         "hands_total": 2 * args.hands, "seconds": dt, "device_ms_last_half": dev_ms, "device_hands_per_s_last_half": args.hands / (dev_ms * 1e-3),
         "env_steps_last_half": steps, "winnings_mbb_per_g": mean, "conf95": d, "agents": "hash(11) vs hash(12)", "data": "synthetic",
+        "steps": 1, "warmup": 0, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+        "config": {"workload": "%d hands per seat assignment between two synthetic tabular agents, dealing / betting / showdown / payout per lane" % args.hands},
+        "roofline": None, "roofline_note": "one lane plays one hand start to finish out of registers: ~17 bytes per hand reach HBM (deck seed in, winnings out); "
+                                            "bound by divergent integer control flow and the two 7-card evaluations of a showdown, no byte or flop roofline applies",
+        "cpu_baseline": {"value": 2 * args.host_hands / host_dt, "unit": "hands/s", "cores": 1, "kind": "port",
+                         "sample": "LocalHead2HeadMaster drop-in (Python episode loop on the native-backed env), %d hands" % (2 * args.host_hands)},
         "host_evaluator_hands_per_s": 2 * args.host_hands / host_dt,
         "host_evaluator_note": "LocalHead2HeadMaster drop-in (Python episode loop on the native-backed env), %d hands" % (2 * args.host_hands)}))
 

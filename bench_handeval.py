@@ -54,10 +54,17 @@ def main():
     ref = oracle.rank_boards(boards[:n_cpu])
     cpu = n_cpu * 1326 / (time.perf_counter() - t0)
     assert np.array_equal(d_o[:n_cpu].cpu().numpy(), ref)
+    bytes_call = args.boards * (5.0 + 4.0 * 1326)  # algorithmic: the board in, one int32 rank per (board, hand) out
+    achieved = bytes_call / (ms * 1e-3) / 1e9
     print(json.dumps({"metric": "7-card hand evaluations/s (all 1326 hands on given boards)", "value": evals / (ms * 1e-3), "unit": "evals/s",
-                      "boards": args.boards, "ms_per_call": ms, "achieved_GBps_store": evals * 4 / (ms * 1e-3) / 1e9,
-                      "cpu_baseline": {"value": cpu, "unit": "evals/s", "cores": 1, "kind": "port", "sample": "%d boards, oracle/prl_oracle.c" % n_cpu},
-                      "data": "synthetic"}))
+                      "n_gpus": 1, "steps": args.reps, "warmup": 1, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "int32", "data": "synthetic", "build_flavor": _native.build_flavor(),
+                      "config": {"workload": "ranks of all 1326 hole-card pairs on %d seeded 5-card boards per call, device buffers in and out" % args.boards,
+                                 "boards": args.boards},
+                      "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                                   "kernel": "prl_k_hand_rank_boards", "kernel_ms_per_launch": ms, "bytes_per_call_algorithmic": bytes_call,
+                                   "note": "integer ALU issue (the evaluator) shares the bound with the int32 store stream (SURVEY.md 8d)"},
+                      "cpu_baseline": {"value": cpu, "unit": "evals/s", "cores": 1, "kind": "port", "sample": "%d boards, oracle/prl_oracle.c" % n_cpu}}))
 
 
 if __name__ == "__main__":
