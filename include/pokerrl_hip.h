@@ -291,9 +291,13 @@ enum { PRL_VARIANT_VANILLA = 0, PRL_VARIANT_PLUS = 1, PRL_VARIANT_LINEAR = 2 };
 
 /* create = upload tree + build showdown plans + CFRBase.reset(); `delay` is CFR+'s linear-averaging delay */
 int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay, prl_solver_t** out_solver);
-/* engine selection: AUTO = FUSED where applicable (Flop5Holdem-shaped tree + CFR+), else LEVELS.
+/* engine selection: AUTO = FUSED where applicable, else LEVELS.
  *   LEVELS keeps every per-node vector in HBM (any supported tree; node.reach_probs / ev / ev_br readable);
- *   FUSED walks each board subtree on chip and only keeps regrets / averages / per-board root values in HBM. */
+ *   FUSED walks each board subtree on chip and only keeps regrets / averages / root values in HBM. It takes 2-hole-card trees whose betting
+ *   after every deal matches a registered subtree shape (fold / call / one raise size, up to four raises per round: 9 / 15 / 21 / 27 nodes):
+ *   one deal (Flop5Holdem: the board pass) or several (LimitHoldem 3 + 1 + 1: one pass per street and direction over its street instances,
+ *   sharded over the first deal's outcomes). Trees it does not take (other bet sets, all-in run-out chains, 1-hole-card games) run on LEVELS;
+ *   asking for FUSED on one of them is an error that says why. PRL_SF_ENGINE tells which engine a solver runs on. */
 enum { PRL_ENGINE_AUTO = 0, PRL_ENGINE_LEVELS = 1, PRL_ENGINE_FUSED = 2 };
 int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out_solver);
 /* Options. PRL_SOLVER_AVG_F32 (opt-in, NOT the reference's numerics): CFR+'s running average strategy of the board columns is STORED as
