@@ -3,7 +3,7 @@ Generates tests/golden/fhp_<n>_<variant>_chunked.npz with the CPU ORACLE for boa
 bench.py's default size: ~290 GB of oracle state in one piece): the boards are evaluated CHUNK BY CHUNK, the trunk in a second small
 instance whose chance node takes the canonical sum of all chunks' board values from outside (oracle: orc_set_override).
 
-    python tests/golden/make_fhp_golden_chunked.py [n_boards] [n_iters] [chunk] [workdir]      (CFR+ delay 0)
+    python tests/golden/make_fhp_golden_chunked.py [n_boards] [n_iters] [chunk] [workdir] [plus|linear|vanilla]      (delay 0)
 
 Per half-iteration of _CFRBase.iteration (_CFRBase.py:122-134) -- EVs, regrets + strategy of seat p, reach, average of seat p --:
   every chunk instance: trunk strategy from the trunk instance, its own boards' state from disk; update_reach; compute_ev (the board values
@@ -11,6 +11,9 @@ Per half-iteration of _CFRBase.iteration (_CFRBase.py:122-134) -- EVs, regrets +
       32, groups of 32 blocks); regrets / strategy / average of seat p's BOARD nodes; state back to disk
   trunk instance: chance node := running sum of all groups in global order; compute_ev; regrets / strategy / reach / average of seat p's
       trunk nodes.
+Vanilla / Linear CFR: the average of seat p needs the reach AFTER seat p's update, boards included (VanillaCFR.py:40-55, LinearCFR.py:41-57), and the
+boards' reach needs the trunk's new strategy, which needs every chunk's values first: a chunk adds seat p's strategy to its averages at the START of its
+next visit (the reach it computes there is the one the reference used: nothing changed in between), the last visit being the closing evaluation.
 The evaluation that closes iteration t is the one iteration t + 1 starts with. The chunked run is checked against the one-piece oracle at
 a size both can do (`--selftest`: 2048 boards in chunks of 1024, every array bit for bit).
 Needs no GPU, ~60 GB of scratch disk and about an hour on 8 cores for 262144 boards x 2 iterations.
@@ -61,8 +64,11 @@ def group_sums(vals):
 
 
 class Chunked:
-    def __init__(self, boards, chunk, workdir):
+    def __init__(self, boards, chunk, workdir, variant="plus"):
         self.boards, self.chunk, self.workdir = boards, chunk, workdir
+        self.variant = variant
+        self.vcode = {"vanilla": 0, "plus": 1, "linear": 2}[variant]
+        self.pending = None  # Vanilla / Linear: (iteration, seat) whose strategy the chunks still have to add to their averages
         self.n = len(boards)
         assert self.n % chunk == 0 and chunk % 1024 == 0
         self.n_chunks = self.n // chunk
@@ -75,7 +81,7 @@ class Chunked:
         self.first_board = self.chance + 1
         assert self.ct.n_nodes == self.first_board + chunk * NB and int(np.where(self.tt.field("kind") == 1)[0][0]) == self.chance
         self.updated = [False, False]  # seats whose strategy comes from regret matching (else the uniform fill)
-        self.T.cfr_reset(1, 0)
+        self.T.cfr_reset(self.vcode, 0)
         self.hist = []
 
     def _path(self, c, name):
@@ -86,11 +92,14 @@ class Chunked:
         del self.O
         _, self.O = make(self.boards[c * self.chunk:(c + 1) * self.chunk], chance_prob=self.cp)
         O = self.O
-        O.cfr_configure(1, 0)  # uniform strategy, zero regrets / averages (no evaluation yet)
+        O.cfr_configure(self.vcode, 0)  # uniform strategy, zero regrets / averages (no evaluation yet)
         if os.path.exists(self._path(c, "regret")):
             O.regret[self.nt:] = np.load(self._path(c, "regret"))
+        if os.path.exists(self._path(c, "avg")):
             O.avg[self.nt:] = np.load(self._path(c, "avg"))
             O.avg_f64[self.first_board:] = np.load(self._path(c, "avg_f64"))
+            if self.variant != "plus":
+                O.avg_sum[self.nt:] = np.load(self._path(c, "avg_sum"))
         for p in (0, 1):
             if self.updated[p]:
                 O.compute_new_strategy(p)  # a pure function of the regrets (CFRPlus.py:43-63)
@@ -105,8 +114,15 @@ class Chunked:
         for c in range(self.n_chunks):
             t0 = time.time()
             O = self._chunk_instance(c)
-            O.set_iter(it)
             O.update_reach()
+            if self.pending is not None:  # Vanilla / Linear: seat q's half of iteration j ends here, with the reach just computed
+                j, q = self.pending
+                O.set_iter(j)
+                O.add_strategy_to_average(q)
+                np.save(self._path(c, "avg"), O.avg[self.nt:])
+                np.save(self._path(c, "avg_f64"), O.avg_f64[self.first_board:])
+                np.save(self._path(c, "avg_sum"), O.avg_sum[self.nt:])
+            O.set_iter(it)
             O.compute_ev()
             roots = self.first_board + NB * np.arange(self.chunk)
             vals = np.concatenate([O.ev[roots], O.ev_br[roots]], axis=1)  # [chunk][4][R]
@@ -114,10 +130,11 @@ class Chunked:
             if p is not None:
                 O.compute_regrets(p)
                 O.compute_new_strategy(p)
-                O.add_strategy_to_average(p)
                 np.save(self._path(c, "regret"), O.regret[self.nt:])
-                np.save(self._path(c, "avg"), O.avg[self.nt:])
-                np.save(self._path(c, "avg_f64"), O.avg_f64[self.first_board:])
+                if self.variant == "plus":  # CFR+'s average does not look at the reach: it is taken here
+                    O.add_strategy_to_average(p)
+                    np.save(self._path(c, "avg"), O.avg[self.nt:])
+                    np.save(self._path(c, "avg_f64"), O.avg_f64[self.first_board:])
             print("  it %d seat %s chunk %d/%d  %.0f s" % (it, p, c + 1, self.n_chunks, time.time() - t0), flush=True)
         g = np.concatenate(groups)  # all groups in global order
         total = g[0].copy()
@@ -128,6 +145,7 @@ class Chunked:
         T.set_iter(it)
         T.compute_ev()
         expl = np.array(T.exploitability, np.float32)
+        self.pending = (it, p) if (p is not None and self.variant != "plus") else None
         if p is not None:
             T.compute_regrets(p)
             T.compute_new_strategy(p)
@@ -147,7 +165,7 @@ class Chunked:
     def state_hashes(self):
         """sha-256 of regret / avg in the flat tree's column order: trunk columns, then every board's, chunk after chunk"""
         out = {}
-        for name, arr in (("regret", self.T.regret), ("avg", self.T.avg)):
+        for name, arr in (("regret", self.T.regret), ("avg", self.T.avg)) + ((("avg_sum", self.T.avg_sum),) if self.variant != "plus" else ()):
             h = hashlib.sha256()
             fold = lambda a: np.ascontiguousarray(a + a.dtype.type(0)).tobytes()  # "+ 0" folds -0.0 into +0.0, as helpers.h32
             h.update(fold(np.asarray(arr[:self.nt])))
@@ -158,15 +176,18 @@ class Chunked:
 
     def full_arrays(self):
         return {name: np.concatenate([np.asarray(getattr(self.T, name))[:self.nt]] + [np.load(self._path(c, name)) for c in range(self.n_chunks)])
-                for name in ("regret", "avg")}
+                for name in ("regret", "avg") + (("avg_sum",) if self.variant != "plus" else ())}
 
 
-def selftest(workdir):
+def selftest(workdir, variant="plus"):
     boards = pc.fhp_boards(2048, seed=5)
-    ch = Chunked(boards, 1024, workdir)
+    for f in os.listdir(workdir):
+        if f.startswith("chunk"):
+            os.remove(os.path.join(workdir, f))
+    ch = Chunked(boards, 1024, workdir, variant)
     hist = ch.run(2)
     t, o = make(boards)
-    o.cfr_reset(1, 0)
+    o.cfr_reset(ch.vcode, 0)
     want = [np.array(o.exploitability, np.float32)]
     for _ in range(2):
         o.cfr_iteration()
@@ -176,28 +197,30 @@ def selftest(workdir):
     assert np.array_equal(full["regret"], np.asarray(o.regret)) and np.array_equal(full["avg"], np.asarray(o.avg))
     hs = ch.state_hashes()
     assert hs["regret"] == h32(np.asarray(o.regret)) and hs["avg"] == h32(np.asarray(o.avg))
-    print("selftest ok: the chunked run equals the one-piece oracle (2048 boards, 2 iterations)")
+    if variant != "plus":
+        assert np.array_equal(full["avg_sum"], np.asarray(o.avg_sum)) and hs["avg_sum"] == h32(np.asarray(o.avg_sum))
+    print("selftest ok: the chunked run equals the one-piece oracle (2048 boards, 2 iterations, %s)" % variant)
 
 
-def main(n_boards, n_iters, chunk, workdir, seed=0):
+def main(n_boards, n_iters, chunk, workdir, variant="plus", seed=0):
     sys.path.insert(0, os.path.join(HERE, "..", ".."))
     import bench
     boards = bench.seeded_boards(n_boards, seed)  # bench.py's rank-0 board list
-    ch = Chunked(boards, chunk, workdir)
+    ch = Chunked(boards, chunk, workdir, variant)
     hist = ch.run(n_iters)
     hs = ch.state_hashes()
-    out = os.path.join(HERE, "fhp_%d_plus_chunked.npz" % n_boards)
-    np.savez(out, n_boards=n_boards, seed=seed, variant="plus", n_iters=n_iters, chunk=chunk, boards_sha256=h32(boards), expl_history=hist,
-             regret_sha256=hs["regret"], avg_sha256=hs["avg"], numpy=np.__version__)
+    out = os.path.join(HERE, "fhp_%d_%s_chunked.npz" % (n_boards, variant))
+    np.savez(out, n_boards=n_boards, seed=seed, variant=variant, n_iters=n_iters, chunk=chunk, boards_sha256=h32(boards), expl_history=hist,
+             regret_sha256=hs["regret"], avg_sha256=hs["avg"], avg_sum_sha256=hs.get("avg_sum", ""), numpy=np.__version__)
     print("wrote", out, hist)
 
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    if a and a[0] == "--selftest":
+    if a and a[0] == "--selftest":   # --selftest [workdir] [variant]
         os.makedirs(a[1] if len(a) > 1 else "/tmp/prl_chunked_selftest", exist_ok=True)
-        selftest(a[1] if len(a) > 1 else "/tmp/prl_chunked_selftest")
+        selftest(a[1] if len(a) > 1 else "/tmp/prl_chunked_selftest", a[2] if len(a) > 2 else "plus")
     else:
         wd = a[3] if len(a) > 3 else "/tmp/prl_chunked"
         os.makedirs(wd, exist_ok=True)
-        main(int(a[0]) if a else 262144, int(a[1]) if len(a) > 1 else 2, int(a[2]) if len(a) > 2 else 16384, wd)
+        main(int(a[0]) if a else 262144, int(a[1]) if len(a) > 1 else 2, int(a[2]) if len(a) > 2 else 16384, wd, a[4] if len(a) > 4 else "plus")

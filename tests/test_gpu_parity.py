@@ -371,28 +371,33 @@ def test_gpu_fhp_properties_at_scale(L):
         assert np.allclose(strat[fc[n]:fc[n] + nc[n]].sum(axis=0), 1, atol=1e-5)
 
 
-def test_gpu_fused_bench_size_vs_oracle_fixture(L):
-    """bench.py's workload at full size (262144 boards, the board list of rank 0) against the ORACLE: two CFR+ iterations, exploitability
-    history and SHA-256 of all 3.67 M regret / average columns. The oracle cannot hold that tree in one piece; the fixture comes from its
-    chunked run (tests/golden/make_fhp_golden_chunked.py: 16 chunks of 16384 boards, the trunk's chance node fed the canonical sum of all
-    chunks; checked against the one-piece oracle at 2048 boards). The arrays are streamed through prl_solver_get_cols."""
+@pytest.mark.parametrize("variant", ["plus", "linear"])
+def test_gpu_fused_bench_size_vs_oracle_fixture(L, variant):
+    """bench.py's workload at full size (262144 boards, the board list of rank 0) against the ORACLE: two CFR+ (Linear CFR: BASELINE config 3)
+    iterations, exploitability history and SHA-256 of all 3.67 M regret / average (/ average-sum) columns. The oracle cannot hold that tree in
+    one piece; the fixture comes from its chunked run (tests/golden/make_fhp_golden_chunked.py: 16 chunks of 16384 boards, the trunk's chance
+    node fed the canonical sum of all chunks; checked against the one-piece oracle at 2048 boards, every variant). The arrays are streamed
+    through prl_solver_get_cols."""
     import os
     import bench
     from pokerrl_amd import _native
     from pokerrl_amd.game import bet_sets
     from pokerrl_amd.game import games as G
     from helpers import GOLDEN, h32, native_tree
-    path = os.path.join(GOLDEN, "fhp_262144_plus_chunked.npz")
+    path = os.path.join(GOLDEN, "fhp_262144_%s_chunked.npz" % variant)
     if not os.path.isfile(path):
         pytest.skip("fixture not generated (an hour of oracle time: tests/golden/make_fhp_golden_chunked.py)")
     g = np.load(path)
+    assert str(g["variant"]) == variant
     boards = bench.seeded_boards(int(g["n_boards"]), int(g["seed"]))
     assert h32(boards) == str(g["boards_sha256"])
     t = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)
-    s = _native.NativeSolver(t, "plus", 0, engine="fused")
+    s = _native.NativeSolver(t, variant, 0, engine="fused")
     s.iterations(int(g["n_iters"]))
     assert np.array_equal(s.get("expl_history"), g["expl_history"]), (s.get("expl_history"), g["expl_history"])
     assert s.sha256_of("regret") == str(g["regret_sha256"])
+    if variant != "plus":  # (the average updates of the last iteration rode on its closing evaluation)
+        assert s.sha256_of("avg_sum") == str(g["avg_sum_sha256"])
     assert s.sha256_of("avg") == str(g["avg_sha256"])
 
 
