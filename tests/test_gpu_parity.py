@@ -215,6 +215,33 @@ def test_gpu_streets_engine_best_response_of_an_explicit_strategy_vs_oracle(L):
     assert t.n_nodes > 60000
 
 
+def test_gpu_streets_engine_bench_tree_vs_oracle_fixture(L):
+    """bench_multistreet.py's tree (4 flops x 2 turns x 2 rivers, 259 330 nodes) on the per-street engine against the ORACLE's own run of it
+    (tests/golden/make_streets_golden.py): exploitability history, average-strategy exploitability, SHA-256 of the regrets / averages"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench_multistreet
+    from helpers import GOLDEN, h32
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import games as G
+    path = os.path.join(GOLDEN, "lh_4x2x2_plus.npz")
+    if not os.path.isfile(path):
+        pytest.skip("fixture not generated (tests/golden/make_streets_golden.py)")
+    g = np.load(path)
+    ro = bench_multistreet.runouts(int(g["flops"]), int(g["turns"]), int(g["rivers"]))
+    assert h32(ro) == str(g["runouts_sha256"])
+    t = _native.NativeTree.for_game(G.LimitHoldem, 48, None, ro, _lib=L)
+    assert t.n_nodes == int(g["n_nodes"])
+    s = _native.NativeSolver(t, str(g["variant"]), 0, engine="auto", _lib=L)
+    assert s.engine == "fused"
+    s.iterations(int(g["n_iters"]))
+    assert np.array_equal(s.get("expl_history"), g["expl_history"]), (s.get("expl_history"), g["expl_history"])
+    assert np.array_equal(s.eval_avg(), g["eval_avg"])
+    assert h32(s.get("regret")) == str(g["regret_sha256"])
+    assert h32(s.get("avg")) == str(g["avg_sha256"])
+
+
 def test_gpu_streets_engine_vs_levels_engine_bench_tree(L):
     """bench_multistreet.py's tree (4 flops x 2 turns x 2 rivers, 259 330 nodes) on both engines of the library: the same exploitability
     history, regrets and averages; the per-street engine in < 1/3 of the level-synchronous engine's HBM"""
