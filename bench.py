@@ -287,6 +287,7 @@ def main():
             "nodes_whole_tree": n_nodes_total, "exchanges": int(solver.get("exchanges")[0]), "exchange": (how if sharded else None),
             "exchange_ms_mean": (exchange.seconds * 1e3 / max(exchange.calls, 1)) if exchange else None,
             "iterations_done": solver.iter, "exploitability_mbb_per_g": float(np.mean(expl) * 10.0),
+            "exploitability_pinned_to": "oracle/ (C restatement of the reference with an explicit float32 summation order; the reference cannot build 2-hole-card trees)",
             "avg_strategy_exploitability_mbb_per_g": float(np.mean(avg_expl) * 10.0), "avg_strategy_evaluation_ms": avg_eval_ms,
             "ms_per_step_with_avg_strategy_evaluation": dt * 1e3 / args.steps + avg_eval_ms,
             "hbm_bytes_allocated": int(solver.get("bytes_allocated")[0]),

@@ -143,7 +143,8 @@ def main():
                                   "stacks 20000, pot-size raises), %d seeded boards per GPU, 1326-hand ranges" % args.boards,
                       "boards_per_gpu": args.boards, "nodes_whole_tree": n_nodes, "node_visits_per_s": n_nodes * args.steps / dt,
                       "engine": s.engine, "exchanges": exchange.calls if exchange else 0,
-                      "exploitability_mbb_per_g": float(np.mean(expl) * 10.0)},
+                      "exploitability_mbb_per_g": float(np.mean(expl) * 10.0),
+                      "exploitability_pinned_to": "oracle/ (C restatement of the reference with an explicit float32 summation order; the reference cannot build 2-hole-card trees)"},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                         "traffic": PMC_TRAFFIC_BYTES_PER_BOARD * args.boards if s.engine == "fused" else None, "traffic_source": PMC_TRAFFIC_SOURCE,
                         "kernel": "prl_k_fhp_pass<EVAL, STRAT32, STRAT32>", "launches_per_evaluation": n_pass / float(args.steps) if n_pass else None,

@@ -398,7 +398,7 @@ def test_gpu_fhp_properties_at_scale(L):
         assert np.allclose(strat[fc[n]:fc[n] + nc[n]].sum(axis=0), 1, atol=1e-5)
 
 
-@pytest.mark.parametrize("variant", ["plus", "linear"])
+@pytest.mark.parametrize("variant", ["plus", "linear", "vanilla"])
 def test_gpu_fused_bench_size_vs_oracle_fixture(L, variant):
     """bench.py's workload at full size (262144 boards, the board list of rank 0) against the ORACLE: two CFR+ (Linear CFR: BASELINE config 3)
     iterations, exploitability history and SHA-256 of all 3.67 M regret / average (/ average-sum) columns. The oracle cannot hold that tree in
