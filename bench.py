@@ -128,6 +128,7 @@ def main():
                     help="OPT-IN, not the reference's numerics: CFR+'s running average stored as float32 (PRL_SOLVER_AVG_F32; the float64 one is "
                          "54 %% of the board pass's HBM traffic). A SECOND bench line beside the default one: config.avg_dtype says so, and "
                          "config.avg_f32_check compares the average-strategy exploitability of both dtypes over 100 iterations on 4096 boards")
+    ap.add_argument("--placement-candidates", type=int, default=3, help="one GPU: solver objects built and timed one after the other before the run, the fastest is kept")
     ap.add_argument("--no-placement-probe", dest="placement_probe", action="store_false",
                     help="one GPU: do not build a second set of arrays to keep the faster-placed one (DESIGN.md section 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -203,24 +204,23 @@ def main():
         if args.placement_probe and not emu_lib and solver.engine == "fused":
             # The board pass streams within ~10 % of what HBM sustains and its speed depends on WHERE its arrays land physically: solver
             # objects of one process differ by up to 15 %, alternating between two levels ("Spread"). One GPU has room
-            # for two sets of arrays at this size, so: build a second solver while the first is alive, time both, keep the faster one.
-            # Both timings are reported (config.placement_probe_ms_per_iteration); --no-placement-probe measures the first allocation as is.
+            # for three sets of arrays at this size (3 x 66 GB), so: build a few solvers side by side, time each, keep the fastest.
+            # All timings are reported (config.placement_probe_ms_per_iteration); --no-placement-probe measures the first allocation as is.
             def probe(sv):
                 sv.iterations(3)  # past the first iterations (uniform strategies, first averages): the steady-state passes are what is compared
                 sv.sync()
                 return sv.time_iterations(4) / 4.0
+            cands = [solver]
+            placement = [probe(solver)]
             try:
-                ms_a = probe(solver)
-                other = _native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib, avg_dtype=avg_dtype)
-                ms_b = probe(other)
-                placement = [ms_a, ms_b]
-                if ms_b < ms_a:
-                    solver, other = other, solver
-                del other
-                solver.reset()
-            except _native.NativeError as e:  # not enough HBM for two sets: measure the one there is
-                sys.stderr.write("bench.py: placement probe skipped (%s)\n" % e)
-                solver.reset()
+                for _ in range(args.placement_candidates - 1):  # all candidates stay alive until the choice (a freed set's place would just be taken again)
+                    cands.append(_native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib, avg_dtype=avg_dtype))
+                    placement.append(probe(cands[-1]))
+            except _native.NativeError as e:  # not enough HBM for another set: choose among those there are
+                sys.stderr.write("bench.py: placement probe cut short (%s)\n" % e)
+            solver = cands[int(np.argmin(placement[:len(cands)]))]
+            cands = None
+            solver.reset()
     solver.sync()
 
     def barrier():
@@ -291,7 +291,7 @@ def main():
             "avg_strategy_exploitability_mbb_per_g": float(np.mean(avg_expl) * 10.0), "avg_strategy_evaluation_ms": avg_eval_ms,
             "ms_per_step_with_avg_strategy_evaluation": dt * 1e3 / args.steps + avg_eval_ms,
             "hbm_bytes_allocated": int(solver.get("bytes_allocated")[0]),
-            "placement_probe_ms_per_iteration": placement,  # [first allocation, second allocation]: the faster one was kept (None: not probed)
+            "placement_probe_ms_per_iteration": placement,  # one entry per candidate allocation: the fastest was kept (None: not probed)
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION * args.boards if (solver.engine == "fused" and args.variant == "plus" and not args.avg_f32) else None,
