@@ -39,6 +39,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # the same bytes (548 KB per board and iteration: 14 regret columns + the plan in, 7 regret columns out, 7 float64 average columns in
 # and out -- the reference's float64 average is 53 % of it -- and the root vectors), so other sizes scale linearly.
 PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION = 143.78e9 / 262144
+# the same with the opt-in float32 running average: (2 x 1.622e7 + 2.07e7) + (2 x 1.622e7 + 2.052e7) KB per launch pair = 106.1 GB (profiles/r05zz_avg_f32_pmc_traffic.txt)
+PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 = 106.1e9 / 262144
 PMC_TRAFFIC_SOURCE = "profiles/r05s_pmc.txt = r03v_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
 
 
@@ -251,7 +253,7 @@ def main():
     avg_eval_ms = (time.perf_counter() - t1) * 1e3 / n_avg
 
     avg_check = None
-    if args.avg_f32 and rank == 0:  # what the float32 storage costs in accuracy: both dtypes, the same 4096 boards, 100 iterations
+    if args.avg_f32 and rank == 0 and not os.environ.get("PRL_BENCH_SKIP_AVG_CHECK"):  # what the float32 storage costs in accuracy (the env knob: profiling runs of the passes alone): both dtypes, the same 4096 boards, 100 iterations
         small = fhp_tree(seeded_boards(4096, 0), lib)
         ev = {}
         for dt_ in ("f64", "f32"):
@@ -294,7 +296,8 @@ def main():
             "placement_probe_ms_per_iteration": placement,  # one entry per candidate allocation: the fastest was kept (None: not probed)
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION * args.boards if (solver.engine == "fused" and args.variant == "plus" and not args.avg_f32) else None,
+                     "traffic": ((PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 if args.avg_f32 else PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION) * args.boards
+                                 if (solver.engine == "fused" and args.variant == "plus") else None),
                      "traffic_source": PMC_TRAFFIC_SOURCE,
                      "kernel": "prl_k_fhp_pass" if n_pass else "all kernels of the iteration",
                      "launches_per_iteration": n_pass / float(args.steps) if n_pass else None,
@@ -302,8 +305,9 @@ def main():
                      "bytes_per_iteration_algorithmic": bytes_iter,
                      # the PMC-measured bytes over the same kernel time: what the kernel actually pulls through HBM (float64 averages
                      # included), against the ~6.3 TB/s MI355X_MICROARCH.md gives as sustained
-                     "traffic_rate_gbps": (PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION * args.boards * args.steps / (kernel_ms * 1e-3) / 1e9)
-                     if (solver.engine == "fused" and args.variant == "plus" and not args.avg_f32) else None,
+                     "traffic_rate_gbps": ((PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 if args.avg_f32 else PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION)
+                                           * args.boards * args.steps / (kernel_ms * 1e-3) / 1e9)
+                     if (solver.engine == "fused" and args.variant == "plus") else None,
                      "sustained_hbm_gbps": 6300.0,
                      "achieved_whole_iteration": bytes_iter * args.steps / (dev_ms * 1e-3) / 1e9},
     }
