@@ -215,7 +215,8 @@ def test_gpu_streets_engine_best_response_of_an_explicit_strategy_vs_oracle(L):
     assert t.n_nodes > 60000
 
 
-def test_gpu_streets_engine_bench_tree_vs_oracle_fixture(L):
+@pytest.mark.parametrize("variant", ["plus", "linear", "vanilla"])
+def test_gpu_streets_engine_bench_tree_vs_oracle_fixture(L, variant):
     """bench_multistreet.py's tree (4 flops x 2 turns x 2 rivers, 259 330 nodes) on the per-street engine against the ORACLE's own run of it
     (tests/golden/make_streets_golden.py): exploitability history, average-strategy exploitability, SHA-256 of the regrets / averages"""
     import os
@@ -225,7 +226,7 @@ def test_gpu_streets_engine_bench_tree_vs_oracle_fixture(L):
     from helpers import GOLDEN, h32
     from pokerrl_amd import _native
     from pokerrl_amd.game import games as G
-    path = os.path.join(GOLDEN, "lh_4x2x2_plus.npz")
+    path = os.path.join(GOLDEN, "lh_4x2x2_%s.npz" % variant)
     if not os.path.isfile(path):
         pytest.skip("fixture not generated (tests/golden/make_streets_golden.py)")
     g = np.load(path)
