@@ -43,7 +43,37 @@ def main(flops=4, turns=2, rivers=2, variant="plus", n_iters=3):
     print("wrote", out)
 
 
+def seeded_strategy(t, seed):
+    """float32 [n_cols][R] strategy in the flat tree's DFS column order, random and normalised per node and hand (fill_random_random semantics)"""
+    kind, nch, fc = t.field("kind"), t.field("n_children"), t.field("first_col")
+    rng = np.random.RandomState(seed)
+    strat = np.empty((t.n_cols, t.range_size), np.float32)
+    for n in np.where(kind == 0)[0]:
+        x = rng.random_sample((nch[n], t.range_size)).astype(np.float32)
+        strat[fc[n]:fc[n] + nch[n]] = x / x.sum(axis=0, keepdims=True)
+    return strat
+
+
+def main_br(flops=4, turns=2, rivers=2, seed=21):
+    """exact best response of a seeded float32 strategy on the same tree (LocalBRMaster.py:67-80) -> lh_<F>x<T>x<R>_br.npz"""
+    ro = bench_multistreet.runouts(flops, turns, rivers)
+    t = _native.NativeTree.for_game(G.LimitHoldem, 48, None, ro)
+    r = G.LimitHoldem.RULES
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS, r._RANK_RULE)
+    o.cfr_configure(1, 0)
+    strat = seeded_strategy(t, seed)
+    o.set_strategy(strat.astype(np.float64), False)
+    o.compute_ev()
+    out = os.path.join(HERE, "lh_%dx%dx%d_br.npz" % (flops, turns, rivers))
+    np.savez(out, flops=flops, turns=turns, rivers=rivers, seed=seed, runouts_sha256=h32(ro), strategy_sha256=h32(strat), n_nodes=t.n_nodes,
+             exploitability=np.array(o.exploitability, np.float32), numpy=np.__version__)
+    print("wrote", out, o.exploitability)
+
+
 if __name__ == "__main__":
     a = sys.argv[1:]
+    if a and a[0] == "br":
+        main_br(*(int(x) for x in a[1:4]))
+        sys.exit(0)
     main(int(a[0]) if a else 4, int(a[1]) if len(a) > 1 else 2, int(a[2]) if len(a) > 2 else 2, a[3] if len(a) > 3 else "plus",
          int(a[4]) if len(a) > 4 else 3)

@@ -243,6 +243,34 @@ def test_gpu_streets_engine_bench_tree_vs_oracle_fixture(L, variant):
     assert h32(s.get("avg")) == str(g["avg_sha256"])
 
 
+def test_gpu_streets_engine_bench_tree_best_response_vs_oracle_fixture(L):
+    """exact best response of a seeded float32 strategy on bench_multistreet.py's tree: the per-street engine's evaluation pass against the
+    oracle's exploitability of the same strategy (tests/golden/make_streets_golden.py br)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import bench_multistreet
+    from helpers import GOLDEN, h32
+    from make_streets_golden import seeded_strategy
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import games as G
+    path = os.path.join(GOLDEN, "lh_4x2x2_br.npz")
+    if not os.path.isfile(path):
+        pytest.skip("fixture not generated (tests/golden/make_streets_golden.py br)")
+    g = np.load(path)
+    ro = bench_multistreet.runouts(int(g["flops"]), int(g["turns"]), int(g["rivers"]))
+    assert h32(ro) == str(g["runouts_sha256"])
+    t = _native.NativeTree.for_game(G.LimitHoldem, 48, None, ro, _lib=L)
+    strat = seeded_strategy(t, int(g["seed"]))
+    assert h32(strat) == str(g["strategy_sha256"])
+    s = _native.NativeSolver(t, "plus", 0, engine="auto", _lib=L)
+    assert s.engine == "fused"
+    s.set_strategy(strat)
+    s.compute_ev()
+    assert np.array_equal(s.exploitability(), g["exploitability"]), (s.exploitability(), g["exploitability"])
+
+
 def test_gpu_streets_engine_vs_levels_engine_bench_tree(L):
     """bench_multistreet.py's tree (4 flops x 2 turns x 2 rivers, 259 330 nodes) on both engines of the library: the same exploitability
     history, regrets and averages; the per-street engine in < 1/3 of the level-synchronous engine's HBM"""
