@@ -186,7 +186,7 @@ def main():
         solver, err = None, None
         try:
             solver = _native.NativeSolver(tree, args.variant, 0, shard=rccl_shard(world, rank, shard_boards if total else None, total or None, lib=lib), _lib=lib)
-        except _native.NativeError as e:  # no librccl.so to bind, or the communicator could not be set up: the callback path still works
+        except (_native.NativeError, RuntimeError) as e:  # no librccl.so to bind (every rank raises: rccl_shard), or the communicator could not be set up: the callback path still works
             err = e
         ok = torch.tensor([0 if solver is None else 1], dtype=torch.int32, device="cpu" if emu_lib else "cuda")
         if world > 1:

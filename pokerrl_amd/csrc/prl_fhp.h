@@ -160,9 +160,19 @@ inline PrlFhpShapeDesc prl_fhp_describe() {
 enum { PRL_FHP_SHAPE_15 = 0, PRL_FHP_SHAPE_9 = 1, PRL_FHP_SHAPE_21 = 2, PRL_FHP_N_SHAPES = 3 };
 const PrlFhpShapeDesc& prl_fhp_shape_desc(int shape_id);  // prl_fhp_kernels.hip
 
+// SORTED STORAGE (round 4). Inside a board subtree nothing but the root vectors ever meets another board, so the board's action columns
+// need not be indexed by hand: they are stored in the board's own RANK-SORTED order, live hands only -- element q of a board column belongs
+// to the hand at sorted position q of that board's showdown plan (PRL_PP_*: `sh`), FHP_NP = 1088 elements per column (1081 live positions
+// of a 5-card board + padding). The hands a board blocks (245 of 1326) have no storage: their regrets are 0 for ever, their strategy is
+// the uniform one, their running average follows a scalar recurrence (prl_solver.hip: blocked_avg) -- 18.5 % fewer HBM bytes per pass.
+// A lane of the board pass owns two ADJACENT POSITIONS, so its scatter into the sorted domain (phase B), its reads at its own position
+// (phase E) and its column loads / stores are all linear. The arrays below are the BOARD REGIONS of the solver's column arrays:
+// [n_boards][n_cols_board][np]; the trunk's columns stay [R] in hand order in front of them. prl_solver_get / set / checkpoints translate
+// (prl_launch_fhp_expand / _compact).
+#define PRL_FHP_NP 1088
 struct PrlFhpParams {
     int32_t n_boards, R;
-    int32_t col_base;           // global action column of board 0, local column 0
+    int32_t np;                 // elements per board column = PRL_FHP_NP
     int32_t variant, iter;
     int32_t max_grid;
     int32_t shape;              // PRL_FHP_SHAPE_*: which instantiation of the board pass walks this tree
@@ -170,27 +180,24 @@ struct PrlFhpParams {
     int32_t dec_nch[PRL_FHP_MAX_DEC], dec_col0[PRL_FHP_MAX_DEC];
     float chance_prob, eq_const;
     float pot[PRL_FHP_MAX_NODES];      // main pot of the terminal nodes (by local node id)
-    const float* chance_reach;  // [2][R] reach at the chance node (trunk state)
-    float* regret;              // [n_cols][R] (global column ids)
-    double* avg;                // [n_cols][R] average strategy, updated by the update passes when avg_mode != 0
+    const float* chance_reach;  // [2][R] reach at the chance node (trunk state, hand order)
+    float* regret;              // board region [n_boards][n_cols_board][np]; PRL_SRC_STRAT32: an explicit float32 strategy in the same layout
+    double* avg;                // board region: average strategy, updated by the update passes when avg_mode != 0
     float* avg32;               // opt-in (prl_solver_create_opts: PRL_SOLVER_AVG_F32): the same average STORED as float32 -- read, widened, blended in
                                 // float64 with the reference's weights, rounded on the store; `avg` is not touched by the board pass then
     int32_t avg_mode;           // 0: no update (before the delay), 1: avg = strategy, 2: avg = m_old * avg + m_new * strategy
     double m_old, m_new;        // CFRPlus.py:65-87 weights (float64)
     // Vanilla / Linear CFR: the reach-weighted average of seat q needs q's NEW reach, known only after the trunk update that
     // follows q's pass -- so it rides on the next pass that walks q's reach (phase B for seat q): bit q of avgsum_mask
-    float* avg_sum;             // [n_cols][R] node.data["avg_strat_sum"] (VanillaCFR.py:40-55, LinearCFR.py:41-57)
+    float* avg_sum;             // board region: node.data["avg_strat_sum"] (VanillaCFR.py:40-55, LinearCFR.py:41-57)
     int32_t avgsum_mask, avgsum_iter[2];
     int32_t block_sum;          // 1: board_out holds one row per PRL_CHANCE_BLOCK boards (level 0 of the chance sum done by the pass)
     int32_t exp;                // FHP_EXPERIMENT builds: run-time switch between two code paths (prl_debug_set_experiment)
     int32_t no_steady;          // tests: 1 = never take the CFR+ steady-state specialisation of the pass (prl_fhp_pass.inc, FhpCtxT)
-    const double* strat_arr;    // explicit strategy (average strategy / caller-provided), [n_cols][R]
-    float* board_out;           // [n_boards][prl_fhp_out_width(mode)][R] root vectors of every board subtree
-    const uint16_t* hole_packed;// [R] c1 | c2 << 8
-    int32_t plan_stride;
-    const int16_t *plan_pos, *plan_hgs, *plan_hge;
+    const double* strat_arr;    // board region of an explicit float64 strategy (the average being evaluated / caller-provided)
+    float* board_out;           // [n_boards or n_blocks][prl_fhp_out_width(mode)][R] root vectors (hand order)
+    const int16_t* plan_pp;     // [n_boards][PRL_PP_STRIDE] position-domain plans (prl_solver_types.h)
     const uint32_t* plan_clx;   // [n_boards][PRL_CLX_WORDS] per-lane records of the per-card scans (prl_solver_types.h)
-    const int32_t* plan_nlive;
     unsigned long long* timing; // PRL_FHP_TIMING builds: [8] shader-clock accumulators per phase (prologue, B, C, D, E, epilogue)
 };
 
@@ -200,8 +207,17 @@ struct PrlFhpParams {
 int prl_fhp_match_shape(const PrlFlatTree& t, int* chance_node, int* first_board_node, int* col_base, float* pots /*[PRL_FHP_MAX_NODES]*/);
 
 int prl_launch_fhp_pass(const PrlFhpParams& prm, int mode, int src0, int src1, void* stream);
-void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_cols, void* stream);
+// the strategy the regrets imply, board region -> board region (float64)
+void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_region, void* stream);
 void prl_launch_fhp_avg_from_sum(const PrlFhpParams& prm, void* stream);  // Vanilla / Linear: avg columns of the boards from avg_sum
+// sorted storage <-> the caller's [n_cols][R] hand-order columns, boards [b0, b0 + nb): elem = 4 (float32) or 8 (float64) bytes.
+// expand: dst[(b - b0) * n_cols_board + j][h] = region[b][j][pos_b(h)] for live hands; blocked hands get fill[j] (elem bytes each, by
+// LOCAL column j; nullptr = zeros) or, when `blocked_src` is given, blocked_src[b][j][k] (k-th blocked hand of the board, hand order).
+// compact: the inverse; `blocked_dst` (optional) keeps what the caller had for the blocked hands.
+void prl_launch_fhp_expand(const PrlFhpParams& prm, const void* region, int elem, int b0, int nb, const void* fill_by_col, const void* blocked_src,
+                           void* dst, void* stream);
+void prl_launch_fhp_compact(const PrlFhpParams& prm, const void* src, int elem, int b0, int nb, void* region, void* blocked_dst, void* stream);
+#define PRL_FHP_NBLOCKED (1326 - 1081)
 // W = floats per board / unit: 2R for both seats' vectors, R for one seat's
 void prl_launch_fhp_chance_sum(const float* d_board_vals, int n_boards, int W, float* d_scratch, float* d_dest, void* stream);
 // sharded solve (prl_solver_create_sharded): local reduction up to `level`, all-gather, then the remaining levels

@@ -6,7 +6,8 @@
 // each chance outcome the board subtree is independent (ValueFiller.py:76-78 is a plain sum over boards), its shape is the
 // same for every board (betting never looks at the cards) and per hand everything except terminal equity is hand-local.
 // So: one workgroup walks ONE board subtree depth-first with the subtree shape known at COMPILE time (prl_fhp_shape.h):
-//   * 768 lanes (663 of them x 2 adjacent hands cover the 1326 hands); reach / ev / regrets of the current DFS path live in VGPRs;
+//   * 768 lanes; 541 of them x 2 adjacent RANK-SORTED POSITIONS cover the 1081 live hands of a board (sorted storage, prl_fhp.h);
+//     reach / ev / regrets of the current DFS path live in VGPRs;
 //   * HBM traffic per board and pass: 14 regret columns + ~15 KB of showdown plan in (prefetched into LDS by LDS-DMA while
 //     the previous board is walked), the updated seat's 7 regret columns and float64 average columns read-modify-written,
 //     one row of 1-4 root vectors out -- nothing else;
@@ -83,25 +84,25 @@ int prl_launch_fhp_pass(const PrlFhpParams& prm, int mode, int src0, int src1, v
     }
 }
 
-// materialise the strategy implied by the regrets (tests / prl_solver_get): [n_board_cols][R] float64
-PRL_GLOBAL void prl_k_fhp_strategy_from_regret(PrlFhpParams prm, double* out_cols) {
-    const size_t per_board = (size_t)prm.n_dec * prm.R;
+// materialise the strategy implied by the regrets (tests / prl_solver_get): board region -> board region, float64
+PRL_GLOBAL void prl_k_fhp_strategy_from_regret(PrlFhpParams prm, double* out_region) {
+    const size_t per_board = (size_t)prm.n_dec * prm.np;
     const size_t total = (size_t)prm.n_boards * per_board;
     for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
         const size_t b = t / per_board;
-        const int j = (int)((t % per_board) / prm.R);
-        const size_t h = t % prm.R;
+        const int j = (int)((t % per_board) / prm.np);
+        const size_t q = t % prm.np;
         const int A = prm.dec_nch[j], col0 = prm.dec_col0[j];
-        const size_t base = ((size_t)prm.col_base + b * prm.n_cols_board + col0) * (size_t)prm.R + h;
+        const size_t base = (b * prm.n_cols_board + col0) * (size_t)prm.np + q;
         float tt[3];
         float sum = 0.f;
         for (int i = 0; i < A; ++i) {
-            float r = prm.regret[base + (size_t)i * prm.R];
+            float r = prm.regret[base + (size_t)i * prm.np];
             tt[i] = prm.variant == PRL_CFR_PLUS ? r : (r > 0.f ? r : 0.f);
             sum = sum + tt[i];
         }
         const float unif = (float)(1.0 / (double)A);
-        for (int i = 0; i < A; ++i) out_cols[base + (size_t)i * prm.R] = (double)(sum > 0.f ? tt[i] / sum : unif);
+        for (int i = 0; i < A; ++i) out_region[base + (size_t)i * prm.np] = (double)(sum > 0.f ? tt[i] / sum : unif);
     }
 }
 
@@ -109,19 +110,55 @@ PRL_GLOBAL void prl_k_fhp_strategy_from_regret(PrlFhpParams prm, double* out_col
 // uniform (VanillaCFR.py:54-77, LinearCFR.py:53-76: float32 division, stored in the float64 column array). The board pass
 // only maintains avg_sum; this runs when the average is read (evaluation, prl_solver_get, checkpoint).
 PRL_GLOBAL void prl_k_fhp_avg_from_sum(PrlFhpParams prm) {
-    const size_t per_board = (size_t)prm.n_dec * prm.R;
+    const size_t per_board = (size_t)prm.n_dec * prm.np;
     const size_t total = (size_t)prm.n_boards * per_board;
     for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
         const size_t b = t / per_board;
-        const int j = (int)((t % per_board) / prm.R);
-        const size_t h = t % prm.R;
+        const int j = (int)((t % per_board) / prm.np);
+        const size_t q = t % prm.np;
         const int A = prm.dec_nch[j], col0 = prm.dec_col0[j];
-        const size_t base = ((size_t)prm.col_base + b * prm.n_cols_board + col0) * (size_t)prm.R + h;
+        const size_t base = (b * prm.n_cols_board + col0) * (size_t)prm.np + q;
         float as[3];
-        for (int i = 0; i < A; ++i) as[i] = prm.avg_sum[base + (size_t)i * prm.R];
+        for (int i = 0; i < A; ++i) as[i] = prm.avg_sum[base + (size_t)i * prm.np];
         float sum = as[0];
         for (int i = 1; i < A; ++i) sum = sum + as[i];
-        for (int i = 0; i < A; ++i) prm.avg[base + (size_t)i * prm.R] = sum == 0.f ? 1.0 / (double)A : (double)(as[i] / sum);
+        for (int i = 0; i < A; ++i) prm.avg[base + (size_t)i * prm.np] = sum == 0.f ? 1.0 / (double)A : (double)(as[i] / sum);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// sorted storage <-> the caller's hand-order columns (prl_fhp.h). Not on the iteration path: prl_solver_get / set / checkpoints.
+// A thread moves one (board, column, position); the permutation is the plan's `sh` (position -> hand).
+// ---------------------------------------------------------------------------------------------------------------------
+template <class E>
+PRL_GLOBAL void prl_k_fhp_expand(PrlFhpParams prm, const E* region, int b0, int nb, const E* fill_by_col, const E* blocked_src, E* dst) {
+    const int ncb = prm.n_cols_board, R = prm.R, NL = R - PRL_FHP_NBLOCKED;
+    const size_t total = (size_t)nb * ncb * R;
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        const int q = (int)(t % R);
+        const size_t bj = t / R;
+        const int j = (int)(bj % ncb);
+        const size_t b = (size_t)b0 + bj / ncb;
+        const int h = prm.plan_pp[b * PRL_PP_STRIDE + q];
+        E v;
+        if (q < NL) v = region[(b * ncb + j) * (size_t)prm.np + q];
+        else if (blocked_src) v = blocked_src[(b * ncb + j) * (size_t)PRL_FHP_NBLOCKED + (q - NL)];
+        else v = fill_by_col ? fill_by_col[j] : (E)0;
+        dst[bj * R + h] = v;
+    }
+}
+template <class E>
+PRL_GLOBAL void prl_k_fhp_compact(PrlFhpParams prm, const E* src, int b0, int nb, E* region, E* blocked_dst) {
+    const int ncb = prm.n_cols_board, R = prm.R, NL = R - PRL_FHP_NBLOCKED, NPX = prm.np + PRL_FHP_NBLOCKED;
+    const size_t total = (size_t)nb * ncb * NPX;  // np region elements (live positions + zero padding), then the blocked hands
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        const int q = (int)(t % NPX);
+        const size_t bj = t / NPX;
+        const int j = (int)(bj % ncb);
+        const size_t b = (size_t)b0 + bj / ncb;
+        const int16_t* sh = prm.plan_pp + b * PRL_PP_STRIDE;
+        if (q < prm.np) region[(b * ncb + j) * (size_t)prm.np + q] = q < NL ? src[bj * R + sh[q]] : (E)0;
+        else if (blocked_dst) blocked_dst[(b * ncb + j) * (size_t)PRL_FHP_NBLOCKED + (q - prm.np)] = src[bj * R + sh[NL + (q - prm.np)]];
     }
 }
 
@@ -160,16 +197,31 @@ static inline int fhp_grid_for(size_t items, int block) {
     return (int)g;
 }
 
-void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_cols, void* stream) {
+void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_region, void* stream) {
     if (prm.n_boards <= 0) return;
-    size_t items = (size_t)prm.n_boards * prm.n_dec * prm.R;
-    PRL_LAUNCH(prl_k_fhp_strategy_from_regret, fhp_grid_for(items, 256), 256, 0, stream, prm, out_cols);
+    size_t items = (size_t)prm.n_boards * prm.n_dec * prm.np;
+    PRL_LAUNCH(prl_k_fhp_strategy_from_regret, fhp_grid_for(items, 256), 256, 0, stream, prm, out_region);
 }
 
 void prl_launch_fhp_avg_from_sum(const PrlFhpParams& prm, void* stream) {
     if (prm.n_boards <= 0) return;
-    size_t items = (size_t)prm.n_boards * prm.n_dec * prm.R;
+    size_t items = (size_t)prm.n_boards * prm.n_dec * prm.np;
     PRL_LAUNCH(prl_k_fhp_avg_from_sum, fhp_grid_for(items, 256), 256, 0, stream, prm);
+}
+
+void prl_launch_fhp_expand(const PrlFhpParams& prm, const void* region, int elem, int b0, int nb, const void* fill_by_col, const void* blocked_src,
+                           void* dst, void* stream) {
+    if (nb <= 0) return;
+    const size_t items = (size_t)nb * prm.n_cols_board * prm.R;
+    if (elem == 4) PRL_LAUNCH(prl_k_fhp_expand<float>, fhp_grid_for(items, 256), 256, 0, stream, prm, (const float*)region, b0, nb, (const float*)fill_by_col, (const float*)blocked_src, (float*)dst);
+    else PRL_LAUNCH(prl_k_fhp_expand<double>, fhp_grid_for(items, 256), 256, 0, stream, prm, (const double*)region, b0, nb, (const double*)fill_by_col, (const double*)blocked_src, (double*)dst);
+}
+
+void prl_launch_fhp_compact(const PrlFhpParams& prm, const void* src, int elem, int b0, int nb, void* region, void* blocked_dst, void* stream) {
+    if (nb <= 0) return;
+    const size_t items = (size_t)nb * prm.n_cols_board * (prm.np + PRL_FHP_NBLOCKED);
+    if (elem == 4) PRL_LAUNCH(prl_k_fhp_compact<float>, fhp_grid_for(items, 256), 256, 0, stream, prm, (const float*)src, b0, nb, (float*)region, (float*)blocked_dst);
+    else PRL_LAUNCH(prl_k_fhp_compact<double>, fhp_grid_for(items, 256), 256, 0, stream, prm, (const double*)src, b0, nb, (double*)region, (double*)blocked_dst);
 }
 
 // per-board [n_boards][2][R] -> dest [2][R] in the canonical nested order; scratch >= (ceil(n/32) + ceil(n/1024)) * 2R floats

@@ -21,7 +21,7 @@
 
 PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
                                  int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx, int32_t* plan_ndealt,
-                                 uint8_t* plan_klh) {
+                                 uint8_t* plan_klh, int16_t* plan_pp) {
     uint32_t* keys = (uint32_t*)prl_smem();  // [2048]
     int* n_live_s = (int*)(keys + 2048);
     const int tid = (int)prl_tid(), nt = (int)prl_nthreads();
@@ -174,13 +174,35 @@ PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, in
             }
             prl_sync();
         }
+        // position-domain plan of the single-deal fused engine (prl_solver_types.h: PRL_PP_*)
+        if (plan_pp && has_board && T.R == PRL_PP_R && n <= PRL_PP_NPAD - 7) {
+            int16_t* pp = plan_pp + (size_t)b * PRL_PP_STRIDE;
+            for (int i = tid; i < PRL_PP_NPAD; i += nt) {
+                const bool lv = i < n;
+                const int h = lv ? (int)(keys[i] & 0x7FFu) : 0;
+                pp[i] = (int16_t)h;  // (positions n .. R-1 are overwritten below)
+                pp[PRL_PP_OFF_GM1 + i] = (int16_t)(lv && gs[i] > 0 ? gs[i] - 1 : (int)PRL_CLX_ZERO_POS);
+                pp[PRL_PP_OFF_EM1 + i] = (int16_t)(lv ? ge[i] - 1 : (int)PRL_CLX_ZERO_POS);
+                pp[PRL_PP_OFF_CC + i] = (int16_t)(lv ? (T.hole[2 * h] & 0xFF) | ((T.hole[2 * h + 1] & 0xFF) << 8) : 0);
+            }
+            for (int i = PRL_PP_OFF_CC + PRL_PP_NPAD + tid; i < PRL_PP_STRIDE; i += nt) pp[i] = 0;
+            prl_sync();
+            // the hands the board blocks, in hand-index order, after the live ones: sh is a permutation of all R hands
+            for (int h = tid; h < T.R; h += nt) {
+                if (pos[h] >= 0) continue;
+                int before = 0;
+                for (int g = 0; g < h; ++g) before += pos[g] < 0;
+                pp[n + before] = (int16_t)h;
+            }
+            prl_sync();
+        }
     }
 }
 
 void prl_launch_plan_build(const PrlDevTree& T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
                            int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx, int32_t* plan_ndealt,
-                           uint8_t* plan_klh, void* stream) {
+                           uint8_t* plan_klh, int16_t* plan_pp, void* stream) {
     int grid = n_plans < 32768 ? n_plans : 32768;
     PRL_LAUNCH(prl_k_plan_build, grid, 256, 2048 * sizeof(uint32_t) + 16, stream, T, n_plans, plan_sh, plan_pos, plan_gs, plan_ge, plan_cl,
-               plan_nlive, plan_hgs, plan_hge, plan_clx, plan_ndealt, plan_klh);
+               plan_nlive, plan_hgs, plan_hge, plan_clx, plan_ndealt, plan_klh, plan_pp);
 }

@@ -101,6 +101,19 @@ struct prl_solver {
     int32_t* d_trunk_leaves = nullptr; // trunk ids of the trunk's chance leaves
     int n_trunk_leaves = 1;
     std::vector<int32_t> col_dfs;      // internal column -> flat-tree (DFS) column; empty = identity (every other engine)
+    // ---- single-deal fused engine: SORTED STORAGE of the board columns (prl_fhp.h) ----
+    // every column array is [trunk columns][R] in hand order, then -- from element `board_ofs` -- the board region
+    // [n_boards][ncb][PRL_FHP_NP] in each board's rank-sorted order, live hands only: `col_elems` elements in all
+    bool sorted = false;
+    int col_base = 0, ncb = 0;         // global column id of board 0's first column, columns per board
+    size_t board_ofs = 0, col_elems = 0;
+    double blk_avg[4] = {0., 0., 0., 0.};  // CFR+ running average of a hand its board blocks, by action count: the board pass keeps no
+                                       // storage for it (regrets 0 for ever -> uniform strategy -> a scalar recurrence per action count)
+    float* d_user_blocked32 = nullptr; // what set_strategy's caller had for the blocked hands, [n_boards * ncb][PRL_FHP_NBLOCKED]: get returns it
+    double* d_user_blocked64 = nullptr;
+    char* d_stage = nullptr;           // translation buffer of get / set: `stage_boards` boards x ncb x R x 8 bytes
+    int stage_boards = 0;
+    double* d_fill = nullptr;          // [PRL_FHP_MAX_NODES * 3] per-column fill values of an expansion
 };
 
 namespace {
@@ -245,6 +258,109 @@ int dev_upload(prl_solver* s, const T** p, const std::vector<T>& v) {
 
 #define TRY(x) do { int e_ = (x); if (e_) return e_; } while (0)
 
+// elements of one column array (regret, avg, ...): hand-order [full_cols][R], or trunk columns + the sorted board region
+static size_t col_array_elems(const prl_solver* s) { return s->sorted ? s->col_elems : (size_t)s->full_cols * s->R; }
+
+// ---- sorted storage <-> the caller's hand-order columns (single-deal fused engine), a chunk of boards at a time -----------------
+static int stage_ready(prl_solver* s) {
+    if (s->d_stage) return PRL_OK;
+    const size_t per_board = (size_t)s->ncb * s->R * 8;
+    size_t nb = ((size_t)192 << 20) / per_board;
+    if (nb < 1) nb = 1;
+    if (nb > (size_t)s->fp.n_boards) nb = (size_t)s->fp.n_boards;
+    TRY(dev_alloc(s, &s->d_stage, nb * per_board, true));
+    TRY(dev_alloc(s, &s->d_fill, (size_t)PRL_FHP_MAX_NODES * 3, true));
+    s->stage_boards = (int)nb;
+    return PRL_OK;
+}
+// local column j of a board -> the action count of its decision node
+static int board_col_actions(const prl_solver* s, int j) {
+    for (int d = 0; d < s->fp.n_dec; ++d)
+        if (j >= s->fp.dec_col0[d] && j < s->fp.dec_col0[d] + s->fp.dec_nch[d]) return s->fp.dec_nch[d];
+    return 1;
+}
+// boards [b0, b0 + nb) of a board region -> host columns [nb * ncb][R] (hand order), `out_elem` bytes per element (8 with elem 4: float32
+// storage widened exactly). fill_by_col: value of the hands a board blocks, by local column (nullptr: 0); blocked_src: or the side array
+static int sorted_get_boards(prl_solver* s, const void* region, int elem, const double* fill_by_col, const void* blocked_src, void* out, int out_elem,
+                             int b0, int nb) {
+    TRY(stage_ready(s));
+    const void* d_fill = nullptr;
+    if (fill_by_col) {
+        char tmp[PRL_FHP_MAX_NODES * 3 * 8];
+        for (int j = 0; j < s->ncb; ++j) {
+            if (elem == 4) ((float*)tmp)[j] = (float)fill_by_col[j];
+            else ((double*)tmp)[j] = fill_by_col[j];
+        }
+        PRL_HIP_TRY(hipMemcpyAsync(s->d_fill, tmp, (size_t)s->ncb * elem, hipMemcpyHostToDevice, s->stream));
+        PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+        d_fill = s->d_fill;
+    }
+    const size_t per_board = (size_t)s->ncb * s->R;
+    std::vector<float> widen;
+    for (int at = 0; at < nb; at += s->stage_boards) {
+        const int n = nb - at < s->stage_boards ? nb - at : s->stage_boards;
+        prl_launch_fhp_expand(s->fp, region, elem, b0 + at, n, d_fill, blocked_src, s->d_stage, s->stream);
+        PRL_HIP_TRY(hipGetLastError());
+        char* o = (char*)out + (size_t)at * per_board * out_elem;
+        if (out_elem == elem) PRL_HIP_TRY(hipMemcpyAsync(o, s->d_stage, (size_t)n * per_board * elem, hipMemcpyDeviceToHost, s->stream));
+        else {
+            widen.resize((size_t)n * per_board);
+            PRL_HIP_TRY(hipMemcpyAsync(widen.data(), s->d_stage, (size_t)n * per_board * 4, hipMemcpyDeviceToHost, s->stream));
+            PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+            double* od = (double*)o;
+            for (size_t i = 0; i < (size_t)n * per_board; ++i) od[i] = (double)widen[i];
+        }
+        PRL_HIP_TRY(hipStreamSynchronize(s->stream));  // the staging buffer is reused
+    }
+    return PRL_OK;
+}
+// host columns [n_boards * ncb][R] (hand order) -> a board region (+ the caller's values for the blocked hands)
+static int sorted_set_boards(prl_solver* s, const void* host_cols, int elem, void* region, void* blocked_dst) {
+    TRY(stage_ready(s));
+    const size_t per_board = (size_t)s->ncb * s->R;
+    const int nb = s->fp.n_boards;
+    for (int at = 0; at < nb; at += s->stage_boards) {
+        const int n = nb - at < s->stage_boards ? nb - at : s->stage_boards;
+        PRL_HIP_TRY(hipMemcpyAsync(s->d_stage, (const char*)host_cols + (size_t)at * per_board * elem, (size_t)n * per_board * elem, hipMemcpyHostToDevice, s->stream));
+        // (the kernel indexes the staging buffer from its start: src row = local board)
+        PrlFhpParams q = s->fp;
+        prl_launch_fhp_compact(q, s->d_stage, elem, at, n, region, blocked_dst, s->stream);
+        PRL_HIP_TRY(hipGetLastError());
+        PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    return PRL_OK;
+}
+// the blocked hands' value of the running average, per local column (see prl_solver::blk_avg)
+static void blocked_avg_fill(const prl_solver* s, double* fill) {
+    for (int j = 0; j < s->ncb; ++j) {
+        const int A = board_col_actions(s, j);
+        if (s->variant == PRL_CFR_PLUS) fill[j] = s->blk_avg[A < 4 ? A : 0];
+        else fill[j] = s->board_avg_f64 ? 1.0 / (double)A : 0.0;  // prl_k_fhp_avg_from_sum on an all-zero sum, once the first sums exist
+    }
+}
+// CFRPlus.py:65-87 for a hand whose regrets are 0 for ever (its strategy is the uniform float32 one): what the board pass would have stored
+static void blocked_avg_step(prl_solver* s, int mode, double m_old, double m_new) {
+    if (!mode) return;
+    for (int A = 1; A < 4; ++A) {
+        const float unif = (float)(1.0 / (double)A);
+        double a = mode == 2 ? m_old * s->blk_avg[A] + m_new * (double)unif : (double)unif;
+        if (s->avg_f32) a = (double)(float)a;
+        s->blk_avg[A] = a;
+    }
+}
+static void cfr_plus_weights(const prl_solver* s, int iter, int* mode, double* m_old, double* m_new) {
+    *mode = 0; *m_old = 0.; *m_new = 0.;
+    if (s->variant != PRL_CFR_PLUS) return;
+    if (iter > s->delay) {  // CFRPlus.py:65-87: float64 weights from integer sums
+        long long cw = 0;
+        for (int k = s->delay + 1; k <= iter; ++k) cw += k;
+        long long nw = iter - s->delay + 1;
+        *m_old = (double)cw / (double)(cw + nw);
+        *m_new = (double)nw / (double)(cw + nw);
+        *mode = 2;
+    } else if (iter == s->delay) *mode = 1;
+}
+
 int alloc_node_vectors(prl_solver* s, PrlDevState* st, bool with_br_idx) {
     const size_t nv = (size_t)s->T.n_nodes * 2 * s->T.R;
     TRY(dev_alloc(s, &st->reach, nv));
@@ -293,8 +409,8 @@ static int ensure_board_avg(prl_solver* s) {
         return PRL_OK;
     }
     PrlFhpParams p = s->fp;
-    p.avg_sum = s->S.avg_sum;
-    p.avg = s->d_avg;
+    p.avg_sum = s->S.avg_sum + s->board_ofs;
+    p.avg = s->d_avg + s->board_ofs;
     prl_launch_fhp_avg_from_sum(p, s->stream);
     PRL_HIP_TRY(hipGetLastError());
     s->board_avg_stale = false;
@@ -405,15 +521,17 @@ int street_sweep(prl_solver* s, const PrlDevState& st, int mode, int src0, int s
 int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, int src1, const double* strat_arr, const float* strat32 = nullptr) {
     if (s->streets) return street_sweep(s, st, mode, src0, src1, strat_arr, strat32);
     PrlFhpParams p = s->fp;
-    if (strat32) p.regret = const_cast<float*>(strat32);  // PRL_SRC_STRAT32: float32 strategy columns in the regret array's layout (read only)
+    // the board regions of the column arrays (sorted storage, prl_fhp.h)
+    // PRL_SRC_STRAT32: float32 strategy columns in the regret array's layout (read only)
+    p.regret = (strat32 ? const_cast<float*>(strat32) : s->d_regret) + s->board_ofs;
     p.iter = s->iter;
     p.variant = s->variant;
     p.chance_reach = st.reach + prl_vidx(s->T, s->chance_trunk, 0);
-    p.strat_arr = strat_arr;
+    p.strat_arr = strat_arr ? strat_arr + s->board_ofs : nullptr;
     // pending Vanilla / Linear average updates ride on the phase-B walk of that seat (the training state only)
-    p.avg_sum = s->S.avg_sum;
-    p.avg = s->d_avg;
-    p.avg32 = s->d_avg32;
+    p.avg_sum = s->S.avg_sum ? s->S.avg_sum + s->board_ofs : nullptr;
+    p.avg = s->avg_f32 ? nullptr : s->d_avg + s->board_ofs;
+    p.avg32 = s->d_avg32 ? s->d_avg32 + s->board_ofs : nullptr;
     p.avgsum_mask = 0;
     // level 0 of the canonical chance sum inside the pass (one row per 32-board block leaves the chip) whenever whole blocks are
     // what comes next: always without an exchange, and with one when the units exchanged are blocks or groups of blocks
@@ -494,6 +612,10 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
 }
 
 int do_compute_ev(prl_solver* s, const PrlDevState& st, int fused_mode = PRL_FHP_EVAL) {
+    // the history slot this evaluation writes (expl_to_history) is consumed HERE, on every exit path: a failed board pass / exchange must
+    // not leave a pointer into a history block that ensure_hist may since have replaced
+    float* const expl_dst = &st == &s->S ? s->expl_copy_dst : nullptr;
+    if (&st == &s->S) s->expl_copy_dst = nullptr;
     if (s->fused) {
         const double* arr = nullptr;
         int s0 = s->src[0], s1 = s->src[1];
@@ -509,8 +631,7 @@ int do_compute_ev(prl_solver* s, const PrlDevState& st, int fused_mode = PRL_FHP
         }
         TRY(fused_board_pass(s, st, fused_mode, s0, s1, arr, arr32));
     }
-    prl_launch_ev(s->T, st, s->ft.level_start.data(), s->d_term_nodes, s->n_term, s->stream, &st == &s->S ? s->expl_copy_dst : nullptr);
-    if (&st == &s->S) s->expl_copy_dst = nullptr;
+    prl_launch_ev(s->T, st, s->ft.level_start.data(), s->d_term_nodes, s->n_term, s->stream, expl_dst);
     PRL_HIP_TRY(hipGetLastError());
     return PRL_OK;
 }
@@ -780,6 +901,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         for (size_t c = 0; c < s->col_dfs.size() && identity; ++c) identity = s->col_dfs[c] == (int32_t)c;
         if (identity) s->col_dfs.clear();
     }
+    s->sorted = fused && !streets;
     s->small_tree = !fused && r.n_hole_cards == 1 && (long long)full.n_nodes * r.range_size <= 32768 && !getenv("PRL_NO_SMALL_TREE");
     s->full_nodes = full.n_nodes;
     s->full_cols = full.n_cols;
@@ -875,7 +997,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         const int n_plans = full.n_boards + 1;
         T.plan_stride = T.R;
         T.cl_stride = T.n_cards * (T.n_cards - 1);
-        int16_t *sh, *pos, *gs, *ge, *cl, *hgs, *hge;
+        int16_t *sh, *pos, *gs, *ge, *cl, *hgs, *hge, *pp = nullptr;
         uint32_t* clx = nullptr;
         int32_t *nl, *nd;
         FAIL_IF(dev_alloc(s, &sh, (size_t)n_plans * T.plan_stride));
@@ -888,11 +1010,12 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         FAIL_IF(dev_alloc(s, &hgs, (size_t)n_plans * T.plan_stride));
         FAIL_IF(dev_alloc(s, &hge, (size_t)n_plans * T.plan_stride));
         if (fused) FAIL_IF(dev_alloc(s, &clx, (size_t)n_plans * PRL_CLX_WORDS));
+        if (s->sorted) FAIL_IF(dev_alloc(s, &pp, (size_t)n_plans * PRL_PP_STRIDE));
         uint8_t* klh = nullptr;  // the LEVELS engine's showdown terminals (a fused solver's trunk has none)
         if (!fused) FAIL_IF(dev_alloc(s, &klh, (size_t)n_plans * T.R * 4));
         PrlDevTree Tb = T;
         Tb.n_boards = full.n_boards;
-        prl_launch_plan_build(Tb, n_plans, sh, pos, gs, ge, cl, nl, hgs, hge, clx, nd, klh, s->stream);
+        prl_launch_plan_build(Tb, n_plans, sh, pos, gs, ge, cl, nl, hgs, hge, clx, nd, klh, pp, s->stream);
         // the LEVELS kernels address plan `board_id`, or plan index T.n_boards for "no board"; in the FUSED engine the
         // trunk tree has n_boards == 0, so its plan pointers are based at the last (no-board) plan
         const size_t off = fused ? (size_t)full.n_boards : 0;
@@ -913,7 +1036,8 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             FAIL_IF(dev_upload(s, &sp.hole_packed, hole_packed));
         } else if (fused) {
             PrlFhpParams& fp = s->fp;
-            fp.n_boards = full.n_boards; fp.R = T.R; fp.col_base = col_base;
+            fp.n_boards = full.n_boards; fp.R = T.R; fp.np = PRL_FHP_NP;
+            if (T.R != PRL_PP_R) { prl_set_error("fused engine: 1326-hand ranges only"); prl_solver_destroy(s); return PRL_ERR_UNSUPPORTED; }
             {   // persistent workgroups, one per CU (LDS-bound occupancy): each walks its boards with the next one prefetching
                 int dev = 0, cus = 256;
                 if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -940,13 +1064,15 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             fp.shape = shape_id; fp.n_cols_board = sd.n_cols; fp.n_dec = sd.n_dec;
             for (int j = 0; j < sd.n_dec; ++j) { fp.dec_nch[j] = sd.dec_nch[j]; fp.dec_col0[j] = sd.dec_col0[j]; }
             for (int n = 0; n < sd.n_nodes; ++n) fp.pot[n] = pots[n];
-            fp.plan_stride = T.plan_stride;
-            fp.plan_pos = pos; fp.plan_hgs = hgs; fp.plan_hge = hge; fp.plan_clx = clx; fp.plan_nlive = nl;
-            FAIL_IF(dev_upload(s, &fp.hole_packed, hole_packed));
+            fp.plan_clx = clx; fp.plan_pp = pp;
+            s->col_base = col_base; s->ncb = sd.n_cols;
+            s->board_ofs = ((size_t)T.n_cols * T.R + 3) & ~(size_t)3;  // 16-byte aligned board region (float32 and float64 arrays alike)
+            s->col_elems = s->board_ofs + (size_t)full.n_boards * sd.n_cols * PRL_FHP_NP;
+            if (col_base != T.n_cols) { prl_set_error("fused engine: the board columns must follow the trunk's"); prl_solver_destroy(s); return PRL_ERR_UNSUPPORTED; }
         }
     }
 
-    const size_t nc_full = (size_t)full.n_cols * T.R;
+    const size_t nc_full = col_array_elems(s);
     FAIL_IF(dev_alloc(s, &s->d_regret, nc_full));
     s->avg_f32 = (flags & PRL_SOLVER_AVG_F32) != 0;
     if (s->avg_f32) {  // float64 for the trunk's few columns (the LEVELS kernels keep the reference's dtype), float32 for the boards'
@@ -1004,7 +1130,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             FAIL_IF(hipMemsetAsync(s->d_xlocal, 0, per_rank * sizeof(float), s->stream) == hipSuccess ? PRL_OK : PRL_ERR_HIP);  // a shorter last shard sends zero padding
         }
         FAIL_IF(dev_alloc(s, &s->d_half, (size_t)(streets ? s->n_trunk_leaves : 1) * 2 * T.R + 4));
-        s->fp.regret = s->d_regret;
+        s->fp.regret = s->d_regret + s->board_ofs;
         s->fp.board_out = s->d_board_out;
 #ifdef PRL_FHP_TIMING
         FAIL_IF(dev_alloc(s, &s->fp.timing, (size_t)72));
@@ -1087,12 +1213,12 @@ struct PrlStateHeader {
     int32_t variant, delay, fused, iter, full_cols, R, trunk_cols, trunk_nodes, src0, src1, board_avg_f64, has_avg_sum;
     uint64_t fingerprint;  // prl_solver::fingerprint of the saving solver
 };
-const uint32_t PRL_STATE_VERSION = 2;
+const uint32_t PRL_STATE_VERSION = 3;  // 3: single-deal fused solvers save their column arrays as they hold them (sorted storage)
 const uint32_t PRL_STATE_MAGIC = 0x50524C53u;  // "PRLS"
 
 struct StateLayout { size_t regret, avg, avg_sum, strategy, strat_f64, avg_f64, hist, total; };
 StateLayout state_layout(const prl_solver* s, int iter) {
-    const size_t nc = (size_t)s->full_cols * s->R, tc = (size_t)s->T.n_cols * s->R;
+    const size_t nc = col_array_elems(s), tc = (size_t)s->T.n_cols * s->R;
     StateLayout L;
     size_t o = sizeof(PrlStateHeader);
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 15) & ~(size_t)15; return at; };
@@ -1126,7 +1252,7 @@ int32_t prl_solver_save_state(prl_solver_t* s, void* out, uint64_t bytes) {
     h.board_avg_f64 = s->board_avg_f64; h.has_avg_sum = s->S.avg_sum != nullptr;
     char* b = (char*)out;
     memcpy(b, &h, sizeof(h));
-    const size_t nc = (size_t)s->full_cols * s->R, tc = (size_t)s->T.n_cols * s->R;
+    const size_t nc = col_array_elems(s), tc = (size_t)s->T.n_cols * s->R;
     PRL_HIP_TRY(hipStreamSynchronize(s->stream));
     PRL_HIP_TRY(hipMemcpy(b + L.regret, s->d_regret, nc * 4, hipMemcpyDeviceToHost));
     PRL_HIP_TRY(hipMemcpy(b + L.avg, s->d_avg, nc * 8, hipMemcpyDeviceToHost));
@@ -1157,7 +1283,7 @@ int32_t prl_solver_load_state(prl_solver_t* s, const void* in, uint64_t bytes) {
     const StateLayout L = state_layout(s, h.iter);
     if (bytes < L.total) { prl_set_error("load_state: truncated blob"); return PRL_ERR_ARG; }
     const char* b = (const char*)in;
-    const size_t nc = (size_t)s->full_cols * s->R, tc = (size_t)s->T.n_cols * s->R;
+    const size_t nc = col_array_elems(s), tc = (size_t)s->T.n_cols * s->R;
     TRY(ensure_hist(s, h.iter + 1));
     PRL_HIP_TRY(hipStreamSynchronize(s->stream));
     PRL_HIP_TRY(hipMemcpy(s->d_regret, b + L.regret, nc * 4, hipMemcpyHostToDevice));
@@ -1170,6 +1296,12 @@ int32_t prl_solver_load_state(prl_solver_t* s, const void* in, uint64_t bytes) {
     s->iter = h.iter; s->src[0] = h.src0; s->src[1] = h.src1; s->board_avg_f64 = h.board_avg_f64 != 0; s->board_avg_stale = false;
     s->user_strategy_f64 = -1; s->expl_pending = false; s->have_half = false; s->avg_pending[0] = s->avg_pending[1] = -1;
     s->ev_valid = false;
+    for (double& a : s->blk_avg) a = 0.;  // the blocked hands' average: a function of the iteration count alone
+    for (int it = 0; it < s->iter; ++it) {
+        int mode; double m_old, m_new;
+        cfr_plus_weights(s, it, &mode, &m_old, &m_new);
+        blocked_avg_step(s, mode, m_old, m_new);
+    }
     return do_update_reach(s, s->S);
 }
 
@@ -1249,8 +1381,9 @@ void prl_solver_destroy(prl_solver_t* s) {
 // CFRBase.reset (_CFRBase.py:110-120): clear regrets / averages, uniform strategy, reach, EV (+ exploitability)
 int32_t prl_solver_reset(prl_solver_t* s) {
     if (!s) { prl_set_error("NULL solver"); return PRL_ERR_ARG; }
-    const size_t nc = (size_t)s->full_cols * s->R;
+    const size_t nc = col_array_elems(s);
     s->iter = 0;
+    for (double& a : s->blk_avg) a = 0.;
     s->expl_pending = false;
     s->have_half = false;
     s->avg_pending[0] = s->avg_pending[1] = -1;
@@ -1299,12 +1432,29 @@ int32_t prl_solver_set_strategy_mixed(prl_solver_t* s, const void* strat, int32_
     }
     const double* src = (const double*)strat;
     if (!is_f64) {
-        tmp.resize(nc);
+        const size_t nconv = s->fused ? (size_t)s->T.n_cols * s->R : nc;  // (FUSED: only the trunk's columns are kept as float64)
+        tmp.resize(nconv);
         const float* f = (const float*)strat;
-        for (size_t i = 0; i < nc; ++i) tmp[i] = (double)f[i];  // exact widening: storage only, arithmetic stays float32
+        for (size_t i = 0; i < nconv; ++i) tmp[i] = (double)f[i];  // exact widening: storage only, arithmetic stays float32
         src = tmp.data();
     }
-    if (s->fused) {
+    if (s->sorted) {
+        // the trunk's columns as they are, the boards' columns into sorted storage (what the caller had for the hands a board blocks is
+        // kept aside so that prl_solver_get returns it)
+        const size_t ne = col_array_elems(s), tc = (size_t)s->T.n_cols * s->R, nblk = (size_t)s->fp.n_boards * s->ncb * PRL_FHP_NBLOCKED;
+        if (is_f64) {
+            if (!s->d_user_strategy) TRY(dev_alloc(s, &s->d_user_strategy, ne));
+            if (!s->d_user_blocked64) TRY(dev_alloc(s, &s->d_user_blocked64, nblk));
+            PRL_HIP_TRY(hipMemcpyAsync(s->d_user_strategy, strat, tc * sizeof(double), hipMemcpyHostToDevice, s->stream));
+            TRY(sorted_set_boards(s, (const double*)strat + tc, 8, s->d_user_strategy + s->board_ofs, s->d_user_blocked64));
+        } else {
+            if (!s->d_user_strategy32) TRY(dev_alloc(s, &s->d_user_strategy32, ne));
+            if (!s->d_user_blocked32) TRY(dev_alloc(s, &s->d_user_blocked32, nblk));
+            PRL_HIP_TRY(hipMemcpyAsync(s->d_user_strategy32, strat, tc * sizeof(float), hipMemcpyHostToDevice, s->stream));
+            TRY(sorted_set_boards(s, (const float*)strat + tc, 4, s->d_user_strategy32 + s->board_ofs, s->d_user_blocked32));
+        }
+        s->user_strategy_f64 = is_f64 ? 1 : 0;
+    } else if (s->fused) {
         if (is_f64) {
             if (!s->d_user_strategy) TRY(dev_alloc(s, &s->d_user_strategy, nc));
             PRL_HIP_TRY(hipMemcpyAsync(s->d_user_strategy, src, nc * sizeof(double), hipMemcpyHostToDevice, s->stream));
@@ -1344,17 +1494,7 @@ static int iteration_core(prl_solver* s, bool closing_eval) {
     if (s->fused && s->user_strategy_f64 >= 0) { prl_set_error("call reset() / fill_uniform() before iterating after set_strategy()"); return PRL_ERR_STATE; }
     int mode = 0;
     double m_old = 0., m_new = 0.;
-    if (s->variant == PRL_CFR_PLUS) {  // CFRPlus.py:65-87: float64 weights from integer sums
-        if (s->iter > s->delay) {
-            long long cw = 0;
-            for (int k = s->delay + 1; k <= s->iter; ++k) cw += k;
-            long long nw = s->iter - s->delay + 1;
-            m_old = (double)cw / (double)(cw + nw);
-            m_new = (double)nw / (double)(cw + nw);
-            mode = 2;
-        } else if (s->iter == s->delay) mode = 1;
-    }
-    s->fp.avg = s->d_avg;
+    cfr_plus_weights(s, s->iter, &mode, &m_old, &m_new);
     s->fp.avg_mode = mode;
     s->fp.m_old = m_old;
     s->fp.m_new = m_new;
@@ -1388,6 +1528,7 @@ static int iteration_core(prl_solver* s, bool closing_eval) {
         if (second_half) s->have_half = true;  // d_half: seat 1's value / best response under the updated strategies
     }
     s->fp.avg_mode = 0;
+    if (s->sorted) blocked_avg_step(s, mode, m_old, m_new);
     s->iter += 1;
     if (s->fused && !closing_eval) {
         s->expl_pending = true;
@@ -1708,17 +1849,43 @@ int32_t prl_solver_get_cols(prl_solver_t* s, int32_t field, int64_t col_begin, i
     if (!s->col_dfs.empty()) { prl_set_error("get_cols: this engine keeps its columns in an internal order; use prl_solver_get"); return PRL_ERR_UNSUPPORTED; }
     const char* src = nullptr;
     size_t elem = 0;
+    double fill[PRL_FHP_MAX_NODES * 3] = {0.};
     switch (field) {
         case PRL_SF_REGRET: src = (const char*)s->d_regret; elem = 4; break;
         case PRL_SF_AVG:
             if (s->avg_f32) { prl_set_error("get_cols(AVG): the average is stored as float32 in this solver; use prl_solver_get"); return PRL_ERR_UNSUPPORTED; }
-            TRY(ensure_board_avg(s)); src = (const char*)s->d_avg; elem = 8; break;
+            TRY(ensure_board_avg(s)); src = (const char*)s->d_avg; elem = 8;
+            if (s->sorted) blocked_avg_fill(s, fill);
+            break;
         case PRL_SF_AVG_SUM: src = (const char*)s->S.avg_sum; elem = 4; break;
         default: prl_set_error("get_cols: REGRET, AVG or AVG_SUM"); return PRL_ERR_ARG;
     }
     if (!src) { prl_set_error("field not available for this variant"); return PRL_ERR_STATE;}
     const size_t cb = (size_t)s->R * elem;
-    PRL_HIP_TRY(hipMemcpyAsync(out, src + (size_t)col_begin * cb, (size_t)n_cols * cb, hipMemcpyDeviceToHost, s->stream));
+    if (!s->sorted) {
+        PRL_HIP_TRY(hipMemcpyAsync(out, src + (size_t)col_begin * cb, (size_t)n_cols * cb, hipMemcpyDeviceToHost, s->stream));
+        return prl_solver_sync(s);
+    }
+    // sorted storage: the trunk's columns as they are, the boards' columns translated board by board (whole boards through the staging buffer)
+    int64_t c = col_begin;
+    const int64_t c_end = col_begin + n_cols;
+    char* o = (char*)out;
+    if (c < s->col_base) {
+        const int64_t n = (c_end < s->col_base ? c_end : (int64_t)s->col_base) - c;
+        PRL_HIP_TRY(hipMemcpyAsync(o, src + (size_t)c * cb, (size_t)n * cb, hipMemcpyDeviceToHost, s->stream));
+        o += (size_t)n * cb; c += n;
+    }
+    if (c < c_end) {
+        const int b_first = (int)((c - s->col_base) / s->ncb), b_last = (int)((c_end - 1 - s->col_base) / s->ncb);
+        const bool whole = (c - s->col_base) % s->ncb == 0 && (c_end - s->col_base) % s->ncb == 0;
+        const char* region = src + s->board_ofs * elem;
+        if (whole) TRY(sorted_get_boards(s, region, (int)elem, fill, nullptr, o, (int)elem, b_first, b_last - b_first + 1));
+        else {
+            std::vector<char> tmp((size_t)(b_last - b_first + 1) * s->ncb * cb);
+            TRY(sorted_get_boards(s, region, (int)elem, fill, nullptr, tmp.data(), (int)elem, b_first, b_last - b_first + 1));
+            memcpy(o, tmp.data() + (size_t)(c - s->col_base - (int64_t)b_first * s->ncb) * cb, (size_t)(c_end - c) * cb);
+        }
+    }
     return prl_solver_sync(s);
 }
 
@@ -1738,6 +1905,37 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
         case PRL_SF_EV: TRY(ensure_ev(s)); src = s->S.ev; bytes = nv * 4; break;
         case PRL_SF_EV_BR: TRY(ensure_ev(s)); src = s->S.ev_br; bytes = nv * 4; break;
         case PRL_SF_STRATEGY:
+            if (s->sorted) {
+                const size_t tcb = (size_t)s->T.n_cols * s->R;
+                double* o = (double*)out;
+                double fill[PRL_FHP_MAX_NODES * 3];
+                if (s->user_strategy_f64 == 1) {
+                    PRL_HIP_TRY(hipMemcpyAsync(o, s->d_user_strategy, tcb * 8, hipMemcpyDeviceToHost, s->stream));
+                    TRY(sorted_get_boards(s, s->d_user_strategy + s->board_ofs, 8, nullptr, s->d_user_blocked64, o + tcb, 8, 0, s->fp.n_boards));
+                    return prl_solver_sync(s);
+                }
+                if (s->user_strategy_f64 == 0) {  // stored as float32: widened on the way out (exact)
+                    std::vector<float> f(tcb);
+                    PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+                    PRL_HIP_TRY(hipMemcpy(f.data(), s->d_user_strategy32, tcb * 4, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < tcb; ++i) o[i] = (double)f[i];
+                    TRY(sorted_get_boards(s, s->d_user_strategy32 + s->board_ofs, 4, nullptr, s->d_user_blocked32, o + tcb, 8, 0, s->fp.n_boards));
+                    return prl_solver_sync(s);
+                }
+                if (s->src[0] != PRL_SRC_REGRET || s->src[1] != PRL_SRC_REGRET) {  // uniform float64 fill
+                    prl_set_error("fused engine: strategy is the implicit uniform fill until both seats have been updated");
+                    return PRL_ERR_STATE;
+                }
+                if (!s->d_user_strategy) TRY(dev_alloc(s, &s->d_user_strategy, col_array_elems(s)));  // (scratch: user_strategy_f64 stays -1)
+                PrlFhpParams fp = s->fp;
+                fp.variant = s->variant;
+                fp.regret = s->d_regret + s->board_ofs;
+                prl_launch_fhp_strategy_from_regret(fp, s->d_user_strategy + s->board_ofs, s->stream);
+                PRL_HIP_TRY(hipMemcpyAsync(o, s->S.strategy, tcb * 8, hipMemcpyDeviceToHost, s->stream));
+                for (int j = 0; j < s->ncb; ++j) fill[j] = (double)(float)(1.0 / (double)board_col_actions(s, j));  // all-zero regrets: uniform
+                TRY(sorted_get_boards(s, s->d_user_strategy + s->board_ofs, 8, fill, nullptr, o + tcb, 8, 0, s->fp.n_boards));
+                return prl_solver_sync(s);
+            }
             if (s->fused) {
                 if (s->user_strategy_f64 == 1) { src = s->d_user_strategy; bytes = nc * 8; break; }
                 if (s->user_strategy_f64 == 0) {  // stored as float32: widened on the way out (exact)
@@ -1773,21 +1971,35 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
             }
             src = s->S.strategy; bytes = nc * 8; break;
         case PRL_SF_STRAT_F64: src = s->S.strat_f64; bytes = (size_t)s->T.n_nodes; break;
-        case PRL_SF_REGRET: src = s->d_regret; bytes = nc * 4; break;
+        case PRL_SF_REGRET:
+            if (s->sorted) {
+                const size_t tcb = (size_t)s->T.n_cols * s->R;
+                PRL_HIP_TRY(hipMemcpyAsync(out, s->d_regret, tcb * 4, hipMemcpyDeviceToHost, s->stream));
+                TRY(sorted_get_boards(s, s->d_regret + s->board_ofs, 4, nullptr, nullptr, (float*)out + tcb, 4, 0, s->fp.n_boards));
+                return prl_solver_sync(s);
+            }
+            src = s->d_regret; bytes = nc * 4; break;
         case PRL_SF_AVG:
-            if (s->avg_f32) {  // trunk columns float64, board columns float32 widened (exact)
-                const size_t nt = (size_t)s->T.n_cols * s->R;
-                std::vector<float> f(nc - nt);
-                PRL_HIP_TRY(hipStreamSynchronize(s->stream));
-                PRL_HIP_TRY(hipMemcpy(out, s->d_avg, nt * 8, hipMemcpyDeviceToHost));
-                PRL_HIP_TRY(hipMemcpy(f.data(), s->d_avg32 + nt, (nc - nt) * 4, hipMemcpyDeviceToHost));
-                double* o = (double*)out + nt;
-                for (size_t i = 0; i < nc - nt; ++i) o[i] = (double)f[i];
-                return PRL_OK;
+            if (s->sorted) {  // trunk columns float64; board columns float64, or float32 widened (exact)
+                const size_t tcb = (size_t)s->T.n_cols * s->R;
+                double fill[PRL_FHP_MAX_NODES * 3];
+                TRY(ensure_board_avg(s));
+                blocked_avg_fill(s, fill);
+                PRL_HIP_TRY(hipMemcpyAsync(out, s->d_avg, tcb * 8, hipMemcpyDeviceToHost, s->stream));
+                if (s->avg_f32) TRY(sorted_get_boards(s, s->d_avg32 + s->board_ofs, 4, fill, nullptr, (double*)out + tcb, 8, 0, s->fp.n_boards));
+                else TRY(sorted_get_boards(s, s->d_avg + s->board_ofs, 8, fill, nullptr, (double*)out + tcb, 8, 0, s->fp.n_boards));
+                return prl_solver_sync(s);
             }
             TRY(ensure_board_avg(s)); src = s->d_avg; bytes = nc * 8; break;
         case PRL_SF_AVG_F64: src = s->S.avg_f64; bytes = (size_t)s->T.n_nodes; break;
-        case PRL_SF_AVG_SUM: src = s->S.avg_sum; bytes = nc * 4; break;
+        case PRL_SF_AVG_SUM:
+            if (s->sorted && s->S.avg_sum) {
+                const size_t tcb = (size_t)s->T.n_cols * s->R;
+                PRL_HIP_TRY(hipMemcpyAsync(out, s->S.avg_sum, tcb * 4, hipMemcpyDeviceToHost, s->stream));
+                TRY(sorted_get_boards(s, s->S.avg_sum + s->board_ofs, 4, nullptr, nullptr, (float*)out + tcb, 4, 0, s->fp.n_boards));
+                return prl_solver_sync(s);
+            }
+            src = s->S.avg_sum; bytes = nc * 4; break;
         case PRL_SF_BR_IDX: TRY(ensure_ev(s)); src = s->S.br_idx; bytes = (size_t)s->T.n_nodes * s->T.R * 4; break;
         case PRL_SF_EXPL_HISTORY: src = s->d_expl_hist; bytes = (size_t)(s->iter + 1) * 2 * 4; break;
         case PRL_SF_ITER: *(int32_t*)out = s->iter; return PRL_OK;

@@ -32,6 +32,21 @@ struct PrlIterDev { int32_t iter, mode; double m_old, m_new; float* hist; };
 #define PRL_CLX_LOWER 0x2000u
 #define PRL_CLX_VALID 0x4000u
 
+// Position-domain plan of a 5-card board for the fused board pass (round 4: a lane owns two ADJACENT SORTED POSITIONS, and the
+// board's action columns are stored in HBM in that order -- prl_fhp.h "sorted storage"). int16 units, one block per board:
+//   sh  [PRL_PP_R]     the permutation position -> hand: the live hands in rank order (positions 0 .. n_live-1), then the hands the
+//                      board blocks, in hand-index order
+//   gm1 [PRL_PP_NPAD]  per live position: tie-group start - 1 = index of P[gs] in the inclusive prefix array (PRL_CLX_ZERO_POS when
+//                      gs == 0: that slot always reads 0); positions past the live ones: PRL_CLX_ZERO_POS
+//   em1 [PRL_PP_NPAD]  tie-group end - 1
+//   cc  [PRL_PP_NPAD]  c1 | c2 << 8 of the hand at the position (0 past the live ones)
+#define PRL_PP_R 1326
+#define PRL_PP_NPAD 1088
+#define PRL_PP_OFF_GM1 PRL_PP_R
+#define PRL_PP_OFF_EM1 (PRL_PP_R + PRL_PP_NPAD)
+#define PRL_PP_OFF_CC (PRL_PP_R + 2 * PRL_PP_NPAD)
+#define PRL_PP_STRIDE 4592   // int16 per board: 1326 + 3 * 1088 = 4590, rounded up to a multiple of 8 (16-byte aligned blocks)
+
 struct PrlDevTree {
     int32_t n_nodes, n_cols, R, n_hole, n_cards, n_suits, rank_rule, n_boards, board_len, n_levels;
     const int32_t *kind, *actor, *parent, *child_idx, *acted_last, *board_id, *main_pot, *n_children, *first_col,
@@ -57,6 +72,7 @@ struct PrlDevTree {
     const int16_t* plan_hgs;     // [n_plans][R]   gs[pos[h]] (0 for blocked hands)
     const int16_t* plan_hge;     // [n_plans][R]   ge[pos[h]]
     const uint32_t* plan_clx;    // [n_plans][PRL_CLX_WORDS] per-lane records of the fused board pass (below); 5-card boards only
+    const int16_t* plan_pp;      // [n_plans][PRL_PP_STRIDE] position-domain plan of the single-deal fused engine (above); nullptr otherwise
 };
 
 struct PrlDevState {

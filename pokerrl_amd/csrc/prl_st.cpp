@@ -121,6 +121,13 @@ int prl_st_build(const PrlFlatTree& t, long long top_weight_children, PrlStPlanH
                     const int ch = leaves[j];
                     const int root = t.child_list[t.child_start[ch] + k];
                     if (t.kind[root] != PRL_NODE_DECISION) return fail("a chance outcome that is not followed by a decision (all-in run-out chain)");
+                    {   // the street pass is laid out for >= 3 board cards on every street (st_npad: <= 1209 live hands; per-card lists of <= 48
+                        // entries): a first deal of one or two cards (custom rules, e.g. 2 + 2 + 1) would overrun both
+                        int dealt = 0;
+                        const int row = t.board_id[root];
+                        if (row >= 0) for (int c = 0; c < t.board_len; ++c) dealt += t.boards[(size_t)row * t.board_len + c] >= 0;
+                        if (dealt < 3) return fail("a street with fewer than 3 board cards out (the street pass holds <= 1209 live hands and per-card lists of <= 48 entries)");
+                    }
                     if (j > 0 && t.board_id[root] != t.board_id[t.child_list[t.child_start[leaves[0]] + k]]) return fail("chance outcomes differ between the leaves of one instance");
                     Listing ls;
                     bool hc = false, hs = false;

@@ -88,15 +88,24 @@ def rccl_shard(world, rank, shard_boards=None, total_boards=None, group=None, li
     from pokerrl_amd import _native
     L = lib or _native.lib()
     buf = (ctypes.c_char * 128)()
+    # every rank enters the broadcast whatever happened on rank 0: a status byte travels with the id, so that a rank 0 that could not
+    # draw one (librccl not loadable) makes ALL ranks raise instead of leaving the others inside the collective
+    status, err = 0, ""
     if rank == 0:
-        _native.check(L.prl_rccl_unique_id(ctypes.cast(buf, ctypes.c_void_p)), L)
+        status = int(L.prl_rccl_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        if status != 0:
+            err = L.prl_last_error().decode("utf-8", "replace")
     if world > 1:
         dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-        t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone().to(dev)
+        t = torch.frombuffer(bytearray(bytes(buf) + bytes([1 if status != 0 else 0])), dtype=torch.uint8).clone().to(dev)
         dist.broadcast(t, src=0, group=group)
-        uid = bytes(t.cpu().numpy().tobytes())
+        raw = bytes(t.cpu().numpy().tobytes())
+        uid, failed = raw[:128], raw[128] != 0
     else:
-        uid = bytes(buf)
+        uid, failed = bytes(buf), status != 0
+    if failed:
+        raise RuntimeError("rccl_shard: rank 0 could not draw an RCCL communicator id" + (": " + err if err else "") +
+                           " (every rank raises; fall back to exchange='torch')")
     if shard_boards is None:
         return ("rccl", world, rank, uid)
     return ("rccl", world, rank, uid, int(shard_boards), int(total_boards))

@@ -289,8 +289,10 @@ class PublicTree:
         self._invalidate()
 
     def copy(self):
+        n_boards, max_outcomes, board_seed = self._board_caps  # (a copy made before build_tree deals the same capped / seeded boards)
         c = PublicTree(self._env_bldr, self._stack_size, self._stop_at_street if self._is_partial else None,
-                       self._put_out_new_round_after_limit, self._is_debugging, self._boards, self._engine)
+                       self._put_out_new_round_after_limit, self._is_debugging, self._boards, self._engine,
+                       n_boards=n_boards, max_outcomes=max_outcomes, board_seed=board_seed)
         c.build_tree(variant=getattr(self, "_variant", "vanilla"), delay=getattr(self, "_delay", 0))
         if self._is_partial:  # structure and states only: there is no solver state to move over
             return c
