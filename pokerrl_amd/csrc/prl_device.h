@@ -95,6 +95,9 @@ PRL_DEV PRL_INLINE float prl_dpp_row_bcast15(float v) {  // rows 1 and 3 <- lane
 PRL_DEV PRL_INLINE float prl_dpp_row_bcast31(float v) {  // lanes 32..63 <- lane 31
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
 }
+PRL_DEV PRL_INLINE float prl_dpp_row_last(float v) {  // every lane <- lane 15 of its row of 16 lanes (row_newbcast:15, gfx90a+)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x15F, 0xF, 0xF, false));
+}
 PRL_DEV PRL_INLINE int prl_dpp_wave_shr1_i(int v, int fill) {  // lane l <- lane l - 1, lane 0 <- fill
     return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xF, 0xF, false);
 }
@@ -165,18 +168,23 @@ PRL_DEV PRL_INLINE void prl_wave_scan_canonical_n(float (&v)[N]) {
 #if defined(PRL_EMU)
     for (int i = 0; i < N; ++i) v[i] = prl_wave_scan_canonical(v[i]);
 #else
-    static_assert(N == 9 || N == 17, "group sizes are spelled out for the two callers");
+    if constexpr (N == 9 || N == 17 || N == 18) {  // group sizes spelled out for the hot callers
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        float x = v[i];
-        x = x + prl_dpp_row_shr<1>(x);
-        x = x + prl_dpp_row_shr<2>(x);
-        x = x + prl_dpp_row_shr<4>(x);
-        x = x + prl_dpp_row_shr<8>(x);
-        v[i] = x;
+        for (int i = 0; i < N; ++i) {
+            float x = v[i];
+            x = x + prl_dpp_row_shr<1>(x);
+            x = x + prl_dpp_row_shr<2>(x);
+            x = x + prl_dpp_row_shr<4>(x);
+            x = x + prl_dpp_row_shr<8>(x);
+            v[i] = x;
+        }
+        prl_scan_tail9(v);
+        if constexpr (N == 17) prl_scan_tail8(v + 9);
+        if constexpr (N == 18) prl_scan_tail9(v + 9);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = prl_wave_scan_canonical(v[i]);
     }
-    prl_scan_tail9(v);
-    if constexpr (N == 17) prl_scan_tail8(v + 9);
 #endif
 }
 

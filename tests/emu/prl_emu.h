@@ -98,6 +98,10 @@ inline float prl_dpp_row_bcast31(float v) {
     float r = prl_shfl(v, lane >= 32 ? 31 : lane);
     return lane >= 32 ? r : 0.f;
 }
+inline float prl_dpp_row_last(float v) {
+    int lane = (int)prl_lane();
+    return prl_shfl(v, lane | 15);
+}
 inline int prl_dpp_wave_shr1_i(int v, int fill) {
     int lane = (int)prl_lane();
     int r = prl_shfl_i(v, lane > 0 ? lane - 1 : 0);

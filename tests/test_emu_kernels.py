@@ -201,13 +201,17 @@ def test_emu_streets_engine_refuses_a_first_deal_of_fewer_than_three_cards(L):
     """custom rules that deal 2 + 2 + 1 board cards: a street with 2 cards out leaves 1225 live hands and 49-entry card lists, beyond what the
     street pass is laid out for (<= 1209 / 48) -- engine=auto must take the level-synchronous engine, engine=fused must say why"""
     import copy
+    import numpy as np
     from helpers import env_args
     from pokerrl_amd import _native
     from pokerrl_amd.game import games as G
     rules = copy.copy(G.LimitHoldem.native_rules())
     rules.board_cards_in_round[1], rules.board_cards_in_round[2], rules.board_cards_in_round[3] = 2, 2, 1
-    rows = np.array([[0, 5, 10, 15, 20], [0, 5, 10, 15, 21], [0, 5, 11, 16, 22], [0, 5, 11, 16, 23]], np.int8)
-    t = _native.NativeTree(G.LimitHoldem.native_game(env_args(G.LimitHoldem, 48, None)), rules, rows, _lib=L)
+    rows = np.array([[0, 5, 10, 15, 20], [0, 5, 10, 15, 21]], np.int8)
+    game = G.LimitHoldem.native_game(env_args(G.LimitHoldem, 48, None))
+    for i in range(4):
+        game.max_raises[i] = 1  # (a small betting tree: the level-synchronous engine runs on the emulator here)
+    t = _native.NativeTree(game, rules, rows, _lib=L)
     assert _native.NativeSolver(t, "plus", 0, engine="auto", _lib=L).engine == "levels"
     with pytest.raises(_native.NativeError, match="fewer than 3 board cards"):
         _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
