@@ -1,7 +1,7 @@
 #!/bin/bash
 # quick checkpoint: a few fused GPU parity tests, headline bench, best-response bench, phase shares
 cd $GRAFT_REPO_ROOT; TAG=${1:-r4c}; mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "fused_engine_vs_oracle or fused_engine_best or bench_size or twentyone or nine_node or fused_br" -p no:cacheprovider > gpurun_out/${TAG}_pytest.log 2>&1; tail -3 gpurun_out/${TAG}_pytest.log
+if [ -n "$PYTEST" ]; then timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "fused_engine_vs_oracle or fused_engine_best or twentyone or nine_node or fused_br" -p no:cacheprovider > gpurun_out/${TAG}_pytest.log 2>&1; tail -3 gpurun_out/${TAG}_pytest.log; fi
 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; python - <<PY
 import json
 d=json.loads(open('gpurun_out/${TAG}_bench.json').read().strip().split('\n')[-1])
