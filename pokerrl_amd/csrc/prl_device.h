@@ -67,7 +67,6 @@ PRL_DEV PRL_INLINE void prl_lds_dma_dword(const void* gbase, uint32_t byte_off, 
                  : "=&s"(saved_m0) : "s"(la), "v"(byte_off), "s"(gbase) : "memory");
 }
 PRL_DEV PRL_INLINE void prl_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-PRL_DEV PRL_INLINE void prl_sched_fence() { __builtin_amdgcn_sched_barrier(0); }  // the instruction scheduler moves nothing across
 PRL_DEV PRL_INLINE int prl_opaque_scalar(int v) { asm volatile("" : "+s"(v)); return v; }  // hides a wave-uniform value's history from the optimiser
 // the same for a per-lane value: what is computed from the result cannot be hoisted out of a loop or shared with other uses (the compiler
 // otherwise precomputes every loop-invariant LDS address of the pass before the loop and SPILLS them: 24 scratch reloads per instance, each
@@ -95,16 +94,6 @@ PRL_DEV PRL_INLINE float prl_dpp_row_bcast15(float v) {  // rows 1 and 3 <- lane
 }
 PRL_DEV PRL_INLINE float prl_dpp_row_bcast31(float v) {  // lanes 32..63 <- lane 31
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
-}
-PRL_DEV PRL_INLINE float prl_dpp_row_last(float v) {  // every lane <- lane 15 of its row of 16 lanes (row_newbcast:15, gfx90a+)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x15F, 0xF, 0xF, false));
-}
-// both halves of a wave next to each other: lo = [v's lanes 0..31, the same again], hi = [v's lanes 32..63, the same again] (one
-// v_permlane32_swap of gfx950: lanes 32..63 of the first operand <-> lanes 0..31 of the second)
-PRL_DEV PRL_INLINE void prl_split_halves(float v, float& lo, float& hi) {
-    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(v), (unsigned)__float_as_int(v), false, false);
-    lo = __int_as_float((int)r[0]);
-    hi = __int_as_float((int)r[1]);
 }
 PRL_DEV PRL_INLINE int prl_dpp_wave_shr1_i(int v, int fill) {  // lane l <- lane l - 1, lane 0 <- fill
     return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xF, 0xF, false);
@@ -176,23 +165,18 @@ PRL_DEV PRL_INLINE void prl_wave_scan_canonical_n(float (&v)[N]) {
 #if defined(PRL_EMU)
     for (int i = 0; i < N; ++i) v[i] = prl_wave_scan_canonical(v[i]);
 #else
-    if constexpr (N == 9 || N == 17 || N == 18) {  // group sizes spelled out for the hot callers
+    static_assert(N == 9 || N == 17, "group sizes are spelled out for the two callers");
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            float x = v[i];
-            x = x + prl_dpp_row_shr<1>(x);
-            x = x + prl_dpp_row_shr<2>(x);
-            x = x + prl_dpp_row_shr<4>(x);
-            x = x + prl_dpp_row_shr<8>(x);
-            v[i] = x;
-        }
-        prl_scan_tail9(v);
-        if constexpr (N == 17) prl_scan_tail8(v + 9);
-        if constexpr (N == 18) prl_scan_tail9(v + 9);
-    } else {
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = prl_wave_scan_canonical(v[i]);
+    for (int i = 0; i < N; ++i) {
+        float x = v[i];
+        x = x + prl_dpp_row_shr<1>(x);
+        x = x + prl_dpp_row_shr<2>(x);
+        x = x + prl_dpp_row_shr<4>(x);
+        x = x + prl_dpp_row_shr<8>(x);
+        v[i] = x;
     }
+    prl_scan_tail9(v);
+    if constexpr (N == 17) prl_scan_tail8(v + 9);
 #endif
 }
 

@@ -196,9 +196,7 @@ struct PrlFhpParams {
     int32_t no_steady;          // tests: 1 = never take the CFR+ steady-state specialisation of the pass (prl_fhp_pass.inc, FhpCtxT)
     const double* strat_arr;    // board region of an explicit float64 strategy (the average being evaluated / caller-provided)
     float* board_out;           // [n_boards or n_blocks][prl_fhp_out_width(mode)][R] root vectors (hand order)
-    const int16_t* plan_pp;     // [n_boards][PRL_PP_STRIDE] position-domain plans (prl_solver_types.h): the translation kernels' permutation
-    const uint32_t* plan_ppk;   // [n_boards][PRL_PPK_WORDS] the same packed for the board pass
-    const uint16_t* hole_packed;// [R] c1 | c2 << 8 of every hand
+    const int16_t* plan_pp;     // [n_boards][PRL_PP_STRIDE] position-domain plans (prl_solver_types.h)
     const uint32_t* plan_clx;   // [n_boards][PRL_CLX_WORDS] per-lane records of the per-card scans (prl_solver_types.h)
     unsigned long long* timing; // PRL_FHP_TIMING builds: [8] shader-clock accumulators per phase (prologue, B, C, D, E, epilogue)
 };

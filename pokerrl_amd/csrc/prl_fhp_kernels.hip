@@ -141,7 +141,7 @@ PRL_GLOBAL void prl_k_fhp_expand(PrlFhpParams prm, const E* region, int b0, int 
         const size_t b = (size_t)b0 + bj / ncb;
         const int h = prm.plan_pp[b * PRL_PP_STRIDE + q];
         E v;
-        if (q < NL) v = region[(b * ncb + j) * (size_t)prm.np + prl_fhp_mem_index(q)];
+        if (q < NL) v = region[(b * ncb + j) * (size_t)prm.np + q];
         else if (blocked_src) v = blocked_src[(b * ncb + j) * (size_t)PRL_FHP_NBLOCKED + (q - NL)];
         else v = fill_by_col ? fill_by_col[j] : (E)0;
         dst[bj * R + h] = v;
@@ -157,7 +157,7 @@ PRL_GLOBAL void prl_k_fhp_compact(PrlFhpParams prm, const E* src, int b0, int nb
         const int j = (int)(bj % ncb);
         const size_t b = (size_t)b0 + bj / ncb;
         const int16_t* sh = prm.plan_pp + b * PRL_PP_STRIDE;
-        if (q < prm.np) region[(b * ncb + j) * (size_t)prm.np + prl_fhp_mem_index(q)] = q < NL ? src[bj * R + sh[q]] : (E)0;
+        if (q < prm.np) region[(b * ncb + j) * (size_t)prm.np + q] = q < NL ? src[bj * R + sh[q]] : (E)0;
         else if (blocked_dst) blocked_dst[(b * ncb + j) * (size_t)PRL_FHP_NBLOCKED + (q - prm.np)] = src[bj * R + sh[NL + (q - prm.np)]];
     }
 }

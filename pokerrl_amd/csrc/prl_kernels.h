@@ -32,6 +32,6 @@ void prl_launch_regret_strategy_dev(const PrlDevTree& T, const PrlDevState& S, c
 void prl_launch_average_dev(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, const PrlIterDev* d_ip, void* stream);
 void prl_launch_plan_build(const PrlDevTree& T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
                            int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx, int32_t* plan_ndealt, uint8_t* plan_klh,
-                           int16_t* plan_pp, uint32_t* plan_ppk, void* stream);
+                           int16_t* plan_pp, void* stream);
 void prl_launch_hand_rank_checksums(const int8_t* d_boards, int n_boards, int chunk, const uint16_t* d_hole_lut, unsigned long long* d_out,
                                     void* stream);

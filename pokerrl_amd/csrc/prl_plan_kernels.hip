@@ -21,7 +21,7 @@
 
 PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
                                  int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx, int32_t* plan_ndealt,
-                                 uint8_t* plan_klh, int16_t* plan_pp, uint32_t* plan_ppk) {
+                                 uint8_t* plan_klh, int16_t* plan_pp) {
     uint32_t* keys = (uint32_t*)prl_smem();  // [2048]
     int* n_live_s = (int*)(keys + 2048);
     const int tid = (int)prl_tid(), nt = (int)prl_nthreads();
@@ -187,25 +187,12 @@ PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, in
             }
             for (int i = PRL_PP_OFF_CC + PRL_PP_NPAD + tid; i < PRL_PP_STRIDE; i += nt) pp[i] = 0;
             prl_sync();
-            if (plan_ppk) {  // the board pass's packed copy (PRL_PPK_*)
-                uint32_t* pk = plan_ppk + (size_t)b * PRL_PPK_WORDS;
-                for (int i = tid; i < 8; i += nt) pk[i] = i == 0 ? (uint32_t)(on_board & 0xFFFFFFFFull) : i == 1 ? (uint32_t)(on_board >> 32) : 0u;
-                for (int i = tid; i < PRL_PP_NPAD; i += nt) {
-                    const bool lv = i < n;
-                    const int h = lv ? (int)(keys[i] & 0x7FFu) : 0;
-                    const uint32_t c1 = lv ? (uint32_t)(T.hole[2 * h] & 63) : 0u, c2 = lv ? (uint32_t)(T.hole[2 * h + 1] & 63) : 0u;
-                    if (lv) pk[PRL_PPK_OFF_A + i] = (uint32_t)h | (c1 << 11) | (c2 << 17);  // (the blocked hands' entries: below)
-                    const uint32_t g = lv && gs[i] > 0 ? (uint32_t)(gs[i] - 1) : PRL_CLX_ZERO_POS, e = lv ? (uint32_t)(ge[i] - 1) : PRL_CLX_ZERO_POS;
-                    pk[PRL_PPK_OFF_B + i] = g | (e << 16);
-                }
-            }
             // the hands the board blocks, in hand-index order, after the live ones: sh is a permutation of all R hands
             for (int h = tid; h < T.R; h += nt) {
                 if (pos[h] >= 0) continue;
                 int before = 0;
                 for (int g = 0; g < h; ++g) before += pos[g] < 0;
                 pp[n + before] = (int16_t)h;
-                if (plan_ppk) plan_ppk[(size_t)b * PRL_PPK_WORDS + PRL_PPK_OFF_A + n + before] = (uint32_t)h;
             }
             prl_sync();
         }
@@ -214,8 +201,8 @@ PRL_GLOBAL void prl_k_plan_build(PrlDevTree T, int n_plans, int16_t* plan_sh, in
 
 void prl_launch_plan_build(const PrlDevTree& T, int n_plans, int16_t* plan_sh, int16_t* plan_pos, int16_t* plan_gs, int16_t* plan_ge,
                            int16_t* plan_cl, int32_t* plan_nlive, int16_t* plan_hgs, int16_t* plan_hge, uint32_t* plan_clx, int32_t* plan_ndealt,
-                           uint8_t* plan_klh, int16_t* plan_pp, uint32_t* plan_ppk, void* stream) {
+                           uint8_t* plan_klh, int16_t* plan_pp, void* stream) {
     int grid = n_plans < 32768 ? n_plans : 32768;
     PRL_LAUNCH(prl_k_plan_build, grid, 256, 2048 * sizeof(uint32_t) + 16, stream, T, n_plans, plan_sh, plan_pos, plan_gs, plan_ge, plan_cl,
-               plan_nlive, plan_hgs, plan_hge, plan_clx, plan_ndealt, plan_klh, plan_pp, plan_ppk);
+               plan_nlive, plan_hgs, plan_hge, plan_clx, plan_ndealt, plan_klh, plan_pp);
 }

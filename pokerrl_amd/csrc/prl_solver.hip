@@ -998,7 +998,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         T.plan_stride = T.R;
         T.cl_stride = T.n_cards * (T.n_cards - 1);
         int16_t *sh, *pos, *gs, *ge, *cl, *hgs, *hge, *pp = nullptr;
-        uint32_t *clx = nullptr, *ppk = nullptr;
+        uint32_t* clx = nullptr;
         int32_t *nl, *nd;
         FAIL_IF(dev_alloc(s, &sh, (size_t)n_plans * T.plan_stride));
         FAIL_IF(dev_alloc(s, &pos, (size_t)n_plans * T.plan_stride));
@@ -1011,12 +1011,11 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         FAIL_IF(dev_alloc(s, &hge, (size_t)n_plans * T.plan_stride));
         if (fused) FAIL_IF(dev_alloc(s, &clx, (size_t)n_plans * PRL_CLX_WORDS));
         if (s->sorted) FAIL_IF(dev_alloc(s, &pp, (size_t)n_plans * PRL_PP_STRIDE));
-        if (s->sorted) FAIL_IF(dev_alloc(s, &ppk, (size_t)n_plans * PRL_PPK_WORDS));
         uint8_t* klh = nullptr;  // the LEVELS engine's showdown terminals (a fused solver's trunk has none)
         if (!fused) FAIL_IF(dev_alloc(s, &klh, (size_t)n_plans * T.R * 4));
         PrlDevTree Tb = T;
         Tb.n_boards = full.n_boards;
-        prl_launch_plan_build(Tb, n_plans, sh, pos, gs, ge, cl, nl, hgs, hge, clx, nd, klh, pp, ppk, s->stream);
+        prl_launch_plan_build(Tb, n_plans, sh, pos, gs, ge, cl, nl, hgs, hge, clx, nd, klh, pp, s->stream);
         // the LEVELS kernels address plan `board_id`, or plan index T.n_boards for "no board"; in the FUSED engine the
         // trunk tree has n_boards == 0, so its plan pointers are based at the last (no-board) plan
         const size_t off = fused ? (size_t)full.n_boards : 0;
@@ -1065,8 +1064,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             fp.shape = shape_id; fp.n_cols_board = sd.n_cols; fp.n_dec = sd.n_dec;
             for (int j = 0; j < sd.n_dec; ++j) { fp.dec_nch[j] = sd.dec_nch[j]; fp.dec_col0[j] = sd.dec_col0[j]; }
             for (int n = 0; n < sd.n_nodes; ++n) fp.pot[n] = pots[n];
-            fp.plan_clx = clx; fp.plan_pp = pp; fp.plan_ppk = ppk;
-            FAIL_IF(dev_upload(s, &fp.hole_packed, hole_packed));
+            fp.plan_clx = clx; fp.plan_pp = pp;
             s->col_base = col_base; s->ncb = sd.n_cols;
             s->board_ofs = ((size_t)T.n_cols * T.R + 3) & ~(size_t)3;  // 16-byte aligned board region (float32 and float64 arrays alike)
             s->col_elems = s->board_ofs + (size_t)full.n_boards * sd.n_cols * PRL_FHP_NP;

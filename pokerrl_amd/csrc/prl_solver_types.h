@@ -32,32 +32,20 @@ struct PrlIterDev { int32_t iter, mode; double m_old, m_new; float* hist; };
 #define PRL_CLX_LOWER 0x2000u
 #define PRL_CLX_VALID 0x4000u
 
-// Position-domain plans of a 5-card board for the single-deal fused engine (sorted storage, prl_fhp.h).
-// (1) plan_pp, int16 units, one block per board -- the permutation the TRANSLATION kernels use (prl_launch_fhp_expand / _compact):
-//   sh  [PRL_PP_R]     position -> hand: the live hands in rank order (positions 0 .. n_live-1), then the hands the board blocks, in
-//                      hand-index order
-//   gm1 / em1 / cc [PRL_PP_NPAD] per live position: tie-group start - 1 (PRL_CLX_ZERO_POS when the group starts at 0: that slot always
-//                      reads 0), tie-group end - 1, c1 | c2 << 8; past the live positions: PRL_CLX_ZERO_POS / PRL_CLX_ZERO_POS / 0
-// (2) plan_ppk, 32-bit words, one block per board -- what the BOARD PASS streams into LDS beside the per-card records:
-//   [0], [1]           the board's cards as a 64-bit mask (low word first); [2 .. 7] zero
-//   A [PRL_PP_R]       per position: hand (11 bits) | c1 << 11 | c2 << 17 -- the whole permutation `sh` (cards only for the live positions)
-//   B [PRL_PP_NPAD]    per position: gm1 | em1 << 16
+// Position-domain plan of a 5-card board for the fused board pass (round 4: a lane owns two ADJACENT SORTED POSITIONS, and the
+// board's action columns are stored in HBM in that order -- prl_fhp.h "sorted storage"). int16 units, one block per board:
+//   sh  [PRL_PP_R]     the permutation position -> hand: the live hands in rank order (positions 0 .. n_live-1), then the hands the
+//                      board blocks, in hand-index order
+//   gm1 [PRL_PP_NPAD]  per live position: tie-group start - 1 = index of P[gs] in the inclusive prefix array (PRL_CLX_ZERO_POS when
+//                      gs == 0: that slot always reads 0); positions past the live ones: PRL_CLX_ZERO_POS
+//   em1 [PRL_PP_NPAD]  tie-group end - 1
+//   cc  [PRL_PP_NPAD]  c1 | c2 << 8 of the hand at the position (0 past the live ones)
 #define PRL_PP_R 1326
 #define PRL_PP_NPAD 1088
 #define PRL_PP_OFF_GM1 PRL_PP_R
 #define PRL_PP_OFF_EM1 (PRL_PP_R + PRL_PP_NPAD)
 #define PRL_PP_OFF_CC (PRL_PP_R + 2 * PRL_PP_NPAD)
 #define PRL_PP_STRIDE 4592   // int16 per board: 1326 + 3 * 1088 = 4590, rounded up to a multiple of 8 (16-byte aligned blocks)
-#define PRL_PPK_OFF_A 8
-#define PRL_PPK_OFF_B (8 + PRL_PP_R + 2)
-#define PRL_PPK_WORDS (8 + PRL_PP_R + 2 + PRL_PP_NPAD)   // 2424 words = 9696 bytes (16-byte aligned blocks)
-// Memory order of a board column (sorted storage): a wave of the board pass owns two whole 64-position chunks (the canonical range prefix
-// scans chunks of 64 sorted positions: they are scanned in registers, lane l = position 64 * chunk + l) and reads its two positions as ONE
-// 8- / 16-byte access: inside every block of 128 positions the two chunks are interleaved element by element; the 17th chunk (positions
-// 1024 .. 1087) has its block to itself and is interleaved half against half (a lane holds positions 1024 + l and 1056 + l).
-PRL_HD PRL_INLINE int prl_fhp_mem_index(int q) {
-    return q < 1024 ? (q & ~127) + 2 * (q & 63) + ((q >> 6) & 1) : 1024 + 2 * ((q - 1024) & 31) + (((q - 1024) >> 5) & 1);
-}
 
 struct PrlDevTree {
     int32_t n_nodes, n_cols, R, n_hole, n_cards, n_suits, rank_rule, n_boards, board_len, n_levels;
@@ -85,7 +73,6 @@ struct PrlDevTree {
     const int16_t* plan_hge;     // [n_plans][R]   ge[pos[h]]
     const uint32_t* plan_clx;    // [n_plans][PRL_CLX_WORDS] per-lane records of the fused board pass (below); 5-card boards only
     const int16_t* plan_pp;      // [n_plans][PRL_PP_STRIDE] position-domain plan of the single-deal fused engine (above); nullptr otherwise
-    const uint32_t* plan_ppk;    // [n_plans][PRL_PPK_WORDS] the same packed for the board pass
 };
 
 struct PrlDevState {

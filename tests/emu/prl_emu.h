@@ -54,7 +54,6 @@ inline void prl_lds_dma_x4_a(const void* gbase, uint32_t byte_off, uint32_t lds_
 }
 inline void prl_dma_wait() {}
 inline int prl_wave_uniform(int v) { return v; }
-inline void prl_sched_fence() {}
 inline int prl_opaque_scalar(int v) { return v; }
 inline int prl_opaque_lane(int v) { return v; }
 inline char* prl_smem() { return prl_emu::g_ctx->smem; }
@@ -98,15 +97,6 @@ inline float prl_dpp_row_bcast31(float v) {
     int lane = (int)prl_lane();
     float r = prl_shfl(v, lane >= 32 ? 31 : lane);
     return lane >= 32 ? r : 0.f;
-}
-inline float prl_dpp_row_last(float v) {
-    int lane = (int)prl_lane();
-    return prl_shfl(v, lane | 15);
-}
-inline void prl_split_halves(float v, float& lo, float& hi) {
-    int lane = (int)prl_lane();
-    lo = prl_shfl(v, lane & 31);
-    hi = prl_shfl(v, (lane & 31) + 32);
 }
 inline int prl_dpp_wave_shr1_i(int v, int fill) {
     int lane = (int)prl_lane();
