@@ -199,30 +199,20 @@ def main():
         from pokerrl_amd.dist import TorchExchange
         exchange = TorchExchange("cpu" if emu_lib else "cuda")
         solver = _native.NativeSolver(tree, args.variant, 0, shard=(world, rank, exchange, shard_boards, total) if total else (world, rank, exchange), _lib=lib)
-    placement = None
+    placement, placement_chosen = None, None
     if not sharded:
         avg_dtype = "f32" if args.avg_f32 else "f64"
-        solver = _native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib, avg_dtype=avg_dtype)
-        if args.placement_probe and not emu_lib and solver.engine == "fused":
-            # The board pass streams within ~10 % of what HBM sustains and its speed depends on WHERE its arrays land physically: solver
-            # objects of one process differ by up to 15 %, alternating between two levels ("Spread"). One GPU has room
-            # for three sets of arrays at this size (3 x 66 GB), so: build a few solvers side by side, time each, keep the fastest.
-            # All timings are reported (config.placement_probe_ms_per_iteration); --no-placement-probe measures the first allocation as is.
-            def probe(sv):
-                sv.iterations(3)  # past the first iterations (uniform strategies, first averages): the steady-state passes are what is compared
-                sv.sync()
-                return sv.time_iterations(4) / 4.0
-            cands = [solver]
-            placement = [probe(solver)]
-            try:
-                for _ in range(args.placement_candidates - 1):  # all candidates stay alive until the choice (a freed set's place would just be taken again)
-                    cands.append(_native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib, avg_dtype=avg_dtype))
-                    placement.append(probe(cands[-1]))
-            except _native.NativeError as e:  # not enough HBM for another set: choose among those there are
-                sys.stderr.write("bench.py: placement probe cut short (%s)\n" % e)
-            solver = cands[int(np.argmin(placement[:len(cands)]))]
-            cands = None
-            solver.reset()
+        # The board pass streams within ~15 % of what HBM sustains and its speed depends on WHERE its arrays land physically: solver
+        # objects of one process differ by up to 15 %, alternating between two levels ("Spread"). The LIBRARY handles it
+        # (prl_solver_create_placed, NativeSolver(place=k)): it builds k solvers side by side (3 x 54 GB fit one GPU at this size), times each,
+        # keeps the fastest. All timings are reported (config.placement_probe_ms_per_iteration; the first entry is what a plain create gets);
+        # --no-placement-probe measures the first allocation as is.
+        probe = args.placement_probe and not emu_lib and args.engine != "levels"
+        solver = _native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib, avg_dtype=avg_dtype,
+                                      place=args.placement_candidates if probe else None)
+        if solver.placement_ms is not None and solver.engine == "fused":
+            placement = [x for x in solver.placement_ms if x > 0.0]
+            placement_chosen = solver.placement_chosen
     solver.sync()
 
     def barrier():
@@ -293,8 +283,18 @@ def main():
             "avg_strategy_exploitability_mbb_per_g": float(np.mean(avg_expl) * 10.0), "avg_strategy_evaluation_ms": avg_eval_ms,
             "ms_per_step_with_avg_strategy_evaluation": dt * 1e3 / args.steps + avg_eval_ms,
             "hbm_bytes_allocated": int(solver.get("bytes_allocated")[0]),
-            "placement_probe_ms_per_iteration": placement,  # one entry per candidate allocation: the fastest was kept (None: not probed)
+            "placement_probe_ms_per_iteration": placement,  # one entry per candidate allocation, built by the library (prl_solver_create_placed): the fastest was kept (None: not probed)
+            "placement_chosen": placement_chosen, "first_allocation_probe_ms_per_iteration": placement[0] if placement else None,
         },
+        # the reference's iteration() also evaluates the AVERAGE strategy every time (_CFRBase.py:134,218-262): the same figure for the
+        # iteration WITH that evaluation pass -- algorithmic bytes of the evaluation: the float64 average once + one rank vector per board
+        # (8 R sum(A) + 4 R N_boards), over kernel time of the iteration + the evaluation's wall time
+        "roofline_with_avg_evaluation": {
+            "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "achieved": (bytes_iter + 8.0 * R * sum_a + 4.0 * R * args.boards) / ((kernel_ms / args.steps + avg_eval_ms) * 1e-3) / 1e9,
+            "frac": (bytes_iter + 8.0 * R * sum_a + 4.0 * R * args.boards) / ((kernel_ms / args.steps + avg_eval_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "ms_per_iteration": kernel_ms / args.steps + avg_eval_ms, "bytes_per_iteration_algorithmic": bytes_iter + 8.0 * R * sum_a + 4.0 * R * args.boards,
+            "kernel": "prl_k_fhp_pass: the two update passes + the two-seat evaluation pass over the float64 averages", "traffic": None},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": ((PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 if args.avg_f32 else PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION) * args.boards
                                  if (solver.engine == "fused" and args.variant == "plus") else None),

@@ -307,6 +307,16 @@ int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t de
  * Regrets, current strategies and the current-strategy exploitability history are unaffected. Single-deal fused engine, CFR+, no checkpoints. */
 enum { PRL_SOLVER_AVG_F32 = 1 };
 int32_t prl_solver_create_opts(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t flags, prl_solver_t** out_solver);
+/* Placement selection. The fused board pass streams within ~15 % of what HBM sustains and its speed depends on WHERE its arrays land
+ * physically: solver objects of one process differ by up to 15 % and keep their speed for life ("Spread"). This entry
+ * point does what a careful user would do by hand: it builds up to `n_candidates` solvers of the tree side by side (all alive until the
+ * choice: a freed set's place would just be taken again; it stops early when HBM runs out), runs `probe_iters` steady-state iterations on
+ * each (after three warm-up iterations), keeps the fastest, destroys the others and resets the winner -- the state handed back is exactly
+ * that of prl_solver_create_opts. out_ms (may be NULL) receives the candidates' milliseconds per iteration (0 for candidates not built),
+ * out_chosen (may be NULL) the index kept. Engines other than FUSED have nothing to choose: one solver is built, out_ms[0] = 0.
+ * reference: the solver object of PokerRL/cfr/_CFRBase.py:18-62 (what CFRPlus(...) builds), which has no such concern on the CPU. */
+int32_t prl_solver_create_placed(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t flags, int32_t n_candidates,
+                                 int32_t probe_iters, float* out_ms, int32_t* out_chosen, prl_solver_t** out_solver);
 /* Sharded solve over `world_size` GPUs, one process per GPU: the tree handed to rank r holds the
  * r-th contiguous block of the global board list (every rank the same number of boards; see _ragged below); the pre-chance trunk is
  * replicated; regrets / averages of a board live on its owner only. The one exchange per EV pass is the pull-up of the

@@ -534,8 +534,11 @@ class NativeSolver:
     shard=(world_size, rank, exchange, shard_boards, total_boards): ragged shards -- every rank before the last holds shard_boards
     boards, the last one the rest (prl_solver_create_sharded_ragged)."""
 
-    def __init__(self, tree, variant, delay=0, engine="auto", _lib=None, shard=None, avg_dtype="f64"):
+    def __init__(self, tree, variant, delay=0, engine="auto", _lib=None, shard=None, avg_dtype="f64", place=None, probe_iters=4):
+        """place=k (unsharded solves): placement selection -- the library builds up to k solvers side by side, times probe_iters steady-state
+        iterations of each and keeps the fastest (prl_solver_create_placed; .placement_ms / .placement_chosen say what it saw)."""
         self._L = _lib or tree._L
+        self.placement_ms, self.placement_chosen = None, None
         if _lib is None and self._L is lib():
             require_device()
         self.tree = tree
@@ -575,6 +578,19 @@ class NativeSolver:
             else:
                 check(self._L.prl_solver_create_sharded(tree.handle, v, int(delay), int(world), int(rank), self._exchange_cb, None,
                                                         ctypes.byref(self._h)), self._L)
+        elif not self._h and place is not None:
+            # placement selection inside the library (prl_solver_create_placed): `place` candidates built side by side, the fastest kept
+            n = int(place)
+            ms = (ctypes.c_float * n)()
+            chosen = ctypes.c_int32(0)
+            self._L.prl_solver_create_placed.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                         ctypes.c_int32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32),
+                                                         ctypes.POINTER(ctypes.c_void_p)]
+            self._L.prl_solver_create_placed.restype = ctypes.c_int32
+            check(self._L.prl_solver_create_placed(tree.handle, v, int(delay), e, 1 if avg_dtype == "f32" else 0, n, int(probe_iters), ms,
+                                                   ctypes.byref(chosen), ctypes.byref(self._h)), self._L)
+            self.placement_ms = [float(x) for x in ms]
+            self.placement_chosen = int(chosen.value)
         elif not self._h:
             if avg_dtype == "f32":  # opt-in: the running average stored as float32 (prl_solver_create_opts: PRL_SOLVER_AVG_F32); not the reference's numerics
                 self._L.prl_solver_create_opts.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]

@@ -144,6 +144,30 @@ PRL_HD PRL_INLINE float prl_lbr_board_equity(const PrlLbrGame& g, const int8_t* 
     return s_big + s_eq / 2.0f;
 }
 
+// The same with the two classes given as ascending index LISTS (cls_list: the n_big hands LBR beats, then the n_eq hands it ties with).
+// With the class bytes every "next element" has to scan forward from where the previous one stopped -- a loop-carried chain through an
+// LDS read per step, which serialises the eight accumulators of NumPy's pairwise sum; with the lists element i is a pure function of i, the
+// eight accumulator chains (each a gather, a blocker test and a correctly rounded division) run side by side. Same values, same order.
+PRL_HD PRL_INLINE float prl_lbr_board_equity_lists(const PrlLbrGame& g, const int8_t* full_board, const uint16_t* cls_list, int n_big, int n_eq,
+                                                   const float* rg, const uint16_t* hole_lut) {
+    unsigned long long bmask = 0ull;
+    for (int i = 0; i < g.n_board_total; ++i) bmask |= 1ull << full_board[i];
+    auto blocked = [&](int h) {
+        if (g.n_hole == 2 && hole_lut) { const unsigned v = hole_lut[h]; return (((bmask >> (v & 0xFFu)) | (bmask >> (v >> 8))) & 1ull) != 0ull; }
+        return (prl_lbr_hand_mask(g, h, hole_lut) & bmask) != 0ull;
+    };
+    int h0 = 0;
+    auto nx = [&]() { const int h = h0++; return blocked(h) ? 0.f : rg[h]; };
+    const float norm = prl_np_sum_stream<4>(g.R, nx);
+    const float unif = (float)(1.0 / (double)g.R);
+    auto value = [&](int h) { return norm == 0.f ? unif : (blocked(h) ? 0.f : rg[h]) / norm; };
+    int ib = 0, ie = n_big;
+    auto next_big = [&]() { return value((int)cls_list[ib++]); };
+    auto next_eq = [&]() { return value((int)cls_list[ie++]); };
+    const float s_big = prl_np_sum_stream<4>(n_big, next_big);
+    const float s_eq = prl_np_sum_stream<4>(n_eq, next_eq);
+    return s_big + s_eq / 2.0f;
+}
 // the cards that can still come, ascending (LocalLBRWorker.py:392-396)
 PRL_HD PRL_INLINE int prl_lbr_possible_cards(const PrlLbrGame& g, int8_t* pc) {
     int n = 0;

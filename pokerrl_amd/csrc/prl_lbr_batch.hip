@@ -29,7 +29,7 @@ extern "C" int32_t prl_device_available(void);
 #define LBRB_MAX_Q 12      // check/call + up to 11 raise sizes considered by LBR (OFF_TREE_11); sized so that TWO workgroups fit the 160 KB of LDS of a CU
 #define LBRB_MAX_LEGAL 16  // fold, check/call and up to 14 bet sizes of either player: per-lane arrays of this size stay small (private memory
                            // per lane bounds how many waves the runtime keeps in flight)
-#define LBRB_MAX_BOARDS 64  // boards per equity kept in LDS: one card to come (52-card turn: 46)
+#define LBRB_MAX_BOARDS 52  // boards per equity kept in LDS: one card to come (52-card turn: 46; >= PRL_LBR_MAX_CARDS: the rows double as work arrays)
 #define LBRB_MAX_BOARDS_2 1088  // two cards to come (hold'em flop: C(47, 2) = 1081 -- the agent's cards are unknown to LBR): the equities go through an HBM scratch row
 
 // PRL_LBRB_TIMING builds (python -m pokerrl_amd.build --variant lbrtiming PRL_LBRB_TIMING): lane 0 of every workgroup accumulates
@@ -235,8 +235,10 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
     float* rg = (float*)lbrb_smem;                 // [R] the agent's range
     float* cand = rg + R;                          // [LBRB_MAX_Q][R] candidate ranges of a look-ahead
     float* eq_lds = cand + (size_t)LBRB_MAX_Q * R;  // [LBRB_MAX_Q][LBRB_MAX_BOARDS]
-    uint8_t* cls = (uint8_t*)(eq_lds + LBRB_MAX_Q * LBRB_MAX_BOARDS);  // [R]
-    uint16_t* hole_lut = (uint16_t*)(((size_t)(cls + R) + 15) & ~(size_t)15);  // [R] c1 | c2 << 8
+    uint16_t* cls_list = (uint16_t*)(eq_lds + LBRB_MAX_Q * LBRB_MAX_BOARDS);  // [R] the hands LBR beats (ascending), then the hands it ties with
+    uint8_t* cls = (uint8_t*)eq_lds;  // [R] class of every hand: lives in the equity rows, which are idle until the lists are built
+    static_assert(LBRB_MAX_Q * LBRB_MAX_BOARDS * 4 >= 1326, "the class bytes fit the equity rows");
+    uint16_t* hole_lut = (uint16_t*)(((size_t)(cls_list + R) + 15) & ~(size_t)15);  // [R] c1 | c2 << 8
     LbrbShared& S = *(LbrbShared*)(((size_t)(hole_lut + R) + 15) & ~(size_t)15);
     LbrbLeaves& Lf = *(LbrbLeaves*)(((size_t)(&S + 1) + 15) & ~(size_t)15);
     float* cpw = (float*)(((size_t)(&Lf + 1) + 15) & ~(size_t)15);  // [LBRB_MAX_Q][PRL_LBR_MAX_CARDS] card probabilities of the look-ahead
@@ -367,6 +369,22 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                         if (ne1) prl_lds_add_i(&S.n_eq, ne1);
                     }
                     prl_sync();
+                    // the two classes as ascending index lists (stable compaction by one wave: ballot + popcount of the lanes below), so that
+                    // the sums over a class read element i directly instead of scanning the class bytes (prl_lbr_board_equity_lists)
+                    if (tid < 64) {
+                        int at_big = 0, at_eq = S.n_big;
+                        for (int base = 0; base < R; base += 64) {
+                            const int h = base + tid;
+                            const int c = h < R ? (int)cls[h] : 0;
+                            const unsigned long long mb = prl_ballot(c == 1), me = prl_ballot(c == 2);
+                            const unsigned long long below = tid == 0 ? 0ull : (~0ull >> (64 - tid));
+                            if (c == 1) cls_list[at_big + prl_popc64(mb & below)] = (uint16_t)h;
+                            if (c == 2) cls_list[at_eq + prl_popc64(me & below)] = (uint16_t)h;
+                            at_big += prl_popc64(mb);
+                            at_eq += prl_popc64(me);
+                        }
+                    }
+                    prl_sync();
                     LBRB_TICK(2);  // candidate fold probabilities + classification
                     // one lane per raise: fold probability and the not-fold mass, NumPy order
                     // two lanes per raise, in different waves so that the two sums run side by side
@@ -397,7 +415,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                         const int q = t / n_boards, b = t % n_boards;
                         int8_t fb[5];
                         prl_lbr_board_at(g, S.pc, S.n_pc, b, fb);
-                        eq[q * eq_stride + b] = prl_lbr_board_equity(g, fb, cls, cand + (size_t)q * R, hole_lut, S.n_big, S.n_eq);
+                        eq[q * eq_stride + b] = prl_lbr_board_equity_lists(g, fb, cls_list, S.n_big, S.n_eq, cand + (size_t)q * R, hole_lut);
                     }
                     prl_sync();
                     LBRB_TICK(5);  // (range, board) equities
@@ -552,7 +570,7 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
     P.n_deal = 2 * nh + nb; P.limit = lbr_game->game_type == PRL_GAME_LIMIT;
     P.seed = agent_seed; P.episode_base = episode_base; P.reward_scalar = reward_scalar; P.ev_normalizer = ev_normalizer;
     const int R = rules->range_size;
-    const size_t smem = ((size_t)(1 + LBRB_MAX_Q) * R + LBRB_MAX_Q * LBRB_MAX_BOARDS) * sizeof(float) + R + 16 + (size_t)R * 2 + 16 + sizeof(LbrbShared) + 16 + sizeof(LbrbLeaves) + 16 + (size_t)LBRB_MAX_Q * PRL_LBR_MAX_CARDS * sizeof(float);
+    const size_t smem = ((size_t)(1 + LBRB_MAX_Q) * R + LBRB_MAX_Q * LBRB_MAX_BOARDS) * sizeof(float) + (size_t)R * 2 + 16 + (size_t)R * 2 + 16 + sizeof(LbrbShared) + 16 + sizeof(LbrbLeaves) + 16 + (size_t)LBRB_MAX_Q * PRL_LBR_MAX_CARDS * sizeof(float);
     int8_t* d_cards = nullptr; float* d_win = nullptr; unsigned long long* d_stats = nullptr; float* d_eq = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = PRL_OK;

@@ -1195,6 +1195,41 @@ int32_t prl_solver_create_opts(const prl_tree_t* tree, int32_t variant, int32_t 
     return solver_create_impl(tree, variant, delay, engine, 1, 0, nullptr, nullptr, out, 0, 0, nullptr, flags);
 }
 
+int32_t prl_solver_create_placed(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t flags, int32_t n_candidates,
+                                 int32_t probe_iters, float* out_ms, int32_t* out_chosen, prl_solver_t** out) {
+    if (!out || n_candidates < 1 || n_candidates > 8 || probe_iters < 1) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    if (out_ms) for (int i = 0; i < n_candidates; ++i) out_ms[i] = 0.f;
+    if (out_chosen) *out_chosen = 0;
+    std::vector<prl_solver*> cand;
+    std::vector<float> ms;
+    int rc = PRL_OK;
+    for (int i = 0; i < n_candidates; ++i) {
+        prl_solver* s = nullptr;
+        rc = prl_solver_create_opts(tree, variant, delay, engine, flags, &s);
+        if (rc != PRL_OK) {
+            if (rc == PRL_ERR_OOM && !cand.empty()) { rc = PRL_OK; break; }  // no room for another set of arrays: choose among those there are
+            for (prl_solver* c : cand) prl_solver_destroy(c);
+            return rc;
+        }
+        cand.push_back(s);
+        if (!s->fused) break;  // nothing to choose
+        // past the first iterations (uniform strategies, first averages): the steady-state passes are what is compared
+        float t = 0.f;
+        rc = prl_solver_iterations(s, 3);
+        if (rc == PRL_OK) rc = prl_solver_sync(s);
+        if (rc == PRL_OK) rc = prl_solver_time_iterations(s, probe_iters, &t);
+        if (rc != PRL_OK) { for (prl_solver* c : cand) prl_solver_destroy(c); return rc; }
+        ms.push_back(t / (float)probe_iters);
+    }
+    size_t best = 0;
+    for (size_t i = 1; i < ms.size(); ++i) if (ms[i] < ms[best]) best = i;
+    for (size_t i = 0; i < cand.size(); ++i) if (i != best) prl_solver_destroy(cand[i]);
+    if (out_ms) for (size_t i = 0; i < ms.size(); ++i) out_ms[i] = ms[i];
+    if (out_chosen) *out_chosen = (int32_t)best;
+    *out = cand[best];
+    return ms.empty() ? PRL_OK : prl_solver_reset(cand[best]);
+}
+
 int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out) {
     return solver_create_impl(tree, variant, delay, engine, 1, 0, nullptr, nullptr, out);
 }

@@ -307,6 +307,102 @@ def walk_env_tree(cls, stack, bets):
     return out
 
 
+def walk_env_tree_runouts(cls, stack, bets, runouts):
+    """The betting tree below SEVERAL run-outs, walked through the REFERENCE env: the DFS of walk_env_tree, but at every deal the env is
+    reloaded once per distinct outcome among the listed run-outs that continue the cards already out (row order), its deck set so that it
+    deals exactly those cards -- the board of every node is what the env then holds. What pins the product's multi-run-out wiring (chance
+    children per prefix, board rows, parents) to the reference, not only the betting tree of one run-out."""
+    bldr, args = make_bldr(cls, stack, bets)
+    env = bldr.get_new_env(is_evaluating=True, stack_size=args.starting_stack_sizes_list)
+    a = env.get_args()
+    a.RETURN_PRE_TRANSITION_STATE_IN_INFO = True
+    env.set_args(a)
+    np.random.seed(0)
+    env.reset()
+    runouts = [[int(c) for c in r] for r in np.asarray(runouts)]
+    n_board = len(runouts[0])
+    rec = dict(kind=[], actor=[], parent=[], child_idx=[], action=[], acted_last=[], round=[], main_pot=[], depth=[], n_children=[], first_col=[])
+    boards = []
+    col_action = []
+    lh = env.lut_holder
+
+    def board_now():
+        b = [int(c) for c in lh.get_1d_cards(env.board)]
+        return [c if c >= 0 else -1 for c in b] + [-1] * (n_board - len(b))
+
+    def add(kind, actor, parent, child_idx, action, acted_last, rnd, pot, depth, board):
+        for k, v in zip(("kind", "actor", "parent", "child_idx", "action", "acted_last", "round", "main_pot", "depth"),
+                        (kind, actor, parent, child_idx, action, acted_last, rnd, pot, depth)):
+            rec[k].append(v)
+        rec["n_children"].append(0)
+        rec["first_col"].append(-1)
+        boards.append(list(board))
+        return len(rec["kind"]) - 1
+
+    def expand(my, state, depth, board):
+        env.load_state_dict(state)
+        legal = env.get_legal_actions()
+        rec["n_children"][my] = len(legal)
+        rec["first_col"][my] = len(col_action)
+        col_action.extend(int(x) for x in legal)
+        actor = state[EnvDictIdxs.current_player]
+        rnd = state[EnvDictIdxs.current_round]
+        n_out = sum(c >= 0 for c in board)
+        for i, act in enumerate(legal):
+            env.load_state_dict(state)
+            _, _, term, info = env.step(act)
+            if term:
+                pre = info["state_dict_before_money_move"]
+                add(2 if act == Poker.FOLD else 3, -1, my, i, int(act), actor, rnd, int(pre[EnvDictIdxs.main_pot]), depth + 1, board)
+            elif info["chance_acts"]:
+                pre = info["state_dict_before_money_move"]
+                n_dealt = sum(c >= 0 for c in board_now()) - n_out  # cards this street deals
+                outs = []
+                for r in runouts:  # distinct continuations of the cards already out, in row order
+                    if r[:n_out] == [c for c in board if c >= 0] and r[n_out:n_out + n_dealt] not in outs:
+                        outs.append(r[n_out:n_out + n_dealt])
+                ch = add(1, -1, my, i, int(act), actor, rnd, int(pre[EnvDictIdxs.main_pot]), depth + 1, board)
+                rec["n_children"][ch] = len(outs)
+                for k, cards in enumerate(outs):
+                    env.load_state_dict(state)
+                    # the env deals from the top of its deck: put this outcome's cards there
+                    top = lh.get_2d_cards(np.array(cards, np.int32))
+                    rest = np.array([c for c in env.deck.deck_remaining if not any((c == t).all() for t in top)], np.int8).reshape(-1, 2)
+                    env.deck.deck_remaining = np.concatenate([top.astype(np.int8), rest], axis=0)
+                    env.step(act)
+                    st = env.state_dict()
+                    nb = board_now()
+                    assert [c for c in nb if c >= 0] == [c for c in board if c >= 0] + cards, (nb, board, cards)
+                    c = add(0, st[EnvDictIdxs.current_player], ch, k, -1, -2, st[EnvDictIdxs.current_round], int(st[EnvDictIdxs.main_pot]), depth + 2, nb)
+                    expand(c, st, depth + 2, nb)
+            else:
+                st = env.state_dict()
+                c = add(0, st[EnvDictIdxs.current_player], my, i, int(act), actor, st[EnvDictIdxs.current_round], int(st[EnvDictIdxs.main_pot]), depth + 1, board)
+                expand(c, st, depth + 1, board)
+
+    st0 = env.state_dict()
+    b0 = [-1] * n_board
+    root = add(0, st0[EnvDictIdxs.current_player], -1, 0, -1, -1, st0[EnvDictIdxs.current_round], int(st0[EnvDictIdxs.main_pot]), 0, b0)
+    expand(root, st0, 0, b0)
+    out = {k: np.array(v, dtype=np.int32) for k, v in rec.items()}
+    out["col_action"] = np.array(col_action, dtype=np.int32)
+    out["board"] = np.array(boards, dtype=np.int8)
+    return out
+
+
+def make_tree_limit_holdem_runouts():
+    """LimitHoldem under 2 flops x 2 turns x 2 rivers (the run-outs of tests/parity_cases.multistreet_runouts(2, 2, 2)): every node's protocol
+    fields AND the board the reference env holds there"""
+    sys.path.insert(0, os.path.dirname(HERE))                     # tests/
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))    # the repository root (oracle/, pokerrl_amd/)
+    import parity_cases as pc
+    sys.setrecursionlimit(20000)
+    ro = pc.multistreet_runouts(2, 2, 2)
+    flat = walk_env_tree_runouts(LimitHoldem, stack=48, bets=None, runouts=ro)
+    print("LimitHoldem 2x2x2 run-outs: nodes", len(flat["kind"]), "per round", np.bincount(flat["round"]).tolist())
+    save("tree_LimitHoldem_2x2x2.npz", runouts=ro, **flat)
+
+
 ENV_FUZZ = {
     "StandardLeduc": (StandardLeduc, 13, [0.0]),
     "BigLeduc": (BigLeduc, 100, [0.0]),
@@ -543,7 +639,7 @@ def make_env_obs():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["luts", "handrank", "tree", "env", "cfr"]
     fns = {"luts": make_luts, "handrank": make_handrank, "handrank_exhaustive": make_handrank_exhaustive,
-           "tree": make_tree, "tree_lh": make_tree_limit_holdem, "env": make_env, "cfr": make_cfr, "env_obs": make_env_obs}
+           "tree": make_tree, "tree_lh": make_tree_limit_holdem, "tree_lh_runouts": make_tree_limit_holdem_runouts, "env": make_env, "cfr": make_cfr, "env_obs": make_env_obs}
     i = 0
     while i < len(what):
         w = what[i]

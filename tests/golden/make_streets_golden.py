@@ -3,7 +3,9 @@ Generates tests/golden/lh_<F>x<T>x<R>_<variant>.npz with the CPU ORACLE (oracle/
 full betting, F flops x T turns x R rivers of bench_multistreet.runouts; default 4 x 2 x 2 = 259 330 nodes) after a few iterations: exploitability
 history, average-strategy exploitability, SHA-256 of the regret / average arrays in the flat tree's DFS column order.
 
-    python tests/golden/make_streets_golden.py [flops] [turns] [rivers] [variant] [n_iters]
+    python tests/golden/make_streets_golden.py [flops] [turns] [rivers] [variant] [n_iters] [delay]
+
+(delay > 0: the file name carries _d<delay>_i<n_iters>; the averaging weights of several blends enter the fixture)
 
 The tree comes from the product's host tree builder (its multi-street structure pinned to the reference env: tree_LimitHoldem_1runout.npz);
 everything else is the oracle. Needs no GPU; ~20 GB of RAM, a few minutes on 8 cores.
@@ -25,19 +27,19 @@ from pokerrl_amd import _native  # noqa: E402
 from pokerrl_amd.game import games as G  # noqa: E402
 
 
-def main(flops=4, turns=2, rivers=2, variant="plus", n_iters=3):
+def main(flops=4, turns=2, rivers=2, variant="plus", n_iters=3, delay=0):
     ro = bench_multistreet.runouts(flops, turns, rivers)
     t = _native.NativeTree.for_game(G.LimitHoldem, 48, None, ro)
     r = G.LimitHoldem.RULES
     o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS, r._RANK_RULE)
-    o.cfr_reset(pc.VARIANT_ID[variant], 0)
+    o.cfr_reset(pc.VARIANT_ID[variant], delay)
     hist = [np.array(o.exploitability, np.float32)]
     for it in range(n_iters):
         o.cfr_iteration()
         hist.append(np.array(o.exploitability, np.float32))
         print("iteration", it + 1, hist[-1], flush=True)
-    out = os.path.join(HERE, "lh_%dx%dx%d_%s.npz" % (flops, turns, rivers, variant))
-    np.savez(out, flops=flops, turns=turns, rivers=rivers, variant=variant, n_iters=n_iters, runouts_sha256=h32(ro), n_nodes=t.n_nodes,
+    out = os.path.join(HERE, "lh_%dx%dx%d_%s%s.npz" % (flops, turns, rivers, variant, "_d%d_i%d" % (delay, n_iters) if delay else ""))
+    np.savez(out, flops=flops, turns=turns, rivers=rivers, variant=variant, n_iters=n_iters, delay=delay, runouts_sha256=h32(ro), n_nodes=t.n_nodes,
              expl_history=np.stack(hist), eval_avg=o.eval_avg(), regret_sha256=h32(np.asarray(o.regret)), avg_sha256=h32(np.asarray(o.avg)),
              numpy=np.__version__)
     print("wrote", out)
@@ -76,4 +78,4 @@ if __name__ == "__main__":
         main_br(*(int(x) for x in a[1:4]))
         sys.exit(0)
     main(int(a[0]) if a else 4, int(a[1]) if len(a) > 1 else 2, int(a[2]) if len(a) > 2 else 2, a[3] if len(a) > 3 else "plus",
-         int(a[4]) if len(a) > 4 else 3)
+         int(a[4]) if len(a) > 4 else 3, delay=int(a[5]) if len(a) > 5 else 0)

@@ -256,7 +256,7 @@ def check_fused_vs_fixture(L, name):
     args = env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)
     t = _native.NativeTree(G.Flop5Holdem.native_game(args), G.Flop5Holdem.native_rules(), boards, _lib=L)
     variant = str(g["variant"])
-    s = _native.NativeSolver(t, variant, 0, engine="fused", _lib=L)
+    s = _native.NativeSolver(t, variant, int(g["delay"]) if "delay" in g else 0, engine="fused", _lib=L)
     s.iterations(int(g["n_iters"]))
     assert np.array_equal(s.get("expl_history"), g["expl_history"])
     assert np.array_equal(s.eval_avg(), g["eval_avg"])

@@ -149,10 +149,16 @@ def test_gpu_fused_many_boards_per_cu_vs_oracle(L, n_boards, variant):
     pc.check_fused_vs_oracle(L, n_boards, 3, variant=variant)
 
 
-def test_gpu_fused_16384_boards_fixture(L):
-    """Oracle-generated fixture (tests/golden/make_fhp_golden.py): exploitability history and SHA-256 of the regrets / averages
-    after 3 CFR+ iterations on 16384 seeded boards (64 boards per CU)."""
-    pc.check_fused_vs_fixture(L, "fhp_16384_plus")
+@pytest.mark.parametrize("name", ["fhp_16384_plus", "fhp_16384_plus_d2_i6"])
+def test_gpu_fused_16384_boards_fixture(L, name):
+    """Oracle-generated fixtures (tests/golden/make_fhp_golden.py): exploitability history and SHA-256 of the regrets / averages on 16384 seeded
+    boards (64 boards per CU) -- after 3 CFR+ iterations; after 6 with an averaging delay of 2 (the blend weights of four averaging steps,
+    CFRPlus.py:65-87, and the scalar recurrence that stands for the averages of the hands a board blocks: sorted storage)."""
+    import os
+    from helpers import GOLDEN
+    if not os.path.isfile(os.path.join(GOLDEN, name + ".npz")):
+        pytest.skip("fixture not generated (tests/golden/make_fhp_golden.py)")
+    pc.check_fused_vs_fixture(L, name)
 
 
 @pytest.mark.parametrize("stack,flop_raises,nodes,n_boards,variant", [
@@ -215,7 +221,7 @@ def test_gpu_streets_engine_best_response_of_an_explicit_strategy_vs_oracle(L):
     assert t.n_nodes > 60000
 
 
-@pytest.mark.parametrize("variant", ["plus", "linear", "vanilla"])
+@pytest.mark.parametrize("variant", ["plus", "linear", "vanilla", "plus_d2_i6"])
 def test_gpu_streets_engine_bench_tree_vs_oracle_fixture(L, variant):
     """bench_multistreet.py's tree (4 flops x 2 turns x 2 rivers, 259 330 nodes) on the per-street engine against the ORACLE's own run of it
     (tests/golden/make_streets_golden.py): exploitability history, average-strategy exploitability, SHA-256 of the regrets / averages"""
@@ -234,7 +240,7 @@ def test_gpu_streets_engine_bench_tree_vs_oracle_fixture(L, variant):
     assert h32(ro) == str(g["runouts_sha256"])
     t = _native.NativeTree.for_game(G.LimitHoldem, 48, None, ro, _lib=L)
     assert t.n_nodes == int(g["n_nodes"])
-    s = _native.NativeSolver(t, str(g["variant"]), 0, engine="auto", _lib=L)
+    s = _native.NativeSolver(t, str(g["variant"]), int(g["delay"]) if "delay" in g else 0, engine="auto", _lib=L)
     assert s.engine == "fused"
     s.iterations(int(g["n_iters"]))
     assert np.array_equal(s.get("expl_history"), g["expl_history"]), (s.get("expl_history"), g["expl_history"])
@@ -513,3 +519,24 @@ def test_gpu_fused_properties_at_bench_size(L):
         del s, t
     for a, b in zip(runs[0], runs[1]):
         assert np.array_equal(a, b)
+
+
+def test_gpu_placement_selection_inside_the_library():
+    """prl_solver_create_placed (NativeSolver(place=k)): k solvers built side by side, each timed, the fastest kept and reset -- the state handed
+    back is that of a plain create: same exploitability history and regrets after the same iterations"""
+    from helpers import env_args
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    boards = pc.fhp_boards(512)
+    t = _native.NativeTree(G.Flop5Holdem.native_game(env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)), G.Flop5Holdem.native_rules(), boards)
+    a = _native.NativeSolver(t, "plus", 0, engine="fused", place=3, probe_iters=2)
+    assert a.engine == "fused" and len(a.placement_ms) == 3 and all(x > 0 for x in a.placement_ms) and 0 <= a.placement_chosen < 3
+    assert a.iter == 0
+    b = _native.NativeSolver(t, "plus", 0, engine="fused")
+    a.iterations(3)
+    b.iterations(3)
+    assert np.array_equal(a.get("expl_history"), b.get("expl_history")) and np.array_equal(a.get("regret"), b.get("regret"))
+    # engines with nothing to choose: one solver, no timings
+    c = _native.NativeSolver(t, "plus", 0, engine="levels", place=2)
+    assert c.engine == "levels" and c.placement_ms == [0.0, 0.0]

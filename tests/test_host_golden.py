@@ -203,6 +203,27 @@ def test_tree_limit_holdem_multistreet_structure_like_reference_env():
     assert sizes == {27}
 
 
+def test_tree_limit_holdem_several_run_outs_like_reference_env():
+    """LimitHoldem under 2 flops x 2 turns x 2 rivers (129 676 nodes): the multi-run-out flat tree node for node against the tree walked through
+    the REFERENCE env with its deck set per outcome (tests/golden/make_golden.py tree_lh_runouts) -- the protocol fields, the chance nodes'
+    child counts and order, and per node the BOARD the reference env holds there against the product's prefix row (board_id -> board_rows):
+    the wiring of chance children to prefix rows, which the one-run-out fixture cannot see"""
+    ref = golden("tree_LimitHoldem_2x2x2.npz")
+    ro = pc_runouts = ref["runouts"]
+    import parity_cases as pc
+    assert np.array_equal(ro, pc.multistreet_runouts(2, 2, 2))
+    t = native_tree(G.LimitHoldem, 48, None, ro)
+    assert t.n_nodes == len(ref["kind"]) == 129676
+    for f in ("kind", "actor", "parent", "child_idx", "action", "acted_last", "round", "main_pot", "depth", "n_children", "first_col", "col_action"):
+        assert np.array_equal(t.field(f), ref[f]), f
+    rows = np.asarray(t.board_rows)
+    bid = t.field("board_id")
+    mine = np.where(bid[:, None] >= 0, rows[np.maximum(bid, 0)], -1)
+    assert np.array_equal(mine, ref["board"].astype(mine.dtype))
+    # prefix rows: 2 flops + 4 flop-turn prefixes + 8 complete run-outs, every chance node fans out into two children
+    assert t.n_boards == 2 + 4 + 8 and set(ref["n_children"][ref["kind"] == 1].tolist()) == {2}
+
+
 def test_tree_flop5holdem_structure():
     ref = golden("tree_Flop5Holdem_1board.npz")
     boards = np.array([[0, 5, 10, 15, 20], [1, 2, 3, 50, 51], [7, 8, 9, 30, 44]], np.int8)
@@ -521,3 +542,10 @@ def test_board_enumeration_like_the_tree_builder_deals():
     tree.build_tree()
     import bench
     assert np.array_equal(tree._boards, bench.seeded_boards(40, 0))
+    # a copy made BEFORE build_tree deals the same capped / seeded boards (the caps travel with it)
+    tree2 = PublicTree(env_bldr=HistoryEnvBuilder(env_cls=G.Flop5Holdem, env_args=args), stack_size=[20000, 20000], stop_at_street=1, n_boards=40, board_seed=0)
+    assert tree2.copy()._board_caps == (40, None, 0)
+    # every board of Flop5Holdem is more than one GPU holds: said so at once, not as a late out-of-memory
+    with pytest.raises(ValueError, match="pass n_boards"):
+        board_enum.single_deal_boards(G.Flop5Holdem)
+    assert board_enum.single_deal_boards(G.Flop5Holdem, n_boards=7).shape == (7, 5)
