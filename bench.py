@@ -200,6 +200,12 @@ def main():
         exchange = TorchExchange("cpu" if emu_lib else "cuda")
         solver = _native.NativeSolver(tree, args.variant, 0, shard=(world, rank, exchange, shard_boards, total) if total else (world, rank, exchange), _lib=lib)
     placement, placement_chosen = None, None
+    rccl_path = None
+    if sharded and not emu_lib:
+        import ctypes
+        buf = ctypes.create_string_buffer(512)
+        (lib or _native.lib()).prl_rccl_info(buf, 512)
+        rccl_path = buf.value.decode("utf-8", "replace")
     if not sharded:
         avg_dtype = "f32" if args.avg_f32 else "f64"
         # The board pass streams within ~15 % of what HBM sustains and its speed depends on WHERE its arrays land physically: solver
@@ -228,10 +234,15 @@ def main():
     dev_ms, pass_ms, n_pass = solver.time_iterations_ex(args.steps)  # the K iterations, HIP events on the solver's stream
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
-        tt = torch.tensor([dt], device="cpu" if emu_lib else "cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        # every rank's own numbers travel to rank 0 (the SCALE line diagnoses itself: which rank is the slow one, how much of the step is the
+        # board pass, what the exchange moves), the step time is the MAX over ranks
+        mine = torch.tensor([dt, dev_ms, pass_ms], device="cpu" if emu_lib else "cuda", dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(x) for x in t.tolist()] for t in allr]
+        dt = max(r[0] for r in per_rank)
 
     # the reference's iteration() also evaluates the AVERAGE strategy every time (_CFRBase.py:134,218-262); timed separately
     # (outside the K steps) as one best-response-style evaluation per iteration
@@ -278,6 +289,13 @@ def main():
             "parallelism": "boards sharded over %d GPU(s), trunk replicated, 1 all-gather of chance-node partial sums per EV pass" % world,
             "nodes_whole_tree": n_nodes_total, "exchanges": int(solver.get("exchanges")[0]), "exchange": (how if sharded else None),
             "exchange_ms_mean": (exchange.seconds * 1e3 / max(exchange.calls, 1)) if exchange else None,
+            # per rank: wall ms per step, device ms per iteration (HIP events on the solver's stream), board-pass kernel ms per iteration
+            "per_rank_ms_per_step": [r[0] * 1e3 / args.steps for r in per_rank] if per_rank else None,
+            "per_rank_device_ms_per_iteration": [r[1] / args.steps for r in per_rank] if per_rank else None,
+            "per_rank_pass_ms_per_iteration": [r[2] / args.steps for r in per_rank] if per_rank else None,
+            # what one all-gather moves: every rank contributes its canonical units (blocks / groups of boards) of <= 3 root vectors
+            "exchange_bytes_per_pass_per_rank_upper": (int(-(-args.boards // 1024)) if args.boards % 1024 == 0 else int(-(-args.boards // 32)) if args.boards % 32 == 0 else args.boards) * 3 * tree.range_size * 4 if sharded else None,
+            "rccl_library": rccl_path,
             "iterations_done": solver.iter, "exploitability_mbb_per_g": float(np.mean(expl) * 10.0),
             "exploitability_pinned_to": "oracle/ (C restatement of the reference with an explicit float32 summation order; the reference cannot build 2-hole-card trees)",
             "avg_strategy_exploitability_mbb_per_g": float(np.mean(avg_expl) * 10.0), "avg_strategy_evaluation_ms": avg_eval_ms,

@@ -99,27 +99,69 @@ def main():
                       "hand_evals_per_s_rank0": sum(s["range_board_equities"] for s in stats) * 1326 / dev_s,
                       "lbr_winnings_mbb_per_g": mean, "conf95_per_seat": [r[1] for r in res]}}
     # The batch kernel keeps a hand's whole state in LDS / registers: HBM moves the decks in and the winnings out (bytes per hand in the
-    # tens), so neither the HBM nor the MFMA roofline says anything about it. Its arithmetic is the (range, board) equities of LBR's
-    # look-aheads (LocalLBRWorker.py:427-512): per equity and hand of the 1326-hand range one add into the normalising sum, one division,
-    # one add into the win / tie sums = 3 R float32 operations; the bound is the vector FP32 pipe (157.3 TFLOP/s spec, MI355X_MICROARCH.md).
-    flops_eq = 3.0 * 1326
-    achieved_tflops = sum(s["range_board_equities"] for s in stats) * flops_eq / dev_s / 1e12
-    out["roofline"] = {"bound": "valu-fp32", "achieved": achieved_tflops, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved_tflops / 157.3, "traffic": None,
-                       "kernel": "prl_k_lbr_batch", "flops_per_range_board_equity_algorithmic": flops_eq,
-                       "range_board_equities_per_hand": sum(s["range_board_equities"] for s in stats) / max(float(n), 1.0),
-                       "note": "not an HBM- or MFMA-bound kernel: state on chip, no contraction; the model counts 3 float32 operations per hand of a "
-                               "(range, board) equity, the kernel also spends integer work on blockers, the betting engine and the agent's draws"}
+    # tens), and nothing in it is a contraction: neither the HBM nor the MFMA roofline says anything about it. It is bound by VECTOR
+    # INSTRUCTION ISSUE, integer and float32 alike, and the model counts what the kernel executes for the dominant step, the (range, board)
+    # equities of LBR's look-aheads (LocalLBRWorker.py:427-512; prl_lbr_board_equity_lists), per equity:
+    #   normalising sum over the R = 1326 hands: hole-card look-up, blocker test (two 64-bit shifts = 4 ops, or, and, compare), select, add      ~10 ops
+    #   sums over the n_big + n_eq <= R hands LBR beats / ties with: list read, the same blocker test, select, a CORRECTLY ROUNDED float32
+    #   division (10 ops: NumPy divides every element of the range by the normalising sum before it sums), add                             ~24 ops
+    # = 10 R + 24 * 0.93 R ~ 43 000 lane operations (0.93: the share of the range LBR beats or ties on an average turn, from the kernel's own
+    # class counts), against the peak of one operation per lane and clock: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s (the
+    # FP32 vector peak of MI355X_MICROARCH.md, 157.3 TFLOP/s, counts an FMA as two). Hand evaluations: the reference's rollout manager applies
+    # the win / tie lists of the FIRST enumerated board to every board (LocalLBRWorker.py:470,509-510), so a look-ahead ranks the 1326 hands
+    # ONCE: rank evaluations = look-aheads x (R + 1), not equities x R.
+    R_ = 1326
+    ops_eq = 10.0 * R_ + 24.0 * 0.93 * R_
+    n_eq_tot = sum(s["range_board_equities"] for s in stats)
+    achieved = n_eq_tot * ops_eq / dev_s / 1e12
+    peak = 256 * 4 * 32 * 2.4e9 / 1e12
+    out["config"]["hand_rank_evaluations_per_s_rank0"] = sum(s["lbr_lookaheads"] for s in stats) * (R_ + 1) / dev_s
+    del out["config"]["hand_evals_per_s_rank0"]
+    out["roofline"] = {"bound": "valu-issue (int + fp32)", "achieved": achieved, "peak": peak, "unit": "T lane-ops/s", "frac": achieved / peak, "traffic": None,
+                       "kernel": "prl_k_lbr_batch", "lane_ops_per_range_board_equity": ops_eq,
+                       "range_board_equities_per_hand": n_eq_tot / max(float(n), 1.0), "range_board_equities_per_s_rank0": n_eq_tot / dev_s,
+                       "note": "not an HBM- or MFMA-bound kernel: state on chip, no contraction. Modelled: the (range, board) equities only (the betting "
+                               "engine, the agent's draws and the range updates are not counted: the model is a lower bound of the work done); the "
+                               "operation counts are read off the kernel's ISA, profiles/r06_lbr_*.txt hold the SQ counters"}
     if rank == 0 and args.cpu_hands > 0 and world == 1:
+        # cpu_baseline: the SAME episode loop (pokerrl_amd.eval.lbr.LocalLBRWorker = the reference's LocalLBRWorker.run) with the check-down
+        # equity of every decision computed ON THE HOST by the NumPy restatement of the reference's rollout manager (oracle/lbr.py, pinned to
+        # the reference bit for bit) -- no device call in the timed region. (Round 3 timed the host worker with its equity queries on the GPU
+        # and called that a CPU baseline; that number is reported beside it as what it is.)
+        import oracle
+        from oracle.lbr import checkdown_equity
         from pokerrl_amd.rl import hash_agent as fx
         from pokerrl_amd.rl.base_cls.EvalAgentBase import EvalAgentBase
-        w = LocalLBRWorker(t_prof=t_prof, chief_handle=None, eval_agent_cls=fx.make_agent_cls(EvalAgentBase, seed=7))
+        from pokerrl_amd.game.Poker import Poker as _P
+
+        def rank_fn(board):
+            return oracle.rank_boards(np.array([board], dtype=np.int8))[0]
+
+        class HostOnlyWorker(LocalLBRWorker):
+            def _checkdown_equity(self, lbr_hand_2d, ranges):
+                lut = self._eval_env_bldr.lut_holder
+                board_1d = np.asarray(lut.get_1d_cards(self._env.board))
+                dealt = [int(c) for c in board_1d if c != _P.CARD_NOT_DEALT_TOKEN_1D]
+                hand_1d = [int(c) for c in lut.get_1d_cards(cards_2d=lbr_hand_2d)]
+                return np.array([checkdown_equity(rank_fn, 2, 52, 5, dealt, hand_1d, r) for r in np.asarray(ranges, np.float32)], np.float32)
+
+        agent_cls = fx.make_agent_cls(EvalAgentBase, seed=7)
+        w = HostOnlyWorker(t_prof=t_prof, chief_handle=None, eval_agent_cls=agent_cls)
         np.random.seed(0)
         t1 = time.perf_counter()
-        w.run(agent_seat_id=0, n_iterations=args.cpu_hands, mode="HASH", stack_size=[20000, 20000])
+        n_host = max(8, args.cpu_hands // 4)
+        w.run(agent_seat_id=0, n_iterations=n_host, mode="HASH", stack_size=[20000, 20000])
+        dth = time.perf_counter() - t1
+        wd = LocalLBRWorker(t_prof=t_prof, chief_handle=None, eval_agent_cls=agent_cls)
+        np.random.seed(0)
+        t1 = time.perf_counter()
+        wd.run(agent_seat_id=0, n_iterations=args.cpu_hands, mode="HASH", stack_size=[20000, 20000])
         dtc = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": args.cpu_hands / dtc, "unit": "hands/s", "cores": 1, "kind": "port",
-                               "sample": "pokerrl_amd.eval.lbr.LocalLBRWorker (the reference's Python episode loop, equity queries on the GPU), "
-                                         "%d hands, same agent and bet sets, %.1f s" % (args.cpu_hands, dtc),
+        out["cpu_baseline"] = {"value": n_host / dth, "unit": "hands/s", "cores": 1, "kind": "port",
+                               "sample": "the reference's LBR episode loop (pokerrl_amd.eval.lbr.LocalLBRWorker) with every check-down equity on the host "
+                                         "(oracle/lbr.py, NumPy, the reference's rollout manager restated), %d hands, same agent and bet sets, %.1f s" % (n_host, dth),
+                               "host_worker_with_device_equity_hands_per_s": args.cpu_hands / dtc,
+                               "host_worker_with_device_equity_sample": "the same loop with prl_lbr_checkdown_equity (one GPU call per LBR decision), %d hands, %.1f s" % (args.cpu_hands, dtc),
                                # the reference's own worker needs /root/reference, which does not travel to the GPU box: its timing is the survey box's
                                "reference_python_hands_per_s_survey_box": 30.0, "reference_timing_source": "BASELINE.md section 2 (LocalLBRWorker, one core)"}
     if rank == 0:

@@ -345,6 +345,9 @@ int32_t prl_solver_create_sharded_ragged(const prl_tree_t* local_tree, int32_t v
  * the same number of first-deal outcomes); else the ragged geometry of prl_solver_create_sharded_ragged. RCCL is bound at run time
  * (dlopen; the one already in the process if PyTorch-ROCm is loaded): single-GPU users never load it. */
 int32_t prl_rccl_unique_id(void* out_id128);
+/* The RCCL the library binds at run time: the path of the file its symbols come from, or -- PRL_ERR_UNSUPPORTED -- why there is none.
+ * Order: PRL_RCCL_LIB=<path> if set, the RCCL already loaded in the process (PyTorch-ROCm's), the loader's search path, /opt/rocm/lib. */
+int32_t prl_rccl_info(char* out, int32_t n);
 int32_t prl_solver_create_sharded_rccl(const prl_tree_t* local_tree, int32_t variant, int32_t delay, int32_t world_size, int32_t rank,
                                        const void* unique_id128, int64_t shard_boards, int64_t total_boards, prl_solver_t** out_solver);
 /* Checkpoint / resume (the reference's CFR has none): the solver's persistent state -- iteration

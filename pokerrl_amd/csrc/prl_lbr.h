@@ -14,54 +14,84 @@
 // algorithm visits a[0], a[1], ... exactly once and in order, so no random access is needed. The recursion (halve until a
 // block has <= 128 elements, 8 accumulators per block) is walked with an explicit frame stack: one instance of the block
 // code, whatever n is. The template argument is kept for call-site compatibility (0 promises n <= 128).
+// the next eight elements of a stream: streams with a member eight(float (&)[8]) deliver them as a group
+template <class Next>
+PRL_HD PRL_INLINE auto prl_nps_eight_impl(Next& next, float (&o)[8], int) -> decltype(next.eight(o), void()) { next.eight(o); }
+template <class Next>
+PRL_HD PRL_INLINE void prl_nps_eight_impl(Next& next, float (&o)[8], long) {
+    for (int j = 0; j < 8; ++j) o[j] = next();
+}
+template <class Next>
+PRL_HD PRL_INLINE void prl_nps_eight(Next& next, float (&o)[8]) { prl_nps_eight_impl(next, o, 0); }
+
+// The frames of the walk live in REGISTERS: five levels (n <= 128 * 2^5: ranges have at most 1326 entries) as individual variables picked by
+// compare-and-select. As an array indexed by the stack pointer they sit in private (scratch) memory, and every push / pop / look at the top
+// frame is a vector-memory round trip that the lane waits for -- the batched LBR kernel spent 77 % of its wave cycles waiting and issued
+// 1.7e9 scratch reads per launch (profiles/r06_lbr_pmc_sq.txt).
 template <int D, class Next>
 PRL_HD PRL_INLINE float prl_np_sum_stream(int n, Next& next) {
-    struct Frame { int n; int stage; float left; };
-    Frame fr[8];  // depth <= log2(n / 128) + 1: n <= 128 * 2^7 (ranges have at most 1326 entries)
+    constexpr int MAXD = 6;
+    int fn[MAXD], fstage[MAXD];
+    float fleft[MAXD];
+#define PRL_NPS_GET(arr, i, out) do { out = arr[0]; for (int d_ = 1; d_ < MAXD; ++d_) out = (i) == d_ ? arr[d_] : out; } while (0)
+#define PRL_NPS_SET(arr, i, val) do { for (int d_ = 0; d_ < MAXD; ++d_) arr[d_] = (i) == d_ ? (val) : arr[d_]; } while (0)
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) { fn[d] = 0; fstage[d] = 0; fleft[d] = 0.f; }
     int sp = 0;
-    fr[0].n = n; fr[0].stage = 0; fr[0].left = 0.f;
+    fn[0] = n;
     float ret = 0.f;
     while (sp >= 0) {
-        Frame& f = fr[sp];
-        if (f.stage == 0) {
-            if (f.n < 8) {
+        int cn, cstage;
+        PRL_NPS_GET(fn, sp, cn);
+        PRL_NPS_GET(fstage, sp, cstage);
+        if (cstage == 0) {
+            if (cn < 8) {
                 float res = 0.f;
-                for (int i = 0; i < f.n; ++i) res = res + next();
+                for (int i = 0; i < cn; ++i) res = res + next();
                 ret = res;
                 --sp;
-            } else if (f.n <= 128 || D == 0) {
-                float r0 = next(), r1 = next(), r2 = next(), r3 = next(), r4 = next(), r5 = next(), r6 = next(), r7 = next();
+            } else if (cn <= 128 || D == 0 || sp == MAXD - 1) {
+                // eight accumulators; the next eight elements are FETCHED TOGETHER (prl_nps_eight: a stream that can hands them over as a
+                // group -- eight independent gathers / divisions for the scheduler to overlap -- else eight calls)
+                float r[8], t[8];
+                prl_nps_eight(next, r);
                 int i = 8;
-                for (; i < f.n - (f.n % 8); i += 8) {
-                    r0 = r0 + next(); r1 = r1 + next(); r2 = r2 + next(); r3 = r3 + next();
-                    r4 = r4 + next(); r5 = r5 + next(); r6 = r6 + next(); r7 = r7 + next();
+                for (; i < cn - (cn % 8); i += 8) {
+                    prl_nps_eight(next, t);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r[j] = r[j] + t[j];
                 }
-                float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-                for (; i < f.n; ++i) res = res + next();
+                float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                for (; i < cn; ++i) res = res + next();
                 ret = res;
                 --sp;
             } else {
-                int n2 = f.n / 2;
+                int n2 = cn / 2;
                 n2 -= n2 % 8;
-                f.stage = 1;
-                fr[sp + 1].n = n2; fr[sp + 1].stage = 0; fr[sp + 1].left = 0.f;
+                PRL_NPS_SET(fstage, sp, 1);
                 ++sp;
+                PRL_NPS_SET(fn, sp, n2);
+                PRL_NPS_SET(fstage, sp, 0);
             }
-        } else if (f.stage == 1) {  // the left half returned
-            int n2 = f.n / 2;
+        } else if (cstage == 1) {  // the left half returned
+            int n2 = cn / 2;
             n2 -= n2 % 8;
-            f.left = ret;
-            f.stage = 2;
-            fr[sp + 1].n = f.n - n2; fr[sp + 1].stage = 0; fr[sp + 1].left = 0.f;
+            PRL_NPS_SET(fleft, sp, ret);
+            PRL_NPS_SET(fstage, sp, 2);
             ++sp;
+            PRL_NPS_SET(fn, sp, cn - n2);
+            PRL_NPS_SET(fstage, sp, 0);
         } else {  // the right half returned
-            ret = f.left + ret;
+            float l;
+            PRL_NPS_GET(fleft, sp, l);
+            ret = l + ret;
             --sp;
         }
     }
+#undef PRL_NPS_GET
+#undef PRL_NPS_SET
     return ret;
 }
-
 struct PrlLbrGame {
     int32_t n_hole, n_cards, n_suits, rank_rule, R;
     int32_t n_board_total;   // board cards of the last round
@@ -152,20 +182,40 @@ PRL_HD PRL_INLINE float prl_lbr_board_equity_lists(const PrlLbrGame& g, const in
                                                    const float* rg, const uint16_t* hole_lut) {
     unsigned long long bmask = 0ull;
     for (int i = 0; i < g.n_board_total; ++i) bmask |= 1ull << full_board[i];
-    auto blocked = [&](int h) {
-        if (g.n_hole == 2 && hole_lut) { const unsigned v = hole_lut[h]; return (((bmask >> (v & 0xFFu)) | (bmask >> (v >> 8))) & 1ull) != 0ull; }
-        return (prl_lbr_hand_mask(g, h, hole_lut) & bmask) != 0ull;
+    struct Ctx {
+        const PrlLbrGame& g; unsigned long long bmask; const float* rg; const uint16_t* hole_lut;
+        PRL_HD PRL_INLINE bool blocked(int h) const {
+            if (g.n_hole == 2 && hole_lut) { const unsigned v = hole_lut[h]; return (((bmask >> (v & 0xFFu)) | (bmask >> (v >> 8))) & 1ull) != 0ull; }
+            return (prl_lbr_hand_mask(g, h, hole_lut) & bmask) != 0ull;
+        }
+        PRL_HD PRL_INLINE float live(int h) const { return blocked(h) ? 0.f : rg[h]; }
     };
-    int h0 = 0;
-    auto nx = [&]() { const int h = h0++; return blocked(h) ? 0.f : rg[h]; };
-    const float norm = prl_np_sum_stream<4>(g.R, nx);
+    const Ctx cx = {g, bmask, rg, hole_lut};
+    struct NormStream {  // the range with the hands the board blocks zeroed, ascending
+        const Ctx& c; int h;
+        PRL_HD PRL_INLINE float operator()() { return c.live(h++); }
+        PRL_HD PRL_INLINE void eight(float (&o)[8]) {
+            for (int j = 0; j < 8; ++j) o[j] = c.live(h + j);
+            h += 8;
+        }
+    };
+    NormStream ns = {cx, 0};
+    const float norm = prl_np_sum_stream<4>(g.R, ns);
     const float unif = (float)(1.0 / (double)g.R);
-    auto value = [&](int h) { return norm == 0.f ? unif : (blocked(h) ? 0.f : rg[h]) / norm; };
-    int ib = 0, ie = n_big;
-    auto next_big = [&]() { return value((int)cls_list[ib++]); };
-    auto next_eq = [&]() { return value((int)cls_list[ie++]); };
-    const float s_big = prl_np_sum_stream<4>(n_big, next_big);
-    const float s_eq = prl_np_sum_stream<4>(n_eq, next_eq);
+    struct ClassStream {  // the normalised range over one class, by its index list
+        const Ctx& c; const uint16_t* list; int i; float norm, unif;
+        PRL_HD PRL_INLINE float value(int h) const { return norm == 0.f ? unif : c.live(h) / norm; }
+        PRL_HD PRL_INLINE float operator()() { return value((int)list[i++]); }
+        PRL_HD PRL_INLINE void eight(float (&o)[8]) {
+            int hh[8];
+            for (int j = 0; j < 8; ++j) hh[j] = (int)list[i + j];
+            for (int j = 0; j < 8; ++j) o[j] = value(hh[j]);
+            i += 8;
+        }
+    };
+    ClassStream sb = {cx, cls_list, 0, norm, unif}, se = {cx, cls_list, n_big, norm, unif};
+    const float s_big = prl_np_sum_stream<4>(n_big, sb);
+    const float s_eq = prl_np_sum_stream<4>(n_eq, se);
     return s_big + s_eq / 2.0f;
 }
 // the cards that can still come, ascending (LocalLBRWorker.py:392-396)

@@ -220,12 +220,13 @@ PRL_DEV PRL_INLINE void lbrb_normalize(float* rg, int R, LbrbLeaves& Lf, LbrbSha
     prl_sync();
 }
 
-// two workgroups (18 waves) per CU: at most 102 VGPRs per lane, i.e. 5 waves per SIMD
+// ONE workgroup (9 waves) per CU with up to 168 VGPRs per lane (round 4): measured 3.3 % ahead of two workgroups at 96 VGPRs (74 spilled),
+// profiles/r06_experiments.txt -- the kernel waits on dependent LDS gathers and division chains, not on occupancy
 #if defined(PRL_EMU)
 #define LBRB_LB
 #else
 #ifndef LBRB_WAVES_PER_SIMD
-#define LBRB_WAVES_PER_SIMD 5
+#define LBRB_WAVES_PER_SIMD 3
 #endif
 #define LBRB_LB __launch_bounds__(LBRB_THREADS, LBRB_WAVES_PER_SIMD)
 #endif

@@ -183,21 +183,35 @@ struct PrlRcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    std::string why, path;  // why it is not usable / the file the symbols come from
 };
 static const PrlRcclApi& prl_rccl_api() {
     static PrlRcclApi api = [] {
         PrlRcclApi a;
-        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        // PRL_RCCL_LIB=<path>: bind exactly that library (a ROCm installed elsewhere, or to force the one a framework ships). Otherwise the
+        // RCCL ALREADY in the process (PyTorch-ROCm's: one RCCL, one HIP runtime per process), then the loader's, then ROCm's default place.
+        void* h = nullptr;
+        const char* forced = getenv("PRL_RCCL_LIB");
+        if (forced && *forced) {
+            h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) { a.why = std::string("PRL_RCCL_LIB=") + forced + ": " + (dlerror() ? dlerror() : "dlopen failed"); return a; }
+        }
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
         if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
         if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) return a;
+        if (!h) { a.why = "librccl.so / librccl.so.1 not found (already loaded, on the loader's path, or /opt/rocm/lib); set PRL_RCCL_LIB=<path to librccl.so>"; return a; }
         a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
         a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
         a.ok = a.GetUniqueId && a.CommInitRank && a.AllGather && a.CommDestroy && a.GetErrorString;
+        if (!a.ok) a.why = "the RCCL library bound lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy / ncclGetErrorString";
+        {   // which file it is: a second RCCL beside the framework's is the classic way to a hang at the first collective
+            Dl_info di;
+            if (a.GetUniqueId && dladdr((void*)a.GetUniqueId, &di) && di.dli_fname) a.path = di.dli_fname;
+        }
         return a;
     }();
     return api;
@@ -920,7 +934,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         ncclComm_t comm = nullptr;
         const ncclResult_t r = prl_rccl_api().CommInitRank(&comm, world, id, rank);
         if (r != ncclSuccess) {
-            prl_set_error(std::string("ncclCommInitRank: ") + prl_rccl_api().GetErrorString(r));
+            prl_set_error(std::string("ncclCommInitRank: ") + prl_rccl_api().GetErrorString(r) + " (RCCL bound from " + prl_rccl_api().path + ")");
             (void)hipStreamDestroy(s->stream);
             delete s;
             return PRL_ERR_HIP;
@@ -1166,13 +1180,26 @@ int32_t prl_rccl_unique_id(void* out128) {
     return PRL_ERR_UNSUPPORTED;
 #else
     if (!out128) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
-    if (!prl_rccl_api().ok) { prl_set_error("librccl.so could not be loaded"); return PRL_ERR_UNSUPPORTED; }
+    if (!prl_rccl_api().ok) { prl_set_error("RCCL is not available: " + prl_rccl_api().why); return PRL_ERR_UNSUPPORTED; }
     ncclUniqueId id;
     const ncclResult_t r = prl_rccl_api().GetUniqueId(&id);
     if (r != ncclSuccess) { prl_set_error(std::string("ncclGetUniqueId: ") + prl_rccl_api().GetErrorString(r)); return PRL_ERR_HIP; }
     static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
     memcpy(out128, &id, sizeof(id));
     return PRL_OK;
+#endif
+}
+
+// the RCCL this library binds (the file its symbols come from), or why there is none: what to look at first when a multi-GPU run hangs
+int32_t prl_rccl_info(char* out, int32_t n) {
+    if (!out || n <= 0) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+#if defined(PRL_EMU)
+    snprintf(out, (size_t)n, "no RCCL in this build");
+    return PRL_ERR_UNSUPPORTED;
+#else
+    const PrlRcclApi& a = prl_rccl_api();
+    snprintf(out, (size_t)n, "%s", a.ok ? a.path.c_str() : a.why.c_str());
+    return a.ok ? PRL_OK : PRL_ERR_UNSUPPORTED;
 #endif
 }
 
@@ -1184,7 +1211,7 @@ int32_t prl_solver_create_sharded_rccl(const prl_tree_t* local_tree, int32_t var
 #else
     if (world_size < 1 || rank < 0 || rank >= world_size || !unique_id128) { prl_set_error("bad world_size / rank / unique id"); return PRL_ERR_ARG; }
     if (shard_boards > 0 && total_boards <= (int64_t)(world_size - 1) * shard_boards) { prl_set_error("bad shard_boards / total_boards"); return PRL_ERR_ARG; }
-    if (!prl_rccl_api().ok) { prl_set_error("librccl.so could not be loaded"); return PRL_ERR_UNSUPPORTED; }
+    if (!prl_rccl_api().ok) { prl_set_error("RCCL is not available: " + prl_rccl_api().why); return PRL_ERR_UNSUPPORTED; }
     return solver_create_impl(local_tree, variant, delay, PRL_ENGINE_FUSED, world_size, rank, prl_exchange_placeholder, nullptr, out,
                               shard_boards > 0 ? shard_boards : 0, shard_boards > 0 ? total_boards : 0, unique_id128);
 #endif
