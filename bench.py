@@ -34,14 +34,18 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per CFR+ iteration of the board-pass kernels, from the PMC passes (FETCH_SIZE / WRITE_SIZE in their own rocprofv3 runs,
-# FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads). Measured at 262144 boards (profiles/r03v_pmc.txt):
-# UPDATE0_BR 2 * 21.00 GB read + 29.82 GB written, UPDATE1_EVAL1 2 * 21.04 + 29.88 = 143.8 GB per iteration; every board subtree moves
-# the same bytes (548 KB per board and iteration: 14 regret columns + the plan in, 7 regret columns out, 7 float64 average columns in
-# and out -- the reference's float64 average is 53 % of it -- and the root vectors), so other sizes scale linearly.
-PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION = 143.78e9 / 262144
-# the same with the opt-in float32 running average: (2 x 1.622e7 + 2.07e7) + (2 x 1.622e7 + 2.052e7) KB per launch pair = 106.1 GB (profiles/r05zz_avg_f32_pmc_traffic.txt)
-PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 = 106.1e9 / 262144
-PMC_TRAFFIC_SOURCE = "profiles/r05s_pmc.txt = r03v_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+# FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads). Measured at 262144 boards with the sorted board
+# storage of round 4 (profiles/r06_pmc.txt): UPDATE0_BR 2 * 17.69 GB read + 24.35 GB written, UPDATE1_EVAL1 2 * 17.71 + 24.45 = 119.6 GB per
+# iteration (round 3, hand-order columns of 1326: 143.8 GB); every board subtree moves the same bytes (456 KB per board and iteration: 14
+# regret columns of 1088 + the plan in, 7 regret columns out, 7 float64 average columns in and out -- the reference's float64 average is
+# 53 % of it -- and the block rows of root vectors), so other sizes scale linearly.
+PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION = 119.6e9 / 262144
+# the opt-in float32 running average has not been re-measured on the sorted storage (round 3, hand-order columns: 106.1 GB,
+# profiles/r05zz_avg_f32_pmc_traffic.txt): its bench line reports traffic null
+PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 = None
+# the two-seat evaluation pass over the float64 averages (prl_k_fhp_pass<EVAL, AVG, AVG>): 2 * 17.65 GB read + 0.17 GB written
+PMC_TRAFFIC_BYTES_PER_BOARD_AVG_EVALUATION = 35.47e9 / 262144
+PMC_TRAFFIC_SOURCE = "profiles/r06_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
 
 
 def seeded_boards(n, seed, offset=0):
@@ -272,6 +276,8 @@ def main():
     bytes_iter = 20.0 * R * sum_a + 8.0 * R * args.boards  # per GPU
     kernel_ms = pass_ms if n_pass else dev_ms
     achieved = bytes_iter * args.steps / (kernel_ms * 1e-3) / 1e9
+    pmc_ok = solver.engine == "fused" and args.variant == "plus"
+    pmc_per_board = (PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 if args.avg_f32 else PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION) if pmc_ok else None
     expl = solver.exploitability()
     out = {
         "metric": "CFR+ node-updates/sec on FHP public tree" if args.variant == "plus" else "%s CFR node-updates/sec on FHP public tree" % args.variant,
@@ -312,10 +318,10 @@ def main():
             "achieved": (bytes_iter + 8.0 * R * sum_a + 4.0 * R * args.boards) / ((kernel_ms / args.steps + avg_eval_ms) * 1e-3) / 1e9,
             "frac": (bytes_iter + 8.0 * R * sum_a + 4.0 * R * args.boards) / ((kernel_ms / args.steps + avg_eval_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "ms_per_iteration": kernel_ms / args.steps + avg_eval_ms, "bytes_per_iteration_algorithmic": bytes_iter + 8.0 * R * sum_a + 4.0 * R * args.boards,
-            "kernel": "prl_k_fhp_pass: the two update passes + the two-seat evaluation pass over the float64 averages", "traffic": None},
+            "kernel": "prl_k_fhp_pass: the two update passes + the two-seat evaluation pass over the float64 averages",
+            "traffic": ((pmc_per_board + PMC_TRAFFIC_BYTES_PER_BOARD_AVG_EVALUATION) * args.boards if (pmc_per_board is not None and not args.avg_f32) else None)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": ((PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 if args.avg_f32 else PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION) * args.boards
-                                 if (solver.engine == "fused" and args.variant == "plus") else None),
+                     "traffic": (pmc_per_board * args.boards if pmc_per_board is not None else None),
                      "traffic_source": PMC_TRAFFIC_SOURCE,
                      "kernel": "prl_k_fhp_pass" if n_pass else "all kernels of the iteration",
                      "launches_per_iteration": n_pass / float(args.steps) if n_pass else None,
@@ -323,9 +329,8 @@ def main():
                      "bytes_per_iteration_algorithmic": bytes_iter,
                      # the PMC-measured bytes over the same kernel time: what the kernel actually pulls through HBM (float64 averages
                      # included), against the ~6.3 TB/s MI355X_MICROARCH.md gives as sustained
-                     "traffic_rate_gbps": ((PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 if args.avg_f32 else PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION)
-                                           * args.boards * args.steps / (kernel_ms * 1e-3) / 1e9)
-                     if (solver.engine == "fused" and args.variant == "plus") else None,
+                     "traffic_rate_gbps": (pmc_per_board * args.boards * args.steps / (kernel_ms * 1e-3) / 1e9
+                                           if pmc_per_board is not None else None),
                      "sustained_hbm_gbps": 6300.0,
                      "achieved_whole_iteration": bytes_iter * args.steps / (dev_ms * 1e-3) / 1e9},
     }

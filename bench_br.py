@@ -28,9 +28,11 @@ import numpy as np  # noqa: E402
 import bench  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0
-# HBM bytes of the best-response-only pass per board, from the PMC counters at 65536 boards: 2 x 2.834e6 + 4.24e4 KB per launch = 5.71 GB
-PMC_TRAFFIC_BYTES_PER_BOARD = 5.71e9 / 65536
-PMC_TRAFFIC_SOURCE = "profiles/r05k_br_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+# HBM bytes of the best-response-only pass per board, from the PMC counters at 65536 boards with the sorted board storage of round 4:
+# 2 x 2.441e6 + 4.24e4 KB per launch = 4.92 GB (round 3, hand-order columns: 5.71 GB). Below the algorithmic bytes, which count all 1326
+# hands of a column: the storage holds the 1081 live ones.
+PMC_TRAFFIC_BYTES_PER_BOARD = 4.924e9 / 65536
+PMC_TRAFFIC_SOURCE = "profiles/r06_br_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
 
 
 def seeded_strategy(n_trunk_cols, n_boards, R, seed):

@@ -70,7 +70,7 @@ def main():
                         "kernel": "prl_k_ebf_random_step" if full else "prl_k_eb_random_step", "kernel_ms_per_launch": ms / args.steps,
                         "bytes_per_env_step_algorithmic": bytes_step}}
     if not args.no_cpu_baseline:
-        n_cpu, k_cpu = 4096, 512
+        n_cpu, k_cpu = 65536, 2048
         t0 = time.perf_counter()
         s3 = _native.env_random_rollout_full_host(game, rules, n_cpu, k_cpu, 2, deck_seed=11) if full else _native.env_random_rollout_host(game, n_cpu, k_cpu, 2)
         dtc = time.perf_counter() - t0

@@ -415,6 +415,8 @@ enum {
     PRL_SF_ENGINE = 14,      /* int32                    PRL_ENGINE_LEVELS or PRL_ENGINE_FUSED  */
     PRL_SF_GRAPH_REPLAY = 15, /* int32                   1 if iterations are replays of a captured hipGraph (LEVELS engine) */
     PRL_SF_EXCHANGES = 17,   /* int64                    all-gathers of a sharded solve so far (0 for an unsharded one) */
+    PRL_SF_VMM_RANGES = 18,  /* int64 [2]                arrays backed by shuffled virtual-memory ranges (the default of a sharded solve, PRL_VMM_SHUFFLE_MB
+                                                         elsewhere) and the bytes they hold; {0, 0}: plain hipMalloc */
     PRL_SF_EXPLICIT_STRATEGY = 16 /* int32               fused engines: -1 strategy follows regrets / uniform fill, 0 an explicit float32
                                                          strategy is loaded (prl_solver_set_strategy), 1 an explicit float64 one; LEVELS: -1 */
 };

@@ -520,7 +520,7 @@ class NativeTree:
 
 # solver field ids (include/pokerrl_hip.h)
 SF = dict(reach=0, ev=1, ev_br=2, strategy=3, strat_f64=4, regret=5, avg=6, avg_f64=7, avg_sum=8, br_idx=9,
-          expl_history=10, iter=11, constants=12, bytes_allocated=13, engine=14, graph_replay=15, explicit_strategy=16, exchanges=17)
+          expl_history=10, iter=11, constants=12, bytes_allocated=13, engine=14, graph_replay=15, explicit_strategy=16, exchanges=17, vmm_ranges=18)
 VARIANTS = {"vanilla": 0, "plus": 1, "linear": 2}
 ENGINES = {"auto": 0, "levels": 1, "fused": 2}
 
@@ -746,7 +746,7 @@ class NativeSolver:
             "strategy": ((c, R), np.float64), "strat_f64": ((n,), np.uint8), "regret": ((c, R), np.float32),
             "avg": ((c, R), np.float64), "avg_f64": ((n,), np.uint8), "avg_sum": ((c, R), np.float32),
             "br_idx": ((n, R), np.int32), "constants": ((2,), np.float32), "bytes_allocated": ((1,), np.int64),
-            "explicit_strategy": ((1,), np.int32), "exchanges": ((1,), np.int64),
+            "explicit_strategy": ((1,), np.int32), "exchanges": ((1,), np.int64), "vmm_ranges": ((2,), np.int64),
         }.get(name, (None, None))
         if name == "expl_history":
             shape, dtype = (self.iter + 1, 2), np.float32

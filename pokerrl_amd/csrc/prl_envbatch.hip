@@ -316,21 +316,120 @@ PRL_HD PRL_INLINE void eb_observation(const PrlGame& g, const EbFull& F, const P
     }
 }
 
+// ---- the observation vectors of a workgroup's envs, written as ONE linear stream (round 4) -------------------------------------------------------
+// A lane that writes its own env's vector stores 4 bytes at a stride of obs_dim floats: every store instruction of a wave touches 64 cache lines and
+// the 436-byte vector of a hold'em env costs 109 of them. Every element of the vector is a function of ONE small word of the env, though: a float
+// copied (seven pot / bet quotients, two stacks, two bets) or 1.0 where an integer (last action, who acted, whose turn, round, all-in flag, a
+// board card's rank / suit) equals the element's own value. So each lane leaves its env's <= 27 SOURCE WORDS in an LDS row, and the workgroup then
+// writes the vectors of its 256 consecutive envs -- one contiguous piece of memory -- with linear, fully coalesced stores: element m of the piece
+// belongs to env m / obs_dim, entry m % obs_dim, whose table entry says which word and which comparison.
+#define EB_OBS_ROW 29  // words per LDS row (odd: the lanes' row writes hit 64 different banks); [27] = 1: leave this env's vector alone
+#define EB_OBS_SKIP 27
+PRL_HD PRL_INLINE size_t eb_obs_smem(int obs_dim, int n_threads) { return (((size_t)obs_dim * 4 + 15) & ~(size_t)15) + (size_t)n_threads * EB_OBS_ROW * 4; }
+// table entry of element j: source word | (value + 1) << 8, value + 1 == 0 for a float that is copied. Source words: 0..6 the seven quotients of
+// eb_observation's first line, 7 last action, 8 who did it, 9 whose turn, 10 round, 11 + 3 p: stack, bet, all-in flag of seat p, 17 + 2 i: rank and
+// suit of board card i (-1: not dealt yet / suits do not matter)
+PRL_HD PRL_INLINE int32_t eb_obs_entry(const EbFull& F, int j) {
+    if (j < 7) return j;
+    j -= 7;
+    if (j < 3) return 7 | ((j + 1) << 8);
+    j -= 3;
+    if (j < 2) return 8 | ((j + 1) << 8);
+    j -= 2;
+    if (j < 2) return 9 | ((j + 1) << 8);
+    j -= 2;
+    if (j < F.rules.n_rounds) return 10 | ((j + 1) << 8);
+    j -= F.rules.n_rounds;
+    if (j < 6) { const int p = j / 3, q = j % 3; return q < 2 ? 11 + 3 * p + q : ((13 + 3 * p) | (2 << 8)); }
+    j -= 6;
+    const int per = F.rules.n_ranks + F.rules.n_suits, i = j / per, q = j % per;
+    return q < F.rules.n_ranks ? ((17 + 2 * i) | ((q + 1) << 8)) : ((18 + 2 * i) | ((q - F.rules.n_ranks + 1) << 8));
+}
+PRL_HD PRL_INLINE uint32_t eb_f32_bits(double v) { const float f = (float)v; uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+// the source words of one env (live = false: a finished episode, the reference's all-zero observation)
+PRL_HD PRL_INLINE void eb_obs_words(const PrlGame& g, const EbFull& F, const PrlEnvState& s, const int8_t* cards, bool live, uint32_t* w) {
+    w[EB_OBS_SKIP] = 0u;
+    if (!live) {
+        for (int k = 0; k < 7; ++k) w[k] = 0u;
+        for (int k = 7; k < 27; ++k) w[k] = 0xFFFFFFFFu;
+        for (int p = 0; p < 2; ++p) { w[11 + 3 * p] = 0u; w[12 + 3 * p] = 0u; }
+        return;
+    }
+    const double norm = (double)(g.start_stack[0] + g.start_stack[1]) / 2.0;
+    const int small = s.bet[0] < s.bet[1] ? s.bet[0] : s.bet[1], big = s.bet[0] < s.bet[1] ? s.bet[1] : s.bet[0];
+    const int min_raise = big + ((big - small) > g.big_blind ? (big - small) : g.big_blind);
+    const bool have_la = s.last_action[0] >= 0;
+    w[0] = eb_f32_bits((double)g.ante / norm); w[1] = eb_f32_bits((double)g.small_blind / norm); w[2] = eb_f32_bits((double)g.big_blind / norm);
+    w[3] = eb_f32_bits((double)min_raise / norm); w[4] = eb_f32_bits((double)s.main_pot / norm); w[5] = eb_f32_bits((double)big / norm);
+    w[6] = eb_f32_bits(have_la ? (double)s.last_action[1] / norm : 0.0);
+    w[7] = have_la ? (uint32_t)s.last_action[0] : 0xFFFFFFFFu;
+    w[8] = have_la ? (uint32_t)s.last_action[2] : 0xFFFFFFFFu;
+    w[9] = (uint32_t)s.cur;
+    w[10] = (uint32_t)s.round;
+    for (int p = 0; p < 2; ++p) {
+        w[11 + 3 * p] = eb_f32_bits((double)s.stack[p] / norm); w[12 + 3 * p] = eb_f32_bits((double)s.bet[p] / norm); w[13 + 3 * p] = s.allin[p] ? 1u : 0u;
+    }
+    const int n_out = eb_cards_out(F.rules, s.round);
+    const int8_t* board = cards + 2 * F.rules.n_hole_cards;
+    for (int i = 0; i < 5; ++i) {
+        const int c = (i < F.rules.n_board_cards && i < n_out) ? board[i] : -1;
+        w[17 + 2 * i] = c >= 0 ? (uint32_t)(c / F.rules.n_suits) : 0xFFFFFFFFu;
+        w[18 + 2 * i] = (c >= 0 && F.suits_matter) ? (uint32_t)(c % F.rules.n_suits) : 0xFFFFFFFFu;
+    }
+}
+// LDS: the entry table, then one row per lane
+PRL_DEV PRL_INLINE void eb_obs_setup(const EbFull& F, int32_t** tab, uint32_t** rows) {
+    char* sm = prl_smem();
+    *tab = (int32_t*)sm;
+    *rows = (uint32_t*)(sm + (((size_t)F.obs_dim * 4 + 15) & ~(size_t)15));
+    for (int j = (int)prl_tid(); j < F.obs_dim; j += (int)prl_nthreads()) (*tab)[j] = eb_obs_entry(F, j);
+}
+// after a workgroup barrier: the vectors of the n_rows envs whose rows the lanes filled, to out (= the first of these envs' vectors)
+template <bool SKIPPABLE>
+PRL_DEV PRL_INLINE void eb_obs_emit(const int32_t* tab, const uint32_t* rows, int obs_dim, int n_rows, float* out) {
+    const int T = (int)prl_nthreads(), total = n_rows * obs_dim, de = T / obs_dim, dj = T % obs_dim;
+    int e = (int)prl_tid() / obs_dim, j = (int)prl_tid() % obs_dim;
+    for (int m = (int)prl_tid(); m < total; m += T) {
+        const int t = tab[j];
+        const uint32_t w = rows[e * EB_OBS_ROW + (t & 255)];
+        const int c = t >> 8;
+        float one = 1.f, v;
+        __builtin_memcpy(&v, &w, 4);
+        if (c != 0) v = (int)w == c - 1 ? one : 0.f;
+        if (!SKIPPABLE || rows[e * EB_OBS_ROW + EB_OBS_SKIP] == 0u) out[m] = v;
+        e += de; j += dj;
+        if (j >= obs_dim) { j -= obs_dim; ++e; }
+    }
+}
+
 // reset of the masked envs: public state, a fresh hand from the env's counter-based deck, the observation of the new hand
 PRL_GLOBAL void prl_k_ebf_reset(const PrlGame* g, EbFull F, int32_t* st, int n, const uint8_t* mask, int8_t* cards, uint32_t* episode, uint64_t deck_seed,
                                 int deal, float* obs) {
-    for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) {
-        if (mask && !mask[i]) continue;
-        PrlEnvState s;
-        prl_env_reset(*g, s);
-        eb_store(st, n, i, s, false);
-        int8_t* c = cards + (size_t)i * F.n_deal;
-        if (deal) {
-            const uint32_t ep = episode[i];
-            episode[i] = ep + 1u;
-            prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, c);
+    int32_t* tab;
+    uint32_t* rows;
+    eb_obs_setup(F, &tab, &rows);
+    const int T = (int)prl_nthreads();
+    for (int i0 = (int)prl_bid() * T; i0 < n; i0 += (int)prl_nblocks() * T) {  // workgroup-uniform: the vectors of T consecutive envs leave together
+        const int i = i0 + (int)prl_tid();
+        uint32_t* w = rows + (size_t)prl_tid() * EB_OBS_ROW;
+        prl_sync();
+        if (i < n) {
+            if (mask && !mask[i]) w[EB_OBS_SKIP] = 1u;
+            else {
+                PrlEnvState s;
+                prl_env_reset(*g, s);
+                eb_store(st, n, i, s, false);
+                int8_t* c = cards + (size_t)i * F.n_deal;
+                if (deal) {
+                    const uint32_t ep = episode[i];
+                    episode[i] = ep + 1u;
+                    prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, c);
+                }
+                if (obs) eb_obs_words(*g, F, s, c, true, w);
+            }
         }
-        if (obs) eb_observation(*g, F, s, c, obs + (size_t)i * F.obs_dim, 1);
+        prl_sync();
+        if (obs) eb_obs_emit<true>(tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
     }
 }
 
@@ -338,47 +437,64 @@ PRL_GLOBAL void prl_k_ebf_reset(const PrlGame* g, EbFull F, int32_t* st, int n, 
 // (done = 1, zero observation, zero reward, info -1 as prl_k_eb_step).
 PRL_GLOBAL void prl_k_ebf_step(const PrlGame* g, EbFull F, int32_t* st, int n, const int32_t* a0, const int32_t* a1, int processed, const int8_t* cards,
                                float* obs, double* rew, uint8_t* done_out, int32_t* info) {
-    for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) {
-        PrlEnvState s;
-        bool done;
-        eb_load(st, n, i, s, &done);
-        const int act = a0[i];
-        int o0 = -1, o1 = 0, o2 = 0, o3 = 0;
-        double r[2] = {0.0, 0.0};
-        const int n_act = g->game_type == PRL_GAME_DISCRETIZED ? g->n_bet_sizes + 2 : 3;
-        float* o = obs + (size_t)i * F.obs_dim;
-        const bool stepped = !done && act >= 0 && act < (processed ? 3 : n_act);
-        if (stepped) {
-            PrlStepInfo si;
-            if (processed) prl_env_step_processed(*g, s, act, a1[i], &si);
-            else prl_env_step(*g, s, act, &si);
-            done = si.is_terminal != 0;
-            eb_store(st, n, i, s, done);
-            o0 = si.is_terminal; o1 = si.chance_acts; o2 = si.pot_before_payout;
-            o3 = si.is_terminal ? (si.terminal_is_fold ? 1 : (si.rundown ? 3 : 2)) : 0;
-            if (done) {
-                bool sd;
-                eb_payout(*g, F, s, cards + (size_t)i * F.n_deal, r, &sd);
+    int32_t* tab;
+    uint32_t* rows;
+    eb_obs_setup(F, &tab, &rows);
+    const int T = (int)prl_nthreads();
+    for (int i0 = (int)prl_bid() * T; i0 < n; i0 += (int)prl_nblocks() * T) {
+        const int i = i0 + (int)prl_tid();
+        prl_sync();
+        if (i < n) {
+            PrlEnvState s;
+            bool done;
+            eb_load(st, n, i, s, &done);
+            const int act = a0[i];
+            int o0 = -1, o1 = 0, o2 = 0, o3 = 0;
+            double r[2] = {0.0, 0.0};
+            const int n_act = g->game_type == PRL_GAME_DISCRETIZED ? g->n_bet_sizes + 2 : 3;
+            const bool stepped = !done && act >= 0 && act < (processed ? 3 : n_act);
+            if (stepped) {
+                PrlStepInfo si;
+                if (processed) prl_env_step_processed(*g, s, act, a1[i], &si);
+                else prl_env_step(*g, s, act, &si);
+                done = si.is_terminal != 0;
+                eb_store(st, n, i, s, done);
+                o0 = si.is_terminal; o1 = si.chance_acts; o2 = si.pot_before_payout;
+                o3 = si.is_terminal ? (si.terminal_is_fold ? 1 : (si.rundown ? 3 : 2)) : 0;
+                if (done) {
+                    bool sd;
+                    eb_payout(*g, F, s, cards + (size_t)i * F.n_deal, r, &sd);
+                }
             }
+            // PokerEnv.get_current_obs(is_terminal=True): zeros
+            eb_obs_words(*g, F, s, cards + (size_t)i * F.n_deal, stepped && !done, rows + (size_t)prl_tid() * EB_OBS_ROW);
+            rew[2 * (size_t)i] = r[0];
+            rew[2 * (size_t)i + 1] = r[1];
+            done_out[i] = done ? 1 : 0;
+            if (info) { info[i] = o0; info[(size_t)n + i] = o1; info[(size_t)2 * n + i] = o2; info[(size_t)3 * n + i] = o3; }
         }
-        if (stepped && !done) eb_observation(*g, F, s, cards + (size_t)i * F.n_deal, o, 1);
-        else for (int k = 0; k < F.obs_dim; ++k) o[k] = 0.f;  // PokerEnv.get_current_obs(is_terminal=True): zeros
-        rew[2 * (size_t)i] = r[0];
-        rew[2 * (size_t)i + 1] = r[1];
-        done_out[i] = done ? 1 : 0;
-        if (info) { info[i] = o0; info[(size_t)n + i] = o1; info[(size_t)2 * n + i] = o2; info[(size_t)3 * n + i] = o3; }
+        prl_sync();
+        eb_obs_emit<false>(tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
     }
 }
 
 // the observation of every env's CURRENT state (PokerEnv.get_current_obs; zeros for a finished episode)
 PRL_GLOBAL void prl_k_ebf_observe(const PrlGame* g, EbFull F, const int32_t* st, int n, const int8_t* cards, float* obs) {
-    for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) {
-        PrlEnvState s;
-        bool done;
-        eb_load(st, n, i, s, &done);
-        float* o = obs + (size_t)i * F.obs_dim;
-        if (!done) eb_observation(*g, F, s, cards + (size_t)i * F.n_deal, o, 1);
-        else for (int k = 0; k < F.obs_dim; ++k) o[k] = 0.f;
+    int32_t* tab;
+    uint32_t* rows;
+    eb_obs_setup(F, &tab, &rows);
+    const int T = (int)prl_nthreads();
+    for (int i0 = (int)prl_bid() * T; i0 < n; i0 += (int)prl_nblocks() * T) {
+        const int i = i0 + (int)prl_tid();
+        prl_sync();
+        if (i < n) {
+            PrlEnvState s;
+            bool done;
+            eb_load(st, n, i, s, &done);
+            eb_obs_words(*g, F, s, cards + (size_t)i * F.n_deal, !done, rows + (size_t)prl_tid() * EB_OBS_ROW);
+        }
+        prl_sync();
+        eb_obs_emit<false>(tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
     }
 }
 
@@ -434,38 +550,47 @@ PRL_GLOBAL void prl_k_ebf_rollout(const PrlGame* g, EbFull F, int n, int n_steps
 PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* g, EbFull F, int32_t* st, int n, int k, uint32_t seed, int8_t* cards, uint32_t* episode, uint64_t deck_seed,
                                       float* obs, double* rew, uint8_t* done_out, unsigned long long* stats) {
     unsigned long long hands = 0, pots = 0, steps = 0;
-    for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) {
-        PrlEnvState s;
-        bool done;
-        eb_load(st, n, i, s, &done);
-        int8_t* c = cards + (size_t)i * F.n_deal;
-        if (done) {
-            prl_env_reset(*g, s);
-            const uint32_t ep = episode[i];
-            episode[i] = ep + 1u;
-            prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, c);
+    int32_t* tab;
+    uint32_t* rows;
+    eb_obs_setup(F, &tab, &rows);
+    const int T = (int)prl_nthreads();
+    for (int i0 = (int)prl_bid() * T; i0 < n; i0 += (int)prl_nblocks() * T) {
+        const int i = i0 + (int)prl_tid();
+        prl_sync();
+        if (i < n) {
+            PrlEnvState s;
+            bool done;
+            eb_load(st, n, i, s, &done);
+            int8_t* c = cards + (size_t)i * F.n_deal;
+            if (done) {
+                prl_env_reset(*g, s);
+                const uint32_t ep = episode[i];
+                episode[i] = ep + 1u;
+                prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, c);
+            }
+            int32_t legal[PRL_MAX_BET_SIZES + 2];
+            const int nl = prl_legal_actions(*g, s, legal);
+            const uint32_t r = eb_mix32(seed ^ eb_mix32((uint32_t)i * 0x9E3779B9u + (uint32_t)k));
+            PrlStepInfo si;
+            const int a = legal[r % (uint32_t)nl];
+            if (g->game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(*g, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(s.stack[s.cur] + s.bet[s.cur] + 1)) : -1, &si);
+            else prl_env_step(*g, s, a, &si);
+            ++steps;
+            double rw[2] = {0.0, 0.0};
+            if (si.is_terminal) {
+                bool sd;
+                eb_payout(*g, F, s, c, rw, &sd);
+                ++hands;
+                pots += (unsigned long long)si.pot_before_payout;
+            }
+            eb_obs_words(*g, F, s, c, !si.is_terminal, rows + (size_t)prl_tid() * EB_OBS_ROW);
+            rew[2 * (size_t)i] = rw[0];
+            rew[2 * (size_t)i + 1] = rw[1];
+            done_out[i] = si.is_terminal ? 1 : 0;
+            eb_store(st, n, i, s, si.is_terminal != 0);
         }
-        int32_t legal[PRL_MAX_BET_SIZES + 2];
-        const int nl = prl_legal_actions(*g, s, legal);
-        const uint32_t r = eb_mix32(seed ^ eb_mix32((uint32_t)i * 0x9E3779B9u + (uint32_t)k));
-        PrlStepInfo si;
-        const int a = legal[r % (uint32_t)nl];
-        if (g->game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(*g, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(s.stack[s.cur] + s.bet[s.cur] + 1)) : -1, &si);
-        else prl_env_step(*g, s, a, &si);
-        ++steps;
-        double rw[2] = {0.0, 0.0};
-        float* o = obs + (size_t)i * F.obs_dim;
-        if (si.is_terminal) {
-            bool sd;
-            eb_payout(*g, F, s, c, rw, &sd);
-            ++hands;
-            pots += (unsigned long long)si.pot_before_payout;
-            for (int j = 0; j < F.obs_dim; ++j) o[j] = 0.f;
-        } else eb_observation(*g, F, s, c, o, 1);
-        rew[2 * (size_t)i] = rw[0];
-        rew[2 * (size_t)i + 1] = rw[1];
-        done_out[i] = si.is_terminal ? 1 : 0;
-        eb_store(st, n, i, s, si.is_terminal != 0);
+        prl_sync();
+        eb_obs_emit<false>(tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
     }
     eb_stats_add(stats, steps, hands, pots);
 }
@@ -547,7 +672,7 @@ int32_t prl_envbatch_reset_full(prl_envbatch_t* b, const uint8_t* mask, float* o
         d_m = (uint8_t*)b->d_mask;
         PRL_HIP_TRY(hipMemcpyAsync(d_m, mask, (size_t)b->n, hipMemcpyHostToDevice, b->stream));
     }
-    PRL_LAUNCH(prl_k_ebf_reset, eb_grid(b->n), 256, 0, b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, (const uint8_t*)d_m, b->d_cards,
+    PRL_LAUNCH(prl_k_ebf_reset, eb_grid(b->n), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, (const uint8_t*)d_m, b->d_cards,
                b->d_episode, b->deck_seed, 1, b->d_obs);
     PRL_HIP_TRY(hipGetLastError());
     if (out_obs) PRL_HIP_TRY(hipMemcpyAsync(out_obs, b->d_obs, (size_t)b->n * b->obs_dim * sizeof(float), hipMemcpyDeviceToHost, b->stream));
@@ -571,7 +696,7 @@ int32_t prl_envbatch_get_cards(prl_envbatch_t* b, int8_t* out_cards) {
 
 int32_t prl_envbatch_observe(prl_envbatch_t* b, float* out_obs) {
     if (!b || !b->with_cards || !out_obs) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
-    PRL_LAUNCH(prl_k_ebf_observe, eb_grid(b->n), 256, 0, b->stream, (const PrlGame*)b->d_game, eb_full(b), (const int32_t*)b->d_state, b->n, (const int8_t*)b->d_cards, b->d_obs);
+    PRL_LAUNCH(prl_k_ebf_observe, eb_grid(b->n), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), (const int32_t*)b->d_state, b->n, (const int8_t*)b->d_cards, b->d_obs);
     PRL_HIP_TRY(hipGetLastError());
     PRL_HIP_TRY(hipMemcpyAsync(out_obs, b->d_obs, (size_t)b->n * b->obs_dim * sizeof(float), hipMemcpyDeviceToHost, b->stream));
     PRL_HIP_TRY(hipStreamSynchronize(b->stream));
@@ -581,7 +706,7 @@ int32_t prl_envbatch_observe(prl_envbatch_t* b, float* out_obs) {
 int32_t prl_envbatch_step_full_device(prl_envbatch_t* b, const int32_t* d_actions, const int32_t* d_amounts, float* d_obs, double* d_reward2, uint8_t* d_done,
                                       int32_t* d_info4) {
     if (!b || !b->with_cards || !d_actions || !d_obs || !d_reward2 || !d_done) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
-    PRL_LAUNCH(prl_k_ebf_step, eb_grid(b->n), 256, 0, b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, d_actions, d_amounts, d_amounts ? 1 : 0,
+    PRL_LAUNCH(prl_k_ebf_step, eb_grid(b->n), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, d_actions, d_amounts, d_amounts ? 1 : 0,
                (const int8_t*)b->d_cards, d_obs, d_reward2, d_done, d_info4);
     PRL_HIP_TRY(hipGetLastError());
     return PRL_OK;
@@ -636,7 +761,7 @@ int32_t prl_envbatch_random_steps_full(prl_envbatch_t* b, int32_t n_launches, ui
     PRL_HIP_TRY(hipEventCreate(&e1));
     PRL_HIP_TRY(hipEventRecord(e0, b->stream));
     for (int k = 0; k < n_launches; ++k)
-        PRL_LAUNCH(prl_k_ebf_random_step, eb_grid(b->n), 256, 0, b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, k, seed, b->d_cards, b->d_episode,
+        PRL_LAUNCH(prl_k_ebf_random_step, eb_grid(b->n), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, k, seed, b->d_cards, b->d_episode,
                    b->deck_seed, b->d_obs, b->d_rew, b->d_done, d_stats);
     PRL_HIP_TRY(hipGetLastError());
     PRL_HIP_TRY(hipEventRecord(e1, b->stream));

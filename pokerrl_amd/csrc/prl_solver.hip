@@ -2070,6 +2070,13 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
         case PRL_SF_ENGINE: *(int32_t*)out = s->fused ? PRL_ENGINE_FUSED : PRL_ENGINE_LEVELS; return PRL_OK;
         case PRL_SF_GRAPH_REPLAY: *(int32_t*)out = s->levels_graph_exec != nullptr; return PRL_OK;
         case PRL_SF_EXCHANGES: *(int64_t*)out = (int64_t)s->n_exchanges; return PRL_OK;
+        case PRL_SF_VMM_RANGES: {
+            int64_t bytes = 0;
+#if !defined(PRL_EMU)
+            for (void* r : s->vmm) bytes += (int64_t)((PrlVmmRange*)r)->size;
+#endif
+            ((int64_t*)out)[0] = (int64_t)s->vmm.size(); ((int64_t*)out)[1] = bytes; return PRL_OK;
+        }
         case PRL_SF_EXPLICIT_STRATEGY: *(int32_t*)out = s->fused ? s->user_strategy_f64 : -1; return PRL_OK;
         default: prl_set_error("unknown solver field"); return PRL_ERR_ARG;
     }

@@ -332,6 +332,45 @@ def test_gpu_sharded_ragged_world2_matches_unsharded(n_local, total):
 
 
 @pytest.mark.gpu
+def test_gpu_two_processes_at_bench_size_on_shuffled_backing():
+    """bench.py's per-GPU shard (262144 boards, ~58 GB) twice on the one GPU of the test box, as the two ranks of a sharded solve: every rank's
+    large arrays sit on the shuffled 2 MB virtual-memory backing a multi-GPU run uses (the test checks that they do), the all-gather goes over gloo
+    through host staging. Afterwards the one-rank solve of all 524288 boards (116 GB) must show the same exploitability history and the same bits in
+    the regret / average columns of each rank's first and last 512 boards."""
+    import bench
+    import sharded_vmm_worker as W
+    n_local, n_iters, seed, world = 262144, 3, 0, 2
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.pop("PRL_VMM_SHUFFLE_MB", None)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_vmm_worker.py"), d, str(n_local), str(n_iters), str(seed)], env=env))
+        try:
+            for p in procs:
+                assert p.wait(timeout=900) == 0
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        ranks = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(world)]
+    for out in ranks:
+        n_arrays, n_bytes = (int(x) for x in out["vmm_ranges"])
+        assert n_arrays >= 3 and n_bytes > 0.8 * int(out["bytes_allocated"][0]) > 40e9, (out["vmm_ranges"], out["bytes_allocated"])
+    t = bench.fhp_tree(bench.seeded_boards(world * n_local, seed))
+    s = _native.NativeSolver(t, "plus", 0, engine="fused")
+    assert int(s.get("vmm_ranges")[0]) == 0  # an unsharded solve allocates plainly
+    s.iterations(n_iters)
+    hist, nt = s.get("expl_history"), int(t.n_cols - world * n_local * 14)
+    k = W.SLICE_BOARDS
+    for r, out in enumerate(ranks):
+        assert np.array_equal(out["expl_history"], hist), "rank %d: exploitability history" % r
+        assert list(out["first"]) == W.digests(s, nt, r * n_local, k), "rank %d: first boards" % r
+        assert list(out["last"]) == W.digests(s, nt, (r + 1) * n_local - k, k), "rank %d: last boards" % r
+
+
+@pytest.mark.gpu
 def test_gpu_chance_sum_ragged_shards():
     L = _native.lib()
     check_chance_sum_ragged(L, 7 * 2048 + 48, 8, 2048)   # the all-boards geometry in small: whole groups, a short last shard
