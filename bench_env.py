@@ -25,6 +25,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0
+# HBM bytes per launch of prl_k_ebf_random_step at 2^20 envs from the PMC counters (profiles/r08_env_pmc.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+# in separate runs; FETCH_SIZE 2.742e4 KB doubled as MI355X_MICROARCH.md prescribes = 54.8 MB -- the 13 state words + 9 cards of an env are 61 bytes --
+# WRITE_SIZE 5.289e5 KB = 528.9 MB): 583.7 MB against 593.5 MB algorithmic. Scales with the number of envs.
+PMC_TRAFFIC_BYTES_PER_ENV_STEP_FULL = 583.7e6 / (1 << 20)
+PMC_TRAFFIC_SOURCE = "profiles/r08_env_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
 
 
 def main():
@@ -66,7 +71,9 @@ def main():
     out = {"metric": "batched PokerEnv.step env-steps/s", "value": steps / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "int32", "data": "synthetic", "build_flavor": _native.build_flavor(), "config": cfg,
-           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                        "traffic": PMC_TRAFFIC_BYTES_PER_ENV_STEP_FULL * args.envs if (full and args.game == "DiscretizedNLHoldem") else None,
+                        "traffic_source": PMC_TRAFFIC_SOURCE,
                         "kernel": "prl_k_ebf_random_step" if full else "prl_k_eb_random_step", "kernel_ms_per_launch": ms / args.steps,
                         "bytes_per_env_step_algorithmic": bytes_step}}
     if not args.no_cpu_baseline:

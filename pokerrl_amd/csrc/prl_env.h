@@ -18,11 +18,24 @@ enum { PRL_GAME_LIMIT = 0, PRL_GAME_DISCRETIZED = 1, PRL_GAME_NOLIMIT = 2 };
 PRL_HD PRL_INLINE int prl_imax(int a, int b) { return a > b ? a : b; }
 PRL_HD PRL_INLINE int prl_imin(int a, int b) { return a < b ? a : b; }
 
+// The two seats' fields are arrays of two; the seat is often a run-time value (the player to act). An array indexed by a run-time value
+// cannot live in registers: the whole state then sits in private (scratch) memory on the GPU and every access is a vector-memory round trip
+// (the batched step kernels carried 400-464 bytes of scratch per lane). Reads and writes by seat go through these select forms instead.
+template <class T>
+PRL_HD PRL_INLINE T prl_at2(const T (&a)[2], int p) { return p ? a[1] : a[0]; }
+template <class T, class V>
+PRL_HD PRL_INLINE void prl_put2(T (&a)[2], int p, V v) {
+    const T x = (T)v, a0 = a[0], a1 = a[1];
+    a[0] = p ? a0 : x;
+    a[1] = p ? x : a1;
+}
+
 PRL_HD PRL_INLINE void prl_player_bet_raise(PrlEnvState& s, int p, int total) {  // _PokerPlayer.py:68-81
-    s.acted[p] = 1;
-    s.stack[p] -= (total - s.bet[p]);
-    s.bet[p] = total;
-    if (s.stack[p] == 0) s.allin[p] = 1;
+    prl_put2(s.acted, p, 1);
+    const int stack = prl_at2(s.stack, p) - (total - prl_at2(s.bet, p));
+    prl_put2(s.stack, p, stack);
+    prl_put2(s.bet, p, total);
+    if (stack == 0) prl_put2(s.allin, p, 1);
 }
 
 // HU sweep of the current bets into the main pot (PokerEnv.py:539-551): refund the uncalled excess first
@@ -45,11 +58,10 @@ PRL_HD PRL_INLINE void prl_env_reset(const PrlGame& g, PrlEnvState& s) {  // Pok
     s.n_actions_ep = 0;
     s.last_action[0] = s.last_action[1] = s.last_action[2] = -1;
     s.pad0 = 0;
-    for (int p = 0; p < 2; ++p) {
-        s.stack[p] = g.start_stack[p];
-        s.bet[p] = 0; s.allin[p] = 0; s.folded[p] = 0; s.acted[p] = 0;
-    }
-    for (int p = 0; p < 2; ++p) { prl_player_bet_raise(s, p, g.ante); s.acted[p] = 0; }
+    s.stack[0] = g.start_stack[0]; s.stack[1] = g.start_stack[1];
+    s.bet[0] = s.bet[1] = 0; s.allin[0] = s.allin[1] = 0; s.folded[0] = s.folded[1] = 0; s.acted[0] = s.acted[1] = 0;
+    prl_player_bet_raise(s, 0, g.ante); s.acted[0] = 0;
+    prl_player_bet_raise(s, 1, g.ante); s.acted[1] = 0;
     prl_sweep_bets(s);                                   // antes do not count as current bet
     prl_player_bet_raise(s, 0, g.small_blind); s.acted[0] = 0;   // HU: seat 0 = BTN = SB (PokerEnv.py:337-340)
     prl_player_bet_raise(s, 1, g.big_blind); s.acted[1] = 0;
@@ -66,12 +78,13 @@ PRL_HD PRL_INLINE int prl_min_raise_total(const PrlGame& g, const PrlEnvState& s
 // pot fraction -> total chips in front (PokerEnv.py:1376-1396). The only float op of the engine: Python computes
 // int(to_call + pot_after_call * fraction) in float64 with separate multiply and add (build with -ffp-contract=off).
 PRL_HD PRL_INLINE int prl_fraction_of_pot_raise(const PrlEnvState& s, double fraction, int p) {
-    int to_call = prl_total_to_call(s) - s.bet[p];
+    const int bet_p = prl_at2(s.bet, p);
+    int to_call = prl_total_to_call(s) - bet_p;
     int pot_after_call = s.main_pot + s.bet[0] + s.bet[1] + to_call;
     double prod = (double)pot_after_call * fraction;
     double sum = (double)to_call + prod;
     int delta = (int)sum;  // truncation toward zero == Python int()
-    return delta + s.bet[p];
+    return delta + bet_p;
 }
 
 // env-specific action int -> (type, amount) (LimitPokerEnv.py:27-35, DiscretizedPokerEnv.py:47-62, evaluation mode)
@@ -84,18 +97,18 @@ PRL_HD PRL_INLINE void prl_adjust_action(const PrlGame& g, const PrlEnvState& s,
 }
 
 PRL_HD PRL_INLINE void prl_process_check_call(const PrlEnvState& s, int total_to_call, int* type, int* amount) {
-    int p = s.cur;
-    int delta = prl_imin(total_to_call - s.bet[p], s.stack[p]);
+    const int p = s.cur, bet_p = prl_at2(s.bet, p);
+    int delta = prl_imin(total_to_call - bet_p, prl_at2(s.stack, p));
     *type = PRL_CHECK_CALL;
-    *amount = delta + s.bet[p];
+    *amount = delta + bet_p;
 }
 
 // PokerEnv.py:885-941
 PRL_HD PRL_INLINE void prl_fixed_action(const PrlGame& g, const PrlEnvState& s, int type, int amount, int* ftype, int* famount) {
-    int p = s.cur;
+    const int p = s.cur, bet_p = prl_at2(s.bet, p), stack_p = prl_at2(s.stack, p);
     int ttc = prl_total_to_call(s);
     if (type == PRL_FOLD) {
-        if (ttc <= s.bet[p]) { prl_process_check_call(s, ttc, ftype, famount); return; }
+        if (ttc <= bet_p) { prl_process_check_call(s, ttc, ftype, famount); return; }
         *ftype = PRL_FOLD; *famount = -1; return;
     }
     if (type == PRL_CHECK_CALL) {
@@ -105,13 +118,13 @@ PRL_HD PRL_INLINE void prl_fixed_action(const PrlGame& g, const PrlEnvState& s, 
     }
     // BET_RAISE
     if (g.game_type == PRL_GAME_LIMIT && s.n_raises_round >= g.max_raises[s.round]) { prl_process_check_call(s, ttc, ftype, famount); return; }
-    if (s.stack[p] + s.bet[p] <= ttc || s.capped_cant_reopen == p) { prl_process_check_call(s, ttc, ftype, famount); return; }
+    if (stack_p + bet_p <= ttc || s.capped_cant_reopen == p) { prl_process_check_call(s, ttc, ftype, famount); return; }
     int raise_to;
     if (g.pot_size_raise) raise_to = prl_fraction_of_pot_raise(s, 1.0, p);                       // games.py:253-254
     else if (g.game_type == PRL_GAME_LIMIT)
         raise_to = (s.n_raises_round + 1) * (s.round >= g.round_big_bet_starts ? g.big_bet : g.small_bet);  // LimitPokerEnv.py:37-39
     else raise_to = prl_imax(prl_min_raise_total(g, s), amount);                                 // Discretized/NoLimit _adjust_raise
-    if (s.bet[p] + s.stack[p] < raise_to) raise_to = s.stack[p] + s.bet[p];
+    if (bet_p + stack_p < raise_to) raise_to = stack_p + bet_p;
     *ftype = PRL_BET_RAISE;
     *famount = raise_to;
 }
@@ -121,11 +134,8 @@ PRL_HD PRL_INLINE int prl_should_continue(const PrlEnvState& s) {  // PokerEnv.p
     if (n_nonfold < 2) return 0;
     int largest = prl_imax(s.bet[0], s.bet[1]);
     int n_ok = 0, n_unacted = 0;
-    for (int p = 0; p < 2; ++p) {
-        if (s.folded[p]) continue;
-        if (s.allin[p] || s.bet[p] == largest) n_ok++;
-        if (!s.allin[p] && !s.acted[p]) n_unacted++;
-    }
+    if (!s.folded[0]) { n_ok += (s.allin[0] || s.bet[0] == largest); n_unacted += (!s.allin[0] && !s.acted[0]); }
+    if (!s.folded[1]) { n_ok += (s.allin[1] || s.bet[1] == largest); n_unacted += (!s.allin[1] && !s.acted[1]); }
     if (n_ok == n_nonfold && n_unacted == 0) return 0;
     return 1;
 }
@@ -138,14 +148,14 @@ PRL_HD PRL_INLINE void prl_env_apply_action(const PrlGame& g, PrlEnvState& s, in
     prl_fixed_action(g, s, type, amount, &ftype, &famount);
     int p = s.cur;
     if (ftype == PRL_CHECK_CALL) {               // _PokerPlayer.py:83-95
-        s.acted[p] = 1;
-        int delta = famount - s.bet[p];
-        s.stack[p] -= delta;
-        s.bet[p] = famount;
-        if (s.stack[p] == 0) s.allin[p] = 1;
+        prl_put2(s.acted, p, 1);
+        const int stack = prl_at2(s.stack, p) - (famount - prl_at2(s.bet, p));
+        prl_put2(s.stack, p, stack);
+        prl_put2(s.bet, p, famount);
+        if (stack == 0) prl_put2(s.allin, p, 1);
     } else if (ftype == PRL_FOLD) {
-        s.acted[p] = 1;
-        s.folded[p] = 1;
+        prl_put2(s.acted, p, 1);
+        prl_put2(s.folded, p, 1);
     } else {                                     // PokerEnv.py:706-728
         if (famount < prl_min_raise_total(g, s)) {
             s.capped_happened = 1;
@@ -178,7 +188,7 @@ PRL_HD PRL_INLINE void prl_env_step_processed(const PrlGame& g, PrlEnvState& s, 
     int n_active = (!s.folded[0] && !s.allin[0]) + (!s.folded[1] && !s.allin[1]);
     if (prl_should_continue(s)) {
         int q = 1 - p;                           // HU: the other seat, if it can act (PokerEnv.py:871-883)
-        if (s.allin[q] || s.folded[q]) q = p;
+        if (prl_at2(s.allin, q) || prl_at2(s.folded, q)) q = p;
         s.cur = (int8_t)q;
     } else if (n_active > 1) {
         if (s.round == g.n_rounds - 1) {         // showdown on the last street
@@ -215,20 +225,22 @@ PRL_HD PRL_INLINE void prl_env_step(const PrlGame& g, PrlEnvState& s, int action
 }
 
 // Legal actions (LimitPokerEnv.py:41-59, DiscretizedPokerEnv.py:99-135). Returns the count, fills `out` (env action ints)
-PRL_HD PRL_INLINE int prl_legal_actions(const PrlGame& g, const PrlEnvState& s, int32_t* out) {
+// `put(a)` receives the legal actions in ascending order
+template <class Put>
+PRL_HD PRL_INLINE int prl_legal_actions_to(const PrlGame& g, const PrlEnvState& s, Put& put) {
     int n = 0, ft, fa;
     prl_fixed_action(g, s, PRL_FOLD, -1, &ft, &fa);
-    if (ft == PRL_FOLD) out[n++] = PRL_FOLD;
+    if (ft == PRL_FOLD) { put(PRL_FOLD); ++n; }
     prl_fixed_action(g, s, PRL_CHECK_CALL, -1, &ft, &fa);
-    if (ft == PRL_CHECK_CALL) out[n++] = PRL_CHECK_CALL;
+    if (ft == PRL_CHECK_CALL) { put(PRL_CHECK_CALL); ++n; }
     if (g.game_type == PRL_GAME_LIMIT) {
         prl_fixed_action(g, s, PRL_BET_RAISE, -1, &ft, &fa);
-        if (s.n_raises_round < g.max_raises[s.round] && ft == PRL_BET_RAISE) out[n++] = PRL_BET_RAISE;
+        if (s.n_raises_round < g.max_raises[s.round] && ft == PRL_BET_RAISE) { put(PRL_BET_RAISE); ++n; }
         return n;
     }
     if (g.game_type == PRL_GAME_NOLIMIT) {  // PokerEnv.get_legal_actions (PokerEnv.py:1313-1330): probe raise amount 1
         prl_fixed_action(g, s, PRL_BET_RAISE, 1, &ft, &fa);
-        if (ft == PRL_BET_RAISE) out[n++] = PRL_BET_RAISE;
+        if (ft == PRL_BET_RAISE) { put(PRL_BET_RAISE); ++n; }
         return n;
     }
     int last_too_small = -1;
@@ -241,10 +253,24 @@ PRL_HD PRL_INLINE int prl_legal_actions(const PrlGame& g, const PrlEnvState& s, 
         if (amt < fa) {
             last_too_small = a;                   // below min-raise: remember the largest such size
         } else {
-            if (last_too_small >= 0) { out[n++] = last_too_small; last_too_small = -1; }
-            out[n++] = a;
+            if (last_too_small >= 0) { put(last_too_small); ++n; last_too_small = -1; }
+            put(a); ++n;
         }
         if (amt > fa) break;                      // clamped to all-in: bigger sizes collapse to the same raise
     }
     return n;
+}
+PRL_HD PRL_INLINE int prl_legal_actions(const PrlGame& g, const PrlEnvState& s, int32_t* out) {
+    int k = 0;
+    auto put = [&](int a) { out[k++] = a; };
+    return prl_legal_actions_to(g, s, put);
+}
+// legal[r % n_legal] without the list (no array indexed at run time): one pass counts, one picks
+PRL_HD PRL_INLINE int prl_legal_action_pick(const PrlGame& g, const PrlEnvState& s, uint32_t r) {
+    auto nothing = [](int) {};
+    const int n = prl_legal_actions_to(g, s, nothing);
+    int want = (int)(r % (uint32_t)n), k = 0, picked = -1;
+    auto pick = [&](int a) { picked = k == want ? a : picked; ++k; };
+    prl_legal_actions_to(g, s, pick);
+    return picked;
 }

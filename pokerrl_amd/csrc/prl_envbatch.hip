@@ -210,12 +210,10 @@ PRL_GLOBAL void prl_k_eb_rollout(const PrlGame* g, int32_t* st, int n, int n_ste
         eb_load(st, n, i, s, &done);
         if (done) { prl_env_reset(*g, s); done = false; }
         for (int k = 0; k < n_steps; ++k) {
-            int32_t legal[PRL_MAX_BET_SIZES + 2];
-            const int nl = prl_legal_actions(*g, s, legal);
             const uint32_t r = eb_mix32(seed ^ eb_mix32((uint32_t)i * 0x9E3779B9u + (uint32_t)k));
             PrlStepInfo si;
-            const int a = legal[r % (uint32_t)nl];
-            if (g->game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(*g, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(s.stack[s.cur] + s.bet[s.cur] + 1)) : -1, &si);
+            const int a = prl_legal_action_pick(*g, s, r);
+            if (g->game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(*g, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(prl_at2(s.stack, s.cur) + prl_at2(s.bet, s.cur) + 1)) : -1, &si);
             else prl_env_step(*g, s, a, &si);
             ++steps;
             if (si.is_terminal) {
@@ -238,12 +236,10 @@ PRL_GLOBAL void prl_k_eb_random_step(const PrlGame* g, int32_t* st, int n, int k
         bool done;
         eb_load(st, n, i, s, &done);
         if (done) prl_env_reset(*g, s);
-        int32_t legal[PRL_MAX_BET_SIZES + 2];
-        const int nl = prl_legal_actions(*g, s, legal);
         const uint32_t r = eb_mix32(seed ^ eb_mix32((uint32_t)i * 0x9E3779B9u + (uint32_t)k));
         PrlStepInfo si;
-        const int a = legal[r % (uint32_t)nl];
-        if (g->game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(*g, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(s.stack[s.cur] + s.bet[s.cur] + 1)) : -1, &si);
+        const int a = prl_legal_action_pick(*g, s, r);
+        if (g->game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(*g, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(prl_at2(s.stack, s.cur) + prl_at2(s.bet, s.cur) + 1)) : -1, &si);
         else prl_env_step(*g, s, a, &si);
         ++steps;
         if (si.is_terminal) { ++hands; pots += (unsigned long long)si.pot_before_payout; }
@@ -274,21 +270,23 @@ PRL_HD PRL_INLINE int eb_hand_idx(const PrlRules& r, const int8_t* hc) {
 // PokerEnv._payout_pots, heads-up (PokerEnv.py:468-481) + the rewards of PokerEnv.py:1069-1072: (stack after - starting stack) / REWARD_SCALAR
 PRL_HD PRL_INLINE void eb_payout(const PrlGame& g, const EbFull& F, const PrlEnvState& s, const int8_t* cards, double rew[2], bool* showdown) {
     const int pot = s.main_pot;
-    double award[2] = {0.0, 0.0};
+    double award0 = 0.0, award1 = 0.0;
     *showdown = false;
-    if (s.folded[0] || s.folded[1]) award[s.folded[0] ? 1 : 0] = (double)pot;
+    if (s.folded[0]) award1 = (double)pot;
+    else if (s.folded[1]) award0 = (double)pot;
     else {
         PrlLbrGame hg;
         hg.n_hole = F.rules.n_hole_cards; hg.n_cards = F.rules.n_cards; hg.n_suits = F.rules.n_suits; hg.rank_rule = F.rules.rank_rule; hg.R = F.rules.range_size;
         hg.n_board_total = F.rules.n_board_cards;
         const int8_t* board = cards + 2 * F.rules.n_hole_cards;
         const int32_t r0 = prl_lbr_rank(hg, eb_hand_idx(F.rules, cards), board), r1 = prl_lbr_rank(hg, eb_hand_idx(F.rules, cards + F.rules.n_hole_cards), board);
-        if (r0 > r1) award[0] = (double)pot;
-        else if (r0 < r1) award[1] = (double)pot;
-        else award[0] = award[1] = (double)pot / 2.0;
+        if (r0 > r1) award0 = (double)pot;
+        else if (r0 < r1) award1 = (double)pot;
+        else award0 = award1 = (double)pot / 2.0;
         *showdown = true;
     }
-    for (int p = 0; p < 2; ++p) rew[p] = ((double)s.stack[p] + award[p] - (double)g.start_stack[p]) / F.reward_scalar;
+    rew[0] = ((double)s.stack[0] + award0 - (double)g.start_stack[0]) / F.reward_scalar;
+    rew[1] = ((double)s.stack[1] + award1 - (double)g.start_stack[1]) / F.reward_scalar;
 }
 // the heads-up "simple" observation (PokerEnv.py:199-261, :989-1031, :1253-1271): float64 quotients rounded to float32 like the
 // reference's np.array(list of Python floats, dtype=float32)
@@ -507,12 +505,10 @@ PRL_HD PRL_INLINE void eb_play_full(const PrlGame& g, const EbFull& F, int n, in
     uint32_t ep = 0;
     prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, cards);
     for (int k = 0; k < n_steps; ++k) {
-        int32_t legal[PRL_MAX_BET_SIZES + 2];
-        const int nl = prl_legal_actions(g, s, legal);
         const uint32_t r = eb_mix32(seed ^ eb_mix32((uint32_t)i * 0x9E3779B9u + (uint32_t)k));
         PrlStepInfo si;
-        const int a = legal[r % (uint32_t)nl];
-        if (g.game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(g, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(s.stack[s.cur] + s.bet[s.cur] + 1)) : -1, &si);
+        const int a = prl_legal_action_pick(g, s, r);
+        if (g.game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(g, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(prl_at2(s.stack, s.cur) + prl_at2(s.bet, s.cur) + 1)) : -1, &si);
         else prl_env_step(g, s, a, &si);
         acc[0] += 1;
         if (si.is_terminal) {
@@ -568,12 +564,10 @@ PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* g, EbFull F, int32_t* st, i
                 episode[i] = ep + 1u;
                 prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, c);
             }
-            int32_t legal[PRL_MAX_BET_SIZES + 2];
-            const int nl = prl_legal_actions(*g, s, legal);
             const uint32_t r = eb_mix32(seed ^ eb_mix32((uint32_t)i * 0x9E3779B9u + (uint32_t)k));
             PrlStepInfo si;
-            const int a = legal[r % (uint32_t)nl];
-            if (g->game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(*g, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(s.stack[s.cur] + s.bet[s.cur] + 1)) : -1, &si);
+            const int a = prl_legal_action_pick(*g, s, r);
+            if (g->game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(*g, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(prl_at2(s.stack, s.cur) + prl_at2(s.bet, s.cur) + 1)) : -1, &si);
             else prl_env_step(*g, s, a, &si);
             ++steps;
             double rw[2] = {0.0, 0.0};
@@ -928,12 +922,10 @@ int32_t prl_env_random_rollout_host(const PrlGame* game, int32_t n_envs, int32_t
         PrlEnvState s;
         prl_env_reset(*game, s);
         for (int k = 0; k < n_steps; ++k) {
-            int32_t legal[PRL_MAX_BET_SIZES + 2];
-            const int nl = prl_legal_actions(*game, s, legal);
             const uint32_t r = eb_mix32(seed ^ eb_mix32((uint32_t)i * 0x9E3779B9u + (uint32_t)k));
             PrlStepInfo si;
-            const int a = legal[r % (uint32_t)nl];
-            if (game->game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(*game, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(s.stack[s.cur] + s.bet[s.cur] + 1)) : -1, &si);
+            const int a = prl_legal_action_pick(*game, s, r);
+            if (game->game_type == PRL_GAME_NOLIMIT) prl_env_step_processed(*game, s, a, a == PRL_BET_RAISE ? (int)(eb_mix32(r) % (uint32_t)(prl_at2(s.stack, s.cur) + prl_at2(s.bet, s.cur) + 1)) : -1, &si);
             else prl_env_step(*game, s, a, &si);
             ++steps;
             if (si.is_terminal) { ++hands; pots += (uint64_t)si.pot_before_payout; prl_env_reset(*game, s); }

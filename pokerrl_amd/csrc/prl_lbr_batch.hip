@@ -220,6 +220,119 @@ PRL_DEV PRL_INLINE void lbrb_normalize(float* rg, int R, LbrbLeaves& Lf, LbrbSha
     prl_sync();
 }
 
+// ---- many NumPy pairwise sums of ONE length at once, by the whole workgroup (round 4) ---------------------------------------------------------------
+// A look-ahead needs n_q x n_boards check-down equities, each three sums over ~1300 elements (the range with the board's hands zeroed; the
+// normalised range over the hands LBR beats; over the hands it ties with). One lane per equity -- the first design -- walks 3500 elements in a
+// row on 368 of the 576 lanes (turn: 8 candidates x 46 boards) and on 8 of them on the river: half of a hand's clocks (profiles/r08_lbr_phases.txt).
+// NumPy's association is a tree, though: blocks of <= 128 elements with eight strided accumulators each, blocks added pairwise up the halving
+// recursion. So the unit of work is one ACCUMULATOR CHAIN (<= 16 elements) of one block of one sum: all lanes take chains of all sums, a second
+// step folds the eight accumulators of a block and adds its tail, a third adds a sum's blocks in the recursion's order. Same values, same order.
+struct LbrbLeafMap { int n, n_leaves; int lo[LBRB_MAX_LEAVES], m[LBRB_MAX_LEAVES]; };
+PRL_DEV PRL_INLINE void lbrb_build_leaf_map(LbrbLeafMap& M, int n) {  // one thread
+    M.n = n; M.n_leaves = 0;
+    if (n < 8) return;  // fewer than eight elements are added one after the other
+    int stack_lo[16], stack_n[16], sp = 0, nl = 0;
+    stack_lo[0] = 0; stack_n[0] = n;
+    while (sp >= 0) {
+        const int lo = stack_lo[sp], m = stack_n[sp];
+        --sp;
+        if (m <= 128) { M.lo[nl] = lo; M.m[nl] = m; ++nl; continue; }
+        int n2 = m / 2;
+        n2 -= n2 % 8;
+        ++sp; stack_lo[sp] = lo + n2; stack_n[sp] = m - n2;
+        ++sp; stack_lo[sp] = lo; stack_n[sp] = n2;
+    }
+    M.n_leaves = nl;
+}
+// the blocks' sums added in the recursion's order (left half + right half, post-order); sums[leaf * 8] is block number `leaf`
+template <int DEPTH>
+PRL_DEV PRL_INLINE float lbrb_comb(int n, const float* sums, int& leaf) {
+    if (DEPTH == 0 || n <= 128) return sums[(leaf++) * 8];
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const float l = lbrb_comb<(DEPTH > 0 ? DEPTH - 1 : 0)>(n2, sums, leaf);
+    const float r = lbrb_comb<(DEPTH > 0 ? DEPTH - 1 : 0)>(n - n2, sums, leaf);
+    return l + r;
+}
+#define LBRB_PART_FLOATS 12288  // 48 KB of accumulator slots: 96 sums of 16 blocks per round
+// make(s) returns the element function of sum s (element index -> float); out(s, total) receives the result. Every lane of the workgroup calls this.
+template <class Make, class Out>
+PRL_DEV PRL_INLINE void lbrb_multi_sum(const LbrbLeafMap& M, int n_sums, float* part, Make make, Out out) {
+    const int tid = (int)prl_tid(), n = M.n;
+    if (n < 8) {
+        for (int s = tid; s < n_sums; s += LBRB_THREADS) {
+            auto el = make(s);
+            float res = 0.f;
+            for (int i = 0; i < n; ++i) res = res + el(i);
+            out(s, res);
+        }
+        prl_sync();
+        return;
+    }
+    const int L = M.n_leaves, per = L * 8, chunk = LBRB_PART_FLOATS / per;
+    for (int s0 = 0; s0 < n_sums; s0 += chunk) {
+        const int ns = n_sums - s0 < chunk ? n_sums - s0 : chunk;
+        for (int t = tid; t < ns * per; t += LBRB_THREADS) {  // accumulator j of block `leaf` of sum s0 + sl
+            const int sl = t / per, r = t - sl * per, leaf = r >> 3, j = r & 7;
+            auto el = make(s0 + sl);
+            const int lo = M.lo[leaf], m8 = M.m[leaf] & ~7;
+            float acc = el(lo + j);
+            for (int i = 8 + j; i < m8; i += 8) acc = acc + el(lo + i);
+            part[t] = acc;
+        }
+        prl_sync();
+        for (int t = tid; t < ns * L; t += LBRB_THREADS) {  // a block: its eight accumulators, then its tail
+            const int sl = t / L, leaf = t - sl * L;
+            float* r = part + (size_t)t * 8;
+            float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            const int lo = M.lo[leaf], m = M.m[leaf];
+            if (m & 7) {
+                auto el = make(s0 + sl);
+                for (int i = m & ~7; i < m; ++i) res = res + el(lo + i);
+            }
+            r[0] = res;
+        }
+        prl_sync();
+        for (int sl = tid; sl < ns; sl += LBRB_THREADS) {
+            int leaf = 0;
+            out(s0 + sl, lbrb_comb<6>(n, part + (size_t)sl * per, leaf));
+        }
+        prl_sync();
+    }
+}
+
+// x / b, correctly rounded, for many x and one b: the reciprocal is refined once, a quotient is a multiply and two residual corrections -- the
+// instruction sequence of the generic float32 division minus its range scaling and special-case fix-up, which are the identity when b, the
+// quotient and the residuals stay in the normal range (prl_fhp_div.inc has the argument and scripts/ubench/div_check.hip the exhaustive-style
+// check on the GPU): b in [2^-35, 2^30] and x either 0 or >= 2^-33 b. Anything else takes the generic division.
+struct LbrbDiv {
+    float b, y, thr;
+    bool box;
+    PRL_DEV PRL_INLINE float operator()(float x) const {
+        if (!box || (x < thr && x != 0.f)) return x / b;
+        float q = x * y;
+        float r = __builtin_fmaf(-b, q, x);
+        q = __builtin_fmaf(r, y, q);
+        r = __builtin_fmaf(-b, q, x);
+        return __builtin_fmaf(r, y, q);
+    }
+};
+PRL_DEV PRL_INLINE LbrbDiv lbrb_div_by(float b) {
+    LbrbDiv d;
+    d.b = b;
+    d.box = b >= 0x1p-35f && b <= 0x1p30f;
+    const float bb = d.box ? b : 1.f;
+#if defined(PRL_EMU)
+    float y = 1.0f / bb;
+#else
+    float y = __builtin_amdgcn_rcpf(bb);
+#endif
+    const float e = __builtin_fmaf(-bb, y, 1.0f);
+    d.y = __builtin_fmaf(e, y, y);
+    d.thr = bb * 0x1p-33f;
+    return d;
+}
+
 // ONE workgroup (9 waves) per CU with up to 168 VGPRs per lane (round 4): measured 3.3 % ahead of two workgroups at 96 VGPRs (74 spilled),
 // profiles/r06_experiments.txt -- the kernel waits on dependent LDS gathers and division chains, not on occupancy
 #if defined(PRL_EMU)
@@ -230,6 +343,12 @@ PRL_DEV PRL_INLINE void lbrb_normalize(float* rg, int R, LbrbLeaves& Lf, LbrbSha
 #endif
 #define LBRB_LB __launch_bounds__(LBRB_THREADS, LBRB_WAVES_PER_SIMD)
 #endif
+PRL_HD PRL_INLINE bool nh_is_two(const PrlRules& r) { return r.n_hole_cards == 2; }
+PRL_HD PRL_INLINE size_t lbrb_smem_bytes(int R) {
+    return ((size_t)(1 + LBRB_MAX_Q) * R + LBRB_MAX_Q * LBRB_MAX_BOARDS) * sizeof(float) + (size_t)R * 2 + 16 + (size_t)R * 2 + 16 + sizeof(LbrbShared) + 16 +
+           sizeof(LbrbLeaves) + 16 + (size_t)LBRB_MAX_Q * PRL_LBR_MAX_CARDS * sizeof(float) + (size_t)LBRB_MAX_Q * LBRB_MAX_BOARDS * sizeof(float) + 16 +
+           3 * sizeof(LbrbLeafMap) + 16 + (size_t)LBRB_PART_FLOATS * sizeof(float);
+}
 PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
     char* lbrb_smem = prl_smem();
     const int R = P.rules.range_size, tid = (int)prl_tid();
@@ -243,7 +362,13 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
     LbrbShared& S = *(LbrbShared*)(((size_t)(hole_lut + R) + 15) & ~(size_t)15);
     LbrbLeaves& Lf = *(LbrbLeaves*)(((size_t)(&S + 1) + 15) & ~(size_t)15);
     float* cpw = (float*)(((size_t)(&Lf + 1) + 15) & ~(size_t)15);  // [LBRB_MAX_Q][PRL_LBR_MAX_CARDS] card probabilities of the look-ahead
+    float* eq_b = cpw + LBRB_MAX_Q * PRL_LBR_MAX_CARDS;              // [LBRB_MAX_Q][LBRB_MAX_BOARDS] the tie sums of the equities under way
+    LbrbLeafMap* maps = (LbrbLeafMap*)(((size_t)(eq_b + LBRB_MAX_Q * LBRB_MAX_BOARDS) + 15) & ~(size_t)15);  // blocks of sums over R / n_big / n_eq elements
+    LbrbLeafMap &MR = maps[0], &MB = maps[1], &ME = maps[2];
+    float* part = (float*)(((size_t)(maps + 3) + 15) & ~(size_t)15);  // [LBRB_PART_FLOATS] accumulator slots of lbrb_multi_sum
+    const bool coop = nh_is_two(P.rules) && R >= 64;  // the cooperative sums (hold'em ranges); tiny ranges keep one lane per sum
     if (tid == 0) lbrb_build_leaves(Lf, R);
+    if (tid == 64) lbrb_build_leaf_map(MR, R);
     const int nh = P.rules.n_hole_cards, lbr_seat = 1 - P.agent_seat, n_board_total = P.rules.n_board_cards;
     unsigned long long n_steps = 0, n_look = 0, n_eq = 0, n_agent = 0;
 #ifdef PRL_LBRB_TIMING
@@ -333,7 +458,8 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     const PrlLbrGame g = S.lg;
                     const int n_q = S.n_q, n_boards = S.n_boards;
                     const bool big = n_boards > LBRB_MAX_BOARDS;
-                    float* eq = big ? P.eq_scratch + (size_t)prl_bid() * LBRB_MAX_Q * LBRB_MAX_BOARDS_2 : eq_lds;
+                    float* eq = big ? P.eq_scratch + (size_t)prl_bid() * 2 * LBRB_MAX_Q * LBRB_MAX_BOARDS_2 : eq_lds;
+                    float* eqb = big ? eq + (size_t)LBRB_MAX_Q * LBRB_MAX_BOARDS_2 : eq_b;
                     const int eq_stride = big ? LBRB_MAX_BOARDS_2 : LBRB_MAX_BOARDS;
                     if (g.n_to_deal > 2 || n_boards > LBRB_MAX_BOARDS_2 || (big && !P.eq_scratch)) {  // run() rejects configurations that get here
                         if (tid == 0) S.done = 1;
@@ -372,6 +498,8 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     prl_sync();
                     // the two classes as ascending index lists (stable compaction by one wave: ballot + popcount of the lanes below), so that
                     // the sums over a class read element i directly instead of scanning the class bytes (prl_lbr_board_equity_lists)
+                    if (tid == 64) lbrb_build_leaf_map(MB, S.n_big);
+                    if (tid == 128) lbrb_build_leaf_map(ME, S.n_eq);
                     if (tid < 64) {
                         int at_big = 0, at_eq = S.n_big;
                         for (int base = 0; base < R; base += 64) {
@@ -389,7 +517,17 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     LBRB_TICK(2);  // candidate fold probabilities + classification
                     // one lane per raise: fold probability and the not-fold mass, NumPy order
                     // two lanes per raise, in different waves so that the two sums run side by side
-                    if (tid >= 1 && tid < n_q) {
+                    if (coop) {
+                        // 2 (n_q - 1) sums over the range: sum 2 (q - 1) = the fold probability of raise q, the next one its not-fold mass
+                        auto make = [&](int si) {
+                            const float* pf = cand + (size_t)(1 + (si >> 1)) * R;
+                            const bool nf = (si & 1) != 0;
+                            const float* r0 = rg;
+                            return [=](int k) { return nf ? r0[k] * (1.f - pf[k]) : r0[k] * pf[k]; };
+                        };
+                        auto out = [&](int si, float v) { if (si & 1) S.notfold_total[1 + (si >> 1)] = v; else S.fold_prob[1 + (si >> 1)] = v; };
+                        lbrb_multi_sum(MR, 2 * (n_q - 1), part, make, out);
+                    } else if (tid >= 1 && tid < n_q) {
                         const float* pf = cand + (size_t)tid * R;
                         int k = 0;
                         auto nx = [&]() { const float v = rg[k] * pf[k]; ++k; return v; };
@@ -412,11 +550,65 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     }
                     prl_sync();
                     LBRB_TICK(4);  // candidate ranges
-                    for (int t = tid; t < n_q * n_boards; t += LBRB_THREADS) {
-                        const int q = t / n_boards, b = t % n_boards;
-                        int8_t fb[5];
-                        prl_lbr_board_at(g, S.pc, S.n_pc, b, fb);
-                        eq[q * eq_stride + b] = prl_lbr_board_equity_lists(g, fb, cls_list, S.n_big, S.n_eq, cand + (size_t)q * R, hole_lut);
+                    if (coop) {
+                        // pair p = (candidate q, board b). Three rounds of sums: the pair's normaliser (the range without the board's hands) into eq,
+                        // its tie sum into eqb, its win sum -- and with it the equity -- into eq (prl_lbr_board_equity_lists, term for term).
+                        unsigned long long base = 0ull;
+                        for (int i = 0; i < g.n_dealt; ++i) base |= 1ull << g.board[i];
+                        const int n_pairs = n_q * n_boards, n_big = S.n_big;
+                        const float unif_r = (float)(1.0 / (double)R);
+                        const int8_t* pcs = S.pc;
+                        const int n_pc = S.n_pc, n_to_deal = g.n_to_deal;
+                        auto board_mask = [&](int b) {
+                            if (n_to_deal == 0) return base;
+                            if (n_to_deal == 1) return base | (1ull << pcs[b]);
+                            int i = 0, left = b;
+                            while (left >= n_pc - 1 - i) { left -= n_pc - 1 - i; ++i; }
+                            return base | (1ull << pcs[i]) | (1ull << pcs[i + 1 + left]);
+                        };
+                        auto make_norm = [&](int p) {
+                            const int q = p / n_boards, b = p - q * n_boards;
+                            const unsigned long long bm = board_mask(b);
+                            const float* r0 = cand + (size_t)q * R;
+                            const uint16_t* hl = hole_lut;
+                            return [=](int h) {
+                                const unsigned v = hl[h];
+                                return (((bm >> (v & 0xFFu)) | (bm >> (v >> 8))) & 1ull) != 0ull ? 0.f : r0[h];
+                            };
+                        };
+                        auto out_norm = [&](int p, float v) { const int q = p / n_boards; eq[q * eq_stride + (p - q * n_boards)] = v; };
+                        lbrb_multi_sum(MR, n_pairs, part, make_norm, out_norm);
+                        auto make_cls = [&](int p, int off) {
+                            const int q = p / n_boards, b = p - q * n_boards;
+                            const unsigned long long bm = board_mask(b);
+                            const float* r0 = cand + (size_t)q * R;
+                            const uint16_t* hl = hole_lut;
+                            const uint16_t* list = cls_list + off;
+                            const float norm = eq[q * eq_stride + b];
+                            const LbrbDiv dv = lbrb_div_by(norm);
+                            return [=](int i) {
+                                const int h = (int)list[i];
+                                const unsigned v = hl[h];
+                                const float x = (((bm >> (v & 0xFFu)) | (bm >> (v >> 8))) & 1ull) != 0ull ? 0.f : r0[h];
+                                return norm == 0.f ? unif_r : dv(x);
+                            };
+                        };
+                        auto make_eq = [&](int p) { return make_cls(p, n_big); };
+                        auto out_eq = [&](int p, float v) { const int q = p / n_boards; eqb[q * eq_stride + (p - q * n_boards)] = v; };
+                        lbrb_multi_sum(ME, n_pairs, part, make_eq, out_eq);
+                        auto make_big = [&](int p) { return make_cls(p, 0); };
+                        auto out_big = [&](int p, float v) {
+                            const int q = p / n_boards, at = q * eq_stride + (p - q * n_boards);
+                            eq[at] = v + eqb[at] / 2.0f;
+                        };
+                        lbrb_multi_sum(MB, n_pairs, part, make_big, out_big);
+                    } else {
+                        for (int t = tid; t < n_q * n_boards; t += LBRB_THREADS) {
+                            const int q = t / n_boards, b = t % n_boards;
+                            int8_t fb[5];
+                            prl_lbr_board_at(g, S.pc, S.n_pc, b, fb);
+                            eq[q * eq_stride + b] = prl_lbr_board_equity_lists(g, fb, cls_list, S.n_big, S.n_eq, cand + (size_t)q * R, hole_lut);
+                        }
                     }
                     prl_sync();
                     LBRB_TICK(5);  // (range, board) equities
@@ -571,7 +763,7 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
     P.n_deal = 2 * nh + nb; P.limit = lbr_game->game_type == PRL_GAME_LIMIT;
     P.seed = agent_seed; P.episode_base = episode_base; P.reward_scalar = reward_scalar; P.ev_normalizer = ev_normalizer;
     const int R = rules->range_size;
-    const size_t smem = ((size_t)(1 + LBRB_MAX_Q) * R + LBRB_MAX_Q * LBRB_MAX_BOARDS) * sizeof(float) + (size_t)R * 2 + 16 + (size_t)R * 2 + 16 + sizeof(LbrbShared) + 16 + sizeof(LbrbLeaves) + 16 + (size_t)LBRB_MAX_Q * PRL_LBR_MAX_CARDS * sizeof(float);
+    const size_t smem = lbrb_smem_bytes(R);
     int8_t* d_cards = nullptr; float* d_win = nullptr; unsigned long long* d_stats = nullptr; float* d_eq = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = PRL_OK;
@@ -590,7 +782,7 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int grid = n_envs < cus * 8 ? n_envs : cus * 8;  // persistent workgroups; every one plays its hands start to finish
         if (to_deal_max == 2) {
-            LB_TRY(hipMalloc((void**)&d_eq, (size_t)grid * LBRB_MAX_Q * LBRB_MAX_BOARDS_2 * sizeof(float)));
+            LB_TRY(hipMalloc((void**)&d_eq, (size_t)grid * 2 * LBRB_MAX_Q * LBRB_MAX_BOARDS_2 * sizeof(float)));  // equities + the tie sums under way
             P.eq_scratch = d_eq;
         }
 #if !defined(PRL_EMU)
