@@ -10,6 +10,7 @@
 #define PRL_LAUNCH_BOUNDS(n)
 inline void prl_atomic_add_u64(unsigned long long* p, unsigned long long v) { *p += v; }  // the emulator runs one fiber at a time
 inline void prl_lds_add_i(int* p, int v) { *p += v; }
+inline void prl_lds_min_u(unsigned* p, unsigned v) { if (v < *p) *p = v; }
 inline int prl_atomic_add_i(int* p, int v) { int o = *p; *p += v; return o; }
 #else
 #include <hip/hip_runtime.h>
@@ -24,6 +25,7 @@ inline int prl_atomic_add_i(int* p, int v) { int o = *p; *p += v; return o; }
 #define PRL_LAUNCH_BOUNDS(n) __launch_bounds__(n)
 PRL_DEV PRL_INLINE void prl_atomic_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 PRL_DEV PRL_INLINE void prl_lds_add_i(int* p, int v) { atomicAdd(p, v); }  // integer add on an LDS word (order-free)
+PRL_DEV PRL_INLINE void prl_lds_min_u(unsigned* p, unsigned v) { atomicMin(p, v); }  // unsigned minimum on an LDS word (order-free)
 PRL_DEV PRL_INLINE int prl_atomic_add_i(int* p, int v) { return atomicAdd(p, v); }  // returns the value before the add
 PRL_DEV PRL_INLINE unsigned prl_tid() { return threadIdx.x; }
 PRL_DEV PRL_INLINE unsigned prl_bid() { return blockIdx.x; }

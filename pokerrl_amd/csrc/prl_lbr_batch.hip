@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "prl_device.h"
@@ -254,17 +255,48 @@ PRL_DEV PRL_INLINE float lbrb_comb(int n, const float* sums, int& leaf) {
     const float r = lbrb_comb<(DEPTH > 0 ? DEPTH - 1 : 0)>(n - n2, sums, leaf);
     return l + r;
 }
+// acc + e(first) + e(first + stride) + ... (cnt elements, added in this order). An element is two or three DEPENDENT LDS gathers (index list ->
+// hole cards and range entry) and the compiler neither pipelines the loop nor interleaves inlined element functions, so one element at a time costs
+// the full latency every time (measured: 300 clocks per element with 2.25 waves per SIMD to hide it). Elements are therefore handled FOUR AT A
+// TIME and in three explicit stages -- four indices, four fetches, four values -- with scheduling fences between the stages. The element type gives
+//   int index(int i)                         which entry (a hand) element i is
+//   void fetch(int h, unsigned& w, float& r)  the loads
+//   float value(unsigned w, float r)          straight-line arithmetic (a branch per element would fence the fetches again)
+// The last group is predicated: its surplus slots repeat the group's first element and are not added.
+// from_first: the sum STARTS with the first element (an accumulator of a block) instead of being added to acc.
+#if defined(PRL_EMU)
+#define LBRB_STAGE_FENCE() do { } while (0)
+#else
+#define LBRB_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+template <class El>
+PRL_DEV PRL_INLINE float lbrb_seq_add(float acc, bool from_first, const El& el, int first, int stride, int cnt) {
+    for (int k = 0; k < cnt; k += 4) {
+        const int rem = cnt - k, at = first + stride * k;
+        const int h0 = el.index(at), h1 = el.index(rem > 1 ? at + stride : at), h2 = el.index(rem > 2 ? at + 2 * stride : at),
+                  h3 = el.index(rem > 3 ? at + 3 * stride : at);
+        LBRB_STAGE_FENCE();
+        unsigned w0, w1, w2, w3;
+        float r0, r1, r2, r3;
+        el.fetch(h0, w0, r0); el.fetch(h1, w1, r1); el.fetch(h2, w2, r2); el.fetch(h3, w3, r3);
+        LBRB_STAGE_FENCE();
+        const float v0 = el.value(w0, r0), v1 = el.value(w1, r1), v2 = el.value(w2, r2), v3 = el.value(w3, r3);
+        acc = (from_first && k == 0) ? v0 : acc + v0;
+        acc = rem > 1 ? acc + v1 : acc;
+        acc = rem > 2 ? acc + v2 : acc;
+        acc = rem > 3 ? acc + v3 : acc;
+    }
+    return acc;
+}
 #define LBRB_PART_FLOATS 12288  // 48 KB of accumulator slots: 96 sums of 16 blocks per round
-// make(s) returns the element function of sum s (element index -> float); out(s, total) receives the result. Every lane of the workgroup calls this.
-template <class Make, class Out>
-PRL_DEV PRL_INLINE void lbrb_multi_sum(const LbrbLeafMap& M, int n_sums, float* part, Make make, Out out) {
+// run(s, acc, from_first, first, stride, cnt) adds cnt elements of sum s (first, first + stride, ...) in order -- normally lbrb_seq_add over the sum's
+// element function, possibly one of several variants picked per call; out(s, total) receives the result. Every lane of the workgroup calls this.
+template <class Run, class Out>
+PRL_DEV PRL_INLINE void lbrb_multi_sum(const LbrbLeafMap& M, int n_sums, float* part, Run run, Out out) {
     const int tid = (int)prl_tid(), n = M.n;
     if (n < 8) {
         for (int s = tid; s < n_sums; s += LBRB_THREADS) {
-            auto el = make(s);
-            float res = 0.f;
-            for (int i = 0; i < n; ++i) res = res + el(i);
-            out(s, res);
+            out(s, run(s, 0.f, false, 0, 1, n));
         }
         prl_sync();
         return;
@@ -274,11 +306,7 @@ PRL_DEV PRL_INLINE void lbrb_multi_sum(const LbrbLeafMap& M, int n_sums, float* 
         const int ns = n_sums - s0 < chunk ? n_sums - s0 : chunk;
         for (int t = tid; t < ns * per; t += LBRB_THREADS) {  // accumulator j of block `leaf` of sum s0 + sl
             const int sl = t / per, r = t - sl * per, leaf = r >> 3, j = r & 7;
-            auto el = make(s0 + sl);
-            const int lo = M.lo[leaf], m8 = M.m[leaf] & ~7;
-            float acc = el(lo + j);
-            for (int i = 8 + j; i < m8; i += 8) acc = acc + el(lo + i);
-            part[t] = acc;
+            part[t] = run(s0 + sl, 0.f, true, M.lo[leaf] + j, 8, M.m[leaf] >> 3);
         }
         prl_sync();
         for (int t = tid; t < ns * L; t += LBRB_THREADS) {  // a block: its eight accumulators, then its tail
@@ -286,10 +314,7 @@ PRL_DEV PRL_INLINE void lbrb_multi_sum(const LbrbLeafMap& M, int n_sums, float* 
             float* r = part + (size_t)t * 8;
             float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
             const int lo = M.lo[leaf], m = M.m[leaf];
-            if (m & 7) {
-                auto el = make(s0 + sl);
-                for (int i = m & ~7; i < m; ++i) res = res + el(lo + i);
-            }
+            if (m & 7) res = run(s0 + sl, res, false, lo + (m & ~7), 1, m & 7);
             r[0] = res;
         }
         prl_sync();
@@ -306,10 +331,9 @@ PRL_DEV PRL_INLINE void lbrb_multi_sum(const LbrbLeafMap& M, int n_sums, float* 
 // quotient and the residuals stay in the normal range (prl_fhp_div.inc has the argument and scripts/ubench/div_check.hip the exhaustive-style
 // check on the GPU): b in [2^-35, 2^30] and x either 0 or >= 2^-33 b. Anything else takes the generic division.
 struct LbrbDiv {
-    float b, y, thr;
+    float b, y;
     bool box;
-    PRL_DEV PRL_INLINE float operator()(float x) const {
-        if (!box || (x < thr && x != 0.f)) return x / b;
+    PRL_DEV PRL_INLINE float fast(float x) const {  // only when box
         float q = x * y;
         float r = __builtin_fmaf(-b, q, x);
         q = __builtin_fmaf(r, y, q);
@@ -317,10 +341,11 @@ struct LbrbDiv {
         return __builtin_fmaf(r, y, q);
     }
 };
-PRL_DEV PRL_INLINE LbrbDiv lbrb_div_by(float b) {
+// small_ok: the caller knows that every non-zero x it will divide is >= 2^-33 b
+PRL_DEV PRL_INLINE LbrbDiv lbrb_div_by(float b, bool small_ok) {
     LbrbDiv d;
     d.b = b;
-    d.box = b >= 0x1p-35f && b <= 0x1p30f;
+    d.box = small_ok && b >= 0x1p-35f && b <= 0x1p30f;
     const float bb = d.box ? b : 1.f;
 #if defined(PRL_EMU)
     float y = 1.0f / bb;
@@ -329,7 +354,6 @@ PRL_DEV PRL_INLINE LbrbDiv lbrb_div_by(float b) {
 #endif
     const float e = __builtin_fmaf(-bb, y, 1.0f);
     d.y = __builtin_fmaf(e, y, y);
-    d.thr = bb * 0x1p-33f;
     return d;
 }
 
@@ -344,28 +368,39 @@ PRL_DEV PRL_INLINE LbrbDiv lbrb_div_by(float b) {
 #define LBRB_LB __launch_bounds__(LBRB_THREADS, LBRB_WAVES_PER_SIMD)
 #endif
 PRL_HD PRL_INLINE bool nh_is_two(const PrlRules& r) { return r.n_hole_cards == 2; }
-PRL_HD PRL_INLINE size_t lbrb_smem_bytes(int R) {
-    return ((size_t)(1 + LBRB_MAX_Q) * R + LBRB_MAX_Q * LBRB_MAX_BOARDS) * sizeof(float) + (size_t)R * 2 + 16 + (size_t)R * 2 + 16 + sizeof(LbrbShared) + 16 +
-           sizeof(LbrbLeaves) + 16 + (size_t)LBRB_MAX_Q * PRL_LBR_MAX_CARDS * sizeof(float) + (size_t)LBRB_MAX_Q * LBRB_MAX_BOARDS * sizeof(float) + 16 +
-           3 * sizeof(LbrbLeafMap) + 16 + (size_t)LBRB_PART_FLOATS * sizeof(float);
+PRL_HD PRL_INLINE size_t lbrb_smem_bytes(int R) {  // the carve-outs of prl_k_lbr_batch, in its order
+    const size_t sizes[] = {(size_t)R * 4, (size_t)LBRB_MAX_Q * R * 4, (size_t)LBRB_MAX_Q * LBRB_MAX_BOARDS * 4, (size_t)R * 2, (size_t)R * 2, sizeof(LbrbShared),
+                            sizeof(LbrbLeaves), (size_t)LBRB_MAX_Q * PRL_LBR_MAX_CARDS * 4, (size_t)LBRB_MAX_Q * LBRB_MAX_BOARDS * 4, 3 * sizeof(LbrbLeafMap),
+                            (size_t)LBRB_PART_FLOATS * 4, LBRB_MAX_Q * sizeof(unsigned), (size_t)R * 2};
+    size_t off = 0;
+    for (size_t b : sizes) off = ((off + 15) & ~(size_t)15) + b;
+    return off + 16;
 }
 PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
     char* lbrb_smem = prl_smem();
     const int R = P.rules.range_size, tid = (int)prl_tid();
-    float* rg = (float*)lbrb_smem;                 // [R] the agent's range
-    float* cand = rg + R;                          // [LBRB_MAX_Q][R] candidate ranges of a look-ahead
-    float* eq_lds = cand + (size_t)LBRB_MAX_Q * R;  // [LBRB_MAX_Q][LBRB_MAX_BOARDS]
-    uint16_t* cls_list = (uint16_t*)(eq_lds + LBRB_MAX_Q * LBRB_MAX_BOARDS);  // [R] the hands LBR beats (ascending), then the hands it ties with
+    // Every array is the LDS base plus a BYTE OFFSET (no pointer -> integer -> pointer round trips): the compiler has to see that these are LDS
+    // addresses. Through an integer cast they became generic pointers and every access to them a FLAT instruction -- slower than ds_read and,
+    // because FLAT operations count on both memory counters, each followed by a full s_waitcnt vmcnt(0) lgkmcnt(0): no two of them ever overlapped
+    // (rounds 1-3 had the hole-card table, the shared state and the card probabilities behind such pointers).
+    size_t lds_off = 0;
+    auto carve = [&](size_t bytes) { const size_t at = (lds_off + 15) & ~(size_t)15; lds_off = at + bytes; return lbrb_smem + at; };
+    float* rg = (float*)carve((size_t)R * 4);                        // [R] the agent's range
+    float* cand = (float*)carve((size_t)LBRB_MAX_Q * R * 4);         // [LBRB_MAX_Q][R] candidate ranges of a look-ahead
+    float* eq_lds = (float*)carve((size_t)LBRB_MAX_Q * LBRB_MAX_BOARDS * 4);  // [LBRB_MAX_Q][LBRB_MAX_BOARDS]
+    uint16_t* cls_list = (uint16_t*)carve((size_t)R * 2);            // [R] the hands LBR beats (ascending), then the hands it ties with
     uint8_t* cls = (uint8_t*)eq_lds;  // [R] class of every hand: lives in the equity rows, which are idle until the lists are built
     static_assert(LBRB_MAX_Q * LBRB_MAX_BOARDS * 4 >= 1326, "the class bytes fit the equity rows");
-    uint16_t* hole_lut = (uint16_t*)(((size_t)(cls_list + R) + 15) & ~(size_t)15);  // [R] c1 | c2 << 8
-    LbrbShared& S = *(LbrbShared*)(((size_t)(hole_lut + R) + 15) & ~(size_t)15);
-    LbrbLeaves& Lf = *(LbrbLeaves*)(((size_t)(&S + 1) + 15) & ~(size_t)15);
-    float* cpw = (float*)(((size_t)(&Lf + 1) + 15) & ~(size_t)15);  // [LBRB_MAX_Q][PRL_LBR_MAX_CARDS] card probabilities of the look-ahead
-    float* eq_b = cpw + LBRB_MAX_Q * PRL_LBR_MAX_CARDS;              // [LBRB_MAX_Q][LBRB_MAX_BOARDS] the tie sums of the equities under way
-    LbrbLeafMap* maps = (LbrbLeafMap*)(((size_t)(eq_b + LBRB_MAX_Q * LBRB_MAX_BOARDS) + 15) & ~(size_t)15);  // blocks of sums over R / n_big / n_eq elements
+    uint16_t* hole_lut = (uint16_t*)carve((size_t)R * 2);            // [R] c1 | c2 << 8
+    LbrbShared& S = *(LbrbShared*)carve(sizeof(LbrbShared));
+    LbrbLeaves& Lf = *(LbrbLeaves*)carve(sizeof(LbrbLeaves));
+    float* cpw = (float*)carve((size_t)LBRB_MAX_Q * PRL_LBR_MAX_CARDS * 4);  // [LBRB_MAX_Q][PRL_LBR_MAX_CARDS] card probabilities of the look-ahead
+    float* eq_b = (float*)carve((size_t)LBRB_MAX_Q * LBRB_MAX_BOARDS * 4);   // [LBRB_MAX_Q][LBRB_MAX_BOARDS] the tie sums of the equities under way
+    LbrbLeafMap* maps = (LbrbLeafMap*)carve(3 * sizeof(LbrbLeafMap));        // blocks of sums over R / n_big / n_eq elements
     LbrbLeafMap &MR = maps[0], &MB = maps[1], &ME = maps[2];
-    float* part = (float*)(((size_t)(maps + 3) + 15) & ~(size_t)15);  // [LBRB_PART_FLOATS] accumulator slots of lbrb_multi_sum
+    float* part = (float*)carve((size_t)LBRB_PART_FLOATS * 4);       // [LBRB_PART_FLOATS] accumulator slots of lbrb_multi_sum
+    unsigned* minpos = (unsigned*)carve(LBRB_MAX_Q * sizeof(unsigned));  // [LBRB_MAX_Q] bits of the smallest non-zero entry of every candidate range
+    uint16_t* hl2 = (uint16_t*)carve((size_t)R * 2);                 // [R] c1 | c2 << 8 of the hands the cards on the table leave, 0xFFFF for the others
     const bool coop = nh_is_two(P.rules) && R >= 64;  // the cooperative sums (hold'em ranges); tiny ranges keep one lane per sum
     if (tid == 0) lbrb_build_leaves(Lf, R);
     if (tid == 64) lbrb_build_leaf_map(MR, R);
@@ -485,6 +520,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                         int8_t fb0[5];
                         prl_lbr_board_at(g, S.pc, S.n_pc, 0, fb0);
                         if (tid == 0) { S.n_big = 0; S.n_eq = 0; }
+                        if (tid < LBRB_MAX_Q) minpos[tid] = 0x7F800000u;
                         prl_sync();
                         int nb1 = 0, ne1 = 0;
                         for (int h = tid; h < R; h += LBRB_THREADS) {
@@ -519,14 +555,21 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     // two lanes per raise, in different waves so that the two sums run side by side
                     if (coop) {
                         // 2 (n_q - 1) sums over the range: sum 2 (q - 1) = the fold probability of raise q, the next one its not-fold mass
-                        auto make = [&](int si) {
+                        auto run = [&](int si, float acc, bool from_first, int first, int stride, int cnt) {
                             const float* pf = cand + (size_t)(1 + (si >> 1)) * R;
                             const bool nf = (si & 1) != 0;
                             const float* r0 = rg;
-                            return [=](int k) { return nf ? r0[k] * (1.f - pf[k]) : r0[k] * pf[k]; };
+                            struct El {
+                                const float *r0, *pf; bool nf;
+                                PRL_DEV PRL_INLINE int index(int k) const { return k; }
+                                PRL_DEV PRL_INLINE void fetch(int k, unsigned& w, float& r) const { const float p = pf[k]; __builtin_memcpy(&w, &p, 4); r = r0[k]; }
+                                PRL_DEV PRL_INLINE float value(unsigned w, float r) const { float p; __builtin_memcpy(&p, &w, 4); return nf ? r * (1.f - p) : r * p; }
+                            };
+                            const El el = {r0, pf, nf};
+                            return lbrb_seq_add(acc, from_first, el, first, stride, cnt);
                         };
                         auto out = [&](int si, float v) { if (si & 1) S.notfold_total[1 + (si >> 1)] = v; else S.fold_prob[1 + (si >> 1)] = v; };
-                        lbrb_multi_sum(MR, 2 * (n_q - 1), part, make, out);
+                        lbrb_multi_sum(MR, 2 * (n_q - 1), part, run, out);
                     } else if (tid >= 1 && tid < n_q) {
                         const float* pf = cand + (size_t)tid * R;
                         int k = 0;
@@ -553,55 +596,111 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     if (coop) {
                         // pair p = (candidate q, board b). Three rounds of sums: the pair's normaliser (the range without the board's hands) into eq,
                         // its tie sum into eqb, its win sum -- and with it the equity -- into eq (prl_lbr_board_equity_lists, term for term).
+                        // Preparation, once per look-ahead: (1) the hole cards of the hands the cards ON THE TABLE leave (the others: 0xFFFF), so that
+                        // "the board blocks hand h" is two byte compares with the card(s) still to come instead of two 64-bit shifts of a board mask;
+                        // (2) the smallest non-zero entry of every candidate range: a candidate's entries sum to 1 within rounding and every
+                        // normaliser is a sum over a subset, so entries >= 1.001 * 2^-33 are inside the shared-reciprocal division's box for every board.
                         unsigned long long base = 0ull;
                         for (int i = 0; i < g.n_dealt; ++i) base |= 1ull << g.board[i];
+                        for (int h = tid; h < R; h += LBRB_THREADS) {
+                            const unsigned v = hole_lut[h];
+                            hl2[h] = (((base >> (v & 0xFFu)) | (base >> (v >> 8))) & 1ull) != 0ull ? (uint16_t)0xFFFFu : (uint16_t)v;
+                        }
+                        for (int q = 0; q < n_q; ++q) {
+                            unsigned mn = 0x7F800000u;
+                            for (int h = tid; h < R; h += LBRB_THREADS) {
+                                const float x = cand[(size_t)q * R + h];
+                                unsigned u;
+                                __builtin_memcpy(&u, &x, 4);
+                                mn = (u - 1u) < (mn - 1u) ? u : mn;  // non-negative floats order like their bits; 0 - 1 wraps to the maximum
+                            }
+                            for (int d = 32; d > 0; d >>= 1) {
+                                const unsigned o = (unsigned)prl_shfl_i((int)mn, (int)prl_lane() ^ d);
+                                mn = o < mn ? o : mn;
+                            }
+                            if (prl_lane() == 0) prl_lds_min_u(&minpos[q], mn);
+                        }
+                        prl_sync();
                         const int n_pairs = n_q * n_boards, n_big = S.n_big;
                         const float unif_r = (float)(1.0 / (double)R);
                         const int8_t* pcs = S.pc;
                         const int n_pc = S.n_pc, n_to_deal = g.n_to_deal;
-                        auto board_mask = [&](int b) {
-                            if (n_to_deal == 0) return base;
-                            if (n_to_deal == 1) return base | (1ull << pcs[b]);
-                            int i = 0, left = b;
-                            while (left >= n_pc - 1 - i) { left -= n_pc - 1 - i; ++i; }
-                            return base | (1ull << pcs[i]) | (1ull << pcs[i + 1 + left]);
+                        // the card(s) still to come on board b, 0xFE where there is none (never a hole card)
+                        auto new_cards = [&](int b, unsigned& x, unsigned& y) {
+                            x = 0xFEu; y = 0xFEu;
+                            if (n_to_deal == 1) x = (unsigned)pcs[b];
+                            else if (n_to_deal == 2) {
+                                int i = 0, left = b;
+                                while (left >= n_pc - 1 - i) { left -= n_pc - 1 - i; ++i; }
+                                x = (unsigned)pcs[i]; y = (unsigned)pcs[i + 1 + left];
+                            }
                         };
-                        auto make_norm = [&](int p) {
-                            const int q = p / n_boards, b = p - q * n_boards;
-                            const unsigned long long bm = board_mask(b);
-                            const float* r0 = cand + (size_t)q * R;
-                            const uint16_t* hl = hole_lut;
-                            return [=](int h) {
-                                const unsigned v = hl[h];
-                                return (((bm >> (v & 0xFFu)) | (bm >> (v >> 8))) & 1ull) != 0ull ? 0.f : r0[h];
+                        auto equities = [&](auto ntd_tag) {
+                            constexpr int NTD = decltype(ntd_tag)::value;  // cards to come: the element functions compare with that many
+                            // MODE 0: the range entry of a hand the board leaves, else 0 (the normaliser's terms); 1: that over the pair's normaliser by the
+                            // shared-reciprocal division; 2: by the generic division; 3: the constant 1 / R (an all-zero range counts as the uniform one)
+                            struct ElBase {
+                                const uint16_t *hl, *list; const float* r0; unsigned x, y; LbrbDiv dv; float unif;
+                                PRL_DEV PRL_INLINE void fetch(int h, unsigned& w, float& r) const { w = hl[h]; r = r0[h]; }
+                                PRL_DEV PRL_INLINE float live(unsigned v, float r) const {
+                                    const unsigned c1 = v & 0xFFu, c2 = v >> 8;
+                                    bool blocked = v == 0xFFFFu;
+                                    if (NTD >= 1) blocked = blocked | (c1 == x) | (c2 == x);
+                                    if (NTD >= 2) blocked = blocked | (c1 == y) | (c2 == y);
+                                    return blocked ? 0.f : r;
+                                }
                             };
-                        };
-                        auto out_norm = [&](int p, float v) { const int q = p / n_boards; eq[q * eq_stride + (p - q * n_boards)] = v; };
-                        lbrb_multi_sum(MR, n_pairs, part, make_norm, out_norm);
-                        auto make_cls = [&](int p, int off) {
-                            const int q = p / n_boards, b = p - q * n_boards;
-                            const unsigned long long bm = board_mask(b);
-                            const float* r0 = cand + (size_t)q * R;
-                            const uint16_t* hl = hole_lut;
-                            const uint16_t* list = cls_list + off;
-                            const float norm = eq[q * eq_stride + b];
-                            const LbrbDiv dv = lbrb_div_by(norm);
-                            return [=](int i) {
-                                const int h = (int)list[i];
-                                const unsigned v = hl[h];
-                                const float x = (((bm >> (v & 0xFFu)) | (bm >> (v >> 8))) & 1ull) != 0ull ? 0.f : r0[h];
-                                return norm == 0.f ? unif_r : dv(x);
+                            struct ElNorm : ElBase {
+                                PRL_DEV PRL_INLINE int index(int h) const { return h; }
+                                PRL_DEV PRL_INLINE float value(unsigned w, float r) const { return this->live(w, r); }
                             };
+                            struct ElFast : ElBase {
+                                PRL_DEV PRL_INLINE int index(int i) const { return (int)this->list[i]; }
+                                PRL_DEV PRL_INLINE float value(unsigned w, float r) const { return this->dv.fast(this->live(w, r)); }
+                            };
+                            struct ElSlow : ElBase {
+                                PRL_DEV PRL_INLINE int index(int i) const { return (int)this->list[i]; }
+                                PRL_DEV PRL_INLINE float value(unsigned w, float r) const { return this->live(w, r) / this->dv.b; }
+                            };
+                            struct ElUnif : ElBase {
+                                PRL_DEV PRL_INLINE int index(int i) const { return (int)this->list[i]; }
+                                PRL_DEV PRL_INLINE float value(unsigned, float) const { return this->unif; }
+                            };
+                            auto run_norm = [&](int p, float acc, bool from_first, int first, int stride, int cnt) {
+                                const int q = p / n_boards, b = p - q * n_boards;
+                                ElNorm el;
+                                new_cards(b, el.x, el.y);
+                                el.r0 = cand + (size_t)q * R; el.hl = hl2; el.list = cls_list; el.unif = unif_r; el.dv = lbrb_div_by(1.f, false);
+                                return lbrb_seq_add(acc, from_first, el, first, stride, cnt);
+                            };
+                            auto out_norm = [&](int p, float v) { const int q = p / n_boards; eq[q * eq_stride + (p - q * n_boards)] = v; };
+                            lbrb_multi_sum(MR, n_pairs, part, run_norm, out_norm);
+                            // the division variant is picked per call, outside the element function (a branch inside it would fence the fetches)
+                            auto run_cls = [&](int p, int off, float acc, bool from_first, int first, int stride, int cnt) {
+                                const int q = p / n_boards, b = p - q * n_boards;
+                                const float norm = eq[q * eq_stride + b];
+                                ElBase e;
+                                new_cards(b, e.x, e.y);
+                                e.r0 = cand + (size_t)q * R; e.hl = hl2; e.list = cls_list + off; e.unif = unif_r;
+                                e.dv = lbrb_div_by(norm, norm <= 1.00125f && minpos[q] >= 0x2F0028F6u /* 1.00125 * 2^-33: >= 2^-33 norm */);
+                                if (norm == 0.f) { ElUnif el; (ElBase&)el = e; return lbrb_seq_add(acc, from_first, el, first, stride, cnt); }
+                                if (e.dv.box) { ElFast el; (ElBase&)el = e; return lbrb_seq_add(acc, from_first, el, first, stride, cnt); }
+                                ElSlow el; (ElBase&)el = e;
+                                return lbrb_seq_add(acc, from_first, el, first, stride, cnt);
+                            };
+                            auto run_eq = [&](int p, float acc, bool from_first, int first, int stride, int cnt) { return run_cls(p, n_big, acc, from_first, first, stride, cnt); };
+                            auto out_eq = [&](int p, float v) { const int q = p / n_boards; eqb[q * eq_stride + (p - q * n_boards)] = v; };
+                            lbrb_multi_sum(ME, n_pairs, part, run_eq, out_eq);
+                            auto run_big = [&](int p, float acc, bool from_first, int first, int stride, int cnt) { return run_cls(p, 0, acc, from_first, first, stride, cnt); };
+                            auto out_big = [&](int p, float v) {
+                                const int q = p / n_boards, at = q * eq_stride + (p - q * n_boards);
+                                eq[at] = v + eqb[at] / 2.0f;
+                            };
+                            lbrb_multi_sum(MB, n_pairs, part, run_big, out_big);
                         };
-                        auto make_eq = [&](int p) { return make_cls(p, n_big); };
-                        auto out_eq = [&](int p, float v) { const int q = p / n_boards; eqb[q * eq_stride + (p - q * n_boards)] = v; };
-                        lbrb_multi_sum(ME, n_pairs, part, make_eq, out_eq);
-                        auto make_big = [&](int p) { return make_cls(p, 0); };
-                        auto out_big = [&](int p, float v) {
-                            const int q = p / n_boards, at = q * eq_stride + (p - q * n_boards);
-                            eq[at] = v + eqb[at] / 2.0f;
-                        };
-                        lbrb_multi_sum(MB, n_pairs, part, make_big, out_big);
+                        if (n_to_deal == 0) equities(std::integral_constant<int, 0>());
+                        else if (n_to_deal == 1) equities(std::integral_constant<int, 1>());
+                        else equities(std::integral_constant<int, 2>());
                     } else {
                         for (int t = tid; t < n_q * n_boards; t += LBRB_THREADS) {
                             const int q = t / n_boards, b = t % n_boards;
