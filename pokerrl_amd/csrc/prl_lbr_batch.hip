@@ -226,8 +226,8 @@ PRL_DEV PRL_INLINE void lbrb_normalize(float* rg, int R, LbrbLeaves& Lf, LbrbSha
 // normalised range over the hands LBR beats; over the hands it ties with). One lane per equity -- the first design -- walks 3500 elements in a
 // row on 368 of the 576 lanes (turn: 8 candidates x 46 boards) and on 8 of them on the river: half of a hand's clocks (profiles/r08_lbr_phases.txt).
 // NumPy's association is a tree, though: blocks of <= 128 elements with eight strided accumulators each, blocks added pairwise up the halving
-// recursion. So the unit of work is one ACCUMULATOR CHAIN (<= 16 elements) of one block of one sum: all lanes take chains of all sums, a second
-// step folds the eight accumulators of a block and adds its tail, a third adds a sum's blocks in the recursion's order. Same values, same order.
+// recursion. So the unit of work is one BLOCK of one sum (<= 128 elements, eight accumulators side by side, its tail): all lanes take blocks of
+// all sums, a second step adds a sum's blocks in the recursion's order. Same values, same order.
 struct LbrbLeafMap { int n, n_leaves; int lo[LBRB_MAX_LEAVES], m[LBRB_MAX_LEAVES]; };
 PRL_DEV PRL_INLINE void lbrb_build_leaf_map(LbrbLeafMap& M, int n) {  // one thread
     M.n = n; M.n_leaves = 0;
@@ -245,82 +245,106 @@ PRL_DEV PRL_INLINE void lbrb_build_leaf_map(LbrbLeafMap& M, int n) {  // one thr
     }
     M.n_leaves = nl;
 }
-// the blocks' sums added in the recursion's order (left half + right half, post-order); sums[leaf * 8] is block number `leaf`
+// the blocks' sums added in the recursion's order (left half + right half, post-order); sums[leaf] is block number `leaf`
 template <int DEPTH>
 PRL_DEV PRL_INLINE float lbrb_comb(int n, const float* sums, int& leaf) {
-    if (DEPTH == 0 || n <= 128) return sums[(leaf++) * 8];
+    if (DEPTH == 0 || n <= 128) return sums[leaf++];
     int n2 = n / 2;
     n2 -= n2 % 8;
     const float l = lbrb_comb<(DEPTH > 0 ? DEPTH - 1 : 0)>(n2, sums, leaf);
     const float r = lbrb_comb<(DEPTH > 0 ? DEPTH - 1 : 0)>(n - n2, sums, leaf);
     return l + r;
 }
-// acc + e(first) + e(first + stride) + ... (cnt elements, added in this order). An element is two or three DEPENDENT LDS gathers (index list ->
-// hole cards and range entry) and the compiler neither pipelines the loop nor interleaves inlined element functions, so one element at a time costs
-// the full latency every time (measured: 300 clocks per element with 2.25 waves per SIMD to hide it). Elements are therefore handled FOUR AT A
-// TIME and in three explicit stages -- four indices, four fetches, four values -- with scheduling fences between the stages. The element type gives
+// Eight elements at a time, in three explicit stages with scheduling fences between them: an element is two or three DEPENDENT LDS gathers
+// (index list -> hole cards and range entry) and the compiler neither pipelines the loop nor interleaves inlined element functions -- one element
+// at a time costs the full latency every time (measured: 300 clocks per element with 2.25 waves per SIMD to hide it). The element type gives
 //   int index(int i)                         which entry (a hand) element i is
 //   void fetch(int h, unsigned& w, float& r)  the loads
 //   float value(unsigned w, float r)          straight-line arithmetic (a branch per element would fence the fetches again)
-// The last group is predicated: its surplus slots repeat the group's first element and are not added.
-// from_first: the sum STARTS with the first element (an accumulator of a block) instead of being added to acc.
+// elements first .. first + 7; slots >= valid repeat element `first` (their values are ignored by the callers)
 #if defined(PRL_EMU)
 #define LBRB_STAGE_FENCE() do { } while (0)
 #else
 #define LBRB_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 template <class El>
-PRL_DEV PRL_INLINE float lbrb_seq_add(float acc, bool from_first, const El& el, int first, int stride, int cnt) {
-    for (int k = 0; k < cnt; k += 4) {
-        const int rem = cnt - k, at = first + stride * k;
-        const int h0 = el.index(at), h1 = el.index(rem > 1 ? at + stride : at), h2 = el.index(rem > 2 ? at + 2 * stride : at),
-                  h3 = el.index(rem > 3 ? at + 3 * stride : at);
-        LBRB_STAGE_FENCE();
-        unsigned w0, w1, w2, w3;
-        float r0, r1, r2, r3;
-        el.fetch(h0, w0, r0); el.fetch(h1, w1, r1); el.fetch(h2, w2, r2); el.fetch(h3, w3, r3);
-        LBRB_STAGE_FENCE();
-        const float v0 = el.value(w0, r0), v1 = el.value(w1, r1), v2 = el.value(w2, r2), v3 = el.value(w3, r3);
-        acc = (from_first && k == 0) ? v0 : acc + v0;
-        acc = rem > 1 ? acc + v1 : acc;
-        acc = rem > 2 ? acc + v2 : acc;
-        acc = rem > 3 ? acc + v3 : acc;
-    }
-    return acc;
+PRL_DEV PRL_INLINE void lbrb_eight(const El& el, int first, int valid, float (&v)[8]) {
+    int h[8];
+    unsigned w[8];
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h[k] = el.index(k < valid ? first + k : first);
+    LBRB_STAGE_FENCE();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) el.fetch(h[k], w[k], r[k]);
+    LBRB_STAGE_FENCE();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = el.value(w[k], r[k]);
 }
-#define LBRB_PART_FLOATS 12288  // 48 KB of accumulator slots: 96 sums of 16 blocks per round
-// run(s, acc, from_first, first, stride, cnt) adds cnt elements of sum s (first, first + stride, ...) in order -- normally lbrb_seq_add over the sum's
-// element function, possibly one of several variants picked per call; out(s, total) receives the result. Every lane of the workgroup calls this.
+// a block of NumPy's pairwise sum: elements lo .. lo + m - 1, 8 <= m <= 128
+template <class El>
+PRL_DEV PRL_INLINE float lbrb_block_sum(const El& el, int lo, int m) {
+    float r[8], t[8];
+    lbrb_eight(el, lo, 8, r);
+    const int m8 = m & ~7;
+    for (int i = 8; i < m8; i += 8) {
+        lbrb_eight(el, lo + i, 8, t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = r[k] + t[k];
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    const int tail = m & 7;
+    if (tail) {
+        lbrb_eight(el, lo + m8, tail, t);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) res = k < tail ? res + t[k] : res;
+    }
+    return res;
+}
+// fewer than eight elements: 0 + e(0) + e(1) + ...
+template <class El>
+PRL_DEV PRL_INLINE float lbrb_small_sum(const El& el, int n) {
+    float res = 0.f, t[8];
+    if (n > 0) {
+        lbrb_eight(el, 0, n, t);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) res = k < n ? res + t[k] : res;
+    }
+    return res;
+}
+// t / d by one multiply-high: exact while t * d < 2^32 (here t < 2^16, d < 2^11)
+struct LbrbMagic {
+    uint32_t m;  // ceil(2^32 / d); 0 stands for d = 1 (2^32 does not fit)
+    PRL_DEV PRL_INLINE int div(int t) const { return m == 0u ? t : (int)(uint32_t)(((unsigned long long)(uint32_t)t * m) >> 32); }
+};
+PRL_DEV PRL_INLINE LbrbMagic lbrb_magic(int d) {
+    LbrbMagic g;
+    g.m = d <= 1 ? 0u : (uint32_t)((0x100000000ull + (unsigned long long)d - 1ull) / (unsigned long long)d);
+    return g;
+}
+#define LBRB_PART_FLOATS 12288  // 48 KB of block sums: every (sum, block) of a turn look-ahead in one round
+// run(s, f) builds the element type of sum s (possibly one of several variants) and returns f(el); out(s, total) receives the result. Every lane of the
+// workgroup calls this.
 template <class Run, class Out>
 PRL_DEV PRL_INLINE void lbrb_multi_sum(const LbrbLeafMap& M, int n_sums, float* part, Run run, Out out) {
     const int tid = (int)prl_tid(), n = M.n;
     if (n < 8) {
-        for (int s = tid; s < n_sums; s += LBRB_THREADS) {
-            out(s, run(s, 0.f, false, 0, 1, n));
-        }
+        for (int s = tid; s < n_sums; s += LBRB_THREADS) out(s, run(s, [&](const auto& el) { return lbrb_small_sum(el, n); }));
         prl_sync();
         return;
     }
-    const int L = M.n_leaves, per = L * 8, chunk = LBRB_PART_FLOATS / per;
+    const int L = M.n_leaves, chunk = LBRB_PART_FLOATS / L;
+    const LbrbMagic by_l = lbrb_magic(L);
     for (int s0 = 0; s0 < n_sums; s0 += chunk) {
         const int ns = n_sums - s0 < chunk ? n_sums - s0 : chunk;
-        for (int t = tid; t < ns * per; t += LBRB_THREADS) {  // accumulator j of block `leaf` of sum s0 + sl
-            const int sl = t / per, r = t - sl * per, leaf = r >> 3, j = r & 7;
-            part[t] = run(s0 + sl, 0.f, true, M.lo[leaf] + j, 8, M.m[leaf] >> 3);
-        }
-        prl_sync();
-        for (int t = tid; t < ns * L; t += LBRB_THREADS) {  // a block: its eight accumulators, then its tail
-            const int sl = t / L, leaf = t - sl * L;
-            float* r = part + (size_t)t * 8;
-            float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-            const int lo = M.lo[leaf], m = M.m[leaf];
-            if (m & 7) res = run(s0 + sl, res, false, lo + (m & ~7), 1, m & 7);
-            r[0] = res;
+        for (int t = tid; t < ns * L; t += LBRB_THREADS) {  // block `leaf` of sum s0 + sl
+            const int sl = by_l.div(t), leaf = t - sl * L, lo = M.lo[leaf], m = M.m[leaf];
+            part[t] = run(s0 + sl, [&](const auto& el) { return lbrb_block_sum(el, lo, m); });
         }
         prl_sync();
         for (int sl = tid; sl < ns; sl += LBRB_THREADS) {
             int leaf = 0;
-            out(s0 + sl, lbrb_comb<6>(n, part + (size_t)sl * per, leaf));
+            out(s0 + sl, lbrb_comb<6>(n, part + (size_t)sl * L, leaf));
         }
         prl_sync();
     }
@@ -555,7 +579,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     // two lanes per raise, in different waves so that the two sums run side by side
                     if (coop) {
                         // 2 (n_q - 1) sums over the range: sum 2 (q - 1) = the fold probability of raise q, the next one its not-fold mass
-                        auto run = [&](int si, float acc, bool from_first, int first, int stride, int cnt) {
+                        auto run = [&](int si, auto f) {
                             const float* pf = cand + (size_t)(1 + (si >> 1)) * R;
                             const bool nf = (si & 1) != 0;
                             const float* r0 = rg;
@@ -566,7 +590,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                                 PRL_DEV PRL_INLINE float value(unsigned w, float r) const { float p; __builtin_memcpy(&p, &w, 4); return nf ? r * (1.f - p) : r * p; }
                             };
                             const El el = {r0, pf, nf};
-                            return lbrb_seq_add(acc, from_first, el, first, stride, cnt);
+                            return f(el);
                         };
                         auto out = [&](int si, float v) { if (si & 1) S.notfold_total[1 + (si >> 1)] = v; else S.fold_prob[1 + (si >> 1)] = v; };
                         lbrb_multi_sum(MR, 2 * (n_q - 1), part, run, out);
@@ -666,34 +690,35 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                                 PRL_DEV PRL_INLINE int index(int i) const { return (int)this->list[i]; }
                                 PRL_DEV PRL_INLINE float value(unsigned, float) const { return this->unif; }
                             };
-                            auto run_norm = [&](int p, float acc, bool from_first, int first, int stride, int cnt) {
-                                const int q = p / n_boards, b = p - q * n_boards;
+                            const LbrbMagic by_boards = lbrb_magic(n_boards);
+                            auto run_norm = [&](int p, auto f) {
+                                const int q = by_boards.div(p), b = p - q * n_boards;
                                 ElNorm el;
                                 new_cards(b, el.x, el.y);
                                 el.r0 = cand + (size_t)q * R; el.hl = hl2; el.list = cls_list; el.unif = unif_r; el.dv = lbrb_div_by(1.f, false);
-                                return lbrb_seq_add(acc, from_first, el, first, stride, cnt);
+                                return f(el);
                             };
-                            auto out_norm = [&](int p, float v) { const int q = p / n_boards; eq[q * eq_stride + (p - q * n_boards)] = v; };
+                            auto out_norm = [&](int p, float v) { const int q = by_boards.div(p); eq[q * eq_stride + (p - q * n_boards)] = v; };
                             lbrb_multi_sum(MR, n_pairs, part, run_norm, out_norm);
                             // the division variant is picked per call, outside the element function (a branch inside it would fence the fetches)
-                            auto run_cls = [&](int p, int off, float acc, bool from_first, int first, int stride, int cnt) {
-                                const int q = p / n_boards, b = p - q * n_boards;
+                            auto run_cls = [&](int p, int off, auto f) {
+                                const int q = by_boards.div(p), b = p - q * n_boards;
                                 const float norm = eq[q * eq_stride + b];
                                 ElBase e;
                                 new_cards(b, e.x, e.y);
                                 e.r0 = cand + (size_t)q * R; e.hl = hl2; e.list = cls_list + off; e.unif = unif_r;
                                 e.dv = lbrb_div_by(norm, norm <= 1.00125f && minpos[q] >= 0x2F0028F6u /* 1.00125 * 2^-33: >= 2^-33 norm */);
-                                if (norm == 0.f) { ElUnif el; (ElBase&)el = e; return lbrb_seq_add(acc, from_first, el, first, stride, cnt); }
-                                if (e.dv.box) { ElFast el; (ElBase&)el = e; return lbrb_seq_add(acc, from_first, el, first, stride, cnt); }
+                                if (norm == 0.f) { ElUnif el; (ElBase&)el = e; return f(el); }
+                                if (e.dv.box) { ElFast el; (ElBase&)el = e; return f(el); }
                                 ElSlow el; (ElBase&)el = e;
-                                return lbrb_seq_add(acc, from_first, el, first, stride, cnt);
+                                return f(el);
                             };
-                            auto run_eq = [&](int p, float acc, bool from_first, int first, int stride, int cnt) { return run_cls(p, n_big, acc, from_first, first, stride, cnt); };
-                            auto out_eq = [&](int p, float v) { const int q = p / n_boards; eqb[q * eq_stride + (p - q * n_boards)] = v; };
+                            auto run_eq = [&](int p, auto f) { return run_cls(p, n_big, f); };
+                            auto out_eq = [&](int p, float v) { const int q = by_boards.div(p); eqb[q * eq_stride + (p - q * n_boards)] = v; };
                             lbrb_multi_sum(ME, n_pairs, part, run_eq, out_eq);
-                            auto run_big = [&](int p, float acc, bool from_first, int first, int stride, int cnt) { return run_cls(p, 0, acc, from_first, first, stride, cnt); };
+                            auto run_big = [&](int p, auto f) { return run_cls(p, 0, f); };
                             auto out_big = [&](int p, float v) {
-                                const int q = p / n_boards, at = q * eq_stride + (p - q * n_boards);
+                                const int q = by_boards.div(p), at = q * eq_stride + (p - q * n_boards);
                                 eq[at] = v + eqb[at] / 2.0f;
                             };
                             lbrb_multi_sum(MB, n_pairs, part, run_big, out_big);
