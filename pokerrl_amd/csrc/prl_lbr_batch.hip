@@ -350,6 +350,25 @@ PRL_DEV PRL_INLINE void lbrb_multi_sum(const LbrbLeafMap& M, int n_sums, float* 
     }
 }
 
+// PokerRange.normalize on the block machinery: the range's sixteen blocks on sixteen lanes (eight elements in flight each), the blocks added in
+// registers. The first version (lbrb_wg_sum) walks the recursion with a frame array indexed at run time -- private memory, a vector-memory round
+// trip per push / pop on one lane while the workgroup waits -- and it runs after every agent action and every deal.
+struct LbrbPlainEl {
+    const float* a;
+    PRL_DEV PRL_INLINE int index(int i) const { return i; }
+    PRL_DEV PRL_INLINE void fetch(int i, unsigned& w, float& r) const { w = 0u; r = a[i]; }
+    PRL_DEV PRL_INLINE float value(unsigned, float r) const { return r; }
+};
+PRL_DEV PRL_INLINE void lbrb_normalize_blocks(float* rg, int R, const LbrbLeafMap& MR, float* part, LbrbShared& S) {
+    prl_sync();
+    auto run = [&](int, auto f) { const LbrbPlainEl el = {rg}; return f(el); };
+    auto out = [&](int, float v) { S.total = v; };
+    lbrb_multi_sum(MR, 1, part, run, out);
+    const float t = S.total, unif = (float)(1.0 / (double)R);
+    for (int h = (int)prl_tid(); h < R; h += LBRB_THREADS) rg[h] = t == 0.f ? unif : rg[h] / t;
+    prl_sync();
+}
+
 // x / b, correctly rounded, for many x and one b: the reciprocal is refined once, a quotient is a multiply and two residual corrections -- the
 // instruction sequence of the generic float32 division minus its range scaling and special-case fix-up, which are the identity when b, the
 // quotient and the residuals stay in the normal range (prl_fhp_div.inc has the argument and scripts/ubench/div_check.hip the exhaustive-style
@@ -461,7 +480,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
             for (int i = 0; i < nh; ++i) m |= 1ull << lbr_hand[i];
             for (int h = tid; h < R; h += LBRB_THREADS) rg[h] = (prl_lbr_hand_mask(hg, h, hole_lut) & m) ? 0.f : unif;
         }
-        lbrb_normalize(rg, R, Lf, S);
+        if (coop) lbrb_normalize_blocks(rg, R, MR, part, S); else lbrb_normalize(rg, R, Lf, S);
         LBRB_TICK(0);  // reset + range init
 
         while (true) {
@@ -482,7 +501,8 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                         if (nh == 2 && g.lbr_hand[0] > g.lbr_hand[1]) { const int8_t t = g.lbr_hand[0]; g.lbr_hand[0] = g.lbr_hand[1]; g.lbr_hand[1] = t; }
                         S.n_pc = prl_lbr_possible_cards(g, S.pc);
                         S.n_boards = prl_lbr_n_boards(g);
-                        S.n_legal = prl_legal_actions(P.g_lbr, S.st, S.legal);
+                        const PrlEnvState st0 = S.st;
+                        S.n_legal = prl_legal_actions(P.g_lbr, st0, S.legal);
                     }
                     prl_sync();
                     {
@@ -547,8 +567,10 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                         if (tid < LBRB_MAX_Q) minpos[tid] = 0x7F800000u;
                         prl_sync();
                         int nb1 = 0, ne1 = 0;
+                        const int32_t rl = prl_lbr_rank(g, S.lbr_idx, fb0);  // LBR's own rank: once per lane, not once per hand
                         for (int h = tid; h < R; h += LBRB_THREADS) {
-                            const uint8_t c = prl_lbr_classify_hand(g, S.lbr_idx, h, fb0);
+                            const int32_t rh = prl_lbr_rank(g, h, fb0);
+                            const uint8_t c = rh < rl ? 1 : (rh == rl ? 2 : 0);  // prl_lbr_classify_hand
                             cls[h] = c;
                             nb1 += c == 1; ne1 += c == 2;
                         }
@@ -779,16 +801,21 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                 }
                 prl_sync();  // every lane has read the state it branched on (seat to act, round) before lane 0 steps the env
                 if (tid == 0) {
+                    PrlEnvState st = S.st;
+                    PrlStepInfo inf;
                     if (!P.limit && action >= 2) {  // step by pot fraction (:287-289)
-                        const int amt = prl_fraction_of_pot_raise(S.st, P.g_lbr.bet_fracs[action - 2], S.st.cur);
-                        prl_env_step_processed(P.g_lbr, S.st, PRL_BET_RAISE, amt, &S.info);
-                    } else prl_env_step(P.g_lbr, S.st, action, &S.info);
+                        const int amt = prl_fraction_of_pot_raise(st, P.g_lbr.bet_fracs[action - 2], st.cur);
+                        prl_env_step_processed(P.g_lbr, st, PRL_BET_RAISE, amt, &inf);
+                    } else prl_env_step(P.g_lbr, st, action, &inf);
+                    S.st = st;
+                    S.info = inf;
                 }
             } else {
                 // ---------------- the agent acts: draw its action, Bayes-update its range (:156-160, :272-281) --------------
                 if (tid == 0) {
-                    S.n_legal = prl_legal_actions(P.g_agent, S.st, S.legal);
-                    S.key = lbrb_state_key(P.seed, S.st, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
+                    const PrlEnvState st = S.st;  // one batch of LDS reads; the engine then works on registers (stores to S.legal may alias S.st otherwise)
+                    S.n_legal = prl_legal_actions(P.g_agent, st, S.legal);
+                    S.key = lbrb_state_key(P.seed, st, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
                     const int hi = lbrb_hand_idx(P.rules, agent_hand);
                     const uint32_t x = lbrb_mix32(P.seed * 0x51ED27u + episode * 0x9E3779B1u + (uint32_t)S.step_ctr);
                     const float u = (float)(x >> 8) / 16777216.0f;
@@ -799,12 +826,16 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                 prl_sync();
                 const int a = S.action;
                 for (int h = tid; h < R; h += LBRB_THREADS) rg[h] = rg[h] * lbrb_agent_prob(P.agent_kind, S.key, h, S.legal, S.n_legal, a);
-                lbrb_normalize(rg, R, Lf, S);
+                if (coop) lbrb_normalize_blocks(rg, R, MR, part, S); else lbrb_normalize(rg, R, Lf, S);
                 if (tid == 0) {
+                    PrlEnvState st = S.st;
+                    PrlStepInfo inf;
                     if (!P.limit && a >= 2) {
-                        const int amt = prl_fraction_of_pot_raise(S.st, P.g_agent.bet_fracs[a - 2], S.st.cur);
-                        prl_env_step_processed(P.g_lbr, S.st, PRL_BET_RAISE, amt, &S.info);
-                    } else prl_env_step(P.g_lbr, S.st, a, &S.info);
+                        const int amt = prl_fraction_of_pot_raise(st, P.g_agent.bet_fracs[a - 2], st.cur);
+                        prl_env_step_processed(P.g_lbr, st, PRL_BET_RAISE, amt, &inf);
+                    } else prl_env_step(P.g_lbr, st, a, &inf);
+                    S.st = st;
+                    S.info = inf;
                 }
             }
             prl_sync();
@@ -846,7 +877,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                 for (int i = nd - n_new; i < nd; ++i) m |= 1ull << S.board[i];
                 for (int h = tid; h < R; h += LBRB_THREADS)
                     if (prl_lbr_hand_mask(hg, h, hole_lut) & m) rg[h] = 0.f;
-                lbrb_normalize(rg, R, Lf, S);
+                if (coop) lbrb_normalize_blocks(rg, R, MR, part, S); else lbrb_normalize(rg, R, Lf, S);
             }
             LBRB_TICK(9);  // after the step: dealing / range update / payout
         }
