@@ -334,12 +334,15 @@ PRL_DEV PRL_INLINE void lbrb_multi_sum(const LbrbLeafMap& M, int n_sums, float* 
         return;
     }
     const int L = M.n_leaves, chunk = LBRB_PART_FLOATS / L;
-    const LbrbMagic by_l = lbrb_magic(L);
     for (int s0 = 0; s0 < n_sums; s0 += chunk) {
         const int ns = n_sums - s0 < chunk ? n_sums - s0 : chunk;
-        for (int t = tid; t < ns * L; t += LBRB_THREADS) {  // block `leaf` of sum s0 + sl
-            const int sl = by_l.div(t), leaf = t - sl * L, lo = M.lo[leaf], m = M.m[leaf];
-            part[t] = run(s0 + sl, [&](const auto& el) { return lbrb_block_sum(el, lo, m); });
+        const LbrbMagic by_ns = lbrb_magic(ns);
+        // block `leaf` of sum s0 + sl, the SUM index fastest: the lanes of a wave then walk the same block of neighbouring sums -- the same hands at
+        // the same moment, so their gathers hit the same few LDS words (broadcasts). With the block index fastest, neighbouring lanes started
+        // ~80 elements apart (80 mod 64 banks = 16): 16 lanes per bank, 59 % of the LDS cycles were conflicts (profiles/r15_lbr_pmc_sq.txt).
+        for (int t = tid; t < ns * L; t += LBRB_THREADS) {
+            const int leaf = by_ns.div(t), sl = t - leaf * ns, lo = M.lo[leaf], m = M.m[leaf];
+            part[sl * L + leaf] = run(s0 + sl, [&](const auto& el) { return lbrb_block_sum(el, lo, m); });
         }
         prl_sync();
         for (int sl = tid; sl < ns; sl += LBRB_THREADS) {

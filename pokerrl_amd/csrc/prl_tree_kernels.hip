@@ -561,9 +561,13 @@ PRL_DEV PRL_INLINE void prl_small_ev(const PrlDevTree& T, const PrlDevState& S, 
     prl_exploitability_body(T, S, S.expl);
     prl_sync();
 }
+// IN_LDS is a template argument so that, in the instantiation that iterates on LDS, every state pointer is VISIBLY an LDS address (base of the
+// dynamic LDS + offset on every path): behind a run-time choice between the HBM and the LDS copy the pointers are generic, every access a FLAT
+// instruction that waits on both memory counters, and nothing overlaps (the kernel had 212 of them).
+template <bool IN_LDS>
 PRL_DEV PRL_INLINE void prl_small_iterations_body(const PrlDevTree& T, const PrlDevState& SG, const PrlSmallIterArgs& A) {
     PrlDevState S = SG;
-    if (A.state_in_lds) prl_small_state_lds(T, SG, A.n_cols, S, 0);
+    if (IN_LDS) prl_small_state_lds(T, SG, A.n_cols, S, 0);
     for (int k = 0; k < A.n_iters; ++k) {
         if (prl_tid() == 0) {  // prl_k_iter_begin
             const int it = A.ip->iter;
@@ -603,9 +607,12 @@ PRL_DEV PRL_INLINE void prl_small_iterations_body(const PrlDevTree& T, const Prl
         }
         prl_sync();
     }
-    if (A.state_in_lds) prl_small_state_lds(T, SG, A.n_cols, S, 1);
+    if (IN_LDS) prl_small_state_lds(T, SG, A.n_cols, S, 1);
 }
-PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations(PrlDevTree T, PrlDevState SG, PrlSmallIterArgs A) { prl_small_iterations_body(T, SG, A); }
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations(PrlDevTree T, PrlDevState SG, PrlSmallIterArgs A) {
+    if (A.state_in_lds) prl_small_iterations_body<true>(T, SG, A);
+    else prl_small_iterations_body<false>(T, SG, A);
+}
 // many independent small trees at once, one workgroup (= one CU) per solve: jobs[blockIdx.y]
 PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations_many(const PrlSmallJob* jobs) {
     const PrlSmallJob& J = jobs[prl_bid_y()];  // launched 1 x n_jobs: the per-item bodies below see a grid of ONE workgroup
@@ -615,7 +622,8 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations_many(const PrlSma
     A.level_start = J.level_start; A.term_nodes = J.term_nodes; A.n_term = J.n_term;
     A.nodes_p[0] = J.nodes_p[0]; A.nodes_p[1] = J.nodes_p[1]; A.n_nodes_p[0] = J.n_nodes_p[0]; A.n_nodes_p[1] = J.n_nodes_p[1];
     A.variant = J.variant; A.delay = J.delay; A.n_iters = J.n_iters; A.state_in_lds = J.state_in_lds; A.n_cols = J.n_cols; A.ip = J.ip;
-    prl_small_iterations_body(T, SG, A);
+    if (A.state_in_lds) prl_small_iterations_body<true>(T, SG, A);
+    else prl_small_iterations_body<false>(T, SG, A);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
