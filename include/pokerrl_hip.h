@@ -423,7 +423,7 @@ enum {
 int32_t prl_solver_get(prl_solver_t* solver, int32_t field, void* out);
 /* n_cols action columns of a per-action-column field (REGRET, AVG, AVG_SUM) starting at flat-tree column col_begin: what lets a caller
  * stream a 20-60 GB array through a small host buffer (hashing, checkpoints to disk). Trees on the per-street engine keep their columns
- * in another order internally and refuse this call (use prl_solver_get). */
+ * in another order internally: the call gathers them (one copy per run of columns that are neighbours in both orders). */
 int32_t prl_solver_get_cols(prl_solver_t* solver, int32_t field, int64_t col_begin, int64_t n_cols, void* out);
 
 /* ---------------------------------------------------------------------------------------------------------------- */

@@ -101,6 +101,7 @@ struct prl_solver {
     int32_t* d_trunk_leaves = nullptr; // trunk ids of the trunk's chance leaves
     int n_trunk_leaves = 1;
     std::vector<int32_t> col_dfs;      // internal column -> flat-tree (DFS) column; empty = identity (every other engine)
+    std::vector<int32_t> col_int;      // its inverse, built by the first prl_solver_get_cols
     // ---- single-deal fused engine: SORTED STORAGE of the board columns (prl_fhp.h) ----
     // every column array is [trunk columns][R] in hand order, then -- from element `board_ofs` -- the board region
     // [n_boards][ncb][PRL_FHP_NP] in each board's rank-sorted order, live hands only: `col_elems` elements in all
@@ -1908,10 +1909,32 @@ int32_t prl_solver_eval_avg(prl_solver_t* s, float* out2) {
 
 int32_t prl_solver_get_cols(prl_solver_t* s, int32_t field, int64_t col_begin, int64_t n_cols, void* out) {
     if (!s || !out || col_begin < 0 || n_cols < 0 || col_begin + n_cols > s->full_cols) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
-    if (!s->col_dfs.empty()) { prl_set_error("get_cols: this engine keeps its columns in an internal order; use prl_solver_get"); return PRL_ERR_UNSUPPORTED; }
     const char* src = nullptr;
     size_t elem = 0;
     double fill[PRL_FHP_MAX_NODES * 3] = {0.};
+    if (!s->col_dfs.empty()) {
+        // the per-street engine keeps its columns in an internal order (trunk, then street by street, instance by instance): every requested flat-tree
+        // column is fetched from where it lives; runs of columns that are neighbours in both orders (a node's actions) travel as one copy
+        switch (field) {
+            case PRL_SF_REGRET: src = (const char*)s->d_regret; elem = 4; break;
+            case PRL_SF_AVG: TRY(ensure_board_avg(s)); src = (const char*)s->d_avg; elem = 8; break;
+            case PRL_SF_AVG_SUM: src = (const char*)s->S.avg_sum; elem = 4; break;
+            default: prl_set_error("get_cols: REGRET, AVG or AVG_SUM"); return PRL_ERR_ARG;
+        }
+        if (!src) { prl_set_error("field not available for this variant"); return PRL_ERR_STATE; }
+        if (s->col_int.empty()) {
+            s->col_int.resize(s->col_dfs.size());
+            for (size_t c = 0; c < s->col_dfs.size(); ++c) s->col_int[s->col_dfs[c]] = (int32_t)c;
+        }
+        const size_t cb = (size_t)s->R * elem;
+        for (int64_t c = col_begin; c < col_begin + n_cols;) {
+            int64_t run = 1;
+            while (c + run < col_begin + n_cols && s->col_int[c + run] == s->col_int[c] + (int32_t)run) ++run;
+            PRL_HIP_TRY(hipMemcpyAsync((char*)out + (size_t)(c - col_begin) * cb, src + (size_t)s->col_int[c] * cb, (size_t)run * cb, hipMemcpyDeviceToHost, s->stream));
+            c += run;
+        }
+        return prl_solver_sync(s);
+    }
     switch (field) {
         case PRL_SF_REGRET: src = (const char*)s->d_regret; elem = 4; break;
         case PRL_SF_AVG:

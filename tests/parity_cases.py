@@ -481,6 +481,12 @@ def check_streets_vs_oracle(L, game_cls, stack, runouts, variant, n_iters, delay
             assert np.array_equal(s.exploitability(), o.exploitability), (it, s.exploitability(), o.exploitability)
             if it > delay:
                 assert np.array_equal(s.eval_avg(), o.eval_avg()), it
+    # prl_solver_get_cols on this engine: any window of flat-tree columns, gathered from the internal order
+    nc = t.n_cols
+    for name in ("regret", "avg") + (() if variant == "plus" else ("avg_sum",)):
+        full = s.get(name)
+        for c0, n in ((0, nc), (nc // 3, min(37, nc - nc // 3)), (nc - 1, 1)):
+            assert np.array_equal(s.get_cols(name, c0, n), full[c0:c0 + n]), (name, c0, n)
     return t, s, o
 
 
