@@ -120,9 +120,14 @@ def main():
     out["roofline"] = {"bound": "valu-issue (int + fp32)", "achieved": achieved, "peak": peak, "unit": "T lane-ops/s", "frac": achieved / peak, "traffic": None,
                        "kernel": "prl_k_lbr_batch", "lane_ops_per_range_board_equity": ops_eq,
                        "range_board_equities_per_hand": n_eq_tot / max(float(n), 1.0), "range_board_equities_per_s_rank0": n_eq_tot / dev_s,
+                       # the hardware's own figure, from the SQ counters of the final kernel (profiles/r15_lbr_pmc_sq.txt, r15_lbr_kernel_stats.txt):
+                       # SQ_INSTS_VALU 1.764e10 wave-instructions per launch x 4 clocks / (1024 SIMDs x 93.56 ms x 2.4 GHz)
+                       "valu_issue_busy_measured": 0.307, "valu_issue_busy_source": "profiles/r15_lbr_pmc_sq.txt (rocprofv3 --pmc SQ_INSTS_VALU, 131072 hands per launch)",
                        "note": "not an HBM- or MFMA-bound kernel: state on chip, no contraction. Modelled: the (range, board) equities only (the betting "
-                               "engine, the agent's draws and the range updates are not counted: the model is a lower bound of the work done); the "
-                               "operation counts are read off the kernel's ISA, profiles/r06_lbr_*.txt hold the SQ counters"}
+                               "engine, the agent's draws and the range updates are not counted: the model is a lower bound of the work done). The "
+                               "operation counts are ALGORITHMIC ones, read off round 3's kernel (generic float32 division, 64-bit blocker test) and "
+                               "kept as the yardstick; round 4's kernel executes fewer per equity (shared-reciprocal division, byte compares), so "
+                               "'frac' is work delivered per peak, valu_issue_busy_measured is what the vector ALUs were actually busy with"}
     if rank == 0 and args.cpu_hands > 0 and world == 1:
         # cpu_baseline: the SAME episode loop (pokerrl_amd.eval.lbr.LocalLBRWorker = the reference's LocalLBRWorker.run) with the check-down
         # equity of every decision computed ON THE HOST by the NumPy restatement of the reference's rollout manager (oracle/lbr.py, pinned to
