@@ -235,14 +235,15 @@ PRL_HD PRL_INLINE int prl_lbr_n_boards(const PrlLbrGame& g) {
 }
 // b-th complete board in the reference's enumeration order (:408-417)
 PRL_HD PRL_INLINE void prl_lbr_board_at(const PrlLbrGame& g, const int8_t* pc, int n_pc, int b, int8_t* fb) {
-    for (int i = 0; i < 5; ++i) fb[i] = i < g.n_dealt ? g.board[i] : (int8_t)0;
-    if (g.n_to_deal == 1) fb[g.n_dealt] = pc[b];
+    int8_t c0 = 0, c1 = 0;  // the card(s) still to come; placed by selects: a write at a run-time position would push the caller's board into private memory
+    if (g.n_to_deal == 1) c0 = pc[b];
     else if (g.n_to_deal == 2) {
         int i = 0, left = b;
         while (left >= n_pc - 1 - i) { left -= n_pc - 1 - i; ++i; }
-        fb[g.n_dealt] = pc[i];
-        fb[g.n_dealt + 1] = pc[i + 1 + left];
+        c0 = pc[i];
+        c1 = pc[i + 1 + left];
     }
+    for (int i = 0; i < 5; ++i) fb[i] = i < g.n_dealt ? g.board[i] : (i == g.n_dealt ? c0 : (i == g.n_dealt + 1 ? c1 : (int8_t)0));
 }
 
 // card-removal-aware board probabilities and the running float32 sum over the boards (:432-468, :470-497).

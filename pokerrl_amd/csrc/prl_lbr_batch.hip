@@ -129,7 +129,7 @@ struct LbrbShared {
     int32_t raise_action[LBRB_MAX_Q], pot_after[LBRB_MAX_Q];
     uint32_t raise_key[LBRB_MAX_Q];
     int32_t raise_n_legal[LBRB_MAX_Q];
-    int32_t raise_legal[LBRB_MAX_Q][8];   // only FOLD's legality matters for the look-ahead; first entries kept for the hash
+    int32_t raise_legal[LBRB_MAX_Q][LBRB_MAX_LEGAL];  // the agent's legal actions after raise q (the hash policy needs the whole list)
     float fold_prob[LBRB_MAX_Q], notfold_total[LBRB_MAX_Q], wp[LBRB_MAX_Q];
     int8_t board[5];
     int8_t pc[PRL_LBR_MAX_CARDS];
@@ -229,20 +229,21 @@ PRL_DEV PRL_INLINE void lbrb_normalize(float* rg, int R, LbrbLeaves& Lf, LbrbSha
 // recursion. So the unit of work is one BLOCK of one sum (<= 128 elements, eight accumulators side by side, its tail): all lanes take blocks of
 // all sums, a second step adds a sum's blocks in the recursion's order. Same values, same order.
 struct LbrbLeafMap { int n, n_leaves; int lo[LBRB_MAX_LEAVES], m[LBRB_MAX_LEAVES]; };
+// the recursion as a template (fully inlined): a stack indexed at run time would live in private memory -- a vector-memory round trip per push and pop
+// on the one lane the workgroup is waiting for
+template <int DEPTH>
+PRL_DEV PRL_INLINE void lbrb_leaf_rec(LbrbLeafMap& M, int lo, int m, int& nl) {
+    if (DEPTH == 0 || m <= 128) { M.lo[nl] = lo; M.m[nl] = m; ++nl; return; }
+    int n2 = m / 2;
+    n2 -= n2 % 8;
+    lbrb_leaf_rec<(DEPTH > 0 ? DEPTH - 1 : 0)>(M, lo, n2, nl);
+    lbrb_leaf_rec<(DEPTH > 0 ? DEPTH - 1 : 0)>(M, lo + n2, m - n2, nl);
+}
 PRL_DEV PRL_INLINE void lbrb_build_leaf_map(LbrbLeafMap& M, int n) {  // one thread
     M.n = n; M.n_leaves = 0;
     if (n < 8) return;  // fewer than eight elements are added one after the other
-    int stack_lo[16], stack_n[16], sp = 0, nl = 0;
-    stack_lo[0] = 0; stack_n[0] = n;
-    while (sp >= 0) {
-        const int lo = stack_lo[sp], m = stack_n[sp];
-        --sp;
-        if (m <= 128) { M.lo[nl] = lo; M.m[nl] = m; ++nl; continue; }
-        int n2 = m / 2;
-        n2 -= n2 % 8;
-        ++sp; stack_lo[sp] = lo + n2; stack_n[sp] = m - n2;
-        ++sp; stack_lo[sp] = lo; stack_n[sp] = n2;
-    }
+    int nl = 0;
+    lbrb_leaf_rec<5>(M, 0, n, nl);  // ranges have at most 1326 entries: 128 * 2^5 covers them (static_assert at the call sites' R bound)
     M.n_leaves = nl;
 }
 // the blocks' sums added in the recursion's order (left half + right half, post-order); sums[leaf] is block number `leaf`
@@ -524,10 +525,12 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                             prl_env_step(P.g_lbr, s2, a, &inf);
                             S.raise_action[q] = a;
                             S.pot_after[q] = s2.main_pot + s2.bet[0] + s2.bet[1];
-                            int32_t lg2[LBRB_MAX_LEGAL];
-                            const int nl2 = prl_legal_actions(P.g_agent, s2, lg2);
+                            // straight into LDS: a per-lane array filled at run-time positions lives in private memory (a vector-memory round trip per entry)
+                            int32_t* lg_q = S.raise_legal[q];
+                            int nk = 0;
+                            auto put = [&](int act) { lg_q[nk++] = act; };
+                            const int nl2 = prl_legal_actions_to(P.g_agent, s2, put);
                             S.raise_n_legal[q] = nl2;
-                            for (int k = 0; k < 8; ++k) S.raise_legal[q][k] = k < nl2 ? lg2[k] : -1;
                             S.raise_key[q] = lbrb_state_key(P.seed, s2, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
                         }
                         if (tid == 0) {
@@ -550,15 +553,8 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     // candidate 0: the range as it is; candidate q: after "agent does not fold to raise q" (:131-141, :241-251)
                     for (int h = tid; h < R; h += LBRB_THREADS) cand[h] = rg[h];
                     for (int q = 1; q < n_q; ++q) {
-                        int32_t lg2[LBRB_MAX_LEGAL];
                         const int nl2 = S.raise_n_legal[q];
-                        // the hash needs the whole legal list: recompute it (cheap, scalar) when it is longer than the cache
-                        if (nl2 > 8) {
-                            PrlEnvState s2 = S.st;
-                            PrlStepInfo inf;
-                            prl_env_step(P.g_lbr, s2, S.raise_action[q], &inf);
-                            prl_legal_actions(P.g_agent, s2, lg2);
-                        } else for (int k = 0; k < nl2; ++k) lg2[k] = S.raise_legal[q][k];
+                        const int32_t* lg2 = S.raise_legal[q];  // read from LDS where it is (the same word for every lane: a broadcast)
                         for (int h = tid; h < R; h += LBRB_THREADS)
                             cand[(size_t)q * R + h] = lbrb_agent_prob(P.agent_kind, S.raise_key[q], h, lg2, nl2, PRL_FOLD);  // p(fold | hand)
                     }
@@ -857,8 +853,8 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     if (S.st.folded[0] || S.st.folded[1]) award_lbr = S.st.folded[lbr_seat] ? 0.0 : (double)pot;
                     else {
                         PrlLbrGame g = hg;
-                        int8_t fb[5] = {0, 0, 0, 0, 0};
-                        for (int i = 0; i < n_board_total; ++i) fb[i] = S.board[i];
+                        int8_t fb[5];
+                        for (int i = 0; i < 5; ++i) fb[i] = i < n_board_total ? S.board[i] : (int8_t)0;
                         const int32_t rl = prl_lbr_rank(g, S.lbr_idx, fb), ra = prl_lbr_rank(g, lbrb_hand_idx(P.rules, agent_hand), fb);
                         award_lbr = rl > ra ? (double)pot : (rl < ra ? 0.0 : (double)pot / 2.0);
                     }
