@@ -497,14 +497,28 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                 if (look) {
                     // ---------------- LBR's one-step look-ahead (:91-154, :205-270) ------------------------------------------
                     if (tid == 0) {
-                        PrlLbrGame& g = S.lg;
-                        g = hg;
-                        g.n_dealt = S.n_dealt; g.n_to_deal = n_board_total - S.n_dealt;
-                        for (int i = 0; i < 5; ++i) g.board[i] = i < S.n_dealt ? S.board[i] : (int8_t)0;
-                        for (int i = 0; i < nh; ++i) g.lbr_hand[i] = lbr_hand[i];
-                        if (nh == 2 && g.lbr_hand[0] > g.lbr_hand[1]) { const int8_t t = g.lbr_hand[0]; g.lbr_hand[0] = g.lbr_hand[1]; g.lbr_hand[1] = t; }
-                        S.n_pc = prl_lbr_possible_cards(g, S.pc);
-                        S.n_boards = prl_lbr_n_boards(g);
+                        // the look-ahead's game description is put together in REGISTERS and stored once: built in place in LDS, every store to the card
+                        // list below might alias it and its fields were re-read from LDS in every iteration of the 52-card loop
+                        PrlLbrGame g = hg;
+                        const int n_dealt = S.n_dealt;
+                        g.n_dealt = n_dealt; g.n_to_deal = n_board_total - n_dealt;
+                        unsigned long long used = 0ull;  // cards on the table and in LBR's hand
+                        for (int i = 0; i < 5; ++i) {
+                            const int8_t c = i < n_dealt ? S.board[i] : (int8_t)0;
+                            g.board[i] = c;
+                            if (i < n_dealt) used |= 1ull << c;
+                        }
+                        int8_t h0 = lbr_hand[0], h1 = nh == 2 ? lbr_hand[1] : (int8_t)0;
+                        if (nh == 2 && h0 > h1) { const int8_t t = h0; h0 = h1; h1 = t; }
+                        g.lbr_hand[0] = h0; g.lbr_hand[1] = h1;
+                        used |= 1ull << h0;
+                        if (nh == 2) used |= 1ull << h1;
+                        int n_pc = 0;  // prl_lbr_possible_cards: the cards that can still come, ascending
+                        for (int c = 0; c < g.n_cards; ++c)
+                            if (!((used >> c) & 1ull)) S.pc[n_pc++] = (int8_t)c;
+                        S.n_pc = n_pc;
+                        S.n_boards = g.n_to_deal == 0 ? 1 : (g.n_to_deal == 1 ? n_pc : (g.n_to_deal == 2 ? n_pc * (n_pc - 1) / 2 : prl_lbr_n_boards(g)));
+                        S.lg = g;
                         const PrlEnvState st0 = S.st;
                         S.n_legal = prl_legal_actions(P.g_lbr, st0, S.legal);
                     }
