@@ -130,7 +130,7 @@ struct LbrbShared {
     uint32_t raise_key[LBRB_MAX_Q];
     int32_t raise_n_legal[LBRB_MAX_Q];
     int32_t raise_legal[LBRB_MAX_Q][LBRB_MAX_LEGAL];  // the agent's legal actions after raise q (the hash policy needs the whole list)
-    float fold_prob[LBRB_MAX_Q], notfold_total[LBRB_MAX_Q], wp[LBRB_MAX_Q];
+    float fold_prob[LBRB_MAX_Q], notfold_total[LBRB_MAX_Q], wp[LBRB_MAX_Q], cp_sum[LBRB_MAX_Q], util[LBRB_MAX_Q];
     int8_t board[5];
     int8_t pc[PRL_LBR_MAX_CARDS];
     int32_t n_pc;
@@ -778,32 +778,83 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                         cpw[q * PRL_LBR_MAX_CARDS + c] = prl_lbr_card_not_held(g, cand + (size_t)q * R, c);
                     }
                     prl_sync();
-                    if (tid < n_q) S.wp[tid] = prl_lbr_reduce_range_cp(g, eq + tid * eq_stride, cpw + tid * PRL_LBR_MAX_CARDS, eq_lds + tid * LBRB_MAX_BOARDS,
-                                                                       S.pc, S.n_pc);
+                    if (coop && g.n_to_deal <= 1) {
+                        // prl_lbr_reduce_range_cp (:449-468) with its chains opened up: the card probabilities' sum by one lane per candidate, the products
+                        // equity x board probability by one lane per (candidate, board), the running sum over the boards from LDS by one lane per candidate
+                        // (one lane doing all of it walked 52 + 52 + 46 dependent LDS round trips). Same operations, same order.
+                        unsigned long long used = 0ull;
+                        for (int i = 0; i < 5; ++i) if (i < g.n_dealt) used |= 1ull << g.board[i];
+                        used |= 1ull << g.lbr_hand[0];
+                        used |= 1ull << g.lbr_hand[1];
+                        for (int t = tid; t < n_q * g.n_cards; t += LBRB_THREADS) {
+                            const int q = t / g.n_cards, c = t - q * g.n_cards;
+                            if ((used >> c) & 1ull) cpw[q * PRL_LBR_MAX_CARDS + c] = 0.f;
+                        }
+                        prl_sync();
+                        if (tid < n_q) {
+                            const float* row = cpw + tid * PRL_LBR_MAX_CARDS;
+                            int k = 0;
+                            auto nx = [&]() { return row[k++]; };
+                            S.cp_sum[tid] = prl_np_sum_stream<0>(g.n_cards, nx);
+                        }
+                        prl_sync();
+                        for (int t = tid; t < n_q * n_boards; t += LBRB_THREADS) {
+                            const int q = t / n_boards, b = t - q * n_boards;
+                            const float e_qb = eq[q * eq_stride + b];
+                            float x = e_qb * 1.0f;
+                            if (g.n_to_deal == 1) {
+                                const float sum = S.cp_sum[q];
+                                float cpv = cpw[q * PRL_LBR_MAX_CARDS + S.pc[b]];
+                                if (sum > 0.f) cpv = cpv / sum;
+                                x = e_qb * cpv;
+                            }
+                            eqb[q * eq_stride + b] = x;
+                        }
+                        prl_sync();
+                        if (tid < n_q) {
+                            const float* row = eqb + tid * eq_stride;
+                            float win = row[0];  // 0.0 (Python float) + float32 -> float32
+                            for (int b0 = 1; b0 < n_boards; b0 += 8) {
+                                float v[8];
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) v[k] = row[b0 + k < n_boards ? b0 + k : 0];
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) win = b0 + k < n_boards ? win + v[k] : win;
+                            }
+                            S.wp[tid] = win * 1.f;  // the factorial of the cards to come: 1
+                        }
+                    } else if (tid < n_q) S.wp[tid] = prl_lbr_reduce_range_cp(g, eq + tid * eq_stride, cpw + tid * PRL_LBR_MAX_CARDS, eq_lds + tid * LBRB_MAX_BOARDS,
+                                                                              S.pc, S.n_pc);
                     prl_sync();
                     LBRB_TICK(6);  // board probabilities + reduction (one lane per candidate)
-                    if (tid == 0) {
-                        const int n_u = P.limit ? 3 : 2 + P.g_lbr.n_bet_sizes;
-                        float best = 0.f;  // utility[FOLD] = 0; illegal actions are -1 (:209-212)
-                        int best_a = PRL_FOLD;
+                    // one lane per candidate computes its utility; lane 0 takes the arg-max in action order. Candidate 0 is check / call (action 1), the
+                    // raises follow in ascending action order, fold is 0 and actions that are not candidates are -1 (:209-212): walking the candidates in
+                    // their order IS np.argmax's "first maximum" over the action-indexed utility vector.
+                    if (tid < n_q) {
                         const int asked = S.st.bet[P.agent_seat] - S.st.bet[lbr_seat];
                         const int pot_before = S.st.main_pot + S.st.bet[0] + S.st.bet[1];
-                        for (int a = 1; a < n_u; ++a) {
-                            float u = -1.f;
-                            if (a == PRL_CHECK_CALL) {
-                                const float wp = S.wp[0];
-                                u = wp * (float)pot_before - (1.f - wp) * (float)asked;
-                            } else {
-                                for (int q = 1; q < n_q; ++q)
-                                    if (S.raise_action[q] == a) {
-                                        const float wp = S.wp[q], fp = S.fold_prob[q];
-                                        const int chips_in = S.pot_after[q] - pot_before;
-                                        const float ev_nf = (wp * (float)S.pot_after[q]) - ((1.f - wp) * (float)chips_in);
-                                        u = fp * (float)pot_before + (1.f - fp) * ev_nf;
-                                    }
-                            }
-                            if (u > best) { best = u; best_a = a; }  // np.argmax: the first maximum
+                        const float wp = S.wp[tid];
+                        float u;
+                        if (tid == 0) u = wp * (float)pot_before - (1.f - wp) * (float)asked;
+                        else {
+                            const float fp = S.fold_prob[tid];
+                            const int pot_after = S.pot_after[tid], chips_in = pot_after - pot_before;
+                            const float ev_nf = (wp * (float)pot_after) - ((1.f - wp) * (float)chips_in);
+                            u = fp * (float)pot_before + (1.f - fp) * ev_nf;
                         }
+                        S.util[tid] = u;
+                    }
+                    prl_sync();
+                    if (tid == 0) {
+                        float best = 0.f;  // utility[FOLD] = 0
+                        int best_a = PRL_FOLD;
+                        float uq[LBRB_MAX_Q];
+                        int aq[LBRB_MAX_Q];
+#pragma unroll
+                        for (int q = 0; q < LBRB_MAX_Q; ++q) { uq[q] = S.util[q < n_q ? q : 0]; aq[q] = q == 0 ? (int)PRL_CHECK_CALL : S.raise_action[q < n_q ? q : 0]; }
+#pragma unroll
+                        for (int q = 0; q < LBRB_MAX_Q; ++q)
+                            if (q < n_q && uq[q] > best) { best = uq[q]; best_a = aq[q]; }  // np.argmax: the first maximum
                         S.action = best_a;
                         n_look += 1;
                         n_eq += (unsigned long long)n_q * n_boards;
