@@ -26,7 +26,10 @@
 
 extern "C" int32_t prl_device_available(void);
 
-#define LBRB_THREADS 576
+// 1024 lanes = 16 waves = 4 per SIMD (128 VGPRs each): measured against 576 and 768 lanes on one box, 1.24 / 1.39 / 1.45 M hands/s (profiles/r20_lbr_threads.txt)
+#ifndef LBRB_THREADS
+#define LBRB_THREADS 1024
+#endif
 #define LBRB_MAX_Q 12      // check/call + up to 11 raise sizes considered by LBR (OFF_TREE_11); sized so that TWO workgroups fit the 160 KB of LDS of a CU
 #define LBRB_MAX_LEGAL 16  // fold, check/call and up to 14 bet sizes of either player: per-lane arrays of this size stay small (private memory
                            // per lane bounds how many waves the runtime keeps in flight)
@@ -404,13 +407,14 @@ PRL_DEV PRL_INLINE LbrbDiv lbrb_div_by(float b, bool small_ok) {
     return d;
 }
 
-// ONE workgroup (9 waves) per CU with up to 168 VGPRs per lane (round 4): measured 3.3 % ahead of two workgroups at 96 VGPRs (74 spilled),
-// profiles/r06_experiments.txt -- the kernel waits on dependent LDS gathers and division chains, not on occupancy
+// ONE workgroup per CU (its LDS holds twelve candidate ranges); 16 waves at up to 128 VGPRs each since the sums of a look-ahead are spread over
+// all lanes (12 VGPRs spill in rarely taken paths). Before that, with one lane per equity, 9 waves at 168 VGPRs were 3.3 % ahead of two workgroups
+// at 96 (profiles/r06_experiments.txt).
 #if defined(PRL_EMU)
 #define LBRB_LB
 #else
 #ifndef LBRB_WAVES_PER_SIMD
-#define LBRB_WAVES_PER_SIMD 3
+#define LBRB_WAVES_PER_SIMD 4
 #endif
 #define LBRB_LB __launch_bounds__(LBRB_THREADS, LBRB_WAVES_PER_SIMD)
 #endif
