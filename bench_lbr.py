@@ -120,9 +120,9 @@ def main():
     out["roofline"] = {"bound": "valu-issue (int + fp32)", "achieved": achieved, "peak": peak, "unit": "T lane-ops/s", "frac": achieved / peak, "traffic": None,
                        "kernel": "prl_k_lbr_batch", "lane_ops_per_range_board_equity": ops_eq,
                        "range_board_equities_per_hand": n_eq_tot / max(float(n), 1.0), "range_board_equities_per_s_rank0": n_eq_tot / dev_s,
-                       # the hardware's own figure, from the SQ counters of the final kernel (profiles/r15_lbr_pmc_sq.txt, r15_lbr_kernel_stats.txt):
-                       # SQ_INSTS_VALU 1.764e10 wave-instructions per launch x 4 clocks / (1024 SIMDs x 93.56 ms x 2.4 GHz)
-                       "valu_issue_busy_measured": 0.307, "valu_issue_busy_source": "profiles/r15_lbr_pmc_sq.txt (rocprofv3 --pmc SQ_INSTS_VALU, 131072 hands per launch)",
+                       # the hardware's own figure, from the SQ counters of the final kernel (profiles/r21_lbr_pmc_sq.txt, r21_lbr_kernel_stats.txt):
+                       # SQ_INSTS_VALU 1.765e10 wave-instructions per launch x 4 clocks / (1024 SIMDs x 61.45 ms x 2.4 GHz)
+                       "valu_issue_busy_measured": 0.467, "valu_issue_busy_source": "profiles/r21_lbr_pmc_sq.txt (rocprofv3 --pmc SQ_INSTS_VALU, 131072 hands per launch)",
                        "note": "not an HBM- or MFMA-bound kernel: state on chip, no contraction. Modelled: the (range, board) equities only (the betting "
                                "engine, the agent's draws and the range updates are not counted: the model is a lower bound of the work done). The "
                                "operation counts are ALGORITHMIC ones, read off round 3's kernel (generic float32 division, 64-bit blocker test) and "
