@@ -614,14 +614,30 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations(PrlDevTree T, Prl
     else prl_small_iterations_body<false>(T, SG, A);
 }
 // many independent small trees at once, one workgroup (= one CU) per solve: jobs[blockIdx.y]
+// A pointer LOADED from memory is a generic one to the compiler (a kernel ARGUMENT is known to be global): every access through it is a FLAT
+// instruction that waits on both memory counters. The job table's pointers all address HBM: rebuild each from its bits as a global pointer.
+#if defined(PRL_EMU)
+template <class E> inline E* prl_global_ptr(E* p) { return p; }
+#else
+template <class E> PRL_DEV PRL_INLINE E* prl_global_ptr(E* p) { return (E*)(__attribute__((address_space(1))) E*)(size_t)p; }
+#endif
 PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations_many(const PrlSmallJob* jobs) {
     const PrlSmallJob& J = jobs[prl_bid_y()];  // launched 1 x n_jobs: the per-item bodies below see a grid of ONE workgroup
-    const PrlDevTree T = J.T;
-    const PrlDevState SG = J.S;
+    PrlDevTree T = J.T;
+    PrlDevState SG = J.S;
+#define PRL_G(x) x = prl_global_ptr(x)
+    PRL_G(T.kind); PRL_G(T.actor); PRL_G(T.parent); PRL_G(T.child_idx); PRL_G(T.acted_last); PRL_G(T.board_id); PRL_G(T.main_pot); PRL_G(T.n_children);
+    PRL_G(T.first_col); PRL_G(T.child_start); PRL_G(T.child_list); PRL_G(T.level_nodes); PRL_G(T.boards); PRL_G(T.hole); PRL_G(T.chance_w);
+    PRL_G(T.plan_sh); PRL_G(T.plan_pos); PRL_G(T.plan_gs); PRL_G(T.plan_ge); PRL_G(T.plan_cl); PRL_G(T.plan_klh); PRL_G(T.plan_nlive); PRL_G(T.plan_ndealt);
+    PRL_G(T.plan_hgs); PRL_G(T.plan_hge); PRL_G(T.plan_clx); PRL_G(T.plan_pp);
+    PRL_G(SG.strategy); PRL_G(SG.strat_f64); PRL_G(SG.reach); PRL_G(SG.ev); PRL_G(SG.ev_br); PRL_G(SG.br_idx); PRL_G(SG.regret); PRL_G(SG.avg_sum); PRL_G(SG.avg);
+    PRL_G(SG.avg_f64); PRL_G(SG.expl);
     PrlSmallIterArgs A;
     A.level_start = J.level_start; A.term_nodes = J.term_nodes; A.n_term = J.n_term;
     A.nodes_p[0] = J.nodes_p[0]; A.nodes_p[1] = J.nodes_p[1]; A.n_nodes_p[0] = J.n_nodes_p[0]; A.n_nodes_p[1] = J.n_nodes_p[1];
     A.variant = J.variant; A.delay = J.delay; A.n_iters = J.n_iters; A.state_in_lds = J.state_in_lds; A.n_cols = J.n_cols; A.ip = J.ip;
+    PRL_G(A.level_start); PRL_G(A.term_nodes); PRL_G(A.nodes_p[0]); PRL_G(A.nodes_p[1]); PRL_G(A.ip);
+#undef PRL_G
     if (A.state_in_lds) prl_small_iterations_body<true>(T, SG, A);
     else prl_small_iterations_body<false>(T, SG, A);
 }
