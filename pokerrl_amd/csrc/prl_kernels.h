@@ -21,6 +21,7 @@ void prl_launch_average(const PrlDevTree& T, const PrlDevState& S, const int32_t
 struct PrlIterDev;
 struct PrlSmallJob;  // prl_solver_types.h
 size_t prl_small_state_bytes(const PrlDevTree& T, const PrlDevState& S);
+void prl_small_lds_plan(const PrlDevTree& T, const PrlDevState& S, int n_term, int n_nodes_p0, int n_nodes_p1, bool* state_in_lds, bool* tree_in_lds, size_t* bytes);
 void prl_launch_small_iterations_many(const PrlSmallJob* d_jobs, int n_jobs, size_t lds_bytes, void* stream);
 void prl_launch_small_iterations(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_level_start, const int32_t* d_term_nodes, int n_term,
                                  const int32_t* d_nodes_p0, int n0, const int32_t* d_nodes_p1, int n1, int variant, int delay, int n_iters,

@@ -1658,14 +1658,15 @@ extern "C" int32_t prl_solver_iterations_many(prl_solver_t** solvers, int32_t n_
         ip.hist = s->d_expl_hist;
         PRL_HIP_TRY(hipMemcpyAsync(s->d_ip, &ip, sizeof(ip), hipMemcpyHostToDevice, s->stream));
         PRL_HIP_TRY(hipStreamSynchronize(s->stream));  // `ip` is a stack variable; the solver's earlier work is complete
-        const size_t lds = prl_small_state_bytes(s->T, s->S);
-        const bool in_lds = lds <= 160 * 1024 - 256;
-        if (in_lds && lds > lds_max) lds_max = lds;
+        size_t lds = 0;
+        bool in_lds = false, tree_lds = false;
+        prl_small_lds_plan(s->T, s->S, s->n_term, s->n_nodes_p[0], s->n_nodes_p[1], &in_lds, &tree_lds, &lds);
+        if (lds > lds_max) lds_max = lds;
         PrlSmallJob& J = jobs[(size_t)i];
         memset(&J, 0, sizeof(J));
         J.T = s->T; J.S = s->S; J.level_start = s->d_level_start; J.term_nodes = s->d_term_nodes; J.n_term = s->n_term;
         J.nodes_p[0] = s->d_nodes_p[0]; J.nodes_p[1] = s->d_nodes_p[1]; J.n_nodes_p[0] = s->n_nodes_p[0]; J.n_nodes_p[1] = s->n_nodes_p[1];
-        J.variant = s->variant; J.delay = s->delay; J.state_in_lds = in_lds ? 1 : 0; J.n_cols = s->T.n_cols; J.ip = s->d_ip;
+        J.variant = s->variant; J.delay = s->delay; J.state_in_lds = in_lds ? 1 : 0; J.tree_in_lds = tree_lds ? 1 : 0; J.n_cols = s->T.n_cols; J.ip = s->d_ip;
     }
     prl_solver* s0 = solvers[0];
     PrlSmallJob* d_jobs = nullptr;

@@ -96,7 +96,7 @@ struct PrlSmallJob {
     const int32_t* level_start;
     const int32_t* term_nodes; int32_t n_term;
     const int32_t* nodes_p[2]; int32_t n_nodes_p[2];
-    int32_t variant, delay, n_iters, state_in_lds, n_cols;
+    int32_t variant, delay, n_iters, state_in_lds, tree_in_lds, n_cols;
     PrlIterDev* ip;
 };
 

@@ -518,14 +518,19 @@ struct PrlSmallIterArgs {
     const int32_t* nodes_p[2]; int32_t n_nodes_p[2];
     int32_t variant, delay, n_iters;
     int32_t state_in_lds;        // the whole per-node / per-column state fits in LDS: iterate there, copy back at the end
+    int32_t tree_in_lds;         // ... and the tree's own arrays beside it (or alone, when the state does not fit)
     int32_t n_cols;
     PrlIterDev* ip;
 };
 
+// the iteration counter and the CFR+ averaging weights of the iteration under way, in LDS: lane 0 writes them, every lane reads them in every
+// phase -- from the PrlIterDev in HBM that was a round trip per use
+#define PRL_SMALL_IP_BYTES 64
+struct PrlSmallIp { int32_t iter, mode; double m_old, m_new; };
 // carve the solver state out of LDS (16-byte aligned pieces) and copy it in (dir = 0) or back out (dir = 1)
-PRL_DEV PRL_INLINE void prl_small_state_lds(const PrlDevTree& T, const PrlDevState& G, int n_cols, PrlDevState& L, int dir) {
+PRL_DEV PRL_INLINE size_t prl_small_state_lds(const PrlDevTree& T, const PrlDevState& G, int n_cols, PrlDevState& L, int dir) {  // returns the bytes it took
     char* base = prl_smem();
-    size_t off = 0;
+    size_t off = PRL_SMALL_IP_BYTES;  // LDS block: the iteration's parameters, the state, then the tree's arrays (prl_small_tree_lds)
     auto piece = [&](auto*& lp, auto* gp, size_t count) {
         typedef typename std::remove_reference<decltype(*gp)>::type E;
         if (!gp) { lp = nullptr; return; }
@@ -550,6 +555,43 @@ PRL_DEV PRL_INLINE void prl_small_state_lds(const PrlDevTree& T, const PrlDevSta
     piece(L.avg_f64, G.avg_f64, (size_t)T.n_nodes);
     L.expl = G.expl;  // two floats, stay in HBM
     prl_sync();
+    return off;
+}
+// The tree's own arrays in LDS (read only). Every phase of an iteration starts with a chain of dependent look-ups in them -- node of the level, its
+// parent, its first column, its children -- and from HBM / L2 each link is most of a microsecond with one workgroup and nothing to overlap:
+// ~35 phases x 2-3 links was most of StandardLeduc's 78 us per iteration.
+// (with the iteration's node lists: the level offsets, the terminals, each player's decision nodes)
+PRL_HD PRL_INLINE size_t prl_small_tree_bytes(const PrlDevTree& T, int n_term, int n_nodes_p0, int n_nodes_p1) {
+    auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t n = (size_t)T.n_nodes;
+    return 10 * al(n * 4) + al((n + 1) * 4) + al((n > 0 ? n - 1 : 0) * 4) + (T.chance_w ? al(n * 4) : 0) + al((size_t)T.R * 2 * 2) +
+           al((size_t)T.n_boards * (size_t)T.board_len) + al(((size_t)T.n_levels + 1) * 4) + al((size_t)n_term * 4) + al((size_t)n_nodes_p0 * 4) +
+           al((size_t)n_nodes_p1 * 4);
+}
+PRL_DEV PRL_INLINE void prl_small_tree_lds(const PrlDevTree& G, PrlDevTree& L, const PrlSmallIterArgs& AG, PrlSmallIterArgs& AL, size_t off) {
+    char* base = prl_smem();
+    auto piece = [&](auto*& lp, auto* gp, size_t count) {
+        typedef typename std::remove_const<typename std::remove_reference<decltype(*gp)>::type>::type E;
+        if (!gp) { lp = nullptr; return; }
+        E* l = (E*)(base + off);
+        off += (count * sizeof(E) + 15) & ~(size_t)15;
+        for (size_t i = prl_tid(); i < count; i += prl_nthreads()) l[i] = gp[i];
+        lp = l;
+    };
+    const size_t n = (size_t)G.n_nodes;
+    piece(L.kind, G.kind, n); piece(L.actor, G.actor, n); piece(L.parent, G.parent, n); piece(L.child_idx, G.child_idx, n);
+    piece(L.acted_last, G.acted_last, n); piece(L.board_id, G.board_id, n); piece(L.main_pot, G.main_pot, n); piece(L.n_children, G.n_children, n);
+    piece(L.first_col, G.first_col, n); piece(L.level_nodes, G.level_nodes, n);
+    piece(L.child_start, G.child_start, n + 1);
+    piece(L.child_list, G.child_list, n > 0 ? n - 1 : 0);
+    piece(L.chance_w, G.chance_w, n);
+    piece(L.hole, G.hole, (size_t)G.R * 2);
+    piece(L.boards, G.boards, (size_t)G.n_boards * (size_t)G.board_len);
+    piece(AL.level_start, AG.level_start, (size_t)G.n_levels + 1);
+    piece(AL.term_nodes, AG.term_nodes, (size_t)AG.n_term);
+    piece(AL.nodes_p[0], AG.nodes_p[0], (size_t)AG.n_nodes_p[0]);
+    piece(AL.nodes_p[1], AG.nodes_p[1], (size_t)AG.n_nodes_p[1]);
+    prl_sync();
 }
 PRL_DEV PRL_INLINE void prl_small_ev(const PrlDevTree& T, const PrlDevState& S, const PrlSmallIterArgs& A) {
     prl_terminal_1card_body(T, S, A.term_nodes, A.n_term);
@@ -564,13 +606,18 @@ PRL_DEV PRL_INLINE void prl_small_ev(const PrlDevTree& T, const PrlDevState& S, 
 // IN_LDS is a template argument so that, in the instantiation that iterates on LDS, every state pointer is VISIBLY an LDS address (base of the
 // dynamic LDS + offset on every path): behind a run-time choice between the HBM and the LDS copy the pointers are generic, every access a FLAT
 // instruction that waits on both memory counters, and nothing overlaps (the kernel had 212 of them).
-template <bool IN_LDS>
-PRL_DEV PRL_INLINE void prl_small_iterations_body(const PrlDevTree& T, const PrlDevState& SG, const PrlSmallIterArgs& A) {
+template <bool IN_LDS, bool TREE_LDS>
+PRL_DEV PRL_INLINE void prl_small_iterations_body(const PrlDevTree& TG, const PrlDevState& SG, const PrlSmallIterArgs& AG) {
+    PrlSmallIterArgs A = AG;
     PrlDevState S = SG;
-    if (IN_LDS) prl_small_state_lds(T, SG, A.n_cols, S, 0);
+    size_t state_bytes = PRL_SMALL_IP_BYTES;
+    PrlSmallIp& IP = *(PrlSmallIp*)prl_smem();
+    if (IN_LDS) state_bytes = prl_small_state_lds(TG, SG, A.n_cols, S, 0);
+    PrlDevTree T = TG;
+    if (TREE_LDS) prl_small_tree_lds(TG, T, AG, A, state_bytes);
     for (int k = 0; k < A.n_iters; ++k) {
         if (prl_tid() == 0) {  // prl_k_iter_begin
-            const int it = A.ip->iter;
+            const int it = k == 0 ? A.ip->iter : IP.iter;
             int mode = 0;
             double m_old = 0., m_new = 0.;
             if (A.variant == PRL_CFR_PLUS) {
@@ -582,12 +629,12 @@ PRL_DEV PRL_INLINE void prl_small_iterations_body(const PrlDevTree& T, const Prl
                     mode = 2;
                 } else if (it == A.delay) mode = 1;
             }
-            A.ip->mode = mode; A.ip->m_old = m_old; A.ip->m_new = m_new;
+            IP.iter = it; IP.mode = mode; IP.m_old = m_old; IP.m_new = m_new;
         }
         prl_sync();
         for (int p = 0; p < 2; ++p) {
             if (p == 1) prl_small_ev(T, S, A);
-            prl_regret_strategy_body(T, S, A.nodes_p[p], A.n_nodes_p[p], p, A.variant, A.ip->iter);
+            prl_regret_strategy_body(T, S, A.nodes_p[p], A.n_nodes_p[p], p, A.variant, IP.iter);
             prl_sync();
             prl_reach_root_body(T, S);
             prl_sync();
@@ -595,24 +642,31 @@ PRL_DEV PRL_INLINE void prl_small_iterations_body(const PrlDevTree& T, const Prl
                 prl_reach_level_body(T, S, A.level_start[d], A.level_start[d + 1] - A.level_start[d]);
                 prl_sync();
             }
-            prl_average_body(T, S, A.nodes_p[p], A.n_nodes_p[p], p, A.variant, A.ip->iter, A.ip->mode, A.ip->m_old, A.ip->m_new);
+            prl_average_body(T, S, A.nodes_p[p], A.n_nodes_p[p], p, A.variant, IP.iter, IP.mode, IP.m_old, IP.m_new);
             prl_sync();
         }
         prl_small_ev(T, S, A);
         if (prl_tid() == 0) {  // prl_k_iter_end
-            const int it = A.ip->iter + 1;
+            const int it = IP.iter + 1;
+            IP.iter = it;
             A.ip->iter = it;
             A.ip->hist[2 * (size_t)it] = S.expl[0];
             A.ip->hist[2 * (size_t)it + 1] = S.expl[1];
         }
         prl_sync();
     }
-    if (IN_LDS) prl_small_state_lds(T, SG, A.n_cols, S, 1);
+    if (IN_LDS) prl_small_state_lds(TG, SG, A.n_cols, S, 1);
 }
-PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations(PrlDevTree T, PrlDevState SG, PrlSmallIterArgs A) {
-    if (A.state_in_lds) prl_small_iterations_body<true>(T, SG, A);
-    else prl_small_iterations_body<false>(T, SG, A);
+PRL_DEV PRL_INLINE void prl_small_iterations_dispatch(const PrlDevTree& T, const PrlDevState& SG, const PrlSmallIterArgs& A) {
+    if (A.state_in_lds) {
+        if (A.tree_in_lds) prl_small_iterations_body<true, true>(T, SG, A);
+        else prl_small_iterations_body<true, false>(T, SG, A);
+    } else {
+        if (A.tree_in_lds) prl_small_iterations_body<false, true>(T, SG, A);
+        else prl_small_iterations_body<false, false>(T, SG, A);
+    }
 }
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations(PrlDevTree T, PrlDevState SG, PrlSmallIterArgs A) { prl_small_iterations_dispatch(T, SG, A); }
 // many independent small trees at once, one workgroup (= one CU) per solve: jobs[blockIdx.y]
 // A pointer LOADED from memory is a generic one to the compiler (a kernel ARGUMENT is known to be global): every access through it is a FLAT
 // instruction that waits on both memory counters. The job table's pointers all address HBM: rebuild each from its bits as a global pointer.
@@ -635,11 +689,10 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(1024) prl_k_small_iterations_many(const PrlSma
     PrlSmallIterArgs A;
     A.level_start = J.level_start; A.term_nodes = J.term_nodes; A.n_term = J.n_term;
     A.nodes_p[0] = J.nodes_p[0]; A.nodes_p[1] = J.nodes_p[1]; A.n_nodes_p[0] = J.n_nodes_p[0]; A.n_nodes_p[1] = J.n_nodes_p[1];
-    A.variant = J.variant; A.delay = J.delay; A.n_iters = J.n_iters; A.state_in_lds = J.state_in_lds; A.n_cols = J.n_cols; A.ip = J.ip;
+    A.variant = J.variant; A.delay = J.delay; A.n_iters = J.n_iters; A.state_in_lds = J.state_in_lds; A.tree_in_lds = J.tree_in_lds; A.n_cols = J.n_cols; A.ip = J.ip;
     PRL_G(A.level_start); PRL_G(A.term_nodes); PRL_G(A.nodes_p[0]); PRL_G(A.nodes_p[1]); PRL_G(A.ip);
 #undef PRL_G
-    if (A.state_in_lds) prl_small_iterations_body<true>(T, SG, A);
-    else prl_small_iterations_body<false>(T, SG, A);
+    prl_small_iterations_dispatch(T, SG, A);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -711,6 +764,15 @@ size_t prl_small_state_bytes(const PrlDevTree& T, const PrlDevState& S) {
            (S.avg_sum ? al(nc * 4) : 0) + al(nc * 8) + al(T.n_nodes);
 }
 
+// what of a small tree goes to LDS: the whole solver state if it fits, and the tree's arrays if they fit beside it (or alone)
+void prl_small_lds_plan(const PrlDevTree& T, const PrlDevState& S, int n_term, int n_nodes_p0, int n_nodes_p1, bool* state_in_lds, bool* tree_in_lds, size_t* bytes) {
+    const size_t limit = 160 * 1024 - 256, st = prl_small_state_bytes(T, S), tr = prl_small_tree_bytes(T, n_term, n_nodes_p0, n_nodes_p1);
+    *state_in_lds = st <= limit;
+    *state_in_lds = PRL_SMALL_IP_BYTES + st <= limit;
+    const size_t base = PRL_SMALL_IP_BYTES + (*state_in_lds ? st : 0);
+    *tree_in_lds = base + tr <= limit;
+    *bytes = base + (*tree_in_lds ? tr : 0);
+}
 void prl_launch_small_iterations_many(const PrlSmallJob* d_jobs, int n_jobs, size_t lds_bytes, void* stream) {
     if (n_jobs > 0) PRL_LAUNCH_Y(prl_k_small_iterations_many, n_jobs, 1024, lds_bytes, stream, d_jobs);
 }
@@ -718,15 +780,17 @@ void prl_launch_small_iterations_many(const PrlSmallJob* d_jobs, int n_jobs, siz
 void prl_launch_small_iterations(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_level_start, const int32_t* d_term_nodes, int n_term,
                                  const int32_t* d_nodes_p0, int n0, const int32_t* d_nodes_p1, int n1, int variant, int delay, int n_iters,
                                  PrlIterDev* d_ip, void* stream) {
-    const size_t lds = prl_small_state_bytes(T, S);
-    const bool in_lds = lds <= 160 * 1024 - 256;
+    size_t lds = 0;
+    bool in_lds = false, tree_lds = false;
+    prl_small_lds_plan(T, S, n_term, n0, n1, &in_lds, &tree_lds, &lds);
     PrlSmallIterArgs A;
     A.state_in_lds = in_lds ? 1 : 0;
+    A.tree_in_lds = tree_lds ? 1 : 0;
     A.n_cols = T.n_cols;
     A.level_start = d_level_start; A.term_nodes = d_term_nodes; A.n_term = n_term;
     A.nodes_p[0] = d_nodes_p0; A.nodes_p[1] = d_nodes_p1; A.n_nodes_p[0] = n0; A.n_nodes_p[1] = n1;
     A.variant = variant; A.delay = delay; A.n_iters = n_iters; A.ip = d_ip;
-    PRL_LAUNCH(prl_k_small_iterations, 1, 1024, in_lds ? lds : 0, stream, T, S, A);
+    PRL_LAUNCH(prl_k_small_iterations, 1, 1024, lds, stream, T, S, A);
 }
 
 void prl_launch_iter_begin(PrlIterDev* d_ip, int variant, int delay, void* stream) { PRL_LAUNCH(prl_k_iter_begin, 1, 64, 0, stream, d_ip, variant, delay); }
