@@ -30,7 +30,7 @@ extern "C" int32_t prl_device_available(void);
 #ifndef LBRB_THREADS
 #define LBRB_THREADS 1024
 #endif
-#define LBRB_MAX_Q 12      // check/call + up to 11 raise sizes considered by LBR (OFF_TREE_11); sized so that TWO workgroups fit the 160 KB of LDS of a CU
+#define LBRB_MAX_Q 12      // check/call + up to 11 raise sizes considered by LBR (OFF_TREE_11): twelve candidate ranges = 64 KB of the workgroup's ~138 KB of LDS
 #define LBRB_MAX_LEGAL 16  // fold, check/call and up to 14 bet sizes of either player: per-lane arrays of this size stay small (private memory
                            // per lane bounds how many waves the runtime keeps in flight)
 #define LBRB_MAX_BOARDS 52  // boards per equity kept in LDS: one card to come (52-card turn: 46; >= PRL_LBR_MAX_CARDS: the rows double as work arrays)
