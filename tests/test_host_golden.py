@@ -331,6 +331,16 @@ def test_c_abi_exports_every_declared_symbol():
     assert _native.build_flavor() == "hip-gfx950"
 
 
+def test_solver_field_ids_of_the_python_host_match_the_header():
+    """the PRL_SF_* ids of include/pokerrl_hip.h are what pokerrl_amd._native passes to prl_solver_get / prl_solver_get_cols"""
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "pokerrl_hip.h")).read()
+    ids = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"\bPRL_SF_([A-Z0-9_]+)\s*=\s*(\d+)", hdr)}
+    assert len(ids) >= 19 and len(set(ids.values())) == len(ids)
+    assert ids == dict(_native.SF), (sorted(set(ids.items()) ^ set(_native.SF.items())))
+
+
 @pytest.mark.parametrize("tag", ["StandardLeduc", "DiscretizedNLLeduc", "DiscretizedNLHoldem"])
 def test_head_to_head_vs_reference(tag, tmp_path):
     """LocalHead2HeadMaster on the native-backed env -- per-hand winnings and logged scalars of the reference's
