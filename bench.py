@@ -40,12 +40,17 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # regret columns of 1088 + the plan in, 7 regret columns out, 7 float64 average columns in and out -- the reference's float64 average is
 # 53 % of it -- and the block rows of root vectors), so other sizes scale linearly.
 PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION = 119.6e9 / 262144
-# the opt-in float32 running average has not been re-measured on the sorted storage (round 3, hand-order columns: 106.1 GB,
-# profiles/r05zz_avg_f32_pmc_traffic.txt): its bench line reports traffic null
-PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 = None
+# the opt-in float32 running average on the sorted storage (round 5, profiles/r30_avg_f32_pmc_traffic.txt): UPDATE0_BR 2 * 13.76 GB read +
+# 16.97 GB written, UPDATE1_EVAL1 2 * 13.75 + 16.89 = 88.9 GB per iteration = 0.89x the algorithmic bytes (which count 1326 entries per column
+# where the storage holds 1088); round 3, hand-order columns: 106.1 GB
+PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 = 88.9e9 / 262144
+# Linear CFR (BASELINE config 3; float32 avg_sum instead of the float64 running average), profiles/r30_linear_pmc_traffic.txt:
+# 2 * 13.74 + 16.30 and 2 * 13.74 + 16.15 = 87.4 GB per iteration
+PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_LINEAR = 87.4e9 / 262144
 # the two-seat evaluation pass over the float64 averages (prl_k_fhp_pass<EVAL, AVG, AVG>): 2 * 17.65 GB read + 0.17 GB written
 PMC_TRAFFIC_BYTES_PER_BOARD_AVG_EVALUATION = 35.47e9 / 262144
-PMC_TRAFFIC_SOURCE = "profiles/r06_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+PMC_TRAFFIC_SOURCE = ("profiles/r06_pmc.txt (CFR+), r30_avg_f32_pmc_traffic.txt (--avg-f32), r30_linear_pmc_traffic.txt (--variant linear): "
+                      "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md")
 
 
 def seeded_boards(n, seed, offset=0):
@@ -219,7 +224,11 @@ def main():
         # --no-placement-probe measures the first allocation as is.
         probe = args.placement_probe and not emu_lib and args.engine != "levels"
         solver = _native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib, avg_dtype=avg_dtype,
-                                      place=args.placement_candidates if probe else None)
+                                      place=args.placement_candidates if probe else None,
+                                      # every candidate is timed the way the headline is: 3 untimed iterations, then as many steady ones as the
+                                      # timed region has (HIP events on the solver's stream), so the first allocation's figure below is what a
+                                      # user who does not probe gets, on the headline's own clock
+                                      probe_iters=max(4, args.steps))
         if solver.placement_ms is not None and solver.engine == "fused":
             placement = [x for x in solver.placement_ms if x > 0.0]
             placement_chosen = solver.placement_chosen
@@ -276,8 +285,11 @@ def main():
     bytes_iter = 20.0 * R * sum_a + 8.0 * R * args.boards  # per GPU
     kernel_ms = pass_ms if n_pass else dev_ms
     achieved = bytes_iter * args.steps / (kernel_ms * 1e-3) / 1e9
-    pmc_ok = solver.engine == "fused" and args.variant == "plus"
-    pmc_per_board = (PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 if args.avg_f32 else PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION) if pmc_ok else None
+    pmc_ok = solver.engine == "fused" and args.variant in ("plus", "linear")
+    pmc_per_board = None
+    if pmc_ok:
+        pmc_per_board = (PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_LINEAR if args.variant == "linear" else
+                         PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 if args.avg_f32 else PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION)
     expl = solver.exploitability()
     out = {
         "metric": "CFR+ node-updates/sec on FHP public tree" if args.variant == "plus" else "%s CFR node-updates/sec on FHP public tree" % args.variant,
@@ -309,6 +321,10 @@ def main():
             "hbm_bytes_allocated": int(solver.get("bytes_allocated")[0]),
             "placement_probe_ms_per_iteration": placement,  # one entry per candidate allocation, built by the library (prl_solver_create_placed): the fastest was kept (None: not probed)
             "placement_chosen": placement_chosen, "first_allocation_probe_ms_per_iteration": placement[0] if placement else None,
+            # the same number under the name it deserves since round 5: device ms per STEADY iteration (3 warm-up iterations, then `steps` timed ones) of
+            # the first allocation, i.e. an unprobed NativeSolver(tree, ...) in this process on this box; and the node-updates/s it corresponds to
+            "first_allocation_steady_ms_per_iteration": placement[0] if placement else None,
+            "first_allocation_node_updates_per_s": (n_nodes_total / (placement[0] * 1e-3)) if placement else None,
         },
         # the reference's iteration() also evaluates the AVERAGE strategy every time (_CFRBase.py:134,218-262): the same figure for the
         # iteration WITH that evaluation pass -- algorithmic bytes of the evaluation: the float64 average once + one rank vector per board
@@ -319,7 +335,8 @@ def main():
             "frac": (bytes_iter + 8.0 * R * sum_a + 4.0 * R * args.boards) / ((kernel_ms / args.steps + avg_eval_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "ms_per_iteration": kernel_ms / args.steps + avg_eval_ms, "bytes_per_iteration_algorithmic": bytes_iter + 8.0 * R * sum_a + 4.0 * R * args.boards,
             "kernel": "prl_k_fhp_pass: the two update passes + the two-seat evaluation pass over the float64 averages",
-            "traffic": ((pmc_per_board + PMC_TRAFFIC_BYTES_PER_BOARD_AVG_EVALUATION) * args.boards if (pmc_per_board is not None and not args.avg_f32) else None)},
+            "traffic": ((pmc_per_board + PMC_TRAFFIC_BYTES_PER_BOARD_AVG_EVALUATION) * args.boards
+                        if (pmc_per_board is not None and not args.avg_f32 and args.variant == "plus") else None)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": (pmc_per_board * args.boards if pmc_per_board is not None else None),
                      "traffic_source": PMC_TRAFFIC_SOURCE,

@@ -195,7 +195,11 @@ static const PrlRcclApi& prl_rccl_api() {
         const char* forced = getenv("PRL_RCCL_LIB");
         if (forced && *forced) {
             h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
-            if (!h) { a.why = std::string("PRL_RCCL_LIB=") + forced + ": " + (dlerror() ? dlerror() : "dlopen failed"); return a; }
+            if (!h) {
+                const char* de = dlerror();  // ONE call: dlerror() clears its state when read
+                a.why = std::string("PRL_RCCL_LIB=") + forced + ": " + (de ? de : "dlopen failed");
+                return a;
+            }
         }
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
         if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
@@ -1235,7 +1239,11 @@ int32_t prl_solver_create_placed(const prl_tree_t* tree, int32_t variant, int32_
         prl_solver* s = nullptr;
         rc = prl_solver_create_opts(tree, variant, delay, engine, flags, &s);
         if (rc != PRL_OK) {
-            if (rc == PRL_ERR_OOM && !cand.empty()) { rc = PRL_OK; break; }  // no room for another set of arrays: choose among those there are
+            if (rc == PRL_ERR_OOM && !cand.empty()) {  // no room for another set of arrays: choose among those there are
+                (void)hipGetLastError();  // the tolerated hipMalloc failure must not be what the survivor's next PRL_HIP_TRY(hipGetLastError()) reports
+                rc = PRL_OK;
+                break;
+            }
             for (prl_solver* c : cand) prl_solver_destroy(c);
             return rc;
         }
@@ -1254,8 +1262,12 @@ int32_t prl_solver_create_placed(const prl_tree_t* tree, int32_t variant, int32_
     for (size_t i = 0; i < cand.size(); ++i) if (i != best) prl_solver_destroy(cand[i]);
     if (out_ms) for (size_t i = 0; i < ms.size(); ++i) out_ms[i] = ms[i];
     if (out_chosen) *out_chosen = (int32_t)best;
+    if (!ms.empty()) {
+        rc = prl_solver_reset(cand[best]);
+        if (rc != PRL_OK) { prl_solver_destroy(cand[best]); *out = nullptr; return rc; }  // the caller gets no handle, so nothing may stay allocated
+    }
     *out = cand[best];
-    return ms.empty() ? PRL_OK : prl_solver_reset(cand[best]);
+    return PRL_OK;
 }
 
 int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out) {
@@ -1332,7 +1344,12 @@ int32_t prl_solver_load_state(prl_solver_t* s, const void* in, uint64_t bytes) {
     PrlStateHeader h;
     memcpy(&h, in, sizeof(h));
     if (s->avg_f32) { prl_set_error("load_state: not for solvers with the float32 running average (PRL_SOLVER_AVG_F32)"); return PRL_ERR_UNSUPPORTED; }
-    if (h.magic != PRL_STATE_MAGIC || h.version != PRL_STATE_VERSION) { prl_set_error("load_state: not a solver state blob (or one of another library version)"); return PRL_ERR_ARG; }
+    if (h.magic != PRL_STATE_MAGIC) { prl_set_error("load_state: not a solver state blob"); return PRL_ERR_ARG; }
+    if (h.version != PRL_STATE_VERSION) {  // version 3 (round 4) stores the sorted board storage as it is held: older blobs cannot be read ("Checkpoints")
+        prl_set_error("load_state: state blob of format version " + std::to_string(h.version) + ", this library reads version " + std::to_string(PRL_STATE_VERSION) +
+                      " only (no migration: re-solve, or load with the library that wrote it and hand the columns over through prl_solver_get / prl_solver_set_strategy)");
+        return PRL_ERR_ARG;
+    }
     if (h.variant != s->variant || h.delay != s->delay || h.fused != (int32_t)s->fused || h.full_cols != s->full_cols || h.R != s->R ||
         h.trunk_cols != s->T.n_cols || h.trunk_nodes != s->T.n_nodes || h.has_avg_sum != (int32_t)(s->S.avg_sum != nullptr) || h.iter < 0) {
         prl_set_error("load_state: the blob was saved by a solver with a different tree / variant / delay / engine");

@@ -767,7 +767,6 @@ size_t prl_small_state_bytes(const PrlDevTree& T, const PrlDevState& S) {
 // what of a small tree goes to LDS: the whole solver state if it fits, and the tree's arrays if they fit beside it (or alone)
 void prl_small_lds_plan(const PrlDevTree& T, const PrlDevState& S, int n_term, int n_nodes_p0, int n_nodes_p1, bool* state_in_lds, bool* tree_in_lds, size_t* bytes) {
     const size_t limit = 160 * 1024 - 256, st = prl_small_state_bytes(T, S), tr = prl_small_tree_bytes(T, n_term, n_nodes_p0, n_nodes_p1);
-    *state_in_lds = st <= limit;
     *state_in_lds = PRL_SMALL_IP_BYTES + st <= limit;
     const size_t base = PRL_SMALL_IP_BYTES + (*state_in_lds ? st : 0);
     *tree_in_lds = base + tr <= limit;
