@@ -71,7 +71,11 @@ def build_variant(name, defines):
     vdir = os.path.join(LIB_DIR, "obj_" + name)
     os.makedirs(vdir, exist_ok=True)
     procs, objs = [], []
+    only = os.environ.get("PRL_VARIANT_ONLY", "").split()  # experiments on one kernel file: the other objects are the product's own
     for s in sources():
+        if only and s not in only:
+            objs.append(os.path.join(OBJ_DIR, s + ".o"))
+            continue
         obj = os.path.join(vdir, s + ".o")
         objs.append(obj)
         extra = os.environ.get("PRL_VARIANT_FLAGS", "").split()  # experiments with compiler options, e.g. "-mllvm -amdgpu-sched-strategy=max-ilp"

@@ -91,6 +91,10 @@ template <int D>
 PRL_DEV PRL_INLINE float prl_dpp_row_shr(float v) {  // lane l <- lane l - D inside its row of 16 lanes
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xF, 0xF, false));
 }
+template <int N>
+PRL_DEV PRL_INLINE float prl_dpp_row_share(float v) {  // every lane <- lane N of its own row of 16 (gfx90a+: row_newbcast / row_share): VALU, no LDS crossbar
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + N, 0xF, 0xF, false));
+}
 PRL_DEV PRL_INLINE float prl_dpp_row_bcast15(float v) {  // rows 1 and 3 <- lane 15 of the previous row
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
 }

@@ -3,7 +3,7 @@
 # pass is judged on: bench.py (CFR+ headline + its average-strategy evaluation) and bench_br.py (best-response-only pass)
 #   gpurun -- bash scripts/gpu_r5b.sh TAG [full]
 cd $GRAFT_REPO_ROOT; TAG=${1:-r31}; mkdir -p gpurun_out
-K="fused and not streets"
+K="fused and not streets"; [ "$2" = quick ] && K="fused and not streets and not bench_size and not properties"
 timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "$K" -p no:cacheprovider > gpurun_out/${TAG}_pytest_fused.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_fused.txt
 tail -3 gpurun_out/${TAG}_pytest_fused.txt
 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err

@@ -87,6 +87,8 @@ inline float prl_dpp_row_shr(float v) {
     float r = prl_shfl(v, (lane & 15) >= D ? lane - D : lane);
     return (lane & 15) >= D ? r : 0.f;
 }
+template <int N>
+inline float prl_dpp_row_share(float v) { return prl_shfl(v, ((int)prl_lane() & 48) + N); }  // every lane <- lane N of its row of 16
 inline float prl_dpp_row_bcast15(float v) {
     int lane = (int)prl_lane();
     int row = lane >> 4;
