@@ -12,7 +12,7 @@ and the env's cards. value = env-steps/s. roofline: HBM, algorithmic bytes per e
 config.rollout_*: the same play with the state held in registers (64 steps per launch, no HBM round trip per step; whole hands incl. dealing,
 showdown ranks and payouts): the integer-ALU figure.
 cpu_baseline: the same hands (same counter-based draws and decks) played by the same C++ engine on ONE host core (kind "port"); the
-reference's Python PokerEnv.step was measured at 16.1 k steps/s on one core of the survey box -- it does not travel to
+reference's own Python PokerEnv.step loop is timed by scripts/time_reference.py (profiles/reference_cpu.json, quoted in the line) -- it does not travel to
 the GPU box, so it cannot be timed in the same run.
 """
 import argparse
@@ -23,6 +23,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+import bench_ref  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0
 # HBM bytes per launch of prl_k_ebf_random_step at 2^20 envs from the PMC counters (profiles/r08_env_pmc.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
@@ -84,7 +86,9 @@ def main():
         out["cpu_baseline"] = {"value": s3[0] / dtc, "unit": "env-steps/s", "cores": 1, "kind": "port",
                                "sample": "%d envs x %d steps, the same engine (csrc/prl_env.h%s) and draws on one host core, %.1f s; no observation vectors on "
                                          "the host leg" % (n_cpu, k_cpu, " + dealing, showdown ranks, payouts" if full else "", dtc),
-                               "reference_python_steps_per_s_survey_box": 16100.0}
+                               # the reference's own env.step loop (random play, the same game), timed by scripts/time_reference.py
+                               "reference_python_steps_per_s": bench_ref.figure("env_step_random_play", "DiscretizedNLHoldem_B_5" if args.game == "DiscretizedNLHoldem" else args.game, "steps_per_s"),
+                               "reference_timing_source": bench_ref.SOURCE, "reference_timing_host": bench_ref.host()}
     print(json.dumps(out), flush=True)
 
 

@@ -2,7 +2,8 @@
 bench_handeval.py -- 7-card hand evaluations/s: all 1326 hole-card pairs on B seeded 5-card boards, device buffers in and out
 (prl_hand_rank_boards_device = get_hand_rank_all_hands_on_given_boards_52_holdem of the reference, CppHandeval.py:34-46).
 Algorithmic bytes: 5 B of board in + 4 B per (board, hand) out; the kernel is bound by integer ALU issue and the int32 store
-(SURVEY.md section 8d). The CPU figure beside it is the C oracle's evaluator on one core.
+(SURVEY.md section 8d). The CPU figure beside it is the C oracle's evaluator on one core (the same run), with the REFERENCE BINARY's batched rate on
+one core of the build container next to it (profiles/reference_cpu.json: lib_hand_eval.so does not travel either) -- the faster of the two baselines.
 
     python bench_handeval.py [--boards B] [--reps K]
 """
@@ -16,6 +17,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
+
+import bench_ref  # noqa: E402
 
 
 def main():
@@ -64,7 +67,10 @@ def main():
                       "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                                    "kernel": "prl_k_hand_rank_boards", "kernel_ms_per_launch": ms, "bytes_per_call_algorithmic": bytes_call,
                                    "note": "integer ALU issue (the evaluator) shares the bound with the int32 store stream (SURVEY.md 8d)"},
-                      "cpu_baseline": {"value": cpu, "unit": "evals/s", "cores": 1, "kind": "port", "sample": "%d boards, oracle/prl_oracle.c" % n_cpu}}))
+                      "cpu_baseline": {"value": cpu, "unit": "evals/s", "cores": 1, "kind": "port", "sample": "%d boards, oracle/prl_oracle.c" % n_cpu,
+                                       # the reference's own evaluator (binary-only lib_hand_eval.so, batched call): timed by scripts/time_reference.py
+                                       "reference_binary_evals_per_s_per_core": bench_ref.figure("hand_evaluator", "batched", "evals_per_s"),
+                                       "reference_timing_source": bench_ref.SOURCE, "reference_timing_host": bench_ref.host()}}))
 
 
 if __name__ == "__main__":

@@ -25,6 +25,8 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+import bench_ref  # noqa: E402
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -167,8 +169,9 @@ def main():
                                          "(oracle/lbr.py, NumPy, the reference's rollout manager restated), %d hands, same agent and bet sets, %.1f s" % (n_host, dth),
                                "host_worker_with_device_equity_hands_per_s": args.cpu_hands / dtc,
                                "host_worker_with_device_equity_sample": "the same loop with prl_lbr_checkdown_equity (one GPU call per LBR decision), %d hands, %.1f s" % (args.cpu_hands, dtc),
-                               # the reference's own worker needs /root/reference, which does not travel to the GPU box: its timing is the survey box's
-                               "reference_python_hands_per_s_survey_box": 30.0, "reference_timing_source": "BASELINE.md section 2 (LocalLBRWorker, one core)"}
+                               # the reference's own worker needs /root/reference, which does not travel to the GPU box: timed by scripts/time_reference.py
+                               "reference_python_hands_per_s": bench_ref.figure("local_lbr_worker_run", "DiscretizedNLHoldem_TURN_OFF_TREE_11", "hands_per_s"),
+                               "reference_timing_source": bench_ref.SOURCE, "reference_timing_host": bench_ref.host()}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -17,6 +17,8 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+import bench_ref  # noqa: E402
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -95,7 +97,12 @@ def main():
         for _ in range(args.cpu_iters):
             o.cfr_iteration()
         out["cpu_baseline"] = {"value": tree.n_nodes * args.cpu_iters / (time.perf_counter() - t1), "unit": "node-updates/s", "cores": 1,
-                               "kind": "port", "sample": "oracle/prl_oracle.c, %d iterations of the same tree" % args.cpu_iters}
+                               "kind": "port", "sample": "oracle/prl_oracle.c, %d iterations of the same tree" % args.cpu_iters,
+                               # the reference's own cfr.iteration() on this game (it runs the Leduc family), timed by scripts/time_reference.py
+                               "reference_python_node_updates_per_s": bench_ref.figure("cfr_iteration", "%s/%s" % (
+                                   "DiscretizedNLLeduc_POT_ONLY" if args.game == "DiscretizedNLLeduc" else args.game,
+                                   {"plus": "CFRPlus", "vanilla": "VanillaCFR", "linear": "LinearCFR"}[args.variant]), "node_updates_per_s"),
+                               "reference_timing_source": bench_ref.SOURCE, "reference_timing_host": bench_ref.host()}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
