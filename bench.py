@@ -108,6 +108,30 @@ def shard_geometry(total, world, rank):
     return per, mine
 
 
+def fixed_problem_check(total, iters, world, rank, how, lib, emu_lib):
+    """The SAME small problem whatever the world size: ONE seeded list of `total` boards split over the ranks (ragged shards of whole canonical
+    units, as --total-boards), `iters` CFR+ iterations through the run's own exchange path, exploitability of both seats as float32 bit
+    patterns. The sharded solve is bit-identical to the one-GPU solve by construction (canonical chance sum): the driver's N = 1, 2, 4, 8
+    lines carry this object, so the claim is checked by the scaling run itself -- equal hex strings in every line."""
+    from pokerrl_amd import _native
+    per, mine = shard_geometry(total, world, rank)
+    tree = fhp_tree(seeded_boards(mine, 0, offset=rank * per), lib)
+    if world == 1:
+        solver = _native.NativeSolver(tree, "plus", 0, engine="fused", _lib=lib)
+    elif how == "rccl":
+        from pokerrl_amd.dist import rccl_shard
+        solver = _native.NativeSolver(tree, "plus", 0, shard=rccl_shard(world, rank, per, total, lib=lib), _lib=lib)
+    else:
+        from pokerrl_amd.dist import TorchExchange
+        solver = _native.NativeSolver(tree, "plus", 0, shard=(world, rank, TorchExchange("cpu" if emu_lib else "cuda"), per, total), _lib=lib)
+    solver.iterations(iters)
+    e = np.asarray(solver.exploitability(), np.float32)
+    a = np.asarray(solver.eval_avg(), np.float32)
+    return {"total_boards": total, "iterations": iters, "world": world, "exchange": how if world > 1 else None,
+            "exploitability_f32_hex": [x.tobytes().hex() for x in e], "avg_strategy_exploitability_f32_hex": [x.tobytes().hex() for x in a],
+            "exploitability_mbb_per_g": float(np.mean(e) * 10.0)}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` outside a launcher: start the N ranks (one process per GPU) the way the driver would."""
     import subprocess
@@ -142,6 +166,9 @@ def main():
     ap.add_argument("--placement-candidates", type=int, default=3, help="one GPU: solver objects built and timed one after the other before the run, the fastest is kept")
     ap.add_argument("--no-placement-probe", dest="placement_probe", action="store_false",
                     help="one GPU: do not build a second set of arrays to keep the faster-placed one (DESIGN.md section 4)")
+    ap.add_argument("--fixed-check-boards", type=int, default=-1,
+                    help="after the timed region: one list of this many boards solved by all ranks together for 3 iterations, exploitability bits in "
+                         "config.fixed_problem_check -- the same in the N = 1, 2, 4, 8 lines (default 8192; 0 = off; the emulator runs of the CPU suite: off unless given)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-boards", type=int, default=384)
     ap.add_argument("--cpu-iters", type=int, default=24)
@@ -278,6 +305,12 @@ def main():
             del sv
         avg_check = {"boards": 4096, "iterations": 100, "avg_strategy_exploitability_mbb_per_g_f64": ev["f64"], "avg_strategy_exploitability_mbb_per_g_f32": ev["f32"],
                      "relative_difference": abs(ev["f32"] - ev["f64"]) / ev["f64"], "current_strategy_exploitability_mbb_per_g_both": cur}
+    fixed = None
+    n_fixed = args.fixed_check_boards if args.fixed_check_boards >= 0 else (0 if emu_lib else 8192)
+    if n_fixed > 0 and n_fixed >= world:
+        # (the check's arrays are small beside the run's: 8192 boards = 1.8 GB over all ranks)
+        fixed = fixed_problem_check(n_fixed, 3, world, rank, how if world > 1 else None, lib, emu_lib)
+        barrier()
     n_board_nodes = args.boards * 15
     n_nodes_total = (tree.n_nodes - n_board_nodes) + (total * 15 if total else n_board_nodes * world)  # one trunk + every rank's board subtrees
     value = n_nodes_total * args.steps / dt
@@ -314,6 +347,7 @@ def main():
             # what one all-gather moves: every rank contributes its canonical units (blocks / groups of boards) of <= 3 root vectors
             "exchange_bytes_per_pass_per_rank_upper": (int(-(-args.boards // 1024)) if args.boards % 1024 == 0 else int(-(-args.boards // 32)) if args.boards % 32 == 0 else args.boards) * 3 * tree.range_size * 4 if sharded else None,
             "rccl_library": rccl_path,
+            "fixed_problem_check": fixed,
             "iterations_done": solver.iter, "exploitability_mbb_per_g": float(np.mean(expl) * 10.0),
             "exploitability_pinned_to": "oracle/ (C restatement of the reference with an explicit float32 summation order; the reference cannot build 2-hole-card trees)",
             "avg_strategy_exploitability_mbb_per_g": float(np.mean(avg_expl) * 10.0), "avg_strategy_evaluation_ms": avg_eval_ms,

@@ -85,8 +85,25 @@ def rccl_shard(world, rank, shard_boards=None, total_boards=None, group=None, li
     all-gather of every EV pass is one ncclAllGather on the solver's stream -- no Python, no callback in the iteration loop.
     torch.distributed is used for this one broadcast only (any other channel would do: the C ABI takes the raw bytes)."""
     import ctypes
+    import os
     from pokerrl_amd import _native
     L = lib or _native.lib()
+    if world > 1:
+        # PRE-FLIGHT, before anybody enters a collective of the new communicator: every rank says whether IT can bind RCCL (prl_rccl_info) and the
+        # ranks agree (all-reduce MIN over the torch group). A rank that cannot (a mistyped PRL_RCCL_LIB on one host, a second ROCm) makes ALL
+        # ranks raise here -- otherwise the others would sit in ncclCommInitRank waiting for it. (PRL_TEST_RCCL_FAIL_RANK=<r>: the tests' way
+        # of failing one rank.)
+        info = ctypes.create_string_buffer(512)
+        ok = int(L.prl_rccl_info(info, 512)) == 0
+        why = info.value.decode("utf-8", "replace")
+        if os.environ.get("PRL_TEST_RCCL_FAIL_RANK") == str(rank):
+            ok, why = False, "forced by PRL_TEST_RCCL_FAIL_RANK"
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            raise RuntimeError("rccl_shard: RCCL cannot be bound on every rank (rank %d: %s); every rank raises before any ncclCommInitRank -- "
+                               "fall back to exchange='torch'" % (rank, why if not ok else "fine here: " + why))
     buf = (ctypes.c_char * 128)()
     # every rank enters the broadcast whatever happened on rank 0: a status byte travels with the id, so that a rank 0 that could not
     # draw one (librccl not loadable) makes ALL ranks raise instead of leaving the others inside the collective

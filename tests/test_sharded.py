@@ -176,18 +176,22 @@ def test_bench_gpus_2_launches_two_ranks_gloo_emu(EMU):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["PRL_BENCH_EMU_LIB"] = EMU
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--boards", "2", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, check=True).stdout
+    out = subprocess.run(cmd + ["--fixed-check-boards", "3"], env=env, capture_output=True, text=True, timeout=900, check=True).stdout
     line = [x for x in out.splitlines() if x.startswith("{")]
     assert len(line) == 1, out  # ONE JSON line, printed by rank 0
     j = json.loads(line[0])
     assert j["n_gpus"] == 2 and j["steps"] == 1 and j["scaling"] == "weak"
     assert j["config"]["nodes_whole_tree"] == 5 + 15 * 4 and j["config"]["exchanges"] > 0 and j["config"]["iterations_done"] == 2
     # the two-rank solve of the 4 boards equals the one-rank solve of the same 4 boards
-    one = subprocess.run(cmd[:2] + ["--gpus", "1", "--steps", "1", "--warmup", "1", "--boards", "4", "--no-cpu-baseline"], env=env,
+    one = subprocess.run(cmd[:2] + ["--gpus", "1", "--steps", "1", "--warmup", "1", "--boards", "4", "--no-cpu-baseline", "--fixed-check-boards", "3"], env=env,
                          capture_output=True, text=True, timeout=900, check=True).stdout
     j1 = json.loads([x for x in one.splitlines() if x.startswith("{")][0])
     assert j1["n_gpus"] == 1 and j1["config"]["exchanges"] == 0
     assert j1["config"]["exploitability_mbb_per_g"] == j["config"]["exploitability_mbb_per_g"]
+    # the fixed problem the SCALE lines carry (one list of boards whatever the world size): the same bits from one rank and from two
+    f1, f2 = j1["config"]["fixed_problem_check"], j["config"]["fixed_problem_check"]
+    assert (f1["world"], f2["world"], f1["total_boards"], f2["total_boards"]) == (1, 2, 3, 3)
+    assert f1["exploitability_f32_hex"] == f2["exploitability_f32_hex"] and f1["avg_strategy_exploitability_f32_hex"] == f2["avg_strategy_exploitability_f32_hex"]
     # ONE list of 3 boards over two ranks (2 + 1, `--all-boards` in small): strong scaling, same result as the one-rank solve of the 3
     rag = subprocess.run(cmd[:2] + ["--gpus", "2", "--steps", "1", "--warmup", "1", "--total-boards", "3", "--no-cpu-baseline"], env=env,
                          capture_output=True, text=True, timeout=900, check=True).stdout
@@ -215,6 +219,36 @@ def test_bench_br_gpus_2_launches_two_ranks_gloo_emu(EMU):
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["exchanges"] > 0
     assert j["config"]["nodes_whole_tree"] == 5 + 15 * 4 and j["config"]["engine"] == "fused"
     assert j["roofline"]["kernel"].startswith("prl_k_fhp_pass") and j["config"]["exploitability_mbb_per_g"] > 0
+
+
+def _preflight_ranks(bad_rank, id_fails, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(HERE, "rccl_preflight_worker.py"), str(bad_rank), "1" if id_fails else "0"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)  # a hang (one rank inside a collective) is the failure mode
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [x for x in out.stdout.splitlines() if x.startswith(("RAISED", "ID"))]
+
+
+@pytest.mark.parametrize("bad_rank", [0, 1])
+def test_rccl_shard_preflight_one_rank_cannot_bind_rccl_every_rank_raises(bad_rank):
+    """pokerrl_amd.dist.rccl_shard: a rank that cannot bind RCCL (rank 0 OR rank 1: e.g. a mistyped PRL_RCCL_LIB on one host) makes EVERY rank raise
+    before anybody enters ncclCommInitRank -- so bench.py's agreement (all ranks fall back to --exchange torch) is reached instead of a hang"""
+    lines = _preflight_ranks(bad_rank, False)
+    assert len(lines) == 2 and all(x.startswith("RAISED") and "every rank raises" in x for x in lines), lines
+
+
+def test_rccl_shard_preflight_forced_failure_on_rank_1_and_id_failure_on_rank_0():
+    lines = _preflight_ranks(-1, False, {"PRL_TEST_RCCL_FAIL_RANK": "1"})  # both can bind, the environment knob fails rank 1
+    assert len(lines) == 2 and all(x.startswith("RAISED") for x in lines), lines
+    lines = _preflight_ranks(-1, True)  # everybody can bind, rank 0 cannot draw the communicator id: the status byte of the broadcast
+    assert len(lines) == 2 and all(x.startswith("RAISED") and "could not draw" in x for x in lines), lines
+    lines = _preflight_ranks(-1, False)  # nothing fails: both ranks hold the same 128 bytes
+    assert len(lines) == 2 and all(x.startswith("ID") for x in lines) and lines[0] == lines[1], lines
 
 
 def test_bench_shard_geometry():
