@@ -153,6 +153,10 @@ def main():
                          "holds the same whole number of canonical summation units, the last one the rest); overrides --boards")
     ap.add_argument("--all-boards", action="store_true", help="--total-boards 2598960: every flop of Flop5Holdem, the whole game (about 88 GB "
                     "of HBM per GPU on 8 GPUs; does not fit fewer than 4)")
+    ap.add_argument("--whole-game", action="store_true",
+                    help="ONE GPU: the whole Flop5Holdem game -- all 2 598 960 boards through their 134 459 suit classes (multiplicities 4 / 12 / 24, "
+                         "chance values averaged over every hand's suit orbit: prl_solver_create_weighted, an algorithmic extension the reference lacks; "
+                         "~28 GB of HBM). A second bench line: config.workload says so; value counts the class nodes actually updated")
     ap.add_argument("--engine", default=os.environ.get("PRL_BENCH_ENGINE", "auto"))
     ap.add_argument("--variant", default="plus", choices=["plus", "linear", "vanilla"],
                     help="CFR variant (the metric is quoted on CFR+; BASELINE config 3 also names LinearCFR)")
@@ -205,7 +209,15 @@ def main():
     shard_boards = args.boards
     if total:
         shard_boards, args.boards = shard_geometry(total, world, rank)
-    boards = seeded_boards(args.boards, 0, offset=rank * shard_boards)
+    board_mult = None
+    if args.whole_game:
+        assert world == 1 and not total, "--whole-game: one GPU (the classes of all boards fit one)"
+        from pokerrl_amd.game import board_enum
+        from pokerrl_amd.game import games as G
+        boards, board_mult = board_enum.single_deal_board_classes(G.Flop5Holdem)
+        args.boards = shard_boards = len(boards)
+    else:
+        boards = seeded_boards(args.boards, 0, offset=rank * shard_boards)
     tree = fhp_tree(boards, lib)
     exchange = None
     sharded = world > 1 or bool(os.environ.get("PRL_BENCH_FORCE_EXCHANGE"))  # the env knob runs the all-gather path on one GPU (tests)
@@ -249,13 +261,16 @@ def main():
         # (prl_solver_create_placed, NativeSolver(place=k)): it builds k solvers side by side (3 x 54 GB fit one GPU at this size), times each,
         # keeps the fastest. All timings are reported (config.placement_probe_ms_per_iteration; the first entry is what a plain create gets);
         # --no-placement-probe measures the first allocation as is.
-        probe = args.placement_probe and not emu_lib and args.engine != "levels"
-        solver = _native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib, avg_dtype=avg_dtype,
-                                      place=args.placement_candidates if probe else None,
-                                      # every candidate is timed the way the headline is: 3 untimed iterations, then as many steady ones as the
-                                      # timed region has (HIP events on the solver's stream), so the first allocation's figure below is what a
-                                      # user who does not probe gets, on the headline's own clock
-                                      probe_iters=max(4, args.steps))
+        probe = args.placement_probe and not emu_lib and args.engine != "levels" and board_mult is None
+        if board_mult is not None:
+            solver = _native.NativeSolver(tree, args.variant, 0, _lib=lib, avg_dtype=avg_dtype, board_mult=board_mult, symmetrize=True)
+        else:
+            solver = _native.NativeSolver(tree, args.variant, 0, engine=args.engine, _lib=lib, avg_dtype=avg_dtype,
+                                          place=args.placement_candidates if probe else None,
+                                          # every candidate is timed the way the headline is: 3 untimed iterations, then as many steady ones as the
+                                          # timed region has (HIP events on the solver's stream), so the first allocation's figure below is what a
+                                          # user who does not probe gets, on the headline's own clock
+                                          probe_iters=max(4, args.steps))
         if solver.placement_ms is not None and solver.engine == "fused":
             placement = [x for x in solver.placement_ms if x > 0.0]
             placement_chosen = solver.placement_chosen
@@ -334,7 +349,15 @@ def main():
         "config": {
             "workload": {"plus": "CFR+ (delay 0)", "linear": "Linear CFR", "vanilla": "vanilla CFR"}[args.variant] +
                         " full-width iterations on the Flop5Holdem public tree (blinds 50/100, stacks 20000, "
-                        "pot-size raises), %s, 1326-hand ranges" % ("%d boards in all (%d on rank 0)" % (total, args.boards) if total else "%d seeded boards per GPU" % args.boards),
+                        "pot-size raises), %s, 1326-hand ranges" % (
+                            "THE WHOLE GAME: all 2598960 boards through their %d suit classes (multiplicities 4 / 12 / 24; chance values averaged over "
+                            "the hands' suit orbits: prl_solver_create_weighted)" % args.boards if board_mult is not None else
+                            "%d boards in all (%d on rank 0)" % (total, args.boards) if total else "%d seeded boards per GPU" % args.boards),
+            # --whole-game: what the class solve stands for -- the full tree's nodes and the rate at which WHOLE-GAME iterations are done
+            "boards_represented": int(board_mult.sum()) if board_mult is not None else None,
+            "whole_game_iterations_per_s": (args.steps / dt) if board_mult is not None else None,
+            "full_tree_nodes_represented": (int(board_mult.sum()) * 15 + (tree.n_nodes - n_board_nodes)) if board_mult is not None else None,
+            "equivalent_full_tree_node_updates_per_s": ((int(board_mult.sum()) * 15 + (tree.n_nodes - n_board_nodes)) * args.steps / dt) if board_mult is not None else None,
             "boards_per_gpu": args.boards, "nodes_per_gpu": tree.n_nodes, "action_columns_per_gpu": sum_a,
             "engine": solver.engine, "avg_dtype": "f32 (opt-in: PRL_SOLVER_AVG_F32; the reference's average is float64)" if args.avg_f32 else "f64", "avg_f32_check": avg_check,
             "parallelism": "boards sharded over %d GPU(s), trunk replicated, 1 all-gather of chance-node partial sums per EV pass" % world,

@@ -307,6 +307,19 @@ int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t de
  * Regrets, current strategies and the current-strategy exploitability history are unaffected. Single-deal fused engine, CFR+, no checkpoints. */
 enum { PRL_SOLVER_AVG_F32 = 1 };
 int32_t prl_solver_create_opts(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t flags, prl_solver_t** out_solver);
+/* WEIGHTED BOARDS / SUIT ISOMORPHISM (round 5; an algorithmic extension the reference lacks -- its public tree lists every board, PokerRL/game/_/tree/
+ * PublicTree.py:188-210, and cannot build 2-hole-card trees at all). `board_mult[i]` >= 1 says how many boards of the game the i-th listed board
+ * stands for; the chance probability counts sum(board_mult) boards. With `symmetrize` != 0 the listed boards are representatives of the classes of
+ * boards under the 24 suit permutations (board_mult = orbit sizes: Flop5Holdem has 134 459 classes for its 2 598 960 boards, ~28 GB of HBM: the WHOLE
+ * game on one GPU) and the chance node's value of a hand is the mean over the hand's own suit orbit of the multiplicity-weighted sum:
+ *     ev_chance[h] = (1 / |O(h)|) * sum_{h' in O(h)} sum_classes c  mult_c * v_c[h']        (O(h): the 4 / 6 / 12 hands h maps to under suit permutations)
+ * which equals the full game's sum over all boards in exact arithmetic (suits do not enter the rules; regret matching keeps strategies suit-symmetric).
+ * A class subtree works with reach scaled by mult_c (values are linear in the opponent's reach, strategies do not depend on the scale), so its
+ * regrets are mult_c x those of one member board. Summation order: the canonical chance sum over the listed boards, then the orbit sum in ascending
+ * hand index, then one correctly rounded division -- oracle/prl_oracle.c restates it (orc_set_board_weights, orc_set_symmetrize).
+ * Single-deal FUSED engine, one GPU (no exchange); flags as prl_solver_create_opts. */
+int32_t prl_solver_create_weighted(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t flags, const int32_t* board_mult, int32_t symmetrize,
+                                   prl_solver_t** out_solver);
 /* Placement selection. The fused board pass streams within ~15 % of what HBM sustains and its speed depends on WHERE its arrays land
  * physically: solver objects of one process differ by up to 15 % and keep their speed for life ("Spread"). This entry
  * point does what a careful user would do by hand: it builds up to `n_candidates` solvers of the tree side by side (all alive until the

@@ -51,6 +51,8 @@ def lib():
         L.orc_np_sum_f32.restype = ctypes.c_float
         L.orc_prefix_chunked.argtypes = [vp, i32, vp]
         L.orc_set_chance_weights.argtypes = [vp, vp]
+        L.orc_set_board_weights.argtypes = [vp, vp, i32]
+        L.orc_set_symmetrize.argtypes = [vp, vp]
         L.orc_unsupported.argtypes = [vp]
         L.orc_unsupported.restype = i32
         for n in ("orc_compute_regrets", "orc_compute_new_strategy", "orc_add_strategy_to_average", "orc_set_iter"):
@@ -177,6 +179,20 @@ class Oracle:
     br_idx = property(lambda s: s._view("orc_br_idx", (s.n_nodes, s.R), np.int32))
     exploitability = property(lambda s: s._view("orc_expl", (2,), np.float32))
     iter = property(lambda s: int(lib().orc_iter(s._h)))
+
+    def set_board_weights(self, mult, total=None):
+        """weighted boards (prl_solver_create_weighted): the i-th child of the chance node stands for mult[i] boards; the chance probability counts
+        sum(mult) boards (or `total`). Returns the float32 weights chance_prob * mult."""
+        mult = np.asarray(mult, np.int64)
+        cp = chance_prob_f32(int(total if total is not None else mult.sum()), 52, 2, int(np.sum(self.boards[0] >= 0)))
+        w = (np.float32(cp) * mult.astype(np.float32)).astype(np.float32)
+        self._board_w = np.ascontiguousarray(w)
+        lib().orc_set_board_weights(self._h, _p(self._board_w), int(len(w)))
+        return w
+
+    def set_symmetrize(self, class_of):
+        self._sym = None if class_of is None else np.ascontiguousarray(class_of, np.int32)
+        lib().orc_set_symmetrize(self._h, None if class_of is None else _p(self._sym))
 
     def fill_uniform(self):
         lib().orc_fill_uniform(self._h)

@@ -214,6 +214,11 @@ typedef struct {
     const int8_t* boards;
     float chance_prob, eq_const;
     float* chance_w;      /* [n_nodes] weight of every outcome of a chance node for a hand it does not block (0 elsewhere) */
+    /* weighted boards / suit isomorphism (include/pokerrl_hip.h: prl_solver_create_weighted; no reference counterpart -- the reference lists every board,
+     * PublicTree.py:188-210): per-child weight of the one chance node = chance_prob x (boards the child stands for), and the chance node's values
+     * averaged over every hand's suit orbit */
+    float* board_w;       /* [children of the chance node] or NULL */
+    int32_t* sym_class;   /* [R] class of a hand under suit permutations, or NULL */
     int16_t* hole;        /* [R][2] */
     /* state */
     double* strategy;     /* [n_cols][R] */
@@ -305,7 +310,7 @@ void orc_destroy(Orc* o) {
     free((void*)o->acted_last); free((void*)o->round); free((void*)o->board_id); free((void*)o->main_pot);
     free((void*)o->n_children); free((void*)o->first_col); free((void*)o->child_start); free((void*)o->child_list);
     free((void*)o->boards);
-    free(o->chance_w);
+    free(o->chance_w); free(o->board_w); free(o->sym_class);
     free(o->hole); free(o->strategy); free(o->strat_f64); free(o->reach); free(o->ev); free(o->ev_br); free(o->br_idx);
     free(o->regret); free(o->avg_sum); free(o->avg); free(o->avg_f64); free(o->plans); free(o->plan_ready); free(o->tmp_ranks);
     free(o);
@@ -582,7 +587,7 @@ static void update_reach(Orc* o, int node) {
             const int8_t* board = o->boards + (size_t)o->board_id[c] * o->board_len;
             for (int p = 0; p < 2; ++p)
                 for (int h = 0; h < R; ++h) {
-                    float w = hand_blocked(o, h, board, o->board_len) ? 0.f : o->chance_w[node]; /* StrategyFiller.py:159-166 */
+                    float w = hand_blocked(o, h, board, o->board_len) ? 0.f : (o->board_w ? o->board_w[i] : o->chance_w[node]); /* StrategyFiller.py:159-166 */
                     V2(o, reach, c, p)[h] = V2(o, reach, node, p)[h] * w;
                 }
             update_reach(o, c);
@@ -630,6 +635,24 @@ static void compute_ev(Orc* o, int node) {
                     }
                     arr[((size_t)node * 2 + p) * R + h] = total;
                 }
+        if (o->sym_class) {
+            /* suit isomorphism: a hand's value = the mean over its suit orbit (the hands of its class, ascending hand index, running adds; one
+             * correctly rounded division) of the multiplicity-weighted sum above */
+            float* tmp = (float*)malloc(sizeof(float) * (size_t)R);
+            for (int p = 0; p < 2; ++p)
+                for (int which = 0; which < 2; ++which) {
+                    float* v = (which ? o->ev_br : o->ev) + ((size_t)node * 2 + p) * R;
+                    for (int h = 0; h < R; ++h) {
+                        float sum = 0.f;
+                        int n = 0;
+                        for (int g = 0; g < R; ++g)
+                            if (o->sym_class[g] == o->sym_class[h]) { sum = n == 0 ? v[g] : sum + v[g]; ++n; }
+                        tmp[h] = sum / (float)n;
+                    }
+                    memcpy(v, tmp, sizeof(float) * (size_t)R);
+                }
+            free(tmp);
+        }
         return;
     }
     const int pl = o->actor[node], op = 1 - pl;
@@ -889,6 +912,18 @@ int32_t* orc_br_idx(Orc* o) { return o->br_idx; }
 float* orc_expl(Orc* o) { return o->expl; }
 int orc_iter(Orc* o) { return o->iter; }
 void orc_set_chance_weights(Orc* o, const float* w) { memcpy(o->chance_w, w, sizeof(float) * (size_t)o->n_nodes); }
+/* weighted boards: w[i] for the i-th child of the (one) chance node; NULL clears */
+void orc_set_board_weights(Orc* o, const float* w, int n) {
+    free(o->board_w);
+    o->board_w = NULL;
+    if (w) { o->board_w = (float*)malloc(sizeof(float) * (size_t)n); memcpy(o->board_w, w, sizeof(float) * (size_t)n); }
+}
+/* suit symmetrisation of the chance node's values: class_of[h] for every hand; NULL clears */
+void orc_set_symmetrize(Orc* o, const int32_t* class_of) {
+    free(o->sym_class);
+    o->sym_class = NULL;
+    if (class_of) { o->sym_class = (int32_t*)malloc(sizeof(int32_t) * (size_t)o->R); memcpy(o->sym_class, class_of, sizeof(int32_t) * (size_t)o->R); }
+}
 int orc_unsupported(Orc* o) { return o->unsupported; }
 /* worker threads for the per-board / per-node loops (results do not depend on it); bench.py's cpu_baseline uses 1 */
 void orc_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }

@@ -534,9 +534,13 @@ class NativeSolver:
     shard=(world_size, rank, exchange, shard_boards, total_boards): ragged shards -- every rank before the last holds shard_boards
     boards, the last one the rest (prl_solver_create_sharded_ragged)."""
 
-    def __init__(self, tree, variant, delay=0, engine="auto", _lib=None, shard=None, avg_dtype="f64", place=None, probe_iters=4):
+    def __init__(self, tree, variant, delay=0, engine="auto", _lib=None, shard=None, avg_dtype="f64", place=None, probe_iters=4, board_mult=None,
+                 symmetrize=False):
         """place=k (unsharded solves): placement selection -- the library builds up to k solvers side by side, times probe_iters steady-state
-        iterations of each and keeps the fastest (prl_solver_create_placed; .placement_ms / .placement_chosen say what it saw)."""
+        iterations of each and keeps the fastest (prl_solver_create_placed; .placement_ms / .placement_chosen say what it saw).
+        board_mult=int array [n_boards] (+ symmetrize=True): weighted boards / suit isomorphism (prl_solver_create_weighted) -- the listed boards
+        stand for board_mult[i] boards each; with symmetrize they are suit-class representatives (pokerrl_amd.game.board_enum.
+        single_deal_board_classes) and the chance node's values are averaged over every hand's suit orbit: the WHOLE game from its classes."""
         self._L = _lib or tree._L
         self.placement_ms, self.placement_chosen = None, None
         if _lib is None and self._L is lib():
@@ -578,6 +582,15 @@ class NativeSolver:
             else:
                 check(self._L.prl_solver_create_sharded(tree.handle, v, int(delay), int(world), int(rank), self._exchange_cb, None,
                                                         ctypes.byref(self._h)), self._L)
+        elif board_mult is not None:
+            assert shard is None and place is None, "weighted boards: one GPU, no placement probe"
+            m = np.ascontiguousarray(board_mult, np.int32)
+            assert m.shape == (tree.n_boards,), "one multiplicity per listed board"
+            self._L.prl_solver_create_weighted.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                                           ctypes.POINTER(ctypes.c_void_p)]
+            self._L.prl_solver_create_weighted.restype = ctypes.c_int32
+            check(self._L.prl_solver_create_weighted(tree.handle, v, int(delay), 1 if avg_dtype == "f32" else 0, _ptr(m), 1 if symmetrize else 0,
+                                                     ctypes.byref(self._h)), self._L)
         elif not self._h and place is not None:
             # placement selection inside the library (prl_solver_create_placed): `place` candidates built side by side, the fastest kept
             n = int(place)

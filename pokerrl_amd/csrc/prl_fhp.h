@@ -181,6 +181,7 @@ struct PrlFhpParams {
     float chance_prob, eq_const;
     float pot[PRL_FHP_MAX_NODES];      // main pot of the terminal nodes (by local node id)
     const float* chance_reach;  // [2][R] reach at the chance node (trunk state, hand order)
+    const float* board_w;       // weighted boards (prl_solver_create_weighted): [n_boards] chance_prob * multiplicity, replaces chance_prob; else nullptr
     float* regret;              // board region [n_boards][n_cols_board][np]; PRL_SRC_STRAT32: an explicit float32 strategy in the same layout
     double* avg;                // board region: average strategy, updated by the update passes when avg_mode != 0
     float* avg32;               // opt-in (prl_solver_create_opts: PRL_SOLVER_AVG_F32): the same average STORED as float32 -- read, widened, blended in
@@ -209,7 +210,9 @@ int prl_fhp_match_shape(const PrlFlatTree& t, int* chance_node, int* first_board
 int prl_launch_fhp_pass(const PrlFhpParams& prm, int mode, int src0, int src1, void* stream);
 // the strategy the regrets imply, board region -> board region (float64)
 void prl_launch_fhp_strategy_from_regret(const PrlFhpParams& prm, double* out_region, void* stream);
-void prl_launch_fhp_avg_from_sum(const PrlFhpParams& prm, void* stream);  // Vanilla / Linear: avg columns of the boards from avg_sum
+void prl_launch_fhp_avg_from_sum(const PrlFhpParams& prm, void* stream);
+// suit symmetrisation of chance-summed root vectors (prl_solver_create_weighted): out[v][h] = (sum over the hands of h's class, ascending) / class size
+void prl_launch_fhp_symmetrize(const float* in, int n_vec, int R, const int32_t* class_of, const int32_t* class_start, const int32_t* class_hands, float* out, void* stream);  // Vanilla / Linear: avg columns of the boards from avg_sum
 // sorted storage <-> the caller's [n_cols][R] hand-order columns, boards [b0, b0 + nb): elem = 4 (float32) or 8 (float64) bytes.
 // expand: dst[(b - b0) * n_cols_board + j][h] = region[b][j][pos_b(h)] for live hands; blocked hands get fill[j] (elem bytes each, by
 // LOCAL column j; nullptr = zeros) or, when `blocked_src` is given, blocked_src[b][j][k] (k-th blocked hand of the board, hand order).

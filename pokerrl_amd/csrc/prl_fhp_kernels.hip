@@ -73,6 +73,21 @@ bool prl_fhp_shape_compiled(int shape_id) {
 #endif
 }
 
+// suit symmetrisation (prl_fhp.h): a thread per (vector, hand); the orbit sum runs over the class's hands in ascending hand index
+PRL_GLOBAL void prl_k_fhp_symmetrize(const float* in, int n_vec, int R, const int32_t* class_of, const int32_t* class_start, const int32_t* class_hands, float* out) {
+    const int i = (int)(prl_bid() * prl_nthreads() + prl_tid());
+    if (i >= n_vec * R) return;
+    const int v = i / R, h = i - v * R, k = class_of[h];
+    const int a = class_start[k], b = class_start[k + 1];
+    float s = in[(size_t)v * R + class_hands[a]];
+    for (int j = a + 1; j < b; ++j) s = s + in[(size_t)v * R + class_hands[j]];
+    out[i] = s / (float)(b - a);
+}
+void prl_launch_fhp_symmetrize(const float* in, int n_vec, int R, const int32_t* class_of, const int32_t* class_start, const int32_t* class_hands, float* out, void* stream) {
+    const int n = n_vec * R;
+    PRL_LAUNCH(prl_k_fhp_symmetrize, (n + 255) / 256, 256, 0, stream, in, n_vec, R, class_of, class_start, class_hands, out);
+}
+
 int prl_launch_fhp_pass(const PrlFhpParams& prm, int mode, int src0, int src1, void* stream) {
     switch (prm.shape) {
         case PRL_FHP_SHAPE_15: return fhp_shape15::launch_pass(prm, mode, src0, src1, stream);

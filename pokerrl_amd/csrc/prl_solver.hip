@@ -67,6 +67,11 @@ struct prl_solver {
     bool have_half = false;      // FUSED steady state: seat 1's half of the exploitability of the current iterate is in d_half
     float* d_board_out = nullptr;  // [n_boards][<= 4][R] root vectors of the last board pass
     float* d_row_sum = nullptr;    // [<= 4][R] their canonical sum
+    // weighted boards / suit isomorphism (prl_solver_create_weighted)
+    const float* d_board_w = nullptr;  // [n_boards] chance_prob * multiplicity
+    bool symmetrize = false;
+    float* d_row_sym = nullptr;        // [<= 4][R] the symmetrised sum
+    const int32_t *d_sym_class_of = nullptr, *d_sym_class_start = nullptr, *d_sym_class_hands = nullptr;
     float* d_half = nullptr;     // [R] chance-summed seat-1 value under its new strategy, [R] its best response
     // LEVELS engine: one captured hipGraph of a whole iteration, replayed per iteration (launch-bound small trees)
     PrlIterDev* d_ip = nullptr;
@@ -605,6 +610,10 @@ int fused_board_pass(prl_solver* s, const PrlDevState& st, int mode, int src0, i
         // (a shorter last shard: its units end before the zero padding of its block, which is therefore never read)
         prl_launch_fhp_chance_finish(s->d_xgather, s->n_units_all, s->xlevel, W, s->d_sum_scratch, summed, s->stream);
     }
+    if (s->symmetrize) {  // suit isomorphism: the hand's value at the chance node = the mean over its suit orbit of the weighted sum (include/pokerrl_hip.h)
+        prl_launch_fhp_symmetrize(summed, prl_fhp_out_width(mode), p.R, s->d_sym_class_of, s->d_sym_class_start, s->d_sym_class_hands, s->d_row_sym, s->stream);
+        summed = s->d_row_sym;
+    }
     const size_t vec = (size_t)p.R * sizeof(float);
     float* ch_ev = st.ev + prl_vidx(s->T, s->chance_trunk, 0);
     float* ch_br = st.ev_br + prl_vidx(s->T, s->chance_trunk, 0);
@@ -833,7 +842,7 @@ extern "C" {
 
 static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t world, int32_t rank,
                                   prl_exchange_fn exchange, void* exchange_user, prl_solver_t** out, int64_t shard_boards = 0, int64_t total_boards = 0,
-                                  const void* rccl_uid = nullptr, int32_t flags = 0) {
+                                  const void* rccl_uid = nullptr, int32_t flags = 0, const int32_t* board_mult = nullptr, int32_t symmetrize = 0) {
     if (!tree || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
     if (variant < 0 || variant > 2 || delay < 0 || engine < 0 || engine > 2) { prl_set_error("bad variant / delay / engine"); return PRL_ERR_ARG; }
     if (!prl_device_available()) { prl_set_error("no HIP device: the solver has no CPU fallback"); return PRL_ERR_NO_DEVICE; }
@@ -867,6 +876,15 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         fused = true;
     } else if (engine == PRL_ENGINE_AUTO) fused = shape_ok || st_ok;
     streets = fused && !shape_ok;
+    long long mult_sum = 0;  // weighted boards: the chance probability counts the boards the listed ones stand for
+    if (board_mult) {
+        if (!fused || streets || exchange) { prl_set_error("weighted boards: single-deal fused engine, one GPU"); return PRL_ERR_UNSUPPORTED; }
+        for (int i = 0; i < full.n_boards; ++i) {
+            if (board_mult[i] < 1) { prl_set_error("weighted boards: every multiplicity must be >= 1"); return PRL_ERR_ARG; }
+            mult_sum += board_mult[i];
+        }
+        if (mult_sum > 0x7fffffffll) { prl_set_error("weighted boards: too many boards in all"); return PRL_ERR_ARG; }
+    } else if (symmetrize) { prl_set_error("symmetrize needs board multiplicities"); return PRL_ERR_ARG; }
     if ((flags & PRL_SOLVER_AVG_F32) && (!fused || streets || variant != PRL_CFR_PLUS)) {
         prl_set_error("PRL_SOLVER_AVG_F32: the single-deal fused engine with CFR+ only (the variant whose running average the board pass blends)");
         return PRL_ERR_UNSUPPORTED;
@@ -904,6 +922,10 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         mix(&r, sizeof(r));
         const int32_t wr[2] = {world, rank};
         mix(wr, sizeof(wr));
+        if (board_mult) {  // weighted boards: the multiplicities and the symmetrisation belong to the problem
+            mix(board_mult, sizeof(int32_t) * (size_t)full.n_boards);
+            mix(&symmetrize, sizeof(symmetrize));
+        }
         s->fingerprint = h;
     }
     s->exchange = exchange;
@@ -990,11 +1012,11 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             const int child = full.child_list[full.child_start[i]];
             const int k = dealt(full.board_id[child]) - before;
             // sharded (one chance node, fused engine): the GLOBAL number of boards
-            const float p = chance_prob_f32(exchange ? (int)total_boards : full.n_children[i], r.n_cards - before, r.n_hole_cards, k);
+            const float p = chance_prob_f32(board_mult ? (int)mult_sum : exchange ? (int)total_boards : full.n_children[i], r.n_cards - before, r.n_hole_cards, k);
             if (first) { T.chance_prob = p; first = false; }
             if (!fused && i < ft.n_nodes) w[i] = p;
         }
-        if (first) T.chance_prob = chance_prob_f32(exchange ? (int)total_boards : n_chance_children, r.n_cards, r.n_hole_cards, full.board_len);
+        if (first) T.chance_prob = chance_prob_f32(board_mult ? (int)mult_sum : exchange ? (int)total_boards : n_chance_children, r.n_cards, r.n_hole_cards, full.board_len);
         FAIL_IF(dev_upload(s, &T.chance_w, w));
     }
     T.eq_const = eq_const_f32(r.n_cards, r.n_hole_cards);
@@ -1079,6 +1101,40 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             }
             fp.no_steady = getenv("PRL_FHP_NO_STEADY") ? 1 : 0;  // tests: the generic pass in the steady state too
             fp.chance_prob = T.chance_prob; fp.eq_const = T.eq_const;
+            if (board_mult) {
+                std::vector<float> bw((size_t)full.n_boards);
+                for (int i = 0; i < full.n_boards; ++i) bw[(size_t)i] = T.chance_prob * (float)board_mult[i];  // one float32 rounding, as the oracle's
+                FAIL_IF(dev_upload(s, &s->d_board_w, bw));
+                fp.board_w = s->d_board_w;
+                if (symmetrize) {
+                    // classes of hands under the 24 suit permutations: (low rank, high rank, suited) -- 13 pairs x 6, 78 suited x 4, 78 offsuit x 12
+                    const int R = r.range_size, NS = r.n_suits;
+                    std::vector<int32_t> key((size_t)R), class_of((size_t)R), start, hands;
+                    std::vector<int> order;
+                    for (int h = 0; h < R; ++h) {
+                        int c1, c2;
+                        prl_hole_cards_2(h, r.n_cards, &c1, &c2);
+                        const int r1 = prl_card_rank(c1, NS), r2 = prl_card_rank(c2, NS);
+                        key[(size_t)h] = ((r1 < r2 ? r1 : r2) * r.n_ranks + (r1 < r2 ? r2 : r1)) * 2 + (prl_card_suit(c1, NS) == prl_card_suit(c2, NS) ? 1 : 0);
+                    }
+                    std::vector<int32_t> first_of((size_t)r.n_ranks * r.n_ranks * 2, -1);
+                    int n_classes = 0;
+                    for (int h = 0; h < R; ++h) {  // classes numbered by their first hand
+                        if (first_of[(size_t)key[(size_t)h]] < 0) first_of[(size_t)key[(size_t)h]] = n_classes++;
+                        class_of[(size_t)h] = first_of[(size_t)key[(size_t)h]];
+                    }
+                    start.assign((size_t)n_classes + 1, 0);
+                    for (int h = 0; h < R; ++h) ++start[(size_t)class_of[(size_t)h] + 1];
+                    for (int k = 0; k < n_classes; ++k) start[(size_t)k + 1] += start[(size_t)k];
+                    hands.resize((size_t)R);
+                    std::vector<int32_t> fill(start.begin(), start.end() - 1);
+                    for (int h = 0; h < R; ++h) hands[(size_t)fill[(size_t)class_of[(size_t)h]]++] = h;  // ascending hand index inside a class
+                    FAIL_IF(dev_upload(s, &s->d_sym_class_of, class_of));
+                    FAIL_IF(dev_upload(s, &s->d_sym_class_start, start));
+                    FAIL_IF(dev_upload(s, &s->d_sym_class_hands, hands));
+                    s->symmetrize = true;
+                }
+            }
             const PrlFhpShapeDesc& sd = prl_fhp_shape_desc(shape_id);
             fp.shape = shape_id; fp.n_cols_board = sd.n_cols; fp.n_dec = sd.n_dec;
             for (int j = 0; j < sd.n_dec; ++j) { fp.dec_nch[j] = sd.dec_nch[j]; fp.dec_col0[j] = sd.dec_col0[j]; }
@@ -1135,6 +1191,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             FAIL_IF(dev_alloc(s, &s->d_board_out, n_rows * 4 * T.R));
         }
         FAIL_IF(dev_alloc(s, &s->d_row_sum, row_w));
+        if (s->symmetrize) FAIL_IF(dev_alloc(s, &s->d_row_sym, row_w));
         const size_t n_blk = ((size_t)total_boards + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK + world;  // sized for the global board list
         const size_t n_grp = (n_blk + PRL_CHANCE_BLOCK - 1) / PRL_CHANCE_BLOCK;
         FAIL_IF(dev_alloc(s, &s->d_sum_scratch, (n_blk + n_grp + 1) * row_w));  // rows of up to 4 vectors (per trunk leaf)
@@ -1225,6 +1282,13 @@ int32_t prl_solver_create_sharded_rccl(const prl_tree_t* local_tree, int32_t var
 int32_t prl_solver_create_opts(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t flags, prl_solver_t** out) {
     if (flags & ~PRL_SOLVER_AVG_F32) { prl_set_error("unknown solver flag"); return PRL_ERR_ARG; }
     return solver_create_impl(tree, variant, delay, engine, 1, 0, nullptr, nullptr, out, 0, 0, nullptr, flags);
+}
+
+int32_t prl_solver_create_weighted(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t flags, const int32_t* board_mult, int32_t symmetrize,
+                                   prl_solver_t** out) {
+    if (flags & ~PRL_SOLVER_AVG_F32) { prl_set_error("unknown solver flag"); return PRL_ERR_ARG; }
+    if (!board_mult) { prl_set_error("board_mult is NULL"); return PRL_ERR_ARG; }
+    return solver_create_impl(tree, variant, delay, PRL_ENGINE_FUSED, 1, 0, nullptr, nullptr, out, 0, 0, nullptr, flags, board_mult, symmetrize);
 }
 
 int32_t prl_solver_create_placed(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t flags, int32_t n_candidates,

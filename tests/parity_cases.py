@@ -520,3 +520,77 @@ def check_fused_avg_f32(L, n_boards, n_iters):
         e32, e64 = s.eval_avg(), o.eval_avg()
         assert np.allclose(e32, e64, rtol=1e-5, atol=0), (it, e32, e64)
     return s.eval_avg(), o.eval_avg()
+
+
+# ---- weighted boards / suit isomorphism (prl_solver_create_weighted; include/pokerrl_hip.h) ---------------------------------------------
+def suit_orbit(board, n_suits=4):
+    """the distinct boards a board maps to under the suit permutations (sorted cards, lexicographic order)"""
+    from itertools import permutations
+    out = set()
+    for perm in permutations(range(n_suits)):
+        out.add(tuple(sorted((c // n_suits) * n_suits + perm[c % n_suits] for c in board)))
+    return sorted(out)
+
+
+def iso_classes(n_classes, seed=3):
+    """a few suit classes of Flop5Holdem boards (representatives + orbit sizes), incl. the three orbit sizes 4 / 12 / 24"""
+    from pokerrl_amd.game import board_enum
+    reps, mult = board_enum.single_deal_board_classes(G.Flop5Holdem)
+    rng = np.random.RandomState(seed)
+    pick = [int(np.where(mult == m)[0][rng.randint(np.sum(mult == m))]) for m in (4, 12, 24)]
+    while len(pick) < n_classes:
+        i = int(rng.randint(len(reps)))
+        if i not in pick:
+            pick.append(i)
+    pick = sorted(pick[:n_classes])
+    return reps[pick], mult[pick]
+
+
+def fhp_tree_of(L, boards):
+    return _native.NativeTree(G.Flop5Holdem.native_game(env_args(G.Flop5Holdem, 20000, bet_sets.POT_ONLY)), G.Flop5Holdem.native_rules(),
+                              np.ascontiguousarray(boards, np.int8), _lib=L)
+
+
+def check_weighted_vs_oracle(L, n_classes, n_iters, variant="plus", symmetrize=True):
+    """the fused engine on suit-class representatives with multiplicities (+ orbit-mean chance values) against the oracle's restatement: every regret /
+    average column, current- and average-strategy exploitability, bit for bit"""
+    from pokerrl_amd.game import board_enum
+    reps, mult = iso_classes(n_classes)
+    t = fhp_tree_of(L, reps)
+    s = _native.NativeSolver(t, variant, 0, _lib=L, board_mult=mult, symmetrize=symmetrize)
+    assert s.engine == "fused"
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, 2, 52, 4, 2)
+    w = o.set_board_weights(mult)
+    if symmetrize:
+        o.set_symmetrize(board_enum.hand_suit_classes(G.Flop5Holdem))
+    o.cfr_reset(VARIANT_ID[variant], 0)
+    assert s.get("constants")[0] == oracle.chance_prob_f32(int(mult.sum()), 52, 2, 5) and w[0] == s.get("constants")[0] * np.float32(mult[0])
+    assert np.array_equal(s.exploitability(), o.exploitability)
+    for it in range(1, n_iters + 1):
+        s.iteration()
+        o.cfr_iteration()
+        for k in FUSED_FIELDS + (() if variant == "plus" else ("avg_sum",)):
+            assert np.array_equal(s.get(k), np.asarray(getattr(o, k))), "weighted it%d: %s" % (it, k)
+        assert np.array_equal(s.exploitability(), o.exploitability), it
+        assert np.array_equal(s.eval_avg(), o.eval_avg()), it
+    return s, o
+
+
+def iso_vs_full(make_iso, make_full, n_classes, n_iters, rtol=2e-5):
+    """suit isomorphism is EXACT in exact arithmetic: the class solve (representatives x multiplicities, orbit-mean chance values) against the
+    solve of the full suit-closed board list the classes stand for (every board listed, weight 1): exploitability of the current and the
+    average strategy after every iteration agree to float32 accumulation noise. make_*(boards, mult or None) -> object with iteration() /
+    exploitability() / eval_avg()."""
+    reps, mult = iso_classes(n_classes)
+    full = [b for r in reps for b in suit_orbit([int(c) for c in r])]
+    assert len(full) == int(mult.sum()) and len(set(full)) == len(full)
+    a, b = make_iso(reps, mult), make_full(np.array(full, np.int8), None)
+    ea, eb = np.asarray(a.exploitability(), np.float64), np.asarray(b.exploitability(), np.float64)
+    assert np.all(np.abs(ea - eb) <= rtol * np.abs(eb)), (ea, eb)
+    for it in range(n_iters):
+        a.iteration(); b.iteration()
+        ea, eb = np.asarray(a.exploitability(), np.float64), np.asarray(b.exploitability(), np.float64)
+        assert np.all(np.abs(ea - eb) <= rtol * np.abs(eb)), (it, ea, eb)
+        va, vb = np.asarray(a.eval_avg(), np.float64), np.asarray(b.eval_avg(), np.float64)
+        assert np.all(np.abs(va - vb) <= rtol * np.abs(vb)), (it, va, vb)
+    return a, b

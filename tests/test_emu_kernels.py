@@ -122,6 +122,13 @@ def test_emu_fused_engine_block_sums_across_a_block_boundary(L, monkeypatch):
     pc.check_fused_batched_vs_oracle(L, 33, 2, delay=0)
 
 
+@pytest.mark.parametrize("variant,symmetrize", [("plus", True), ("linear", True), ("plus", False)])
+def test_emu_fused_engine_weighted_boards_suit_classes(L, variant, symmetrize):
+    """prl_solver_create_weighted: suit-class representatives with multiplicities (orbit sizes 4 / 12 / 24 among them), chance values averaged over
+    the hands' suit orbits -- the fused engine against the oracle's restatement, bit for bit"""
+    pc.check_weighted_vs_oracle(L, 4, 2, variant, symmetrize)
+
+
 def test_emu_fused_engine_float32_running_average_opt_in(L):
     """PRL_SOLVER_AVG_F32: generic and steady-state instantiations of the update passes with the average stored as float32"""
     pc.check_fused_avg_f32(L, 3, 4)

@@ -404,6 +404,36 @@ def test_gpu_fused_float32_running_average_opt_in(L):
     pc.check_fused_avg_f32(L, 600, 6)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,symmetrize,n_classes", [("plus", True, 40), ("linear", True, 6), ("vanilla", True, 6), ("plus", False, 6)])
+def test_gpu_fused_weighted_boards_suit_classes_vs_oracle(L, variant, symmetrize, n_classes):
+    """prl_solver_create_weighted (suit isomorphism): class representatives with multiplicities, chance values averaged over the hands' suit
+    orbits -- bit for bit against the oracle's restatement (40 classes: two 32-board blocks of the canonical sum)"""
+    pc.check_weighted_vs_oracle(L, n_classes, 3, variant, symmetrize)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_suit_isomorphism_equals_the_full_board_list(L):
+    """the class solve against the fused solve of the FULL suit-closed board list the classes stand for (every board listed, weight 1): the
+    isomorphism is exact in exact arithmetic; float32 runs agree to 2e-5 over 5 CFR+ iterations (6 classes = 100-odd boards)"""
+    class S:
+        def __init__(self, boards, mult):
+            from pokerrl_amd import _native
+            self.s = _native.NativeSolver(pc.fhp_tree_of(L, boards), "plus", 0, engine="fused", _lib=L, board_mult=mult, symmetrize=mult is not None)
+
+        def iteration(self):
+            self.s.iteration()
+
+        def exploitability(self):
+            return self.s.exploitability()
+
+        def eval_avg(self):
+            return self.s.eval_avg()
+
+    pc.iso_vs_full(S, S, 6, 5)
+
+
+@pytest.mark.gpu
 def test_gpu_fused_vs_levels_2048_boards(L):
     """2048 boards = 64 canonical chance blocks = 2 groups: both engines of the library must agree bit for bit."""
     pc.check_fused_vs_levels(L, 2048, 6)

@@ -107,3 +107,40 @@ def test_oracle_two_card_equity_against_the_quadratic_definition():
     for h in (0, 17, 700, 1325):
         comp = ~np.isin(lut, lut[h]).any(axis=1)
         assert ef[h] == np.float32(x[comp].astype(np.float64).sum())
+
+
+def test_oracle_suit_isomorphism_equals_the_full_board_list():
+    """weighted boards + orbit-mean chance values (the oracle's restatement of prl_solver_create_weighted) against the SAME oracle on the full
+    suit-closed board list the classes stand for: suit isomorphism is exact in exact arithmetic, the float32 runs agree to 2e-5 over 4 CFR+ iterations"""
+    import parity_cases as pc
+    from pokerrl_amd.game import board_enum
+    from pokerrl_amd.game import games as G
+
+    class O:
+        def __init__(self, boards, mult):
+            t = pc.fhp_tree_of(None, boards)
+            self.o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, 2, 52, 4, 2)
+            if mult is not None:
+                self.o.set_board_weights(mult)
+                self.o.set_symmetrize(board_enum.hand_suit_classes(G.Flop5Holdem))
+            self.o.cfr_reset(1, 0)
+
+        def iteration(self):
+            self.o.cfr_iteration()
+
+        def exploitability(self):
+            return np.array(self.o.exploitability)
+
+        def eval_avg(self):
+            return self.o.eval_avg()
+
+    a, b = pc.iso_vs_full(O, O, 4, 4)
+    # a class subtree works with reach x multiplicity: its regrets are multiplicity x those of its representative in the full list
+    reps, mult = pc.iso_classes(4)
+    ra, rb = np.asarray(a.o.regret), np.asarray(b.o.regret)
+    nt = ra.shape[0] - 14 * len(reps)
+    full_index = 0
+    for c, m in enumerate(mult):
+        mine, theirs = ra[nt + 14 * c: nt + 14 * (c + 1)], rb[nt + 14 * full_index: nt + 14 * (full_index + 1)]  # the representative is its orbit's first board
+        assert np.allclose(mine, float(m) * theirs, rtol=1e-4, atol=1e-4 * float(np.max(np.abs(mine)))), c
+        full_index += int(m)
