@@ -31,7 +31,7 @@ class CFRBase:
     _VARIANT = None
 
     def __init__(self, name, chief_handle, game_cls, agent_bet_set, algo_name, starting_stack_sizes=None, delay=0, boards=None,
-                 engine="auto", n_boards=None, max_outcomes=None, board_seed=None):
+                 engine="auto", n_boards=None, max_outcomes=None, board_seed=None, suit_isomorphism=None):
         self._name = name
         self._n_seats = 2
         self._chief_handle = chief_handle
@@ -45,9 +45,16 @@ class CFRBase:
             engine = "levels"
         if boards is None:  # the builder deals the chance outcomes from the deck (all of them, or the capped / seeded subset): board_enum.py
             from pokerrl_amd.game import board_enum
-            boards = board_enum.default_boards(get_env_cls_from_str(self._game_cls_str), n_boards=n_boards, max_outcomes=max_outcomes, seed=board_seed)
+            # (Flop5Holdem with the reference's default arguments -- every board -- is solved through its 134 459 suit classes: board_enum)
+            boards, board_mult = board_enum.default_boards_or_classes(get_env_cls_from_str(self._game_cls_str), n_boards=n_boards, max_outcomes=max_outcomes,
+                                                                      seed=board_seed, suit_isomorphism=suit_isomorphism)
+        else:
+            board_mult = None
+        if board_mult is not None and self._host_hooks:
+            raise ValueError("a CFR variant written against the reference's hook methods runs on per-node vectors (LEVELS engine): give it boards= / "
+                             "n_boards=; the whole game through its suit classes needs a built-in variant (CFRPlus / LinearCFR / VanillaCFR)")
         self._boards, self._engine = boards, engine
-        self._trees = [PublicTree(env_bldr=b, stack_size=a.starting_stack_sizes_list, stop_at_street=None, boards=boards, engine=engine)
+        self._trees = [PublicTree(env_bldr=b, stack_size=a.starting_stack_sizes_list, stop_at_street=None, boards=boards, engine=engine, board_mult=board_mult)
                        for b, a in zip(self._env_bldrs, self._env_args)]
         self._eval_trees = None
         for tree in self._trees:

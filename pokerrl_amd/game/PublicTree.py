@@ -142,7 +142,7 @@ class PublicTree:
     CHANCE_ID = "Ch"
 
     def __init__(self, env_bldr, stack_size, stop_at_street, put_out_new_round_after_limit=False, is_debugging=False, boards=None,
-                 engine="levels", n_boards=None, max_outcomes=None, board_seed=None):
+                 engine="levels", n_boards=None, max_outcomes=None, board_seed=None, suit_isomorphism=None, board_mult=None):
         """boards=None: the builder deals the chance outcomes from the deck itself as the reference does (PublicTree.py:188-210) -- every board
         of the game (Leduc: the 6 cards; Flop5Holdem: all C(52,5) five-card boards), or a subset: n_boards= (games that deal once) /
         max_outcomes=(flops, turns, rivers) (games that deal on several streets), the first ones in combinatorial order or, with board_seed=,
@@ -157,6 +157,9 @@ class PublicTree:
         self._is_partial = self._stop_at_street <= max(env_bldr.rules.ALL_ROUNDS_LIST)
         self._boards = boards
         self._board_caps = (n_boards, max_outcomes, board_seed)
+        # suit isomorphism (board_enum.default_boards_or_classes): class representatives + multiplicities instead of every board; board_mult comes
+        # with explicit `boards` that are such representatives
+        self._suit_iso, self._board_mult = suit_isomorphism, board_mult
         self._engine = engine
         self._n_seats = env_bldr.N_SEATS
         self.dir_tree_vis_data = None
@@ -196,14 +199,21 @@ class PublicTree:
         if boards is None:  # PublicTree.py:188-210: the chance outcomes come from the deck, cards ascending
             from pokerrl_amd.game import board_enum
             n_boards, max_outcomes, seed = self._board_caps
-            boards = self._boards = board_enum.default_boards(env_cls, n_boards=n_boards, max_outcomes=max_outcomes, seed=seed)
+            boards, self._board_mult = board_enum.default_boards_or_classes(env_cls, n_boards=n_boards, max_outcomes=max_outcomes, seed=seed,
+                                                                                suit_isomorphism=self._suit_iso)
+            self._boards = boards
         self._native_tree = _native.NativeTree(env_cls.native_game(args), env_cls.native_rules(), boards,
                                                stop_at_round=self._stop_at_street if self._is_partial else None)
         t = self._native_tree
         for f in ("kind", "actor", "parent", "action", "acted_last", "depth", "n_children", "first_col", "child_start", "child_list",
                   "col_action", "board_id", "main_pot", "round", "child_idx"):
             setattr(self, "_" + f, t.field(f))
-        self._solver = None if self._is_partial else _native.NativeSolver(t, variant, delay, engine=self._engine)
+        if self._is_partial:
+            self._solver = None
+        elif self._board_mult is not None:  # the whole game through its suit classes: fused engine, prl_solver_create_weighted
+            self._solver = _native.NativeSolver(t, variant, delay, board_mult=self._board_mult, symmetrize=True)
+        else:
+            self._solver = _native.NativeSolver(t, variant, delay, engine=self._engine)
         self.root = self.node(0)
         self._invalidate()
 
@@ -292,7 +302,7 @@ class PublicTree:
         n_boards, max_outcomes, board_seed = self._board_caps  # (a copy made before build_tree deals the same capped / seeded boards)
         c = PublicTree(self._env_bldr, self._stack_size, self._stop_at_street if self._is_partial else None,
                        self._put_out_new_round_after_limit, self._is_debugging, self._boards, self._engine,
-                       n_boards=n_boards, max_outcomes=max_outcomes, board_seed=board_seed)
+                       n_boards=n_boards, max_outcomes=max_outcomes, board_seed=board_seed, suit_isomorphism=self._suit_iso, board_mult=self._board_mult)
         c.build_tree(variant=getattr(self, "_variant", "vanilla"), delay=getattr(self, "_delay", 0))
         if self._is_partial:  # structure and states only: there is no solver state to move over
             return c

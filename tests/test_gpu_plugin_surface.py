@@ -328,3 +328,25 @@ def test_public_tree_copy():
         fc.compute_ev()
         assert int(fc.solver.get("explicit_strategy")[0]) == (0 if as_f32 else 1)
         assert np.array_equal(ft.root.exploitability, fc.root.exploitability)
+
+
+def test_cfr_plus_on_flop5holdem_with_the_references_default_arguments_solves_the_whole_game_through_its_suit_classes():
+    """CFRPlus(name, chief_handle, game_cls=Flop5Holdem, agent_bet_set) -- no boards, no cap: the reference's call (which its 1-hole-card tree code
+    cannot serve at all). Here the builder deals ALL 2 598 960 boards as their 134 459 suit classes (board_enum.default_boards_or_classes,
+    prl_solver_create_weighted) and the whole game is iterated on one GPU: the logged series exist, exploitability falls."""
+    from pokerrl_amd.cfr.CFRPlus import CFRPlus
+    from pokerrl_amd.game.games import Flop5Holdem
+    chief = ChiefBase(t_prof=None)
+    cfr = CFRPlus(name="w", game_cls=Flop5Holdem, agent_bet_set=bet_sets.POT_ONLY, chief_handle=chief, delay=0)
+    tree = cfr._trees[0]
+    assert tree.native_tree.n_boards == 134459 and tree.n_nodes == 5 + 15 * 134459 - 1 and tree.solver.engine == "fused"
+    assert int(tree._board_mult.sum()) == 2598960
+    for _ in range(4):
+        cfr.iteration()
+    vals, _names = chief.get_new_values()
+    curr = [k for k in vals if "_Curr_S" in k and "total_CFRp" in k][0]
+    series = np.array(vals[curr]["Evaluation/" + Flop5Holdem.WIN_METRIC], dtype=np.float64)
+    assert series.shape[0] == 5 and np.all(np.isfinite(series[:, 1])) and series[-1, 1] < series[0, 1]
+    avg = [k for k in vals if "_Avg_total_S" in k][0]
+    a = np.array(vals[avg]["Evaluation/" + Flop5Holdem.WIN_METRIC], dtype=np.float64)
+    assert a.shape[0] == 4 and a[-1, 1] < series[0, 1]
