@@ -324,7 +324,10 @@ def main():
     n_fixed = args.fixed_check_boards if args.fixed_check_boards >= 0 else (0 if emu_lib else 8192)
     if n_fixed > 0 and n_fixed >= world:
         # (the check's arrays are small beside the run's: 8192 boards = 1.8 GB over all ranks)
-        fixed = fixed_problem_check(n_fixed, 3, world, rank, how if world > 1 else None, lib, emu_lib)
+        try:  # (an extra after the timed region: whatever goes wrong here must not cost the line)
+            fixed = fixed_problem_check(n_fixed, 3, world, rank, how if world > 1 else None, lib, emu_lib)
+        except Exception as e:  # noqa: BLE001
+            fixed = {"error": "%s: %s" % (type(e).__name__, e)}
         barrier()
     n_board_nodes = args.boards * 15
     n_nodes_total = (tree.n_nodes - n_board_nodes) + (total * 15 if total else n_board_nodes * world)  # one trunk + every rank's board subtrees
