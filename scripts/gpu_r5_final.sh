@@ -45,3 +45,16 @@ for nv in "bench=$B" "br=$BR"; do
   grep "pass<[45], 0, 0, 1\|pass<2, 4, 4" $R/gpurun_out/${TAG}_${n}_pmc.txt | cut -c1-330
   rm -rf $R/gpurun_out/${TAG}_pmc_${n}?
 done
+# the 7-card evaluator: is it integer-issue bound? SQ counters of prl_k_hand_rank_boards (VALU instructions x 4 clocks / (1024 SIMDs x kernel clocks))
+HE="python $R/bench_handeval.py"
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_he -o p -- $HE > $R/gpurun_out/${TAG}_prof_he.log 2>&1
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench_handeval.py (131072 boards x 1326 hands per call)   (MI355X, checkpoint $TAG)"; python $R/scripts/rocprof_summary.py $(find $R/gpurun_out/${TAG}_prof_he -name "*.db" | head -1) | head -6; } > $R/gpurun_out/${TAG}_handeval_kernel_stats.txt 2>&1
+i=0
+for grp in "$SQ1" "$SQ2" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp -d $R/gpurun_out/${TAG}_pmc_he$i -o p --output-format csv -- $HE > $R/gpurun_out/${TAG}_pmc_he$i.log 2>&1
+done
+{ echo "# rocprofv3 --kernel-trace --pmc <one counter group per run> -- python bench_handeval.py ; mean per dispatch; checkpoint $TAG"
+  python $R/scripts/pmc_summary.py $(find $R/gpurun_out/${TAG}_pmc_he1 $R/gpurun_out/${TAG}_pmc_he2 $R/gpurun_out/${TAG}_pmc_he3 $R/gpurun_out/${TAG}_pmc_he4 -name '*counter_collection.csv') | grep "hand_rank\|==" | cut -c1-700; } > $R/gpurun_out/${TAG}_handeval_pmc.txt 2>&1
+cat $R/gpurun_out/${TAG}_handeval_kernel_stats.txt | cut -c1-160; grep hand_rank $R/gpurun_out/${TAG}_handeval_pmc.txt | cut -c1-400
+rm -rf $R/gpurun_out/${TAG}_prof_he $R/gpurun_out/${TAG}_pmc_he?
