@@ -32,7 +32,7 @@ HBM_PEAK_GBPS = 8000.0
 # 2 x 2.441e6 + 4.24e4 KB per launch = 4.92 GB (round 3, hand-order columns: 5.71 GB). Below the algorithmic bytes, which count all 1326
 # hands of a column: the storage holds the 1081 live ones.
 PMC_TRAFFIC_BYTES_PER_BOARD = 4.924e9 / 65536
-PMC_TRAFFIC_SOURCE = "profiles/r06_br_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+PMC_TRAFFIC_SOURCE = "profiles/r06_br_pmc.txt, re-measured in r50_br_pmc.txt: 2 * 2.442 GB read + 0.042 GB written (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
 
 
 def seeded_strategy(n_trunk_cols, n_boards, R, seed):

@@ -66,7 +66,12 @@ def main():
                                  "boards": args.boards},
                       "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                                    "kernel": "prl_k_hand_rank_boards", "kernel_ms_per_launch": ms, "bytes_per_call_algorithmic": bytes_call,
-                                   "note": "integer ALU issue (the evaluator) shares the bound with the int32 store stream (SURVEY.md 8d)"},
+                                   # SQ counters of this kernel (profiles/r50_handeval_pmc.txt, r50_handeval_kernel_stats.txt): 3.892e8 VALU + 1.644e8 SALU
+                                   # wave-instructions per launch of 131072 boards in 0.581 ms; a wave64 VALU instruction issues over 2 cycles on a 32-lane SIMD
+                                   "valu_issue_busy_measured": 3.892e8 * 2.0 / (1024 * 0.581e-3 * 2.4e9),
+                                   "pmc_traffic_bytes_per_call": 6.82e8 + 2.0 * 2.634e6,
+                                   "note": "bound by integer vector issue: the VALU issue slots are 0.55 busy (measured) where the int32 result stream is 0.15 of HBM; "
+                                           "HBM traffic = the algorithmic bytes (WRITE_SIZE 682 MB per 695 MB call)"},
                       "cpu_baseline": {"value": cpu, "unit": "evals/s", "cores": 1, "kind": "port", "sample": "%d boards, oracle/prl_oracle.c" % n_cpu,
                                        # the reference's own evaluator (binary-only lib_hand_eval.so, batched call): timed by scripts/time_reference.py
                                        "reference_binary_evals_per_s_per_core": bench_ref.figure("hand_evaluator", "batched", "evals_per_s"),

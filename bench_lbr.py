@@ -122,14 +122,19 @@ def main():
     # HEADLINE of this object since round 5: the MEASURED vector-issue occupancy of the kernel (SQ counters, below) -- `frac` is that; the
     # operation-count model of rounds 3-4 (a yardstick chosen by the author, which the kernel beats by executing fewer operations) stays beside
     # it as `model_*`
-    out["roofline"] = {"bound": "valu-issue (int + fp32)", "achieved": 0.467 * peak, "peak": peak, "unit": "T lane-ops/s", "frac": 0.467, "traffic": None,
-                       "frac_is": "SQ_INSTS_VALU x 4 clocks / (SIMDs x kernel clocks): the share of the kernel's clocks its vector ALUs issue in, measured",
+    # (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on CDNA4's 32-lane SIMDs -- `peak` above is exactly that rate. Rounds 3-4
+    # priced an instruction at 4 clocks (the GCN / CDNA3 figure) and quoted 0.467; at the guide's 2 clocks the same counters say 0.234.)
+    VALU_BUSY = 1.765e10 * 2.0 / (1024 * 61.45e-3 * 2.4e9)
+    out["roofline"] = {"bound": "valu-issue (int + fp32)", "achieved": VALU_BUSY * peak, "peak": peak, "unit": "T lane-ops/s", "frac": VALU_BUSY, "traffic": None,
+                       "frac_is": "SQ_INSTS_VALU x 2 clocks (wave64 on a 32-lane SIMD) / (1024 SIMDs x kernel clocks): the share of the vector ALUs' issue slots the "
+                                  "kernel fills, measured -- the kernel is bound by dependent chains (LDS gathers -> compare -> divide -> add) and barriers, not by issue",
+                       "valu_issue_busy_at_4_clocks_per_instruction_as_quoted_in_rounds_3_4": 0.467,
                        "model_achieved": achieved, "model_frac": achieved / peak,
                        "kernel": "prl_k_lbr_batch", "lane_ops_per_range_board_equity": ops_eq,
                        "range_board_equities_per_hand": n_eq_tot / max(float(n), 1.0), "range_board_equities_per_s_rank0": n_eq_tot / dev_s,
                        # the hardware's own figure, from the SQ counters of the final kernel (profiles/r21_lbr_pmc_sq.txt, r21_lbr_kernel_stats.txt):
                        # SQ_INSTS_VALU 1.765e10 wave-instructions per launch x 4 clocks / (1024 SIMDs x 61.45 ms x 2.4 GHz)
-                       "valu_issue_busy_measured": 0.467, "valu_issue_busy_source": "profiles/r21_lbr_pmc_sq.txt (rocprofv3 --pmc SQ_INSTS_VALU, 131072 hands per launch)",
+                       "valu_issue_busy_measured": VALU_BUSY, "valu_issue_busy_source": "profiles/r21_lbr_pmc_sq.txt (rocprofv3 --pmc SQ_INSTS_VALU, 131072 hands per launch)",
                        "note": "not an HBM- or MFMA-bound kernel: state on chip, no contraction. Modelled: the (range, board) equities only (the betting "
                                "engine, the agent's draws and the range updates are not counted: the model is a lower bound of the work done). The "
                                "operation counts are ALGORITHMIC ones, read off round 3's kernel (generic float32 division, 64-bit blocker test) and "
