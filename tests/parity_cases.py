@@ -594,3 +594,26 @@ def iso_vs_full(make_iso, make_full, n_classes, n_iters, rtol=2e-5):
         va, vb = np.asarray(a.eval_avg(), np.float64), np.asarray(b.eval_avg(), np.float64)
         assert np.all(np.abs(va - vb) <= rtol * np.abs(vb)), (it, va, vb)
     return a, b
+
+
+def check_weighted_checkpoint(L):
+    """save_state / load_state of a weighted (suit-class) solver: a resumed run continues bit-identically; a blob does not load into a solver whose
+    multiplicities differ (they are part of the fingerprint)"""
+    reps, mult = iso_classes(4)
+    t = fhp_tree_of(L, reps)
+    mk = lambda m: _native.NativeSolver(t, "plus", 0, _lib=L, board_mult=m, symmetrize=True)  # noqa: E731
+    a = mk(mult)
+    a.iterations(3)
+    b = mk(mult)
+    b.iterations(2)
+    blob = b.save_state()
+    c = mk(mult)
+    c.load_state(blob)
+    c.iterations(1)
+    for k in ("regret", "avg", "expl_history"):
+        assert np.array_equal(a.get(k), c.get(k)), k
+    assert np.array_equal(a.eval_avg(), c.eval_avg())
+    other = mult.copy()
+    other[0] = 12 if other[0] != 12 else 24
+    with pytest.raises(Exception):
+        mk(other).load_state(blob)

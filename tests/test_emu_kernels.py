@@ -129,6 +129,10 @@ def test_emu_fused_engine_weighted_boards_suit_classes(L, variant, symmetrize):
     pc.check_weighted_vs_oracle(L, 4, 2, variant, symmetrize)
 
 
+def test_emu_fused_engine_weighted_boards_checkpoint_resume(L):
+    pc.check_weighted_checkpoint(L)
+
+
 def test_emu_fused_engine_float32_running_average_opt_in(L):
     """PRL_SOLVER_AVG_F32: generic and steady-state instantiations of the update passes with the average stored as float32"""
     pc.check_fused_avg_f32(L, 3, 4)

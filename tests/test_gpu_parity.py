@@ -413,6 +413,11 @@ def test_gpu_fused_weighted_boards_suit_classes_vs_oracle(L, variant, symmetrize
 
 
 @pytest.mark.gpu
+def test_gpu_fused_weighted_boards_checkpoint_resume(L):
+    pc.check_weighted_checkpoint(L)
+
+
+@pytest.mark.gpu
 def test_gpu_fused_suit_isomorphism_equals_the_full_board_list(L):
     """the class solve against the fused solve of the FULL suit-closed board list the classes stand for (every board listed, weight 1): the
     isomorphism is exact in exact arithmetic; float32 runs agree to 2e-5 over 5 CFR+ iterations (6 classes = 100-odd boards)"""

@@ -559,3 +559,25 @@ def test_board_enumeration_like_the_tree_builder_deals():
     with pytest.raises(ValueError, match="pass n_boards"):
         board_enum.single_deal_boards(G.Flop5Holdem)
     assert board_enum.single_deal_boards(G.Flop5Holdem, n_boards=7).shape == (7, 5)
+
+
+def test_board_classes_and_the_default_board_choice():
+    """board_enum: Flop5Holdem's 2 598 960 boards fall into 134 459 suit classes with orbit sizes 4 / 12 / 24 (the literature's count); asking for every
+    board of the game picks the classes, a capped / seeded list stays literal, Leduc is untouched; 169 suit classes of hands"""
+    from pokerrl_amd.game import board_enum
+    reps, mult = board_enum.single_deal_board_classes(G.Flop5Holdem)
+    assert reps.shape == (134459, 5) and int(mult.sum()) == 2598960 and sorted(set(mult.tolist())) == [4, 12, 24]
+    assert np.all(np.diff(reps.astype(np.int64), axis=1) > 0)                       # cards ascending
+    assert tuple(reps[0]) == (0, 1, 2, 3, 4)                                        # the smallest member of the first class
+    keys = reps.astype(np.int64) @ (52 ** np.arange(4, -1, -1, dtype=np.int64))
+    assert np.all(np.diff(keys) > 0)                                                # classes in ascending order of their smallest member
+    b, m = board_enum.default_boards_or_classes(G.Flop5Holdem)
+    assert m is not None and np.array_equal(b, reps)
+    b, m = board_enum.default_boards_or_classes(G.Flop5Holdem, n_boards=100, seed=3)
+    assert m is None and b.shape == (100, 5)
+    b, m = board_enum.default_boards_or_classes(G.StandardLeduc)
+    assert m is None and b.shape == (6, 1)
+    with pytest.raises(ValueError):
+        board_enum.default_boards_or_classes(G.Flop5Holdem, n_boards=100, suit_isomorphism=True)
+    cls = board_enum.hand_suit_classes(G.Flop5Holdem)
+    assert cls.shape == (1326,) and int(cls.max()) == 168 and sorted(np.bincount(np.bincount(cls)).nonzero()[0].tolist()) == [4, 6, 12]
