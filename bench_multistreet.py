@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--engine", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--avg-f32", action="store_true", help="OPT-IN, not the reference's numerics: the street columns' running average stored as float32 "
+                    "(PRL_SOLVER_AVG_F32, on this engine since round 5); a second line, config.avg_dtype says so")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--placement-candidates", type=int, default=3, help="one GPU: solver objects built and timed before the run, the fastest is kept (1 = no probe)")
@@ -125,7 +127,8 @@ def main():
             from pokerrl_amd.dist import rccl_shard
             s = _native.NativeSolver(tree, "plus", 0, shard=rccl_shard(world, rank))
     else:
-        s = _native.NativeSolver(tree, "plus", 0, engine=args.engine, _lib=lib)
+        avg_dtype = "f32" if args.avg_f32 else "f64"
+        s = _native.NativeSolver(tree, "plus", 0, engine=args.engine, _lib=lib, avg_dtype=avg_dtype)
         if args.placement_candidates > 1 and not emu_lib and s.engine == "fused":
             # as bench.py's placement probe: solver objects of one process differ by ~7 % on this tree, repeatably per object, with where their
             # arrays land physically (scripts/ms_placement_probe.py: 2.38 .. 2.54 ms per iteration). 4 GB each: build a few, keep the fastest,
@@ -137,7 +140,7 @@ def main():
             cands = [(probe(s), s)]
             try:
                 for _ in range(args.placement_candidates - 1):
-                    c = _native.NativeSolver(tree, "plus", 0, engine=args.engine, _lib=lib)
+                    c = _native.NativeSolver(tree, "plus", 0, engine=args.engine, _lib=lib, avg_dtype=avg_dtype)
                     cands.append((probe(c), c))
             except _native.NativeError as e:
                 sys.stderr.write("bench_multistreet.py: placement probe cut short (%s)\n" % e)
@@ -179,7 +182,8 @@ def main():
         "metric": "CFR+ node-updates/sec on a multi-street LimitHoldem public tree", "value": n_nodes_job * args.steps / dt, "unit": "node-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "build_flavor": (lib or _native.lib()).prl_build_flavor().decode(),
-        "config": {"workload": "CFR+ (delay 0) on LimitHoldem, %d flops per GPU x %d turns x %d rivers of seeded run-outs, 1326-hand ranges" % (args.flops, args.turns, args.rivers),
+        "config": {"avg_dtype": "f32 (opt-in: PRL_SOLVER_AVG_F32; the reference's average is float64)" if args.avg_f32 else "f64",
+                   "workload": "CFR+ (delay 0) on LimitHoldem, %d flops per GPU x %d turns x %d rivers of seeded run-outs, 1326-hand ranges" % (args.flops, args.turns, args.rivers),
                    "engine": s.engine + (" (per-street)" if s.engine == "fused" else ""), "nodes": tree.n_nodes, "nodes_whole_job": n_nodes_job,
                    "placement_probe_ms_per_iteration": placement, "flops_per_gpu": args.flops, "exchanges": int(s.get("exchanges")[0]) if world > 1 else 0, "action_columns": tree.n_cols,
                    "action_columns_last_street": cols_last, "board_rows": int(tree.n_boards), "tree_build_s": t_tree,

@@ -304,7 +304,8 @@ int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t de
  * float32 -- read, widened, blended in float64 with the reference's weights (CFRPlus.py:65-87), rounded on the store. The reference's average
  * is float64 (a NumPy-2 promotion of its integer weights) and is 54 % of the board pass's HBM traffic; with float32 storage the average
  * differs from the reference's by one rounding per iteration (bench.py --avg-f32 reports the average-strategy exploitability of both).
- * Regrets, current strategies and the current-strategy exploitability history are unaffected. Single-deal fused engine, CFR+, no checkpoints. */
+ * Regrets, current strategies and the current-strategy exploitability history are unaffected. Fused engines (the single-deal board pass and, since
+ * round 5, the per-street passes: the trunk's few columns stay float64), CFR+, no checkpoints; prl_solver_get(AVG) widens, prl_solver_get_cols(AVG) refuses. */
 enum { PRL_SOLVER_AVG_F32 = 1 };
 int32_t prl_solver_create_opts(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t flags, prl_solver_t** out_solver);
 /* WEIGHTED BOARDS / SUIT ISOMORPHISM (round 5; an algorithmic extension the reference lacks -- its public tree lists every board, PokerRL/game/_/tree/

@@ -446,7 +446,8 @@ static int ensure_board_avg(prl_solver* s) {
 int street_sweep(prl_solver* s, const PrlDevState& st, int mode, int src0, int src1, const double* strat_arr, const float* strat32) {
     PrlStParams p = s->sp;
     p.regret = strat32 ? const_cast<float*>(strat32) : s->d_regret;
-    p.avg = s->d_avg;
+    p.avg = s->avg_f32 ? nullptr : s->d_avg;  // (PRL_SOLVER_AVG_F32: the street columns' average lives in d_avg32; d_avg holds the trunk's float64 columns only)
+    p.avg32 = s->d_avg32;
     p.avg_sum = s->S.avg_sum;
     p.strat_arr = strat_arr;
     p.variant = s->variant;
@@ -885,8 +886,8 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         }
         if (mult_sum > 0x7fffffffll) { prl_set_error("weighted boards: too many boards in all"); return PRL_ERR_ARG; }
     } else if (symmetrize) { prl_set_error("symmetrize needs board multiplicities"); return PRL_ERR_ARG; }
-    if ((flags & PRL_SOLVER_AVG_F32) && (!fused || streets || variant != PRL_CFR_PLUS)) {
-        prl_set_error("PRL_SOLVER_AVG_F32: the single-deal fused engine with CFR+ only (the variant whose running average the board pass blends)");
+    if ((flags & PRL_SOLVER_AVG_F32) && (!fused || variant != PRL_CFR_PLUS)) {
+        prl_set_error("PRL_SOLVER_AVG_F32: the fused engines (single-deal board pass, per-street passes) with CFR+ only (the variant whose running average the passes blend)");
         return PRL_ERR_UNSUPPORTED;
     }
     if (exchange && !fused) { prl_set_error("sharded solve: FUSED engine only (board / street subtrees of registered shapes, prl_fhp.h, prl_st.h)"); return PRL_ERR_UNSUPPORTED; }
@@ -1999,7 +2000,9 @@ int32_t prl_solver_get_cols(prl_solver_t* s, int32_t field, int64_t col_begin, i
         // column is fetched from where it lives; runs of columns that are neighbours in both orders (a node's actions) travel as one copy
         switch (field) {
             case PRL_SF_REGRET: src = (const char*)s->d_regret; elem = 4; break;
-            case PRL_SF_AVG: TRY(ensure_board_avg(s)); src = (const char*)s->d_avg; elem = 8; break;
+            case PRL_SF_AVG:
+                if (s->avg_f32) { prl_set_error("get_cols(AVG): the average is stored as float32 in this solver; use prl_solver_get"); return PRL_ERR_UNSUPPORTED; }
+                TRY(ensure_board_avg(s)); src = (const char*)s->d_avg; elem = 8; break;
             case PRL_SF_AVG_SUM: src = (const char*)s->S.avg_sum; elem = 4; break;
             default: prl_set_error("get_cols: REGRET, AVG or AVG_SUM"); return PRL_ERR_ARG;
         }
@@ -2156,6 +2159,21 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
                 if (s->avg_f32) TRY(sorted_get_boards(s, s->d_avg32 + s->board_ofs, 4, fill, nullptr, (double*)out + tcb, 8, 0, s->fp.n_boards));
                 else TRY(sorted_get_boards(s, s->d_avg + s->board_ofs, 8, fill, nullptr, (double*)out + tcb, 8, 0, s->fp.n_boards));
                 return prl_solver_sync(s);
+            }
+            if (s->avg_f32 && s->streets) {  // trunk columns float64, street columns float32 widened (exact); internal column order -> the flat tree's
+                const size_t tcb = (size_t)s->T.n_cols * s->R;
+                std::vector<float> f(nc);
+                std::vector<double> tr(tcb);
+                PRL_HIP_TRY(hipStreamSynchronize(s->stream));
+                PRL_HIP_TRY(hipMemcpy(f.data(), s->d_avg32, nc * 4, hipMemcpyDeviceToHost));
+                PRL_HIP_TRY(hipMemcpy(tr.data(), s->d_avg, tcb * 8, hipMemcpyDeviceToHost));
+                double* o = (double*)out;
+                for (int c = 0; c < s->full_cols; ++c) {
+                    double* dst = o + (size_t)(s->col_dfs.empty() ? c : s->col_dfs[c]) * s->R;
+                    if (c < s->T.n_cols) memcpy(dst, tr.data() + (size_t)c * s->R, (size_t)s->R * 8);
+                    else for (int h = 0; h < s->R; ++h) dst[h] = (double)f[(size_t)c * s->R + h];
+                }
+                return PRL_OK;
             }
             TRY(ensure_board_avg(s)); src = s->d_avg; bytes = nc * 8; break;
         case PRL_SF_AVG_F64: src = s->S.avg_f64; bytes = (size_t)s->T.n_nodes; break;

@@ -58,6 +58,7 @@ struct PrlStParams {
     float* val;                  // [n_inst][prl_fhp_out_width(mode)][R] PASS output
     float* regret;               // [n_cols][R] internal column order (PRL_SRC_STRAT32: the float32 strategy array, read only)
     double* avg;
+    float* avg32;                // opt-in PRL_SOLVER_AVG_F32 (as PrlFhpParams::avg32): the running average of the street columns STORED as float32; `avg` unused then
     float* avg_sum;
     const double* strat_arr;     // PRL_SRC_ARR64 / ARR32
     int32_t avg_mode;            // as PrlFhpParams

@@ -617,3 +617,53 @@ def check_weighted_checkpoint(L):
     other[0] = 12 if other[0] != 12 else 24
     with pytest.raises(Exception):
         mk(other).load_state(blob)
+
+
+def check_streets_avg_f32(L, game_cls, stack, runouts, n_iters, max_raises=None, batched=False):
+    """PRL_SOLVER_AVG_F32 on the per-street fused engine (round 5: feature parity with the single-deal board pass): the street columns' running
+    average stored as float32 -- regrets, current-strategy exploitability history: bit-exact to the oracle; the average = the reference's
+    recurrence with one float32 rounding per iteration, restated here from the oracle's strategies; the trunk's columns stay float64 = the
+    oracle's; average-strategy exploitability within 1e-5 relative of the float64 one."""
+    args = env_args(game_cls, stack, None)
+    game = game_cls.native_game(args)
+    if max_raises is not None:
+        for i, v in enumerate(max_raises):
+            game.max_raises[i] = v
+    t = _native.NativeTree(game, game_cls.native_rules(), runouts, _lib=L)
+    s = _native.NativeSolver(t, "plus", 0, engine="auto", _lib=L, avg_dtype="f32")
+    assert s.engine == "fused"
+    r = game_cls.RULES
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS, r._RANK_RULE)
+    o.cfr_reset(1, 0)
+    kind, rnd, first_col, n_ch = t.field("kind"), t.field("round"), t.field("first_col"), t.field("n_children")
+    trunk = np.zeros(t.n_cols, bool)
+    for n in np.where(kind == 0)[0]:
+        if rnd[n] == 0:  # the betting before the first deal: the trunk (LEVELS kernels, float64 average as the reference)
+            trunk[first_col[n]:first_col[n] + n_ch[n]] = True
+    a32 = None
+    hist = [np.array(o.exploitability, np.float32)]
+    for it in range(n_iters):
+        o.cfr_iteration()
+        hist.append(np.array(o.exploitability, np.float32))
+        strat = np.asarray(o.strategy)
+        if it == 0:
+            a32 = strat.astype(np.float32)
+        else:
+            cw, nw = sum(range(1, it + 1)), it + 1
+            a32 = (cw / (cw + nw) * a32.astype(np.float64) + nw / (cw + nw) * strat).astype(np.float32)
+        if not batched:
+            s.iteration()
+            assert np.array_equal(s.get("regret"), np.asarray(o.regret)), it
+            assert np.array_equal(s.exploitability(), o.exploitability), it
+    if batched:
+        s.iterations(n_iters)
+        assert np.array_equal(s.get("regret"), np.asarray(o.regret))
+    assert np.array_equal(s.get("expl_history"), np.stack(hist))
+    avg = s.get("avg")
+    assert np.array_equal(avg[trunk], np.asarray(o.avg)[trunk]), "trunk average"
+    assert np.array_equal(avg[~trunk], a32.astype(np.float64)[~trunk]), "street columns: the float32 recurrence"
+    e32, e64 = s.eval_avg(), o.eval_avg()
+    assert np.allclose(e32, e64, rtol=1e-5, atol=0), (e32, e64)
+    with pytest.raises(Exception):
+        s.get_cols("avg", 0, 1)  # float32 storage: prl_solver_get translates, get_cols does not
+    return s, o

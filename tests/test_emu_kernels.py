@@ -173,6 +173,12 @@ def test_emu_streets_engine_limit_holdem(L, variant, runouts, max_raises, batche
     pc.check_streets_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(*runouts), variant, 3 if batched else 2, max_raises=max_raises, batched=batched)
 
 
+@pytest.mark.parametrize("batched", [False, True])
+def test_emu_streets_engine_float32_running_average_opt_in(L, batched):
+    from pokerrl_amd.game import games as G
+    pc.check_streets_avg_f32(L, G.LimitHoldem, 48, pc.multistreet_runouts(1, 2, 1), 3, max_raises=(1, 1, 1, 1), batched=batched)
+
+
 def test_emu_streets_engine_best_response_of_an_explicit_strategy(L):
     """LocalBRMaster's evaluation on a multi-street tree: explicit float32 / float64 strategies on the per-street engine against the oracle"""
     from pokerrl_amd.game import games as G

@@ -213,6 +213,13 @@ def test_gpu_streets_engine_cfr_plus_with_averaging_delay_vs_oracle(L, batched):
     pc.check_streets_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(2, 2, 2), "plus", 5, delay=2, max_raises=(2, 2, 2, 2), batched=batched)
 
 
+@pytest.mark.parametrize("batched,max_raises", [(False, (1, 2, 1, 1)), (True, None)])
+def test_gpu_streets_engine_float32_running_average_opt_in(L, batched, max_raises):
+    """PRL_SOLVER_AVG_F32 on the per-street engine (full betting = the 27-node shape when max_raises is None)"""
+    from pokerrl_amd.game import games as G
+    pc.check_streets_avg_f32(L, G.LimitHoldem, 48, pc.multistreet_runouts(2, 2, 2), 4, max_raises=max_raises, batched=batched)
+
+
 def test_gpu_streets_engine_best_response_of_an_explicit_strategy_vs_oracle(L):
     """LocalBRMaster's evaluation (LocalBRMaster.py:67-80) on LimitHoldem with its full betting, 2 flops x 2 turns x 1 river: explicit float32 /
     float64 strategies on the per-street engine against the oracle; iterating again after reset()"""
