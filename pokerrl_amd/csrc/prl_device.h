@@ -74,6 +74,10 @@ PRL_DEV PRL_INLINE int prl_opaque_scalar(int v) { asm volatile("" : "+s"(v)); re
 // otherwise precomputes every loop-invariant LDS address of the pass before the loop and SPILLS them: 24 scratch reloads per instance, each
 // with a full s_waitcnt vmcnt(0), on the 27-node shape; profiles/r05_experiments.txt)
 PRL_DEV PRL_INLINE int prl_opaque_lane(int v) { asm volatile("" : "+v"(v)); return v; }
+// a USE of a loaded value, in the compiler's eyes: its wait for the load is placed here and not where the value is used next. (Values loaded before a
+// loop and used at the top of its body otherwise count as pending at the loop header, and the wait inserted there is sized for the entry path: it then
+// also waits for everything the previous iteration left in flight -- on gfx9 that includes its stores.)
+PRL_DEV PRL_INLINE void prl_use(float& x) { asm volatile("" : "+v"(x)); }
 PRL_DEV PRL_INLINE int prl_wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }  // v is the same in every lane: keep it scalar
 PRL_DEV PRL_INLINE char* prl_smem() {
     extern __shared__ __attribute__((aligned(16))) char prl_dyn_smem[];

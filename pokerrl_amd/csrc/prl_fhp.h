@@ -181,7 +181,7 @@ struct PrlFhpParams {
     float chance_prob, eq_const;
     float pot[PRL_FHP_MAX_NODES];      // main pot of the terminal nodes (by local node id)
     const float* chance_reach;  // [2][R] reach at the chance node (trunk state, hand order)
-    const float* board_w;       // weighted boards (prl_solver_create_weighted): [n_boards] chance_prob * multiplicity, replaces chance_prob; else nullptr
+    const float* board_w;       // [n_boards] the chance weight of every board: chance_prob, or chance_prob * multiplicity of a weighted board (prl_solver_create_weighted)
     float* regret;              // board region [n_boards][n_cols_board][np]; PRL_SRC_STRAT32: an explicit float32 strategy in the same layout
     double* avg;                // board region: average strategy, updated by the update passes when avg_mode != 0
     float* avg32;               // opt-in (prl_solver_create_opts: PRL_SOLVER_AVG_F32): the same average STORED as float32 -- read, widened, blended in

@@ -1102,11 +1102,13 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             }
             fp.no_steady = getenv("PRL_FHP_NO_STEADY") ? 1 : 0;  // tests: the generic pass in the steady state too
             fp.chance_prob = T.chance_prob; fp.eq_const = T.eq_const;
-            if (board_mult) {
+            {   // the boards' chance weights as an array (the pass reads a board's weight a board ahead, unconditionally)
                 std::vector<float> bw((size_t)full.n_boards);
-                for (int i = 0; i < full.n_boards; ++i) bw[(size_t)i] = T.chance_prob * (float)board_mult[i];  // one float32 rounding, as the oracle's
+                for (int i = 0; i < full.n_boards; ++i) bw[(size_t)i] = board_mult ? T.chance_prob * (float)board_mult[i] : T.chance_prob;  // one float32 rounding, as the oracle's
                 FAIL_IF(dev_upload(s, &s->d_board_w, bw));
                 fp.board_w = s->d_board_w;
+            }
+            if (board_mult) {
                 if (symmetrize) {
                     // classes of hands under the 24 suit permutations: (low rank, high rank, suited) -- 13 pairs x 6, 78 suited x 4, 78 offsuit x 12
                     const int R = r.range_size, NS = r.n_suits;

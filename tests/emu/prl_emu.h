@@ -106,6 +106,7 @@ inline int prl_dpp_wave_shr1_i(int v, int fill) {
     return lane > 0 ? r : fill;
 }
 inline float prl_readlane(float v, int lane) { return prl_shfl(v, lane); }
+inline void prl_use(float&) {}
 
 // ---- the sliver of the HIP runtime API the C-ABI layer uses, mapped onto the host heap ---------------------------------
 typedef int hipError_t;
