@@ -9,6 +9,8 @@ timeout 600 python bench.py --variant linear --no-cpu-baseline > gpurun_out/${TA
 timeout 600 python bench.py --avg-f32 --no-cpu-baseline > gpurun_out/${TAG}_bench_avg_f32.json 2>> gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --whole-game --no-cpu-baseline > gpurun_out/${TAG}_bench_whole_game.json 2>> gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --whole-game --variant linear --no-cpu-baseline > gpurun_out/${TAG}_bench_whole_game_linear.json 2>> gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --whole-game --avg-f32 --no-cpu-baseline > gpurun_out/${TAG}_bench_whole_game_avg_f32.json 2>> gpurun_out/${TAG}_bench.err
+timeout 300 python bench_multistreet.py --avg-f32 --no-cpu-baseline > gpurun_out/${TAG}_bench_multistreet_avg_f32.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python bench_br.py > gpurun_out/${TAG}_bench_br.json 2>> gpurun_out/${TAG}_bench.err
 timeout 600 python bench_lbr.py > gpurun_out/${TAG}_bench_lbr.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python bench_env.py > gpurun_out/${TAG}_bench_env.json 2>> gpurun_out/${TAG}_bench.err
@@ -16,7 +18,7 @@ timeout 300 python bench_multistreet.py > gpurun_out/${TAG}_bench_multistreet.js
 timeout 300 python bench_leduc.py > gpurun_out/${TAG}_bench_leduc.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python bench_h2h.py > gpurun_out/${TAG}_bench_h2h.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python bench_handeval.py > gpurun_out/${TAG}_bench_handeval.json 2>> gpurun_out/${TAG}_bench.err
-for f in bench bench_linear bench_avg_f32 bench_whole_game bench_whole_game_linear bench_br bench_lbr bench_env bench_multistreet bench_leduc bench_h2h bench_handeval; do python -c "
+for f in bench bench_linear bench_avg_f32 bench_whole_game bench_whole_game_linear bench_whole_game_avg_f32 bench_multistreet_avg_f32 bench_br bench_lbr bench_env bench_multistreet bench_leduc bench_h2h bench_handeval; do python -c "
 import json
 try:
     d=json.loads(open('gpurun_out/${TAG}_$f.json').read().strip().splitlines()[-1]); print('$f', '%.5g' % d['value'], d.get('unit'), 'ms/step %.4g' % d['ms_per_step'], 'frac', (d.get('roofline') or {}).get('frac'), 'with-eval', (d.get('roofline_with_avg_evaluation') or {}).get('frac'))
