@@ -532,10 +532,15 @@ def suit_orbit(board, n_suits=4):
     return sorted(out)
 
 
+_ALL_CLASSES = []
+
+
 def iso_classes(n_classes, seed=3):
     """a few suit classes of Flop5Holdem boards (representatives + orbit sizes), incl. the three orbit sizes 4 / 12 / 24"""
     from pokerrl_amd.game import board_enum
-    reps, mult = board_enum.single_deal_board_classes(G.Flop5Holdem)
+    if not _ALL_CLASSES:  # (8 s of enumeration: once per process)
+        _ALL_CLASSES.append(board_enum.single_deal_board_classes(G.Flop5Holdem))
+    reps, mult = _ALL_CLASSES[0]
     rng = np.random.RandomState(seed)
     pick = [int(np.where(mult == m)[0][rng.randint(np.sum(mult == m))]) for m in (4, 12, 24)]
     while len(pick) < n_classes:
