@@ -556,11 +556,17 @@ def fhp_tree_of(L, boards):
                               np.ascontiguousarray(boards, np.int8), _lib=L)
 
 
-def check_weighted_vs_oracle(L, n_classes, n_iters, variant="plus", symmetrize=True):
+def classes_of(boards):
+    """(representatives, orbit sizes) of the suit classes a few boards belong to, without enumerating the game (smoke test)"""
+    orbits = sorted({tuple(suit_orbit([int(c) for c in b])[0]): len(suit_orbit([int(c) for c in b])) for b in boards}.items())
+    return np.array([o[0] for o in orbits], np.int8), np.array([o[1] for o in orbits], np.int32)
+
+
+def check_weighted_vs_oracle(L, n_classes, n_iters, variant="plus", symmetrize=True, classes=None):
     """the fused engine on suit-class representatives with multiplicities (+ orbit-mean chance values) against the oracle's restatement: every regret /
     average column, current- and average-strategy exploitability, bit for bit"""
     from pokerrl_amd.game import board_enum
-    reps, mult = iso_classes(n_classes)
+    reps, mult = classes if classes is not None else iso_classes(n_classes)
     t = fhp_tree_of(L, reps)
     s = _native.NativeSolver(t, variant, 0, _lib=L, board_mult=mult, symmetrize=symmetrize)
     assert s.engine == "fused"
