@@ -477,6 +477,31 @@ int32_t prl_h2h_batch_run(const PrlGame* game, const PrlRules* rules, int32_t n_
                           int32_t opp_kind, uint32_t opp_seed, uint32_t episode_base, double reward_scalar, double ev_normalizer,
                           const int8_t* cards, float* out_winnings, uint64_t* out_stats2, float* out_device_ms);
 
+/* Tabular agents for the batched evaluators (agent kind 2): a policy addressed by the public state, resident in HBM. This is what the reference's
+ * evaluators get from EvalAgentBase.get_a_probs_for_each_hand / get_action (PokerRL/rl/base_cls/EvalAgentBase.py:35-62; used by
+ * LocalLBRWorker.py:120-160,241-281 and LocalHead2HeadMaster.py:100-118) when the agent is tabular -- e.g. the average strategy a CFR solver left
+ * in its PublicTree (pokerrl_amd/rl/tabular_agent.py builds the arrays from a tree and is the same policy as a host EvalAgent).
+ *   keys / rows [capacity]: open-addressed table (linear probing, capacity a power of two > n_rows, key 0 = empty slot) from a state's 64-bit key to
+ *     its row; the key's low word is the hash chain of csrc/prl_lbr_batch.hip (lbrb_state_key: round, pot, bets, stacks, seat to act, board) under
+ *     key_seed, the high word the same chain under key_seed ^ 0x5BD1E995; slot of first probe: (lo ^ hi * 0x9E3779B1) & (capacity - 1);
+ *   probs [n_rows][n_actions][range_size] float32: P(action | hand), 0 for actions that are not legal in the row's state.
+ * A state the table does not hold (LBR stepped outside the agent's tree) plays uniformly over the legal actions. Returns NULL on error. */
+typedef struct PrlPolicyTable prl_policy_table_t;
+prl_policy_table_t* prl_policy_table_create(const uint64_t* keys, const int32_t* rows, uint32_t capacity, const float* probs, int32_t n_rows,
+                                            int32_t n_actions, int32_t range_size, uint32_t key_seed);
+void prl_policy_table_destroy(prl_policy_table_t* table);
+
+/* prl_lbr_batch_run against a tabular agent: `table` is the agent's policy; agent_seed drives its action draws as for the synthetic agents. */
+int32_t prl_lbr_batch_run_table(const PrlGame* lbr_game, const PrlGame* agent_game, const PrlRules* rules, int32_t n_envs, int32_t agent_seat,
+                                int32_t check_to_round, const prl_policy_table_t* table, uint32_t agent_seed, uint32_t episode_base, double reward_scalar,
+                                double ev_normalizer, const int8_t* cards, float* out_winnings, uint64_t* out_stats4, float* out_device_ms);
+
+/* prl_h2h_batch_run with tabular agents: a non-NULL table makes that side a tabular agent (its kind argument is ignored), NULL keeps the synthetic one. */
+int32_t prl_h2h_batch_run_tables(const PrlGame* game, const PrlRules* rules, int32_t n_envs, int32_t ref_seat, int32_t ref_kind, uint32_t ref_seed,
+                                 const prl_policy_table_t* ref_table, int32_t opp_kind, uint32_t opp_seed, const prl_policy_table_t* opp_table,
+                                 uint32_t episode_base, double reward_scalar, double ev_normalizer, const int8_t* cards, float* out_winnings,
+                                 uint64_t* out_stats2, float* out_device_ms);
+
 /* Counter-based decks for the batched engines (no reference counterpart: the reference shuffles with np.random, one hand at a
  * time): hand i gets the first n_deal cards of a Fisher-Yates shuffle of 0..n_cards_in_deck-1 keyed by (seed, first_hand + i),
  * so any split of the hands over GPUs deals the same cards. out_cards: host int8 [n_hands][n_deal] (n_deal <= 16). */

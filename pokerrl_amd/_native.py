@@ -172,6 +172,16 @@ def _bind_solver(L):
     L.prl_h2h_batch_run.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), i32, i32, i32, ctypes.c_uint32, i32, ctypes.c_uint32,
                                     ctypes.c_uint32, ctypes.c_double, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.prl_h2h_batch_run.restype = i32
+    L.prl_policy_table_create.argtypes = [vp, vp, ctypes.c_uint32, vp, i32, i32, i32, ctypes.c_uint32]
+    L.prl_policy_table_create.restype = vp
+    L.prl_policy_table_destroy.argtypes = [vp]
+    L.prl_policy_table_destroy.restype = None
+    L.prl_lbr_batch_run_table.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), i32, i32, i32, vp,
+                                          ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.prl_lbr_batch_run_table.restype = i32
+    L.prl_h2h_batch_run_tables.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), i32, i32, i32, ctypes.c_uint32, vp, i32, ctypes.c_uint32, vp,
+                                           ctypes.c_uint32, ctypes.c_double, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.prl_h2h_batch_run_tables.restype = i32
     L.prl_solver_iterations_many.argtypes = [ctypes.POINTER(vp), i32, i32]
     L.prl_solver_iterations_many.restype = i32
     L.prl_deal_decks.argtypes = [i32, i32, i32, ctypes.c_uint64, ctypes.c_uint64, vp]

@@ -10,6 +10,10 @@
 //   kind 1  seeded hash policy: weight ((mix32(key + h * 0x9E3779B1 + a * 0x85EBCA6B) >> 8) & 0xFFFF) + 1 per (hand, legal
 //           action), key = hash chain over the public betting state and the board, normalised per hand in float32;
 //           tests/lbr_fixture_agent.py is the same policy as a host EvalAgent (the reference plays against that one)
+//   kind 2  TABULAR policy in HBM (PrlPolicyTable: prl_policy_table_create): float32 [row][action][hand] columns addressed by a 64-bit hash of the
+//           public state (the same hash chain under two seeds) through an open-addressed key table; pokerrl_amd/rl/tabular_agent.py builds it from a
+//           PublicTree (a solver's average strategy) and is the same policy as a host EvalAgent. A state the table does not hold (LBR left the agent's
+//           tree) plays uniformly over the legal actions -- on both sides.
 // The agent's action is drawn with a counter-based hash of (seed, episode, step): no RNG state.
 #include <cstdlib>
 #include <string.h>
@@ -45,6 +49,16 @@ extern "C" int32_t prl_device_available(void);
 #endif
 #define LBRB_N_STATS 16
 
+// agent kind 2 (see the header comment): the device arrays of one tabular policy
+struct PrlPolicyTable {
+    unsigned long long* keys;     // [mask + 1] 64-bit state keys, 0 = empty slot (linear probing)
+    int32_t* rows;                // [mask + 1] row of the key in the same slot
+    float* probs;                 // [n_rows][n_actions][range_size] P(action | hand); 0 for actions that are not legal in the row's state
+    uint32_t mask, key_seed;
+    int32_t n_rows, n_actions, range_size;
+};
+#define LBRB_KEY_SEED_HI 0x5BD1E995u  // the high word of a state's key is the hash chain under key_seed ^ this
+
 struct PrlLbrBatchParams {
     PrlGame g_lbr, g_agent;
     PrlRules rules;
@@ -55,6 +69,7 @@ struct PrlLbrBatchParams {
     float* winnings;              // [n_envs]
     unsigned long long* stats;    // [4] env steps, LBR look-ahead decisions, (range, board) equities, agent actions
     float* eq_scratch;            // [grid][LBRB_MAX_Q][LBRB_MAX_BOARDS_2] when LBR may decide with two cards to come, else NULL
+    PrlPolicyTable tab;           // agent kind 2
 };
 
 PRL_HD PRL_INLINE uint32_t lbrb_mix32(uint32_t x) {
@@ -115,6 +130,55 @@ PRL_HD PRL_INLINE int lbrb_agent_draw(int kind, uint32_t key, int h, const int32
     return legal[n_legal - 1];
 }
 
+// Tabular agent. A policy row belongs to a node of the agent's public TREE, not to a public state (two betting histories can meet in one state), so the
+// key is a chain over the states of the hand so far: key(root) = lbrb_state_key(key_seed, root state), key(next) = lbrb_state_key(key(now), next state)
+// after every env step (with the new board cards on the table when the step ends a round) -- two 32-bit chains make the 64-bit key. States, not action
+// ids: LBR raising by a pot fraction of ITS bet set reaches the agent's node whenever the agent's tree has a raise to the same amount.
+struct LbrbHistKey { uint32_t lo, hi; };
+
+PRL_HD PRL_INLINE LbrbHistKey lbrb_hist_root(uint32_t key_seed) { return LbrbHistKey{key_seed, key_seed ^ LBRB_KEY_SEED_HI}; }
+
+PRL_HD PRL_INLINE LbrbHistKey lbrb_hist_step(const LbrbHistKey& k, const PrlEnvState& s, const int8_t* board, int n_dealt, int n_board_total, int n_suits) {
+    return LbrbHistKey{lbrb_state_key(k.lo, s, board, n_dealt, n_board_total, n_suits), lbrb_state_key(k.hi, s, board, n_dealt, n_board_total, n_suits)};
+}
+
+// the row of a history key in the table, -1 if the table does not hold it (one lane; a handful of dependent HBM reads per agent decision)
+PRL_HD PRL_INLINE int lbrb_table_row(const PrlPolicyTable& T, const LbrbHistKey& hk) {
+    unsigned long long k = ((unsigned long long)hk.hi << 32) | hk.lo;
+    if (k == 0ull) k = 1ull;
+    for (uint32_t i = (hk.lo ^ (hk.hi * 0x9E3779B1u)) & T.mask;; i = (i + 1u) & T.mask) {  // the table is never full: the loop ends at an empty slot
+        const unsigned long long ki = T.keys[i];
+        if (ki == k) return T.rows[i];
+        if (ki == 0ull) return -1;
+    }
+}
+
+// P(a | hand h) of agent `kind` in the state (key, row, legal list); TABLE builds read kind 2 from the table, the others never touch it
+template <bool TABLE>
+PRL_HD PRL_INLINE float lbrb_prob(const PrlPolicyTable& T, int kind, uint32_t key, int row, int h, const int32_t* legal, int n_legal, int a) {
+    if (TABLE && kind == 2) {
+        if (row >= 0) return T.probs[((size_t)row * T.n_actions + a) * T.range_size + h];
+        kind = 0;
+    }
+    return lbrb_agent_prob(kind, key, h, legal, n_legal, a);
+}
+
+template <bool TABLE>
+PRL_HD PRL_INLINE int lbrb_draw(const PrlPolicyTable& T, int kind, uint32_t key, int row, int h, const int32_t* legal, int n_legal, float u) {
+    if (TABLE && kind == 2) {
+        if (row >= 0) {
+            float c = 0.f;
+            for (int j = 0; j < n_legal; ++j) {
+                c = c + T.probs[((size_t)row * T.n_actions + legal[j]) * T.range_size + h];
+                if (u < c) return legal[j];
+            }
+            return legal[n_legal - 1];
+        }
+        kind = 0;
+    }
+    return lbrb_agent_draw(kind, key, h, legal, n_legal, u);
+}
+
 PRL_HD PRL_INLINE int lbrb_hand_idx(const PrlRules& r, const int8_t* hc) {
     if (r.n_hole_cards == 1) return hc[0];
     const int a = hc[0] < hc[1] ? hc[0] : hc[1], b = hc[0] < hc[1] ? hc[1] : hc[0];
@@ -128,6 +192,8 @@ struct LbrbShared {
     int32_t legal[LBRB_MAX_LEGAL];
     int32_t n_legal, action, done, n_dealt, step_ctr, n_q, n_boards, lbr_idx;
     uint32_t key;
+    int32_t row, raise_row[LBRB_MAX_Q];  // tabular agent: the table rows of the state / of the states after LBR's candidate raises
+    LbrbHistKey hk;                      // ... and the history key of the hand so far
     float total;
     int32_t raise_action[LBRB_MAX_Q], pot_after[LBRB_MAX_Q];
     uint32_t raise_key[LBRB_MAX_Q];
@@ -427,6 +493,7 @@ PRL_HD PRL_INLINE size_t lbrb_smem_bytes(int R) {  // the carve-outs of prl_k_lb
     for (size_t b : sizes) off = ((off + 15) & ~(size_t)15) + b;
     return off + 16;
 }
+template <bool TABLE>  // TABLE: the agent may be a tabular one (kind 2); the synthetic agents' kernel carries no table code
 PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
     char* lbrb_smem = prl_smem();
     const int R = P.rules.range_size, tid = (int)prl_tid();
@@ -477,6 +544,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
             prl_env_reset(P.g_lbr, S.st);
             S.done = 0; S.n_dealt = 0; S.step_ctr = 0;
             S.lbr_idx = lbrb_hand_idx(P.rules, lbr_hand);
+            if (TABLE) S.hk = lbrb_hist_step(lbrb_hist_root(P.tab.key_seed), S.st, S.board, 0, n_board_total, P.rules.n_suits);
         }
         // agent_range.reset(); set_cards_to_zero_prob(lbr_hand) (:73-74, :190-191)
         const float unif = (float)(1.0 / (double)R);
@@ -550,6 +618,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                             const int nl2 = prl_legal_actions_to(P.g_agent, s2, put);
                             S.raise_n_legal[q] = nl2;
                             S.raise_key[q] = lbrb_state_key(P.seed, s2, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
+                            if (TABLE) S.raise_row[q] = P.agent_kind == 2 ? lbrb_table_row(P.tab, lbrb_hist_step(S.hk, s2, S.board, S.n_dealt, n_board_total, P.rules.n_suits)) : -1;
                         }
                         if (tid == 0) {
                             if (P.limit) S.step_ctr += n_raises;  // the limit branch asks get_action(step_env=False): one draw per raise is consumed (:120)
@@ -574,7 +643,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                         const int nl2 = S.raise_n_legal[q];
                         const int32_t* lg2 = S.raise_legal[q];  // read from LDS where it is (the same word for every lane: a broadcast)
                         for (int h = tid; h < R; h += LBRB_THREADS)
-                            cand[(size_t)q * R + h] = lbrb_agent_prob(P.agent_kind, S.raise_key[q], h, lg2, nl2, PRL_FOLD);  // p(fold | hand)
+                            cand[(size_t)q * R + h] = lbrb_prob<TABLE>(P.tab, P.agent_kind, S.raise_key[q], TABLE ? S.raise_row[q] : -1, h, lg2, nl2, PRL_FOLD);  // p(fold | hand)
                     }
                     // first complete board for the classification (see the quirk in prl_lbr_kernels.hip)
                     {
@@ -884,16 +953,17 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     const PrlEnvState st = S.st;  // one batch of LDS reads; the engine then works on registers (stores to S.legal may alias S.st otherwise)
                     S.n_legal = prl_legal_actions(P.g_agent, st, S.legal);
                     S.key = lbrb_state_key(P.seed, st, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
+                    if (TABLE) S.row = P.agent_kind == 2 ? lbrb_table_row(P.tab, S.hk) : -1;
                     const int hi = lbrb_hand_idx(P.rules, agent_hand);
                     const uint32_t x = lbrb_mix32(P.seed * 0x51ED27u + episode * 0x9E3779B1u + (uint32_t)S.step_ctr);
                     const float u = (float)(x >> 8) / 16777216.0f;
                     S.step_ctr += 1;
-                    S.action = lbrb_agent_draw(P.agent_kind, S.key, hi, S.legal, S.n_legal, u);
+                    S.action = lbrb_draw<TABLE>(P.tab, P.agent_kind, S.key, TABLE ? S.row : -1, hi, S.legal, S.n_legal, u);
                     n_agent += 1;
                 }
                 prl_sync();
                 const int a = S.action;
-                for (int h = tid; h < R; h += LBRB_THREADS) rg[h] = rg[h] * lbrb_agent_prob(P.agent_kind, S.key, h, S.legal, S.n_legal, a);
+                for (int h = tid; h < R; h += LBRB_THREADS) rg[h] = rg[h] * lbrb_prob<TABLE>(P.tab, P.agent_kind, S.key, TABLE ? S.row : -1, h, S.legal, S.n_legal, a);
                 if (coop) lbrb_normalize_blocks(rg, R, MR, part, S); else lbrb_normalize(rg, R, Lf, S);
                 if (tid == 0) {
                     PrlEnvState st = S.st;
@@ -937,6 +1007,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     const int n_new = P.rules.board_cards_in_round[S.st.round];
                     for (int i = 0; i < n_new; ++i) { S.board[S.n_dealt] = deck_board[S.n_dealt]; S.n_dealt += 1; }
                     S.n_legal = n_new;  // scratch: how many cards are new
+                    if (TABLE) S.hk = lbrb_hist_step(S.hk, S.st, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
                 }
                 prl_sync();
                 // agent_range.update_after_new_round (PokerRange.py:60-65): the new board cards leave the range
@@ -946,7 +1017,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                 for (int h = tid; h < R; h += LBRB_THREADS)
                     if (prl_lbr_hand_mask(hg, h, hole_lut) & m) rg[h] = 0.f;
                 if (coop) lbrb_normalize_blocks(rg, R, MR, part, S); else lbrb_normalize(rg, R, Lf, S);
-            }
+            } else if (TABLE && tid == 0) S.hk = lbrb_hist_step(S.hk, S.st, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
             LBRB_TICK(9);  // after the step: dealing / range update / payout
         }
     }
@@ -958,10 +1029,48 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
     }
 }
 
-extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* agent_game, const PrlRules* rules, int32_t n_envs, int32_t agent_seat,
-                                     int32_t check_to_round, int32_t agent_kind, uint32_t agent_seed, uint32_t episode_base, double reward_scalar,
-                                     double ev_normalizer, const int8_t* cards, float* out_winnings, uint64_t* out_stats4, float* out_device_ms) {
-    if (!lbr_game || !agent_game || !rules || !cards || !out_winnings || n_envs <= 0 || agent_seat < 0 || agent_seat > 1) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+// ---- tabular policies in HBM (agent kind 2) ---------------------------------------------------------------------------------------------------------
+// keys / rows: the open-addressed key table as the host built it (capacity a power of two, 0 = empty); probs: [n_rows][n_actions][range_size] float32.
+extern "C" PrlPolicyTable* prl_policy_table_create(const uint64_t* keys, const int32_t* rows, uint32_t capacity, const float* probs, int32_t n_rows,
+                                                   int32_t n_actions, int32_t range_size, uint32_t key_seed) {
+    if (!keys || !rows || !probs || capacity < 2 || (capacity & (capacity - 1)) || n_rows <= 0 || (uint32_t)n_rows >= capacity || n_actions < 2 || range_size <= 0) {
+        prl_set_error("prl_policy_table_create: bad argument (capacity: a power of two above the number of rows)"); return nullptr;
+    }
+    if (!prl_device_available()) { prl_set_error("no HIP device: policy tables live in HBM"); return nullptr; }
+    PrlPolicyTable* T = new PrlPolicyTable();
+    memset(T, 0, sizeof(*T));
+    T->mask = capacity - 1; T->key_seed = key_seed; T->n_rows = n_rows; T->n_actions = n_actions; T->range_size = range_size;
+    const size_t np = (size_t)n_rows * n_actions * range_size;
+    if (hipMalloc((void**)&T->keys, (size_t)capacity * 8) != hipSuccess || hipMalloc((void**)&T->rows, (size_t)capacity * 4) != hipSuccess ||
+        hipMalloc((void**)&T->probs, np * 4) != hipSuccess || hipMemcpy(T->keys, keys, (size_t)capacity * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(T->rows, rows, (size_t)capacity * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(T->probs, probs, np * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(T->keys); (void)hipFree(T->rows); (void)hipFree(T->probs);
+        delete T;
+        prl_set_error("prl_policy_table_create: HIP allocation / copy failed"); return nullptr;
+    }
+    return T;
+}
+
+extern "C" void prl_policy_table_destroy(PrlPolicyTable* T) {
+    if (!T) return;
+    (void)hipFree(T->keys); (void)hipFree(T->rows); (void)hipFree(T->probs);
+    delete T;
+}
+
+static int lbrb_check_table(int kind, const PrlPolicyTable* T, const PrlGame* agent_game, const PrlRules* rules, const char* who) {
+    if (kind != 2) return PRL_OK;
+    if (!T) { prl_set_error(std::string(who) + ": agent kind 2 needs a policy table"); return PRL_ERR_ARG; }
+    const int n_act = agent_game->game_type == PRL_GAME_LIMIT ? 3 : agent_game->n_bet_sizes + 2;
+    if (T->range_size != rules->range_size || T->n_actions < n_act) { prl_set_error(std::string(who) + ": the policy table was built for another game (range size / number of actions)"); return PRL_ERR_ARG; }
+    return PRL_OK;
+}
+
+static int32_t lbr_batch_run_impl(const PrlGame* lbr_game, const PrlGame* agent_game, const PrlRules* rules, int32_t n_envs, int32_t agent_seat,
+                                  int32_t check_to_round, int32_t agent_kind, uint32_t agent_seed, uint32_t episode_base, double reward_scalar,
+                                  double ev_normalizer, const int8_t* cards, float* out_winnings, uint64_t* out_stats4, float* out_device_ms, const PrlPolicyTable* table) {
+    if (!lbr_game || !agent_game || !rules || !cards || !out_winnings || n_envs <= 0 || agent_seat < 0 || agent_seat > 1 || agent_kind < 0 || agent_kind > 2) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    if (const int trc = lbrb_check_table(agent_kind, table, agent_game, rules, "batched LBR")) return trc;
     if (!prl_device_available()) { prl_set_error("no HIP device: batched LBR has no CPU fallback"); return PRL_ERR_NO_DEVICE; }
     const int nh = rules->n_hole_cards, nb = rules->n_board_cards;
     if (nh < 1 || nh > 2 || rules->n_cards > PRL_LBR_MAX_CARDS || nb > 5 || (nh == 2 && (rules->n_cards != 52 || nb != 5))) {
@@ -985,6 +1094,7 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
     P.n_envs = n_envs; P.agent_seat = agent_seat; P.check_to_round = check_to_round; P.agent_kind = agent_kind;
     P.n_deal = 2 * nh + nb; P.limit = lbr_game->game_type == PRL_GAME_LIMIT;
     P.seed = agent_seed; P.episode_base = episode_base; P.reward_scalar = reward_scalar; P.ev_normalizer = ev_normalizer;
+    if (agent_kind == 2) P.tab = *table;
     const int R = rules->range_size;
     const size_t smem = lbrb_smem_bytes(R);
     int8_t* d_cards = nullptr; float* d_win = nullptr; unsigned long long* d_stats = nullptr; float* d_eq = nullptr;
@@ -1011,16 +1121,17 @@ extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* age
 #if !defined(PRL_EMU)
         if (getenv("PRL_LBRB_DEBUG")) {
             int nb = -1;
-            hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, prl_k_lbr_batch, LBRB_THREADS, smem);
+            hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, prl_k_lbr_batch<false>, LBRB_THREADS, smem);
             hipFuncAttributes fa;
             memset(&fa, 0, sizeof(fa));
-            hipError_t fe = hipFuncGetAttributes(&fa, (const void*)prl_k_lbr_batch);
+            hipError_t fe = hipFuncGetAttributes(&fa, (const void*)prl_k_lbr_batch<false>);
             fprintf(stderr, "lbrb: smem %zu, occupancy %d workgroups per CU (err %d); regs %d, static smem %zu, local %zu, maxDyn %d (err %d)\n", smem, nb, (int)oe,
                     fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fa.maxDynamicSharedSizeBytes, (int)fe);
         }
 #endif
         LB_TRY(hipEventRecord(e0, nullptr));
-        PRL_LAUNCH(prl_k_lbr_batch, grid, LBRB_THREADS, smem, nullptr, P);
+        if (agent_kind == 2) PRL_LAUNCH(prl_k_lbr_batch<true>, grid, LBRB_THREADS, smem, nullptr, P);
+        else PRL_LAUNCH(prl_k_lbr_batch<false>, grid, LBRB_THREADS, smem, nullptr, P);
         LB_TRY(hipEventRecord(e1, nullptr));
     }
     LB_TRY(hipDeviceSynchronize());
@@ -1046,6 +1157,22 @@ done:
     return rc;
 }
 
+extern "C" int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* agent_game, const PrlRules* rules, int32_t n_envs, int32_t agent_seat,
+                                     int32_t check_to_round, int32_t agent_kind, uint32_t agent_seed, uint32_t episode_base, double reward_scalar,
+                                     double ev_normalizer, const int8_t* cards, float* out_winnings, uint64_t* out_stats4, float* out_device_ms) {
+    if (agent_kind == 2) { prl_set_error("prl_lbr_batch_run: a tabular agent goes through prl_lbr_batch_run_table"); return PRL_ERR_ARG; }
+    return lbr_batch_run_impl(lbr_game, agent_game, rules, n_envs, agent_seat, check_to_round, agent_kind, agent_seed, episode_base, reward_scalar, ev_normalizer, cards,
+                              out_winnings, out_stats4, out_device_ms, nullptr);
+}
+
+// LBR against a tabular agent (kind 2): `table` holds the agent's policy (a solver's average strategy); agent_seed drives the action draws as before
+extern "C" int32_t prl_lbr_batch_run_table(const PrlGame* lbr_game, const PrlGame* agent_game, const PrlRules* rules, int32_t n_envs, int32_t agent_seat,
+                                           int32_t check_to_round, const PrlPolicyTable* table, uint32_t agent_seed, uint32_t episode_base, double reward_scalar,
+                                           double ev_normalizer, const int8_t* cards, float* out_winnings, uint64_t* out_stats4, float* out_device_ms) {
+    return lbr_batch_run_impl(lbr_game, agent_game, rules, n_envs, agent_seat, check_to_round, 2, agent_seed, episode_base, reward_scalar, ev_normalizer, cards,
+                              out_winnings, out_stats4, out_device_ms, table);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Batched head-to-head (LocalHead2HeadMaster.py:82-126 on the batched env): two synthetic agents
 // play n_envs hands, ONE LANE PER HAND -- a head-to-head hand touches only the two players' own rows of the policy, so the
@@ -1064,8 +1191,10 @@ struct PrlH2hBatchParams {
     const int8_t* cards;          // [n_envs][n_deal]: seat 0's hole cards, seat 1's, then the board in deal order
     float* winnings;              // [n_envs]
     unsigned long long* stats;    // [2] env steps, showdowns
+    PrlPolicyTable tab[2];        // agents of kind 2
 };
 
+template <bool TABLE>
 PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_h2h_batch(PrlH2hBatchParams P) {
     const int e = (int)(prl_bid() * prl_nthreads() + prl_tid());
     unsigned long long n_steps = 0, n_show = 0;
@@ -1079,6 +1208,9 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_h2h_batch(PrlH2hBatchParams P) {
         int8_t board[5] = {0, 0, 0, 0, 0};
         int n_dealt = 0;
         int step_ctr[2] = {0, 0};  // per agent: its own get_action calls of this episode
+        LbrbHistKey hk[2];         // per tabular agent: the history key of the hand so far under its table's seed
+        if (TABLE)
+            for (int w = 0; w < 2; ++w) hk[w] = lbrb_hist_step(lbrb_hist_root(P.tab[w].key_seed), st, board, 0, nb, P.rules.n_suits);
         int hand_idx[2];
         for (int p = 0; p < 2; ++p) hand_idx[p] = lbrb_hand_idx(P.rules, cards + p * nh);
         PrlLbrGame hg;
@@ -1093,7 +1225,8 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_h2h_batch(PrlH2hBatchParams P) {
             const uint32_t x = lbrb_mix32(P.seed[who] * 0x51ED27u + episode * 0x9E3779B1u + (uint32_t)step_ctr[who]);
             const float u = (float)(x >> 8) / 16777216.0f;
             step_ctr[who] += 1;
-            const int a = lbrb_agent_draw(P.kind[who], key, hand_idx[seat], legal, n_legal, u);
+            const int row = TABLE && P.kind[who] == 2 ? lbrb_table_row(P.tab[who], hk[who]) : -1;
+            const int a = lbrb_draw<TABLE>(P.tab[who], P.kind[who], key, row, hand_idx[seat], legal, n_legal, u);
             PrlStepInfo info;
             if (!P.limit && a >= 2) {  // discretized games step by pot fraction
                 const int amt = prl_fraction_of_pot_raise(st, P.game.bet_fracs[a - 2], st.cur);
@@ -1118,6 +1251,8 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_h2h_batch(PrlH2hBatchParams P) {
                 const int n_new = P.rules.board_cards_in_round[st.round];
                 for (int i = 0; i < n_new; ++i) { board[n_dealt] = deck_board[n_dealt]; n_dealt += 1; }
             }
+            if (TABLE && !info.is_terminal)
+                for (int w = 0; w < 2; ++w) hk[w] = lbrb_hist_step(hk[w], st, board, n_dealt, nb, P.rules.n_suits);
         }
     }
     // one pair of atomics per wave: butterfly sum of the per-lane counts (each far below 2^31)
@@ -1127,10 +1262,13 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_h2h_batch(PrlH2hBatchParams P) {
     if (lane == 0) { prl_atomic_add_u64(P.stats + 0, (unsigned long long)cs); prl_atomic_add_u64(P.stats + 1, (unsigned long long)cw); }
 }
 
-extern "C" int32_t prl_h2h_batch_run(const PrlGame* game, const PrlRules* rules, int32_t n_envs, int32_t ref_seat, int32_t ref_kind, uint32_t ref_seed,
-                                     int32_t opp_kind, uint32_t opp_seed, uint32_t episode_base, double reward_scalar, double ev_normalizer,
-                                     const int8_t* cards, float* out_winnings, uint64_t* out_stats2, float* out_device_ms) {
-    if (!game || !rules || !cards || !out_winnings || n_envs <= 0 || ref_seat < 0 || ref_seat > 1) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+static int32_t h2h_batch_run_impl(const PrlGame* game, const PrlRules* rules, int32_t n_envs, int32_t ref_seat, int32_t ref_kind, uint32_t ref_seed,
+                                  int32_t opp_kind, uint32_t opp_seed, uint32_t episode_base, double reward_scalar, double ev_normalizer,
+                                  const int8_t* cards, float* out_winnings, uint64_t* out_stats2, float* out_device_ms, const PrlPolicyTable* ref_table,
+                                  const PrlPolicyTable* opp_table) {
+    if (!game || !rules || !cards || !out_winnings || n_envs <= 0 || ref_seat < 0 || ref_seat > 1 || ref_kind < 0 || ref_kind > 2 || opp_kind < 0 || opp_kind > 2) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    if (const int trc = lbrb_check_table(ref_kind, ref_table, game, rules, "batched head-to-head")) return trc;
+    if (const int trc = lbrb_check_table(opp_kind, opp_table, game, rules, "batched head-to-head")) return trc;
     if (!prl_device_available()) { prl_set_error("no HIP device: batched head-to-head has no CPU fallback"); return PRL_ERR_NO_DEVICE; }
     const int nh = rules->n_hole_cards, nb = rules->n_board_cards;
     if (nh < 1 || nh > 2 || rules->n_cards > PRL_LBR_MAX_CARDS || nb > 5 || (nh == 2 && (rules->n_cards != 52 || nb != 5))) {
@@ -1142,6 +1280,8 @@ extern "C" int32_t prl_h2h_batch_run(const PrlGame* game, const PrlRules* rules,
     memset(&P, 0, sizeof(P));
     P.game = *game; P.rules = *rules; P.n_envs = n_envs; P.ref_seat = ref_seat; P.n_deal = 2 * nh + nb; P.limit = game->game_type == PRL_GAME_LIMIT;
     P.kind[0] = ref_kind; P.kind[1] = opp_kind; P.seed[0] = ref_seed; P.seed[1] = opp_seed;
+    if (ref_kind == 2) P.tab[0] = *ref_table;
+    if (opp_kind == 2) P.tab[1] = *opp_table;
     P.episode_base = episode_base; P.reward_scalar = reward_scalar; P.ev_normalizer = ev_normalizer;
     int8_t* d_cards = nullptr; float* d_win = nullptr; unsigned long long* d_stats = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1156,7 +1296,8 @@ extern "C" int32_t prl_h2h_batch_run(const PrlGame* game, const PrlRules* rules,
     HB_TRY(hipEventCreate(&e0));
     HB_TRY(hipEventCreate(&e1));
     HB_TRY(hipEventRecord(e0, nullptr));
-    PRL_LAUNCH(prl_k_h2h_batch, (n_envs + 255) / 256, 256, 0, nullptr, P);
+    if (ref_kind == 2 || opp_kind == 2) PRL_LAUNCH(prl_k_h2h_batch<true>, (n_envs + 255) / 256, 256, 0, nullptr, P);
+    else PRL_LAUNCH(prl_k_h2h_batch<false>, (n_envs + 255) / 256, 256, 0, nullptr, P);
     HB_TRY(hipEventRecord(e1, nullptr));
     HB_TRY(hipDeviceSynchronize());
     if (out_device_ms) HB_TRY(hipEventElapsedTime(out_device_ms, e0, e1));
@@ -1168,6 +1309,23 @@ done:
     if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(d_cards); (void)hipFree(d_win); (void)hipFree(d_stats);
     return rc;
+}
+
+extern "C" int32_t prl_h2h_batch_run(const PrlGame* game, const PrlRules* rules, int32_t n_envs, int32_t ref_seat, int32_t ref_kind, uint32_t ref_seed,
+                                     int32_t opp_kind, uint32_t opp_seed, uint32_t episode_base, double reward_scalar, double ev_normalizer,
+                                     const int8_t* cards, float* out_winnings, uint64_t* out_stats2, float* out_device_ms) {
+    if (ref_kind == 2 || opp_kind == 2) { prl_set_error("prl_h2h_batch_run: tabular agents go through prl_h2h_batch_run_tables"); return PRL_ERR_ARG; }
+    return h2h_batch_run_impl(game, rules, n_envs, ref_seat, ref_kind, ref_seed, opp_kind, opp_seed, episode_base, reward_scalar, ev_normalizer, cards, out_winnings,
+                              out_stats2, out_device_ms, nullptr, nullptr);
+}
+
+// head-to-head with tabular agents: a NULL table keeps that side's synthetic agent (its kind argument), a table makes it kind 2
+extern "C" int32_t prl_h2h_batch_run_tables(const PrlGame* game, const PrlRules* rules, int32_t n_envs, int32_t ref_seat, int32_t ref_kind, uint32_t ref_seed,
+                                            const PrlPolicyTable* ref_table, int32_t opp_kind, uint32_t opp_seed, const PrlPolicyTable* opp_table,
+                                            uint32_t episode_base, double reward_scalar, double ev_normalizer, const int8_t* cards, float* out_winnings,
+                                            uint64_t* out_stats2, float* out_device_ms) {
+    return h2h_batch_run_impl(game, rules, n_envs, ref_seat, ref_table ? 2 : ref_kind, ref_seed, opp_table ? 2 : opp_kind, opp_seed, episode_base, reward_scalar,
+                              ev_normalizer, cards, out_winnings, out_stats2, out_device_ms, ref_table, opp_table);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

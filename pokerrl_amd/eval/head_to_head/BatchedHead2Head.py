@@ -1,9 +1,11 @@
 """
 BatchedHead2Head: head-to-head evaluation with every hand played on the GPU, one lane per hand (SURVEY.md section 8f-3 on the
 batched env). Same episodes as LocalHead2HeadMaster.play -- identical float32 winnings for the same decks and agent draws --
-but both players have to be the library's synthetic tabular agents (a host EvalAgent cannot be queried from inside a kernel).
+but both players have to be agents the kernel can query: the library's synthetic agents or tabular policies in HBM (kind "table":
+pokerrl_amd.rl.tabular_agent.PolicyTable) -- a host EvalAgent cannot be queried from inside a kernel.
 
     h2h = BatchedHead2Head(t_prof, kinds=("hash", "hash"), seeds=(11, 12))
+    h2h = BatchedHead2Head(t_prof, kinds=("table", "hash"), seeds=(11, 12), tables=(PolicyTable.from_cfr(cfr), None))
     w = h2h.play(n_hands=1 << 20, deck_seed=0)        # float32 [2 * n_hands]: the reference agent in seat 0, then in seat 1
 """
 import ctypes
@@ -16,8 +18,10 @@ from pokerrl_amd.rl import rl_util
 
 
 class BatchedHead2Head:
-    def __init__(self, t_prof, kinds=("hash", "hash"), seeds=(11, 12)):
+    def __init__(self, t_prof, kinds=("hash", "hash"), seeds=(11, 12), tables=(None, None)):
         assert t_prof.n_seats == 2
+        assert all((k == "table") == (t is not None) for k, t in zip(kinds, tables)), "kind 'table' plays a PolicyTable"
+        self.tables = tuple(tables)
         self.t_prof = t_prof
         self._bldr = rl_util.get_env_builder(t_prof=t_prof)
         env_cls = self._bldr.env_cls
@@ -47,10 +51,15 @@ class BatchedHead2Head:
         out = np.zeros(n_hands, np.float32)
         stats = np.zeros(2, np.uint64)
         ms = ctypes.c_float()
-        _native.check(L.prl_h2h_batch_run(ctypes.byref(self._game), ctypes.byref(self._rules), int(n_hands), int(ref_seat), self.kinds[0],
-                                          self.seeds[0], self.kinds[1], self.seeds[1], int(episode_base), reward_scalar,
-                                          float(self._env_cls.EV_NORMALIZER), decks.ctypes.data_as(ctypes.c_void_p),
-                                          out.ctypes.data_as(ctypes.c_void_p), stats.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ms)), L)
+        tail = (int(episode_base), reward_scalar, float(self._env_cls.EV_NORMALIZER), decks.ctypes.data_as(ctypes.c_void_p),
+                out.ctypes.data_as(ctypes.c_void_p), stats.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ms))
+        if any(t is not None for t in self.tables):
+            dev = [None if t is None else t.device() for t in self.tables]
+            _native.check(L.prl_h2h_batch_run_tables(ctypes.byref(self._game), ctypes.byref(self._rules), int(n_hands), int(ref_seat), self.kinds[0],
+                                                     self.seeds[0], dev[0], self.kinds[1], self.seeds[1], dev[1], *tail), L)
+        else:
+            _native.check(L.prl_h2h_batch_run(ctypes.byref(self._game), ctypes.byref(self._rules), int(n_hands), int(ref_seat), self.kinds[0],
+                                              self.seeds[0], self.kinds[1], self.seeds[1], *tail), L)
         self.last_stats = {"env_steps": int(stats[0]), "showdowns": int(stats[1]), "device_ms": float(ms.value)}
         return out
 

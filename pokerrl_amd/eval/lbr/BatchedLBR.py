@@ -1,11 +1,13 @@
 """
 BatchedLBR: LBR with every hand played start to finish on the GPU (BASELINE.json config 5: "2^20 batched PokerEnv rollouts +
 7-card eval"). Same computation as LocalLBRWorker.run -- the per-hand winnings are bit-identical for the same decks and the
-same agent draws -- but the agent has to be one of the library's synthetic tabular agents, because a host EvalAgent cannot be
+same agent draws -- but the agent has to be one the kernel can query: one of the library's synthetic agents ("uniform", "hash") or a TABULAR policy
+resident in HBM ("table": pokerrl_amd.rl.tabular_agent.PolicyTable, e.g. a CFR solver's average strategy), because a host EvalAgent cannot be
 queried from inside a kernel (batched querying of neural agents is the "next" row of SURVEY.md section 8f).
 
     lbr = BatchedLBR(t_prof, agent_kind="hash", agent_seed=7)
     winnings = lbr.run(agent_seat_id=0, n_hands=1 << 20, deck_seed=0)          # float32 [n_hands], mbb per hand
+    lbr = BatchedLBR(t_prof, agent_kind="table", table=PolicyTable.from_cfr(cfr))   # LBR against the solver's own output
 """
 import ctypes
 
@@ -14,7 +16,7 @@ import numpy as np
 from pokerrl_amd import _native
 from pokerrl_amd.eval.lbr import _util
 
-AGENT_KINDS = {"uniform": 0, "hash": 1}
+AGENT_KINDS = {"uniform": 0, "hash": 1, "table": 2}
 
 
 def deal_decks(n_hands, n_cards_in_deck, n_deal, seed, first_hand=0):
@@ -48,8 +50,10 @@ def deal_decks_host(n_hands, n_cards_in_deck, n_deal, seed, first_hand=0):
 
 
 class BatchedLBR:
-    def __init__(self, t_prof, agent_kind="hash", agent_seed=7):
+    def __init__(self, t_prof, agent_kind="hash", agent_seed=7, table=None):
         assert t_prof.n_seats == 2
+        assert (agent_kind == "table") == (table is not None), "agent_kind 'table' plays a PolicyTable"
+        self.table = table
         self.t_prof = t_prof
         self.lbr_args = t_prof.module_args["lbr"]
         self._lbr_bldr = _util.get_env_builder_lbr(t_prof=t_prof)
@@ -83,11 +87,12 @@ class BatchedLBR:
         out = np.zeros(n_hands, np.float32)
         stats = np.zeros(4, np.uint64)
         ms = ctypes.c_float()
-        _native.check(L.prl_lbr_batch_run(ctypes.byref(self._g_lbr), ctypes.byref(self._g_agent), ctypes.byref(self._rules), int(n_hands),
-                                          int(agent_seat_id), -1 if ctr is None else int(ctr), self.agent_kind, self.agent_seed,
-                                          int(episode_base), reward_scalar, float(self._env_cls.EV_NORMALIZER),
-                                          decks.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
-                                          stats.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ms)), L)
+        fn, agent = (L.prl_lbr_batch_run, self.agent_kind) if self.table is None else (L.prl_lbr_batch_run_table, self.table.device())
+        _native.check(fn(ctypes.byref(self._g_lbr), ctypes.byref(self._g_agent), ctypes.byref(self._rules), int(n_hands),
+                         int(agent_seat_id), -1 if ctr is None else int(ctr), agent, self.agent_seed,
+                         int(episode_base), reward_scalar, float(self._env_cls.EV_NORMALIZER),
+                         decks.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
+                         stats.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ms)), L)
         self.last_stats = {"env_steps": int(stats[0]), "lbr_lookaheads": int(stats[1]), "range_board_equities": int(stats[2]),
                            "agent_actions": int(stats[3]), "device_ms": float(ms.value)}
         return out

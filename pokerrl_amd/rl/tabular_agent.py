@@ -1,0 +1,203 @@
+"""
+Tabular agents for the evaluators: the policy a CFR solver left in its PublicTree, served (a) to the host evaluators as an EvalAgent and (b) to the
+batched GPU evaluators (BatchedLBR / BatchedHead2Head, agent kind "table") as a table in HBM -- the same float32 numbers on both sides, so the batched
+engines stay bit-identical to LocalLBRWorker / LocalHead2HeadMaster playing the host agent. This is what the reference's evaluators get from
+EvalAgentBase.get_a_probs_for_each_hand / get_action (PokerRL/rl/base_cls/EvalAgentBase.py:35-62, used by eval/lbr/LocalLBRWorker.py:120-160,241-281 and
+eval/head_to_head/LocalHead2HeadMaster.py:100-118) when the agent is tabular.
+
+    cfr = CFRPlus(name, chief, game_cls=StandardLeduc, agent_bet_set=None); cfr.reset(); cfr.iterations(500)
+    table = PolicyTable.from_cfr(cfr)                                    # average strategy, float32 [row][action][hand]
+    BatchedLBR(t_prof, agent_kind="table", table=table).run(agent_seat_id=0, n_hands=1 << 20)
+    LocalLBRWorker(t_prof, chief_handle=None, eval_agent_cls=make_table_agent_cls(EvalAgentBase, table))   # the same hands on the host
+
+A row belongs to a NODE of the agent's public tree, not to a public state (two betting histories can meet in one state), so rows are addressed by a
+history key: key(root) = state_key(root state, seed), key(next) = state_key(next state, seed = key(now)) after every env step, with the new board
+cards on the table when the step ends a round (csrc/prl_lbr_batch.hip: lbrb_hist_step; two 32-bit chains make the 64-bit key). The chain runs over
+STATES, not action ids: LBR raising by a pot fraction of its own bet set reaches the agent's node whenever the agent's tree has a raise to the same
+amount. A history the table does not hold (LBR left the tree) plays uniformly over the legal actions, on both sides.
+"""
+import ctypes
+
+import numpy as np
+
+from pokerrl_amd import _native
+from pokerrl_amd.game.PublicTree import KIND_CHANCE, KIND_DECISION
+from pokerrl_amd.rl.hash_agent import make_agent_cls, state_key
+
+KEY_SEED = 0x7AB1E5
+KEY_SEED_HI_XOR = 0x5BD1E995  # LBRB_KEY_SEED_HI
+
+
+def hist_root(key_seed=KEY_SEED):
+    return int(key_seed) & 0xFFFFFFFF, (int(key_seed) ^ KEY_SEED_HI_XOR) & 0xFFFFFFFF
+
+
+def hist_step(hk, env):
+    """the history key after the env reached its present state (lbrb_hist_step)"""
+    return int(state_key(env, hk[0])), int(state_key(env, hk[1]))
+
+
+def _key64(hk):
+    return ((hk[1] << 32) | hk[0]) or 1
+
+
+def _first_slot(hk, mask):
+    return (hk[0] ^ ((hk[1] * 0x9E3779B1) & 0xFFFFFFFF)) & mask
+
+
+class PolicyTable:
+    """probs: float32 [n_rows][n_actions][range_size]; hist_keys: the (lo, hi) history key of every row"""
+
+    def __init__(self, hist_keys, probs, key_seed=KEY_SEED, node_keys=None):
+        self.probs = np.ascontiguousarray(probs, dtype=np.float32)
+        self.n_rows, self.n_actions, self.range_size = self.probs.shape
+        assert len(hist_keys) == self.n_rows
+        self.key_seed = int(key_seed)
+        self.node_keys = node_keys or {}  # tree node index -> history key (set_to_public_tree_node_state)
+        cap = 2
+        while cap < 2 * self.n_rows:
+            cap *= 2
+        self.capacity = cap
+        self.keys = np.zeros(cap, np.uint64)
+        self.rows = np.full(cap, -1, np.int32)
+        self._row_of = {}
+        for r, hk in enumerate(hist_keys):
+            k = _key64(hk)
+            assert k not in self._row_of, "two tree nodes share a 64-bit history key: build the table under another key_seed"
+            self._row_of[k] = r
+            i = _first_slot(hk, cap - 1)
+            while self.keys[i] != 0:
+                i = (i + 1) & (cap - 1)
+            self.keys[i], self.rows[i] = k, r
+        self._dev = None
+
+    # ---- building it from a public tree ----------------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_tree(cls, tree, columns=None, key_seed=KEY_SEED):
+        """one row per expanded decision node of `tree` (pokerrl_amd.game.PublicTree); columns: [n_cols, R] strategy columns in the tree's order
+        (column first_col[node] + j = P(j-th allowed action | hand)), default: the strategy the tree holds now"""
+        cols = np.asarray(tree.solver.get("strategy") if columns is None else columns)
+        kind, parent, first_col, n_children = tree._kind, tree._parent, tree._first_col, tree._n_children
+        n_actions = int(tree._env_bldr.N_ACTIONS)
+        env = tree._get_replay_env()
+        key_of, keys, rows = {}, [], []
+        for i in range(len(kind)):  # parents come before their children in the tree's node order
+            p = int(parent[i])
+            if kind[i] == KIND_CHANCE:
+                key_of[i] = key_of[p]  # the deal is part of the step that ended the round: the outcome's state carries the new board
+                continue
+            if kind[i] != KIND_DECISION:
+                continue
+            env.load_state_dict(tree.node(i).env_state, blank_private_info=True)
+            key_of[i] = hist_step(hist_root(key_seed) if p < 0 else key_of[p], env)
+            if n_children[i] == 0:
+                continue  # unexpanded node of a partial tree
+            pr = np.zeros((n_actions, cols.shape[1]), np.float32)
+            for j, a in enumerate(tree.node(i).allowed_actions):
+                pr[a] = cols[first_col[i] + j].astype(np.float32)
+            keys.append(key_of[i])
+            rows.append(pr)
+        return cls(keys, np.stack(rows), key_seed=key_seed, node_keys=key_of)
+
+    @classmethod
+    def from_cfr(cls, cfr, t_idx=0, key_seed=KEY_SEED):
+        """the AVERAGE strategy of a CFR instance's tree (what the reference evaluates, _CFRBase.py:218-262)"""
+        return cls.from_tree(cfr._trees[t_idx], columns=cfr.average_strategy(t_idx), key_seed=key_seed)
+
+    # ---- host lookups --------------------------------------------------------------------------------------------------------------------------------
+    def row_of(self, hk):
+        return self._row_of.get(_key64(hk), -1)
+
+    def policy(self, hk, legal):
+        """float32 [R, N_ACTIONS] at history `hk`; uniform over `legal` when the table does not hold it"""
+        r = self.row_of(hk)
+        if r >= 0:
+            return np.ascontiguousarray(self.probs[r].T)
+        p = np.zeros((self.range_size, self.n_actions), np.float32)
+        p[:, list(legal)] = np.float32(1.0 / len(legal))
+        return p
+
+    # ---- the device copy -------------------------------------------------------------------------------------------------------------------------
+    def device(self):
+        if self._dev is None:
+            L = _native.lib()
+            _native.require_device()
+            h = L.prl_policy_table_create(self.keys.ctypes.data_as(ctypes.c_void_p), self.rows.ctypes.data_as(ctypes.c_void_p), self.capacity,
+                                          self.probs.ctypes.data_as(ctypes.c_void_p), self.n_rows, self.n_actions, self.range_size, self.key_seed & 0xFFFFFFFF)
+            if not h:
+                raise _native.NativeError("prl_policy_table_create: " + L.prl_last_error().decode("utf-8", "replace"))
+            self._dev = (L, h)
+        return self._dev[1]
+
+    def close(self):
+        if self._dev is not None:
+            self._dev[0].prl_policy_table_destroy(self._dev[1])
+            self._dev = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_table_agent_cls(EvalAgentBase, table, seed=7, record=None):
+    """An EvalAgent that plays `table`: the host twin of agent kind "table" (action draws: the counter-based stream of the hash agent, rl/hash_agent.py)."""
+    Base = make_agent_cls(EvalAgentBase, seed=seed, record=record)
+
+    class TableAgent(Base):
+        ALL_MODES = ["TABLE", "HASH2"]  # head-to-head tests pit the table against the hash agent (seed + 1): one class, two modes
+        TABLE = table
+
+        def __init__(self, t_prof, mode=None, device=None):
+            super().__init__(t_prof=t_prof, mode=mode, device=device)
+            self._hk = hist_root(self.TABLE.key_seed)
+
+        def _advance(self):
+            self._hk = hist_step(self._hk, self._internal_env_wrapper.env)
+
+        def reset(self, deck_state_dict=None):
+            super().reset(deck_state_dict=deck_state_dict)
+            self._hk = hist_root(self.TABLE.key_seed)
+            self._advance()
+
+        def notify_of_reset(self):
+            super().notify_of_reset()
+            self._hk = hist_root(self.TABLE.key_seed)
+            self._advance()
+
+        def notify_of_action(self, p_id_acted, action_he_did):
+            super().notify_of_action(p_id_acted=p_id_acted, action_he_did=action_he_did)
+            self._advance()
+
+        def notify_of_processed_tuple_action(self, p_id_acted, action_he_did):
+            super().notify_of_processed_tuple_action(p_id_acted=p_id_acted, action_he_did=action_he_did)
+            self._advance()
+
+        def notify_of_raise_frac_action(self, p_id_acted, frac):
+            super().notify_of_raise_frac_action(p_id_acted=p_id_acted, frac=frac)
+            self._advance()
+
+        def set_to_public_tree_node_state(self, node):
+            super().set_to_public_tree_node_state(node=node)
+            self._hk = self.TABLE.node_keys[node._i]
+
+        def env_state_dict(self):
+            return {"env": super().env_state_dict(), "hk": self._hk}
+
+        def load_env_state_dict(self, state_dict):
+            super().load_env_state_dict(state_dict["env"])
+            self._hk = state_dict["hk"]
+
+        def get_a_probs_for_each_hand(self):
+            if self._mode == "HASH2":
+                return super().get_a_probs_for_each_hand()
+            return self.TABLE.policy(self._hk, self._internal_env_wrapper.env.get_legal_actions())
+
+        def get_action(self, step_env=True, need_probs=False):
+            out = super().get_action(step_env=step_env, need_probs=need_probs)
+            if step_env:
+                self._advance()
+            return out
+
+    return TableAgent

@@ -276,6 +276,116 @@ def test_gpu_batched_lbr_vs_reference(tag, tmp_path):
     check_batched_vs_golden(tag, tmp_path)
 
 
+# ---- tabular agents (agent kind "table": a CFR solver's average strategy in HBM) --------------------------------------------------------------------
+TABLE_CASES = {
+    "StandardLeduc": (StandardLeduc, None, dict(lbr_check_to_round=None), 12),
+    # LBR with the agent's own bet set: every hand stays in the agent's tree
+    "DiscretizedNLLeduc": (DiscretizedNLLeduc, bet_sets.POT_ONLY, dict(lbr_bet_set=bet_sets.POT_ONLY, lbr_check_to_round=None), 6),
+    # LBR with more bet sizes than the agent: raises outside the agent's tree meet the uniform fall-back, on both sides
+    "DiscretizedNLLeduc_off_tree": (DiscretizedNLLeduc, bet_sets.POT_ONLY, dict(lbr_bet_set=bet_sets.B_3, lbr_check_to_round=None), 6),
+}
+
+
+class _Chief:
+    def create_experiment(self, name):
+        return name
+
+    def add_scalar(self, *a):
+        pass
+
+
+def solved_table(game_cls, agent_bets, n_iters):
+    """CFR+ on the agent's game, its average strategy as a PolicyTable (and the tree it came from)"""
+    from pokerrl_amd.cfr.CFRPlus import CFRPlus
+    from pokerrl_amd.rl.tabular_agent import PolicyTable
+    cfr = CFRPlus(name="tab", chief_handle=_Chief(), game_cls=game_cls, agent_bet_set=agent_bets, delay=0)
+    cfr.reset()
+    for _ in range(n_iters):
+        cfr.iteration()
+    return PolicyTable.from_cfr(cfr), cfr
+
+
+def check_batched_table_vs_host(tag, tmp_path, n_hands):
+    """BatchedLBR against a tabular agent = the host LocalLBRWorker playing the same table as an EvalAgent, hand by hand (float32, bit for bit);
+    the table is the average strategy CFR+ left in the agent's public tree"""
+    from pokerrl_amd.rl.tabular_agent import make_table_agent_cls
+    game_cls, agent_bets, lbr_kwargs, n_iters = TABLE_CASES[tag]
+    table, cfr = solved_table(game_cls, agent_bets, n_iters)
+    # the table is the tree's average strategy, node by node: filling a tree from the agent gives the columns back
+    tree = cfr._trees[0]
+    t_prof = make_t_prof(game_cls, agent_bets, lbr_kwargs, n_hands, tmp_path)
+    agent_cls = make_table_agent_cls(EvalAgentBase, table, seed=7)
+    tree.fill_with_agent_policy(agent_cls(t_prof=t_prof, mode="TABLE"))
+    assert np.array_equal(tree.solver.get("strategy").astype(np.float32), cfr.average_strategy().astype(np.float32))
+    record = []
+    w = LocalLBRWorker(t_prof=t_prof, chief_handle=None, eval_agent_cls=make_table_agent_cls(EvalAgentBase, table, seed=7, record=record))
+    b = BatchedLBR(t_prof, agent_kind="table", agent_seed=7, table=table)
+    lut = game_cls.get_lut_holder()
+    n_off = 0
+    for seat in (0, 1):
+        np.random.seed(4242 + seat)
+        n0 = len(record)
+        agent = w.agent.cpu_agent
+        misses = []
+        lookup = agent.TABLE.row_of
+        agent.TABLE.row_of = lambda hk, _f=lookup: (misses.append(1) if _f(hk) < 0 else None, _f(hk))[1]
+        want = w.run(agent_seat_id=seat, n_iterations=n_hands, mode="TABLE", stack_size=[game_cls.DEFAULT_STACK_SIZE] * 2)
+        del agent.TABLE.row_of
+        n_off += len(misses)
+        decks = decks_from_record(record[n0:], lut, b.n_deal - 2 * b._rules.n_hole_cards)
+        got = b.run(agent_seat_id=seat, n_hands=n_hands, decks=decks)
+        assert np.array_equal(got, want), "%s seat %d: %d of %d hands differ (first at %s)" % (tag, seat, int(np.sum(got != want)), n_hands, np.flatnonzero(got != want)[:5])
+        assert b.last_stats["agent_actions"] > 0
+    assert (n_off > 0) == tag.endswith("off_tree"), n_off  # the off-tree case does leave the tree, the others never do
+    # a solved agent is not the uniform one: the table is in use (LBR wins less against it)
+    if not tag.endswith("off_tree"):
+        uni = BatchedLBR(t_prof, agent_kind="uniform").run(agent_seat_id=0, n_hands=n_hands, decks=decks)
+        assert not np.array_equal(uni, got)
+    table.close()
+
+
+@pytest.mark.parametrize("tag", ["StandardLeduc", "DiscretizedNLLeduc", "DiscretizedNLLeduc_off_tree"])
+def test_batched_lbr_table_agent_vs_host_worker_emu(emu_lib, tag, tmp_path):
+    check_batched_table_vs_host(tag, tmp_path, 60)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["StandardLeduc", "DiscretizedNLLeduc", "DiscretizedNLLeduc_off_tree"])
+def test_gpu_batched_lbr_table_agent_vs_host_worker(tag, tmp_path):
+    check_batched_table_vs_host(tag, tmp_path, 400)
+
+
+def check_batched_h2h_table_vs_host(tmp_path, n_hands):
+    """head-to-head: the solver's average strategy (mode "TABLE") against the hash agent (mode "HASH2") -- BatchedHead2Head with kinds ("table", "hash")
+    = the host LocalHead2HeadMaster with the two modes of the table agent class, hand by hand"""
+    from pokerrl_amd.eval.head_to_head import BatchedHead2Head, H2HArgs, LocalHead2HeadMaster
+    from pokerrl_amd.rl.tabular_agent import make_table_agent_cls
+    table, _cfr = solved_table(StandardLeduc, None, 10)
+    t_prof = TrainingProfileBase(
+        name="h2h_tab", log_verbose=False, log_export_freq=1, checkpoint_freq=10 ** 9, eval_agent_export_freq=10 ** 9, game_cls=StandardLeduc,
+        env_bldr_cls=HistoryEnvBuilder, start_chips=None, eval_modes_of_algo=("TABLE", "HASH2"), eval_stack_sizes=None,
+        module_args={"env": StandardLeduc.ARGS_CLS(n_seats=2), "h2h": H2HArgs(n_hands=n_hands)}, path_data=str(tmp_path))
+    record = []
+    m = LocalHead2HeadMaster(t_prof=t_prof, chief_handle=_Chief(), eval_agent_cls=make_table_agent_cls(EvalAgentBase, table, seed=11, record=record))
+    m.set_modes(["TABLE", "HASH2"])
+    np.random.seed(99)
+    want = m.play(stack_size=t_prof.eval_stack_sizes[0])
+    b = BatchedHead2Head(t_prof, kinds=("table", "hash"), seeds=(11, 12), tables=(table, None))
+    decks = decks_from_record(record[::2], StandardLeduc.get_lut_holder(), b.n_deal - 2 * b._rules.n_hole_cards)
+    got = b.play(n_hands=n_hands, decks=decks)
+    assert np.array_equal(got, want), "%d of %d hands differ (first at %s)" % (int(np.sum(got != want)), 2 * n_hands, np.flatnonzero(got != want)[:5])
+    table.close()
+
+
+def test_batched_h2h_table_agent_vs_host_master_emu(emu_lib, tmp_path):
+    check_batched_h2h_table_vs_host(tmp_path, 150)
+
+
+@pytest.mark.gpu
+def test_gpu_batched_h2h_table_agent_vs_host_master(tmp_path):
+    check_batched_h2h_table_vs_host(tmp_path, 2000)
+
+
 H2H_CASES = {"StandardLeduc": (StandardLeduc, None), "DiscretizedNLLeduc": (DiscretizedNLLeduc, bet_sets.B_3),
              "DiscretizedNLHoldem": (DiscretizedNLHoldem, bet_sets.B_5)}
 
