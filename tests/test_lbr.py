@@ -355,6 +355,25 @@ def test_gpu_batched_lbr_table_agent_vs_host_worker(tag, tmp_path):
     check_batched_table_vs_host(tag, tmp_path, 400)
 
 
+@pytest.mark.gpu
+def test_gpu_lbr_against_the_solvers_average_strategy_is_a_lower_bound_of_its_exploitability(tmp_path):
+    """the two evaluators on ONE tabular agent: LBR's winnings against the average strategy of CFR+ (policy table in HBM, 2^17 hands per seat) stay
+    below the exact best response the solver computes for the same strategy (LBR is a lower bound: Lisy & Bowling 2017), and both fall as CFR+ runs"""
+    game_cls, n = StandardLeduc, 1 << 17
+    t_prof = make_t_prof(game_cls, None, dict(lbr_check_to_round=None), n, tmp_path)
+    seen = []
+    for n_iters in (2, 300):
+        table, cfr = solved_table(game_cls, None, n_iters)
+        expl = cfr._scaled(0, cfr._trees[0].solver.eval_avg())
+        b = BatchedLBR(t_prof, agent_kind="table", agent_seed=7, table=table)
+        w = np.concatenate([b.run(agent_seat_id=s, n_hands=n, deck_seed=5, first_hand=s * n, episode_base=s * n) for s in (0, 1)]).astype(np.float64)
+        half = 1.96 * w.std() / np.sqrt(w.size)
+        assert w.mean() - half <= expl, (n_iters, w.mean(), half, expl)
+        seen.append((expl, w.mean(), half))
+        table.close()
+    assert seen[1][0] < 0.2 * seen[0][0] and seen[1][1] + seen[1][2] < seen[0][1] - seen[0][2], seen  # exploitability and LBR winnings both fell
+
+
 def check_batched_h2h_table_vs_host(tmp_path, n_hands):
     """head-to-head: the solver's average strategy (mode "TABLE") against the hash agent (mode "HASH2") -- BatchedHead2Head with kinds ("table", "hash")
     = the host LocalHead2HeadMaster with the two modes of the table agent class, hand by hand"""
