@@ -490,6 +490,10 @@ typedef struct PrlPolicyTable prl_policy_table_t;
 prl_policy_table_t* prl_policy_table_create(const uint64_t* keys, const int32_t* rows, uint32_t capacity, const float* probs, int32_t n_rows,
                                             int32_t n_actions, int32_t range_size, uint32_t key_seed);
 void prl_policy_table_destroy(prl_policy_table_t* table);
+/* n look-ups on the device (host arrays in and out): out_row[i] = the row of history key (key_lo[i], key_hi[i]) or -1, out_prob[i] = P(action[i] | hand[i])
+ * of that row (0 without one) -- what the batched engines read, so that a table can be verified where it lives. */
+int32_t prl_policy_table_probe(const prl_policy_table_t* table, int32_t n, const uint32_t* key_lo, const uint32_t* key_hi, const int32_t* action,
+                               const int32_t* hand, int32_t* out_row, float* out_prob);
 
 /* prl_lbr_batch_run against a tabular agent: `table` is the agent's policy; agent_seed drives its action draws as for the synthetic agents. */
 int32_t prl_lbr_batch_run_table(const PrlGame* lbr_game, const PrlGame* agent_game, const PrlRules* rules, int32_t n_envs, int32_t agent_seat,

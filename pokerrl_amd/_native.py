@@ -176,6 +176,8 @@ def _bind_solver(L):
     L.prl_policy_table_create.restype = vp
     L.prl_policy_table_destroy.argtypes = [vp]
     L.prl_policy_table_destroy.restype = None
+    L.prl_policy_table_probe.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+    L.prl_policy_table_probe.restype = i32
     L.prl_lbr_batch_run_table.argtypes = [ctypes.POINTER(PrlGame), ctypes.POINTER(PrlGame), ctypes.POINTER(PrlRules), i32, i32, i32, vp,
                                           ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.prl_lbr_batch_run_table.restype = i32

@@ -1058,6 +1058,40 @@ extern "C" void prl_policy_table_destroy(PrlPolicyTable* T) {
     delete T;
 }
 
+// n look-ups on the device, one lane each: the row of the history key (lo[i], hi[i]) and, where it exists, P(action[i] | hand[i]) of that row --
+// what the batched engines read, exposed so that a table can be verified where it lives (tests; -1 / 0 for a key the table does not hold)
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_policy_table_probe(PrlPolicyTable T, int n, const uint32_t* lo, const uint32_t* hi, const int32_t* action, const int32_t* hand,
+                                                               int32_t* out_row, float* out_prob) {
+    const int i = (int)(prl_bid() * prl_nthreads() + prl_tid());
+    if (i >= n) return;
+    const int row = lbrb_table_row(T, LbrbHistKey{lo[i], hi[i]});
+    out_row[i] = row;
+    out_prob[i] = row >= 0 ? T.probs[((size_t)row * T.n_actions + action[i]) * T.range_size + hand[i]] : 0.f;
+}
+
+extern "C" int32_t prl_policy_table_probe(const PrlPolicyTable* T, int32_t n, const uint32_t* key_lo, const uint32_t* key_hi, const int32_t* action, const int32_t* hand,
+                                          int32_t* out_row, float* out_prob) {
+    if (!T || n <= 0 || !key_lo || !key_hi || !action || !hand || !out_row || !out_prob) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    for (int i = 0; i < n; ++i)
+        if (action[i] < 0 || action[i] >= T->n_actions || hand[i] < 0 || hand[i] >= T->range_size) { prl_set_error("prl_policy_table_probe: action / hand out of range"); return PRL_ERR_ARG; }
+    void* d = nullptr;
+    const size_t n4 = (size_t)n * 4;
+    if (hipMalloc(&d, 6 * n4) != hipSuccess) { (void)hipGetLastError(); prl_set_error("prl_policy_table_probe: hipMalloc failed"); return PRL_ERR_HIP; }
+    char* b = (char*)d;
+    int rc = PRL_OK;
+    if (hipMemcpy(b, key_lo, n4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(b + n4, key_hi, n4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(b + 2 * n4, action, n4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(b + 3 * n4, hand, n4, hipMemcpyHostToDevice) != hipSuccess) rc = PRL_ERR_HIP;
+    if (rc == PRL_OK) {
+        PRL_LAUNCH(prl_k_policy_table_probe, (n + 255) / 256, 256, 0, nullptr, *T, (int)n, (const uint32_t*)b, (const uint32_t*)(b + n4), (const int32_t*)(b + 2 * n4),
+                   (const int32_t*)(b + 3 * n4), (int32_t*)(b + 4 * n4), (float*)(b + 5 * n4));
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out_row, b + 4 * n4, n4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(out_prob, b + 5 * n4, n4, hipMemcpyDeviceToHost) != hipSuccess) rc = PRL_ERR_HIP;
+    }
+    (void)hipFree(d);
+    if (rc != PRL_OK) prl_set_error("HIP error in prl_policy_table_probe");
+    return rc;
+}
+
 static int lbrb_check_table(int kind, const PrlPolicyTable* T, const PrlGame* agent_game, const PrlRules* rules, const char* who) {
     if (kind != 2) return PRL_OK;
     if (!T) { prl_set_error(std::string(who) + ": agent kind 2 needs a policy table"); return PRL_ERR_ARG; }

@@ -129,6 +129,18 @@ class PolicyTable:
             self._dev = (L, h)
         return self._dev[1]
 
+    def probe(self, hist_keys, actions, hands):
+        """(rows, probs) of n look-ups done ON THE DEVICE: what the batched engines read for history key i, action i, hand i"""
+        n = len(hist_keys)
+        lo = np.ascontiguousarray([k[0] for k in hist_keys], np.uint32)
+        hi = np.ascontiguousarray([k[1] for k in hist_keys], np.uint32)
+        a, h = np.ascontiguousarray(actions, np.int32), np.ascontiguousarray(hands, np.int32)
+        rows, probs = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        dev = self.device()
+        L = self._dev[0]
+        _native.check(L.prl_policy_table_probe(dev, n, *(x.ctypes.data_as(ctypes.c_void_p) for x in (lo, hi, a, h, rows, probs))), L)
+        return rows, probs
+
     def close(self):
         if self._dev is not None:
             self._dev[0].prl_policy_table_destroy(self._dev[1])

@@ -305,6 +305,22 @@ def solved_table(game_cls, agent_bets, n_iters):
     return PolicyTable.from_cfr(cfr), cfr
 
 
+def check_table_on_device(table):
+    """the table where it lives: every node's history key finds its row through the device's open-addressed look-up and the device reads the host's
+    float32 probabilities; keys the table does not hold miss"""
+    rng = np.random.RandomState(3)
+    keys = [hk for hk in table.node_keys.values() if table.row_of(hk) >= 0]
+    keys = [keys[i] for i in rng.permutation(len(keys))[:512]]
+    a, h = rng.randint(0, table.n_actions, len(keys)), rng.randint(0, table.range_size, len(keys))
+    rows, probs = table.probe(keys, a, h)
+    want_rows = np.array([table.row_of(k) for k in keys])
+    assert np.array_equal(rows, want_rows), (rows[:8], want_rows[:8])
+    assert np.array_equal(probs, table.probs[want_rows, a, h])
+    strangers = [(k[0] ^ 0x55, k[1]) for k in keys[:64]]
+    rows, probs = table.probe(strangers, a[:64], h[:64])
+    assert np.all(rows == -1) and np.all(probs == 0)
+
+
 def check_batched_table_vs_host(tag, tmp_path, n_hands):
     """BatchedLBR against a tabular agent = the host LocalLBRWorker playing the same table as an EvalAgent, hand by hand (float32, bit for bit);
     the table is the average strategy CFR+ left in the agent's public tree"""
@@ -317,6 +333,7 @@ def check_batched_table_vs_host(tag, tmp_path, n_hands):
     agent_cls = make_table_agent_cls(EvalAgentBase, table, seed=7)
     tree.fill_with_agent_policy(agent_cls(t_prof=t_prof, mode="TABLE"))
     assert np.array_equal(tree.solver.get("strategy").astype(np.float32), cfr.average_strategy().astype(np.float32))
+    check_table_on_device(table)
     record = []
     w = LocalLBRWorker(t_prof=t_prof, chief_handle=None, eval_agent_cls=make_table_agent_cls(EvalAgentBase, table, seed=7, record=record))
     b = BatchedLBR(t_prof, agent_kind="table", agent_seed=7, table=table)
