@@ -2,7 +2,12 @@
 # round 5 evidence: smoke, every bench line, rocprofv3 kernel statistics of the headline / best-response / whole-game runs, PMC traffic (FETCH_SIZE,
 # WRITE_SIZE: one counter per run, --kernel-trace only) and the two SQ groups of the headline and the best-response pass.
 #   gpurun -- bash scripts/gpu_r5_final.sh TAG
+#   NO_PMC=1: skip the counter passes (kernel statistics only); PYTEST_K="expr": run those GPU tests first
 cd $GRAFT_REPO_ROOT; TAG=${1:-r50}; mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT
+if [ -n "$PYTEST_K" ]; then
+  timeout 900 python -m pytest tests -m gpu -q -k "$PYTEST_K" -p no:cacheprovider --durations=5 > gpurun_out/${TAG}_gpu_tests_selected.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_gpu_tests_selected.txt
+  tail -8 gpurun_out/${TAG}_gpu_tests_selected.txt
+fi
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee gpurun_out/${TAG}_smoke.txt
 timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --variant linear --no-cpu-baseline > gpurun_out/${TAG}_bench_linear.json 2>> gpurun_out/${TAG}_bench.err
@@ -34,6 +39,7 @@ for nv in "bench=$B" "br=$BR" "whole_game=$WG"; do
   head -7 $R/gpurun_out/${TAG}_${n}_kernel_stats.txt | cut -c1-170
   rm -rf $R/gpurun_out/${TAG}_prof_$n
 done
+if [ -n "$NO_PMC" ]; then exit 0; fi
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"
 SQ2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU"
 for nv in "bench=$B" "br=$BR"; do
