@@ -13,6 +13,18 @@ timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_
 timeout 600 python bench.py --variant linear --no-cpu-baseline > gpurun_out/${TAG}_bench_linear.json 2>> gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --avg-f32 --no-cpu-baseline > gpurun_out/${TAG}_bench_avg_f32.json 2>> gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --whole-game --no-cpu-baseline > gpurun_out/${TAG}_bench_whole_game.json 2>> gpurun_out/${TAG}_bench.err
+pushd /tmp > /dev/null; export TMPDIR=/tmp
+B="python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-placement-probe --fixed-check-boards 0"
+BR="python $R/bench_br.py --steps 4 --warmup 1 --no-cpu-baseline"
+WG="python $R/bench.py --whole-game --steps 4 --warmup 1 --no-cpu-baseline --fixed-check-boards 0"
+for nv in "bench=$B" "br=$BR" "whole_game=$WG"; do
+  n=${nv%%=*}; c=${nv#*=}
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_$n -o p -- $c > $R/gpurun_out/${TAG}_prof_$n.log 2>&1
+  { echo "# rocprofv3 --kernel-trace --stats -- $c   (MI355X, checkpoint $TAG)" | sed "s#$R/##g"; python $R/scripts/rocprof_summary.py $(find $R/gpurun_out/${TAG}_prof_$n -name "*.db" | head -1); } > $R/gpurun_out/${TAG}_${n}_kernel_stats.txt 2>&1
+  head -7 $R/gpurun_out/${TAG}_${n}_kernel_stats.txt | cut -c1-170
+  rm -rf $R/gpurun_out/${TAG}_prof_$n
+done
+popd > /dev/null
 timeout 600 python bench.py --whole-game --variant linear --no-cpu-baseline > gpurun_out/${TAG}_bench_whole_game_linear.json 2>> gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --whole-game --avg-f32 --no-cpu-baseline > gpurun_out/${TAG}_bench_whole_game_avg_f32.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python bench_multistreet.py --avg-f32 --no-cpu-baseline > gpurun_out/${TAG}_bench_multistreet_avg_f32.json 2>> gpurun_out/${TAG}_bench.err
@@ -29,16 +41,6 @@ try:
     d=json.loads(open('gpurun_out/${TAG}_$f.json').read().strip().splitlines()[-1]); print('$f', '%.5g' % d['value'], d.get('unit'), 'ms/step %.4g' % d['ms_per_step'], 'frac', (d.get('roofline') or {}).get('frac'), 'with-eval', (d.get('roofline_with_avg_evaluation') or {}).get('frac'))
 except Exception as e: print('$f', 'FAILED', e)"; done
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-placement-probe --fixed-check-boards 0"
-BR="python $R/bench_br.py --steps 4 --warmup 1 --no-cpu-baseline"
-WG="python $R/bench.py --whole-game --steps 4 --warmup 1 --no-cpu-baseline --fixed-check-boards 0"
-for nv in "bench=$B" "br=$BR" "whole_game=$WG"; do
-  n=${nv%%=*}; c=${nv#*=}
-  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_$n -o p -- $c > $R/gpurun_out/${TAG}_prof_$n.log 2>&1
-  { echo "# rocprofv3 --kernel-trace --stats -- $c   (MI355X, checkpoint $TAG)" | sed "s#$R/##g"; python $R/scripts/rocprof_summary.py $(find $R/gpurun_out/${TAG}_prof_$n -name "*.db" | head -1); } > $R/gpurun_out/${TAG}_${n}_kernel_stats.txt 2>&1
-  head -7 $R/gpurun_out/${TAG}_${n}_kernel_stats.txt | cut -c1-170
-  rm -rf $R/gpurun_out/${TAG}_prof_$n
-done
 if [ -n "$NO_PMC" ]; then exit 0; fi
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"
 SQ2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU"
