@@ -13,6 +13,8 @@ import ctypes
 import numpy as np
 
 from pokerrl_amd import _native
+from pokerrl_amd.eval._.EvaluatorMasterBase import EvaluatorMasterBase
+from pokerrl_amd.eval.head_to_head.LocalHead2HeadMaster import LocalHead2HeadMaster
 from pokerrl_amd.eval.lbr.BatchedLBR import AGENT_KINDS, deal_decks
 from pokerrl_amd.rl import rl_util
 
@@ -63,11 +65,62 @@ class BatchedHead2Head:
         self.last_stats = {"env_steps": int(stats[0]), "showdowns": int(stats[1]), "device_ms": float(ms.value)}
         return out
 
-    def play(self, n_hands, decks=None, deck_seed=0):
+    def play(self, n_hands, decks=None, deck_seed=0, first_hand=0):
         """LocalHead2HeadMaster.play's layout: [2 * n_hands], seat 0 block then seat 1 block; episodes are numbered through both
-        blocks like the host evaluator's agents count them. decks: [2 * n_hands, n_deal] or None."""
+        blocks like the host evaluator's agents count them. decks: [2 * n_hands, n_deal] or None (counter-based decks from hand `first_hand` on)."""
         halves = []
         for ref_seat in range(2):
             d = None if decks is None else decks[ref_seat * n_hands:(ref_seat + 1) * n_hands]
-            halves.append(self.run(ref_seat, n_hands, decks=d, deck_seed=deck_seed, episode_base=ref_seat * n_hands, first_hand=ref_seat * n_hands))
+            at = first_hand + ref_seat * n_hands
+            halves.append(self.run(ref_seat, n_hands, decks=d, deck_seed=deck_seed, episode_base=at, first_hand=at))
         return np.concatenate(halves)
+
+
+class _BatchedSide:
+    """one player of BatchedHead2HeadMaster: what LocalHead2HeadMaster asks of an EvalAgent, for an agent that lives in the kernel"""
+
+    def __init__(self, kind, seed, table):
+        self.kind, self.seed, self.table, self._mode = kind, int(seed), table, None
+
+    def set_mode(self, mode):
+        self._mode = mode
+
+    def get_mode(self):
+        return self._mode
+
+    def set_stack_size(self, stack_size):
+        pass  # the master hands the stack size to play()
+
+    def can_compute_mode(self):
+        return self.kind != "table" or self.table is not None
+
+    def update_weights(self, w):
+        """w: None (keep), a PolicyTable (this side plays it), or a dict mode -> PolicyTable (each side picks its mode's, like the reference's agents)"""
+        if isinstance(w, dict):
+            w = w.get(self._mode)
+        if w is not None:
+            self.kind, self.table = "table", w
+
+
+class BatchedHead2HeadMaster(LocalHead2HeadMaster):
+    """LocalHead2HeadMaster (PokerRL/eval/head_to_head/LocalHead2HeadMaster.py:10-135: set_modes / update_weights / evaluate(iter_nr), mean +- 95 %
+    confidence under the reference's experiment names) with the hands played by BatchedHead2Head: tabular policies in HBM (what update_weights pulls
+    from the chief: a PolicyTable per mode) or the synthetic agents. Counter-based decks; every evaluation continues the hand numbering."""
+
+    def __init__(self, t_prof, chief_handle, kinds=("table", "table"), seeds=(11, 12), tables=(None, None), deck_seed=0):
+        bldr = rl_util.get_env_builder(t_prof=t_prof)
+        assert bldr.N_SEATS == 2, "Only HU supported!"
+        EvaluatorMasterBase.__init__(self, t_prof=t_prof, eval_env_bldr=bldr, chief_handle=chief_handle, eval_type="Head2Head_Winnings", log_conf_interval=True)
+        self._args = t_prof.module_args["h2h"]
+        self._env_bldr = bldr
+        self._eval_agents = [_BatchedSide(k, s, t) for k, s, t in zip(kinds, seeds, tables)]
+        self._REFERENCE_AGENT = 0
+        self.deck_seed, self._next_hand = int(deck_seed), 0
+
+    def play(self, stack_size):
+        a = self._eval_agents
+        b = BatchedHead2Head(self._t_prof, kinds=(a[0].kind, a[1].kind), seeds=(a[0].seed, a[1].seed), tables=(a[0].table, a[1].table))
+        b.set_stack_size(stack_size)
+        w = b.play(self._args.n_hands, deck_seed=self.deck_seed, first_hand=self._next_hand)
+        self._next_hand += 2 * self._args.n_hands
+        return w

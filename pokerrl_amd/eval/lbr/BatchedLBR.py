@@ -117,3 +117,38 @@ class BatchedLBR:
         mean = tot / cnt
         sd = np.sqrt(max(sq / cnt - mean * mean, 0.0))
         return mean, 1.96 * sd / np.sqrt(cnt), int(cnt), x
+
+
+class BatchedLBRWorker:
+    """LocalLBRWorker's interface (`run(agent_seat_id, n_iterations, mode, stack_size)`, `update_weights`; PokerRL/eval/lbr/LocalLBRWorker.py:27-59) on
+    the batched engine, so that LocalLBRMaster (LocalLBRMaster.py:36-69: per mode / stack size / seat it concatenates its workers' scores and logs mean and
+    95 % confidence under the reference's experiment names) drives the GPU evaluation unchanged:
+
+        master = LocalLBRMaster(t_prof, chief); master.set_worker_handles(BatchedLBRWorker(t_prof, table=PolicyTable.from_cfr(cfr)))
+        master.update_weights(); master.evaluate(iter_nr)
+
+    The agent is a tabular one (what `update_weights` receives from the chief's `pull_current_eval_strategy` -- a PolicyTable, or None to keep the
+    present one) or one of the synthetic kinds. Decks are counter-based (deck_seed, hand number): every `run` continues the hand numbering, so
+    successive evaluations -- and several workers given disjoint `first_hand` -- play fresh, reproducible hands."""
+
+    def __init__(self, t_prof, chief_handle=None, agent_kind="table", agent_seed=7, table=None, deck_seed=0, first_hand=0):
+        self.t_prof = t_prof
+        self.chief_handle = chief_handle
+        self._kind, self._seed = agent_kind, int(agent_seed)
+        self._lbr = None if (agent_kind == "table" and table is None) else BatchedLBR(t_prof, agent_kind=agent_kind, agent_seed=agent_seed, table=table)
+        self.deck_seed, self._next_hand = int(deck_seed), int(first_hand)
+
+    def update_weights(self, weights_for_eval_agent):
+        if weights_for_eval_agent is None:
+            return
+        assert self._kind == "table", "only the tabular agent has weights"
+        self._lbr = BatchedLBR(self.t_prof, agent_kind="table", agent_seed=self._seed, table=weights_for_eval_agent)
+
+    def run(self, agent_seat_id, n_iterations, mode, stack_size):
+        """float32 [n_iterations] per-hand winnings of LBR; None when there is no table yet (the reference's worker returns None for a mode its agent cannot play)"""
+        if self._lbr is None:
+            return None
+        self._lbr.set_stack_size(stack_size)
+        w = self._lbr.run(agent_seat_id, int(n_iterations), deck_seed=self.deck_seed, first_hand=self._next_hand, episode_base=self._next_hand)
+        self._next_hand += int(n_iterations)
+        return w

@@ -391,6 +391,50 @@ def test_gpu_lbr_against_the_solvers_average_strategy_is_a_lower_bound_of_its_ex
     assert seen[1][0] < 0.2 * seen[0][0] and seen[1][1] + seen[1][2] < seen[0][1] - seen[0][2], seen  # exploitability and LBR winnings both fell
 
 
+def check_master_drives_batched_worker(tmp_path, n_hands):
+    """LocalLBRMaster with a BatchedLBRWorker: the chief hands the solver's table over through update_weights, the master logs mean and confidence of
+    exactly the hands BatchedLBR plays for those deck / episode numbers"""
+    from pokerrl_amd.eval.lbr import BatchedLBRWorker
+    game_cls = StandardLeduc
+    table, _cfr = solved_table(game_cls, None, 8)
+    t_prof = make_t_prof(game_cls, None, dict(lbr_check_to_round=None), n_hands, tmp_path)
+
+    class Chief(ChiefBase):
+        def pull_current_eval_strategy(self, last):
+            return table, last
+
+    chief = Chief(t_prof)
+    m = LocalLBRMaster(t_prof=t_prof, chief_handle=chief)
+    worker = BatchedLBRWorker(t_prof, chief_handle=chief, deck_seed=3)
+    assert worker.run(0, 4, "HASH", [game_cls.DEFAULT_STACK_SIZE] * 2) is None  # no table yet
+    m.set_worker_handles(worker)
+    m.update_weights()
+    m.evaluate(iter_nr=0)
+    vals, _ = chief.get_new_values()
+    total = [g for n, g in vals.items() if n.endswith("LBR Total")]
+    assert len(total) == 1
+    logged = list(total[0].values())[0][-1][1]
+    b = BatchedLBR(t_prof, agent_kind="table", agent_seed=7, table=table)
+    n = int(t_prof.module_args["lbr"].n_lbr_hands / t_prof.module_args["lbr"].n_workers)
+    want = np.concatenate([b.run(s, n, deck_seed=3, first_hand=s * n, episode_base=s * n) for s in (0, 1)])
+    assert logged == float(np.mean(want)), (logged, float(np.mean(want)))
+    m.evaluate(iter_nr=1)  # the next evaluation plays the next hands
+    vals, _ = chief.get_new_values()
+    logged2 = [list(g.values())[0][-1][1] for nme, g in vals.items() if nme.endswith("LBR Total")][0]
+    want2 = np.concatenate([b.run(s, n, deck_seed=3, first_hand=(2 + s) * n, episode_base=(2 + s) * n) for s in (0, 1)])
+    assert logged2 == float(np.mean(want2)) and logged2 != logged
+    table.close()
+
+
+def test_lbr_master_drives_the_batched_worker_emu(emu_lib, tmp_path):
+    check_master_drives_batched_worker(tmp_path, 40)
+
+
+@pytest.mark.gpu
+def test_gpu_lbr_master_drives_the_batched_worker(tmp_path):
+    check_master_drives_batched_worker(tmp_path, 4096)
+
+
 def check_batched_h2h_table_vs_host(tmp_path, n_hands):
     """head-to-head: the solver's average strategy (mode "TABLE") against the hash agent (mode "HASH2") -- BatchedHead2Head with kinds ("table", "hash")
     = the host LocalHead2HeadMaster with the two modes of the table agent class, hand by hand"""
@@ -411,6 +455,49 @@ def check_batched_h2h_table_vs_host(tmp_path, n_hands):
     got = b.play(n_hands=n_hands, decks=decks)
     assert np.array_equal(got, want), "%d of %d hands differ (first at %s)" % (int(np.sum(got != want)), 2 * n_hands, np.flatnonzero(got != want)[:5])
     table.close()
+
+
+def check_h2h_master_on_the_batched_engine(tmp_path, n_hands):
+    """BatchedHead2HeadMaster: the reference's master protocol (set_modes / update_weights / evaluate) with the hands on the GPU; the chief hands a table
+    per mode over; the logged mean is the mean of the hands BatchedHead2Head plays for those deck numbers, the next evaluation plays the next hands"""
+    from pokerrl_amd.eval.head_to_head import BatchedHead2Head, BatchedHead2HeadMaster, H2HArgs
+    table_a, _ = solved_table(StandardLeduc, None, 10)
+    table_b, _ = solved_table(StandardLeduc, None, 2)
+    t_prof = TrainingProfileBase(
+        name="h2h_m", log_verbose=False, log_export_freq=1, checkpoint_freq=10 ** 9, eval_agent_export_freq=10 ** 9, game_cls=StandardLeduc,
+        env_bldr_cls=HistoryEnvBuilder, start_chips=None, eval_modes_of_algo=("A", "B"), eval_stack_sizes=None,
+        module_args={"env": StandardLeduc.ARGS_CLS(n_seats=2), "h2h": H2HArgs(n_hands=n_hands)}, path_data=str(tmp_path))
+
+    class Chief(ChiefBase):
+        def pull_current_eval_strategy(self, last):
+            return {"A": table_a, "B": table_b}, last
+
+    chief = Chief(t_prof)
+    m = BatchedHead2HeadMaster(t_prof=t_prof, chief_handle=chief, deck_seed=21)
+    m.set_modes(["A", "B"])
+    m.evaluate(iter_nr=0)  # no tables yet: nothing can be played, nothing is logged
+    assert not any(n.endswith("Head2Head_Winnings Total") and list(g.values())[0] for n, g in chief.get_new_values()[0].items())
+    m.update_weights()
+    b = BatchedHead2Head(t_prof, kinds=("table", "table"), seeds=(11, 12), tables=(table_a, table_b))
+    for it in range(2):
+        m.evaluate(iter_nr=it + 1)
+        vals, _ = chief.get_new_values()
+        logged = [list(g.values())[0][-1][1] for n, g in vals.items() if n.endswith("Head2Head_Winnings Total") and n.startswith("h2h_m A")]
+        want = b.play(n_hands, deck_seed=21, first_hand=it * 2 * n_hands)
+        assert logged == [float(np.mean(want))], (logged, float(np.mean(want)))
+    # ten CFR+ iterations beat two (mean over many hands; the emulator run is too short to assert the sign)
+    if n_hands >= 1 << 15:
+        assert float(np.mean(want)) > 0
+    table_a.close(), table_b.close()
+
+
+def test_h2h_master_on_the_batched_engine_emu(emu_lib, tmp_path):
+    check_h2h_master_on_the_batched_engine(tmp_path, 100)
+
+
+@pytest.mark.gpu
+def test_gpu_h2h_master_on_the_batched_engine(tmp_path):
+    check_h2h_master_on_the_batched_engine(tmp_path, 1 << 16)
 
 
 def test_batched_h2h_table_agent_vs_host_master_emu(emu_lib, tmp_path):
