@@ -581,3 +581,26 @@ def test_board_classes_and_the_default_board_choice():
         board_enum.default_boards_or_classes(G.Flop5Holdem, n_boards=100, suit_isomorphism=True)
     cls = board_enum.hand_suit_classes(G.Flop5Holdem)
     assert cls.shape == (1326,) and int(cls.max()) == 168 and sorted(np.bincount(np.bincount(cls)).nonzero()[0].tolist()) == [4, 6, 12]
+
+
+def test_policy_table_host_logic():
+    """pokerrl_amd.rl.tabular_agent.PolicyTable without a device: the open-addressed key table holds every row where the device's probe sequence finds it,
+    unknown histories fall back to uniform play over the legal actions, two rows under one key are refused"""
+    from pokerrl_amd.rl.tabular_agent import PolicyTable, _first_slot, _key64
+    rng = np.random.RandomState(0)
+    keys = [(int(a), int(b)) for a, b in rng.randint(0, 2 ** 32, size=(300, 2), dtype=np.uint64)]
+    keys[5] = (0, 0)  # the all-zero key is stored as 1 (0 marks an empty slot)
+    probs = rng.random_sample((300, 4, 6)).astype(np.float32)
+    t = PolicyTable(keys, probs)
+    assert t.capacity == 1024 and (t.keys != 0).sum() == 300
+    for r, hk in enumerate(keys):
+        i = _first_slot(hk, t.capacity - 1)
+        while t.keys[i] != _key64(hk):  # the device's probe: linear from the first slot, never across an empty one
+            assert t.keys[i] != 0
+            i = (i + 1) & (t.capacity - 1)
+        assert t.rows[i] == r and t.row_of(hk) == r
+        assert np.array_equal(t.policy(hk, [0, 1]), probs[r].T)
+    p = t.policy((123, 456), [1, 3])
+    assert t.row_of((123, 456)) == -1 and np.array_equal(p[:, [1, 3]], np.full((6, 2), np.float32(0.5))) and not p[:, [0, 2]].any()
+    with pytest.raises(AssertionError):
+        PolicyTable([(1, 2), (1, 2)], probs[:2])
