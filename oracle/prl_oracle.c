@@ -596,12 +596,33 @@ static void update_reach(Orc* o, int node) {
 }
 
 /* ValueFiller.compute_cf_values_heads_up (ValueFiller.py:21-101) */
+/* suit isomorphism: a hand's value at the chance node = the mean over its suit orbit (the hands of its class, ascending hand index, running adds; one
+ * correctly rounded division) of the multiplicity-weighted sum of the board values */
+static void symmetrize_node(Orc* o, int node) {
+    const int R = o->R;
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)R);
+    for (int p = 0; p < 2; ++p)
+        for (int which = 0; which < 2; ++which) {
+            float* v = (which ? o->ev_br : o->ev) + ((size_t)node * 2 + p) * R;
+            for (int h = 0; h < R; ++h) {
+                float sum = 0.f;
+                int n = 0;
+                for (int g = 0; g < R; ++g)
+                    if (o->sym_class[g] == o->sym_class[h]) { sum = n == 0 ? v[g] : sum + v[g]; ++n; }
+                tmp[h] = sum / (float)n;
+            }
+            memcpy(v, tmp, sizeof(float) * (size_t)R);
+        }
+    free(tmp);
+}
+
 static void compute_ev(Orc* o, int node) {
     const int R = o->R;
     const int A = o->n_children[node];
     if (o->ov_ev && node == o->ov_node) {
         memcpy(V2(o, ev, node, 0), o->ov_ev, sizeof(float) * 2 * (size_t)R);
         memcpy(V2(o, ev_br, node, 0), o->ov_ev_br, sizeof(float) * 2 * (size_t)R);
+        if (o->kind[node] == K_CHANCE && o->sym_class) symmetrize_node(o, node);  /* the override is the weighted SUM of a chunked run (make_fhp_golden_chunked.py) */
         return;
     }
     if (o->kind[node] >= K_FOLD) { terminal_values(o, node); return; }
@@ -635,24 +656,7 @@ static void compute_ev(Orc* o, int node) {
                     }
                     arr[((size_t)node * 2 + p) * R + h] = total;
                 }
-        if (o->sym_class) {
-            /* suit isomorphism: a hand's value = the mean over its suit orbit (the hands of its class, ascending hand index, running adds; one
-             * correctly rounded division) of the multiplicity-weighted sum above */
-            float* tmp = (float*)malloc(sizeof(float) * (size_t)R);
-            for (int p = 0; p < 2; ++p)
-                for (int which = 0; which < 2; ++which) {
-                    float* v = (which ? o->ev_br : o->ev) + ((size_t)node * 2 + p) * R;
-                    for (int h = 0; h < R; ++h) {
-                        float sum = 0.f;
-                        int n = 0;
-                        for (int g = 0; g < R; ++g)
-                            if (o->sym_class[g] == o->sym_class[h]) { sum = n == 0 ? v[g] : sum + v[g]; ++n; }
-                        tmp[h] = sum / (float)n;
-                    }
-                    memcpy(v, tmp, sizeof(float) * (size_t)R);
-                }
-            free(tmp);
-        }
+        if (o->sym_class) symmetrize_node(o, node);
         return;
     }
     const int pl = o->actor[node], op = 1 - pl;

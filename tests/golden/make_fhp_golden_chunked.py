@@ -4,6 +4,8 @@ bench.py's default size: ~290 GB of oracle state in one piece): the boards are e
 instance whose chance node takes the canonical sum of all chunks' board values from outside (oracle: orc_set_override).
 
     python tests/golden/make_fhp_golden_chunked.py [n_boards] [n_iters] [chunk] [workdir] [plus|linear|vanilla]      (delay 0)
+    python tests/golden/make_fhp_golden_chunked.py --whole-game [n_iters] [chunk] [workdir]    the WHOLE Flop5Holdem game through its 134 459 suit classes
+        (prl_solver_create_weighted: multiplicities in the chance weights, orbit-mean chance values), CFR+ -> tests/golden/fhp_whole_game_plus_chunked.npz
 
 Per half-iteration of _CFRBase.iteration (_CFRBase.py:122-134) -- EVs, regrets + strategy of seat p, reach, average of seat p --:
   every chunk instance: trunk strategy from the trunk instance, its own boards' state from disk; update_reach; compute_ev (the board values
@@ -48,10 +50,21 @@ def make(boards, chance_prob=None):
 
 
 def group_sums(vals):
-    """[n_boards][4][R] float32 (ev seat 0 / 1, ev_br seat 0 / 1 of the board roots) -> [n_boards / 1024][4][R]: running adds over blocks of 32
-    boards, then over the 32 blocks of a group (the canonical chance sum of DESIGN.md, levels 0 and 1)"""
+    """[n_boards][4][R] float32 (ev seat 0 / 1, ev_br seat 0 / 1 of the board roots) -> [ceil(n_boards / 1024)][4][R]: running adds over blocks of 32
+    boards, then over the 32 blocks of a group (the canonical chance sum of DESIGN.md, levels 0 and 1). A ragged tail (the last chunk of a board list
+    that is no multiple of 1024) makes a last group of fewer blocks and a last block of fewer boards: the same running adds over what there is."""
     n = vals.shape[0]
-    assert n % 1024 == 0
+    if n % 1024:
+        full = n - n % 1024
+        out = [group_sums(vals[:full])] if full else []
+        tail = vals[full:]
+        gsum = None
+        for b0 in range(0, len(tail), 32):
+            bsum = tail[b0].copy()
+            for i in range(b0 + 1, min(b0 + 32, len(tail))):
+                bsum = bsum + tail[i]
+            gsum = bsum if gsum is None else gsum + bsum
+        return np.concatenate(out + [gsum[None]])
     v = vals.reshape(n // 32, 32, *vals.shape[1:])
     blk = v[:, 0].copy()
     for i in range(1, 32):
@@ -64,15 +77,19 @@ def group_sums(vals):
 
 
 class Chunked:
-    def __init__(self, boards, chunk, workdir, variant="plus"):
+    def __init__(self, boards, chunk, workdir, variant="plus", mult=None, sym_class=None):
+        """mult / sym_class: weighted boards (suit classes with multiplicities) and the hands' suit classes for the orbit-mean chance values"""
         self.boards, self.chunk, self.workdir = boards, chunk, workdir
+        self.mult, self.sym_class = (None if mult is None else np.asarray(mult, np.int64)), sym_class
+        assert mult is None or variant == "plus", "weighted boards: CFR+ only here"
         self.variant = variant
         self.vcode = {"vanilla": 0, "plus": 1, "linear": 2}[variant]
         self.pending = None  # Vanilla / Linear: (iteration, seat) whose strategy the chunks still have to add to their averages
         self.n = len(boards)
-        assert self.n % chunk == 0 and chunk % 1024 == 0
-        self.n_chunks = self.n // chunk
-        self.cp = oracle.chance_prob_f32(self.n, 52, 2, 5)
+        assert chunk % 1024 == 0 and (self.n % chunk == 0 or mult is not None)
+        self.n_chunks = -(-self.n // chunk)
+        self.total = self.n if mult is None else int(self.mult.sum())  # the boards the listed ones stand for
+        self.cp = oracle.chance_prob_f32(self.total, 52, 2, 5)
         self.tt, self.T = make(boards[:32], chance_prob=self.cp)       # trunk instance (its own boards are never looked at)
         self.ct, self.O = make(boards[:chunk], chance_prob=self.cp)    # chunk instance, re-used for every chunk (same tree shape; boards swapped below)
         self.nt = self.ct.n_cols - chunk * NC                          # trunk columns come first
@@ -81,6 +98,8 @@ class Chunked:
         self.first_board = self.chance + 1
         assert self.ct.n_nodes == self.first_board + chunk * NB and int(np.where(self.tt.field("kind") == 1)[0][0]) == self.chance
         self.updated = [False, False]  # seats whose strategy comes from regret matching (else the uniform fill)
+        if sym_class is not None:
+            self.T.set_symmetrize(sym_class)  # applies to the chance node's override: the weighted sum of all chunks (oracle: compute_ev)
         self.T.cfr_reset(self.vcode, 0)
         self.hist = []
 
@@ -92,6 +111,8 @@ class Chunked:
         del self.O
         _, self.O = make(self.boards[c * self.chunk:(c + 1) * self.chunk], chance_prob=self.cp)
         O = self.O
+        if self.mult is not None:
+            O.set_board_weights(self.mult[c * self.chunk:(c + 1) * self.chunk], total=self.total)
         O.cfr_configure(self.vcode, 0)  # uniform strategy, zero regrets / averages (no evaluation yet)
         if os.path.exists(self._path(c, "regret")):
             O.regret[self.nt:] = np.load(self._path(c, "regret"))
@@ -124,7 +145,7 @@ class Chunked:
                 np.save(self._path(c, "avg_sum"), O.avg_sum[self.nt:])
             O.set_iter(it)
             O.compute_ev()
-            roots = self.first_board + NB * np.arange(self.chunk)
+            roots = self.first_board + NB * np.arange(len(self.boards[c * self.chunk:(c + 1) * self.chunk]))
             vals = np.concatenate([O.ev[roots], O.ev_br[roots]], axis=1)  # [chunk][4][R]
             groups.append(group_sums(vals))
             if p is not None:
@@ -202,6 +223,47 @@ def selftest(workdir, variant="plus"):
     print("selftest ok: the chunked run equals the one-piece oracle (2048 boards, 2 iterations, %s)" % variant)
 
 
+def selftest_weighted(workdir):
+    """weights + orbit-mean chance values + a ragged last chunk against the one-piece oracle: the first 2363 suit classes of Flop5Holdem (two full
+    chunks of 1024 and one of 315 = 9 blocks of 32 + 27), 3 iterations"""
+    from pokerrl_amd.game import board_enum
+    reps, mult = pc.iso_classes(2363)
+    cls = board_enum.hand_suit_classes(G.Flop5Holdem)
+    for f in os.listdir(workdir):
+        if f.startswith("chunk"):
+            os.remove(os.path.join(workdir, f))
+    ch = Chunked(reps, 1024, workdir, "plus", mult=mult, sym_class=cls)
+    hist = ch.run(3)
+    t, o = make(reps)
+    o.set_board_weights(mult)
+    o.set_symmetrize(cls)
+    o.cfr_reset(1, 0)
+    want = [np.array(o.exploitability, np.float32)]
+    for _ in range(3):
+        o.cfr_iteration()
+        want.append(np.array(o.exploitability, np.float32))
+    assert np.array_equal(hist, np.stack(want)), (hist, want)
+    full = ch.full_arrays()
+    assert np.array_equal(full["regret"], np.asarray(o.regret)) and np.array_equal(full["avg"], np.asarray(o.avg))
+    hs = ch.state_hashes()
+    assert hs["regret"] == h32(np.asarray(o.regret)) and hs["avg"] == h32(np.asarray(o.avg))
+    print("selftest ok: the chunked weighted run equals the one-piece oracle (2363 suit classes in chunks of 1024 + 1024 + 315, 3 iterations)", hist[-1])
+
+
+def main_whole_game(n_iters, chunk, workdir):
+    """the WHOLE Flop5Holdem game: every board through its suit class (134 459 representatives x multiplicities 4 / 12 / 24 = 2 598 960 boards)"""
+    from pokerrl_amd.game import board_enum
+    reps, mult = board_enum.single_deal_board_classes(G.Flop5Holdem)
+    assert int(mult.sum()) == 2598960 and len(reps) == 134459
+    ch = Chunked(reps, chunk, workdir, "plus", mult=mult, sym_class=board_enum.hand_suit_classes(G.Flop5Holdem))
+    hist = ch.run(n_iters)
+    hs = ch.state_hashes()
+    out = os.path.join(HERE, "fhp_whole_game_plus_chunked.npz")
+    np.savez(out, n_classes=len(reps), n_boards=int(mult.sum()), variant="plus", n_iters=n_iters, chunk=chunk, boards_sha256=h32(reps), mult_sha256=h32(mult.astype(np.int32)),
+             expl_history=hist, regret_sha256=hs["regret"], avg_sha256=hs["avg"], numpy=np.__version__)
+    print("wrote", out, hist)
+
+
 def main(n_boards, n_iters, chunk, workdir, variant="plus", seed=0):
     sys.path.insert(0, os.path.join(HERE, "..", ".."))
     import bench
@@ -217,9 +279,16 @@ def main(n_boards, n_iters, chunk, workdir, variant="plus", seed=0):
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    if a and a[0] == "--selftest":   # --selftest [workdir] [variant]
+    if a and a[0] == "--selftest":   # --selftest [workdir] [variant | weighted]
         os.makedirs(a[1] if len(a) > 1 else "/tmp/prl_chunked_selftest", exist_ok=True)
-        selftest(a[1] if len(a) > 1 else "/tmp/prl_chunked_selftest", a[2] if len(a) > 2 else "plus")
+        if len(a) > 2 and a[2] == "weighted":
+            selftest_weighted(a[1])
+        else:
+            selftest(a[1] if len(a) > 1 else "/tmp/prl_chunked_selftest", a[2] if len(a) > 2 else "plus")
+    elif a and a[0] == "--whole-game":   # --whole-game [n_iters] [chunk] [workdir]
+        wd = a[3] if len(a) > 3 else "/tmp/prl_chunked_whole"
+        os.makedirs(wd, exist_ok=True)
+        main_whole_game(int(a[1]) if len(a) > 1 else 4, int(a[2]) if len(a) > 2 else 16384, wd)
     else:
         wd = a[3] if len(a) > 3 else "/tmp/prl_chunked"
         os.makedirs(wd, exist_ok=True)
