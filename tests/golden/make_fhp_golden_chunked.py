@@ -4,8 +4,8 @@ bench.py's default size: ~290 GB of oracle state in one piece): the boards are e
 instance whose chance node takes the canonical sum of all chunks' board values from outside (oracle: orc_set_override).
 
     python tests/golden/make_fhp_golden_chunked.py [n_boards] [n_iters] [chunk] [workdir] [plus|linear|vanilla]      (delay 0)
-    python tests/golden/make_fhp_golden_chunked.py --whole-game [n_iters] [chunk] [workdir]    the WHOLE Flop5Holdem game through its 134 459 suit classes
-        (prl_solver_create_weighted: multiplicities in the chance weights, orbit-mean chance values), CFR+ -> tests/golden/fhp_whole_game_plus_chunked.npz
+    python tests/golden/make_fhp_golden_chunked.py --whole-game [n_iters] [chunk] [workdir] [variant]    the WHOLE Flop5Holdem game through its 134 459 suit
+        classes (prl_solver_create_weighted: multiplicities in the chance weights, orbit-mean chance values) -> tests/golden/fhp_whole_game_<variant>_chunked.npz
 
 Per half-iteration of _CFRBase.iteration (_CFRBase.py:122-134) -- EVs, regrets + strategy of seat p, reach, average of seat p --:
   every chunk instance: trunk strategy from the trunk instance, its own boards' state from disk; update_reach; compute_ev (the board values
@@ -81,7 +81,6 @@ class Chunked:
         """mult / sym_class: weighted boards (suit classes with multiplicities) and the hands' suit classes for the orbit-mean chance values"""
         self.boards, self.chunk, self.workdir = boards, chunk, workdir
         self.mult, self.sym_class = (None if mult is None else np.asarray(mult, np.int64)), sym_class
-        assert mult is None or variant == "plus", "weighted boards: CFR+ only here"
         self.variant = variant
         self.vcode = {"vanilla": 0, "plus": 1, "linear": 2}[variant]
         self.pending = None  # Vanilla / Linear: (iteration, seat) whose strategy the chunks still have to add to their averages
@@ -223,7 +222,7 @@ def selftest(workdir, variant="plus"):
     print("selftest ok: the chunked run equals the one-piece oracle (2048 boards, 2 iterations, %s)" % variant)
 
 
-def selftest_weighted(workdir):
+def selftest_weighted(workdir, variant="plus"):
     """weights + orbit-mean chance values + a ragged last chunk against the one-piece oracle: the first 2363 suit classes of Flop5Holdem (two full
     chunks of 1024 and one of 315 = 9 blocks of 32 + 27), 3 iterations"""
     from pokerrl_amd.game import board_enum
@@ -232,12 +231,12 @@ def selftest_weighted(workdir):
     for f in os.listdir(workdir):
         if f.startswith("chunk"):
             os.remove(os.path.join(workdir, f))
-    ch = Chunked(reps, 1024, workdir, "plus", mult=mult, sym_class=cls)
+    ch = Chunked(reps, 1024, workdir, variant, mult=mult, sym_class=cls)
     hist = ch.run(3)
     t, o = make(reps)
     o.set_board_weights(mult)
     o.set_symmetrize(cls)
-    o.cfr_reset(1, 0)
+    o.cfr_reset(ch.vcode, 0)
     want = [np.array(o.exploitability, np.float32)]
     for _ in range(3):
         o.cfr_iteration()
@@ -247,20 +246,22 @@ def selftest_weighted(workdir):
     assert np.array_equal(full["regret"], np.asarray(o.regret)) and np.array_equal(full["avg"], np.asarray(o.avg))
     hs = ch.state_hashes()
     assert hs["regret"] == h32(np.asarray(o.regret)) and hs["avg"] == h32(np.asarray(o.avg))
-    print("selftest ok: the chunked weighted run equals the one-piece oracle (2363 suit classes in chunks of 1024 + 1024 + 315, 3 iterations)", hist[-1])
+    if variant != "plus":
+        assert np.array_equal(full["avg_sum"], np.asarray(o.avg_sum)) and hs["avg_sum"] == h32(np.asarray(o.avg_sum))
+    print("selftest ok: the chunked weighted run equals the one-piece oracle (2363 suit classes in chunks of 1024 + 1024 + 315, 3 iterations, %s)" % variant, hist[-1])
 
 
-def main_whole_game(n_iters, chunk, workdir):
+def main_whole_game(n_iters, chunk, workdir, variant="plus"):
     """the WHOLE Flop5Holdem game: every board through its suit class (134 459 representatives x multiplicities 4 / 12 / 24 = 2 598 960 boards)"""
     from pokerrl_amd.game import board_enum
     reps, mult = board_enum.single_deal_board_classes(G.Flop5Holdem)
     assert int(mult.sum()) == 2598960 and len(reps) == 134459
-    ch = Chunked(reps, chunk, workdir, "plus", mult=mult, sym_class=board_enum.hand_suit_classes(G.Flop5Holdem))
+    ch = Chunked(reps, chunk, workdir, variant, mult=mult, sym_class=board_enum.hand_suit_classes(G.Flop5Holdem))
     hist = ch.run(n_iters)
     hs = ch.state_hashes()
-    out = os.path.join(HERE, "fhp_whole_game_plus_chunked.npz")
-    np.savez(out, n_classes=len(reps), n_boards=int(mult.sum()), variant="plus", n_iters=n_iters, chunk=chunk, boards_sha256=h32(reps), mult_sha256=h32(mult.astype(np.int32)),
-             expl_history=hist, regret_sha256=hs["regret"], avg_sha256=hs["avg"], numpy=np.__version__)
+    out = os.path.join(HERE, "fhp_whole_game_%s_chunked.npz" % variant)
+    np.savez(out, n_classes=len(reps), n_boards=int(mult.sum()), variant=variant, n_iters=n_iters, chunk=chunk, boards_sha256=h32(reps), mult_sha256=h32(mult.astype(np.int32)),
+             expl_history=hist, regret_sha256=hs["regret"], avg_sha256=hs["avg"], avg_sum_sha256=hs.get("avg_sum", ""), numpy=np.__version__)
     print("wrote", out, hist)
 
 
@@ -281,14 +282,14 @@ if __name__ == "__main__":
     a = sys.argv[1:]
     if a and a[0] == "--selftest":   # --selftest [workdir] [variant | weighted]
         os.makedirs(a[1] if len(a) > 1 else "/tmp/prl_chunked_selftest", exist_ok=True)
-        if len(a) > 2 and a[2] == "weighted":
-            selftest_weighted(a[1])
+        if len(a) > 2 and a[2] == "weighted":   # --selftest <dir> weighted [variant]
+            selftest_weighted(a[1], a[3] if len(a) > 3 else "plus")
         else:
             selftest(a[1] if len(a) > 1 else "/tmp/prl_chunked_selftest", a[2] if len(a) > 2 else "plus")
-    elif a and a[0] == "--whole-game":   # --whole-game [n_iters] [chunk] [workdir]
+    elif a and a[0] == "--whole-game":   # --whole-game [n_iters] [chunk] [workdir] [variant]
         wd = a[3] if len(a) > 3 else "/tmp/prl_chunked_whole"
         os.makedirs(wd, exist_ok=True)
-        main_whole_game(int(a[1]) if len(a) > 1 else 4, int(a[2]) if len(a) > 2 else 16384, wd)
+        main_whole_game(int(a[1]) if len(a) > 1 else 4, int(a[2]) if len(a) > 2 else 16384, wd, a[4] if len(a) > 4 else "plus")
     else:
         wd = a[3] if len(a) > 3 else "/tmp/prl_chunked"
         os.makedirs(wd, exist_ok=True)

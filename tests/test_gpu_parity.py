@@ -505,29 +505,33 @@ def test_gpu_fused_bench_size_vs_oracle_fixture(L, variant):
     assert s.sha256_of("avg") == str(g["avg_sha256"])
 
 
-def test_gpu_whole_game_vs_oracle_fixture(L):
+@pytest.mark.parametrize("variant", ["plus", "linear"])
+def test_gpu_whole_game_vs_oracle_fixture(L, variant):
     """The WHOLE Flop5Holdem game on the GPU -- all 2 598 960 boards through their 134 459 suit classes (prl_solver_create_weighted: multiplicities in
-    the chance weights, orbit-mean chance values; BASELINE config 3's "full public tree") -- against the ORACLE: four CFR+ iterations, exploitability
-    history and SHA-256 of all 1.88 M regret / average columns. The fixture comes from the oracle's chunked run (make_fhp_golden_chunked.py
-    --whole-game: 8 chunks of 16384 classes + one of 3387, the trunk's chance node fed the canonical weighted sum and symmetrised; equal to the
-    one-piece oracle on 2363 classes in ragged chunks, `--selftest <dir> weighted`)."""
+    the chance weights, orbit-mean chance values) -- against the ORACLE: four iterations of CFR+ and of Linear CFR (BASELINE config 3: "LinearCFR, full
+    public tree, 1 MI355X"), exploitability history and SHA-256 of all 1.88 M regret / average (/ average-sum) columns. The fixtures come from the
+    oracle's chunked run (make_fhp_golden_chunked.py --whole-game: 8 chunks of 16384 classes + one of 3387, the trunk's chance node fed the canonical
+    weighted sum and symmetrised; equal to the one-piece oracle on 2363 classes in ragged chunks, `--selftest <dir> weighted [variant]`)."""
     import os
     from pokerrl_amd import _native
     from pokerrl_amd.game import bet_sets, board_enum
     from pokerrl_amd.game import games as G
     from helpers import GOLDEN, h32, native_tree
-    path = os.path.join(GOLDEN, "fhp_whole_game_plus_chunked.npz")
+    path = os.path.join(GOLDEN, "fhp_whole_game_%s_chunked.npz" % variant)
     if not os.path.isfile(path):
         pytest.skip("fixture not generated (an hour of oracle time: tests/golden/make_fhp_golden_chunked.py --whole-game)")
     g = np.load(path)
+    assert str(g["variant"]) == variant
     reps, mult = board_enum.single_deal_board_classes(G.Flop5Holdem)
     assert len(reps) == int(g["n_classes"]) and int(mult.sum()) == int(g["n_boards"]) == 2598960
     assert h32(reps) == str(g["boards_sha256"]) and h32(mult.astype(np.int32)) == str(g["mult_sha256"])
     t = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, reps)
-    s = _native.NativeSolver(t, "plus", 0, engine="fused", board_mult=mult, symmetrize=True)
+    s = _native.NativeSolver(t, variant, 0, engine="fused", board_mult=mult, symmetrize=True)
     s.iterations(int(g["n_iters"]))
     assert np.array_equal(s.get("expl_history"), g["expl_history"]), (s.get("expl_history"), g["expl_history"])
     assert s.sha256_of("regret") == str(g["regret_sha256"])
+    if variant != "plus":  # (the average updates of the last iteration rode on its closing evaluation)
+        assert s.sha256_of("avg_sum") == str(g["avg_sum_sha256"])
     assert s.sha256_of("avg") == str(g["avg_sha256"])
 
 
