@@ -581,6 +581,15 @@ def test_board_classes_and_the_default_board_choice():
         board_enum.default_boards_or_classes(G.Flop5Holdem, n_boards=100, suit_isomorphism=True)
     cls = board_enum.hand_suit_classes(G.Flop5Holdem)
     assert cls.shape == (1326,) and int(cls.max()) == 168 and sorted(np.bincount(np.bincount(cls)).nonzero()[0].tolist()) == [4, 6, 12]
+    # the whole-game fixtures (oracle's chunked run over exactly these classes, make_fhp_golden_chunked.py --whole-game) still describe this enumeration
+    import os
+    from helpers import GOLDEN, h32
+    for variant in ("plus", "linear"):
+        path = os.path.join(GOLDEN, "fhp_whole_game_%s_chunked.npz" % variant)
+        if os.path.isfile(path):
+            g = np.load(path)
+            assert h32(reps) == str(g["boards_sha256"]) and h32(mult.astype(np.int32)) == str(g["mult_sha256"]) and int(g["n_iters"]) >= 4
+            assert g["expl_history"].shape == (int(g["n_iters"]) + 1, 2) and np.all(np.isfinite(g["expl_history"]))
 
 
 def test_policy_table_host_logic():
