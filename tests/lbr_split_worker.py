@@ -1,5 +1,6 @@
 """One rank of the LBR hand-split test (spawned by tests/test_lbr.py): BatchedLBR.run_sharded over gloo on the emulator build.
-argv: lib_path out_dir n_hands_total seed   (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the env)"""
+argv: lib_path out_dir n_hands_total seed [hash|table]   (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the env)
+"table": every rank solves the agent's game itself (CFR+, deterministic: the ranks hold identical tables) and plays LBR against the average strategy."""
 import os
 import sys
 import tempfile
@@ -26,7 +27,11 @@ def main():
     import test_lbr as T
     game_cls, agent_bets, lbr_kwargs = T.CASES["DiscretizedNLLeduc"]
     t_prof = T.make_t_prof(game_cls, agent_bets, lbr_kwargs, n_total, tempfile.mkdtemp())
-    b = T.BatchedLBR(t_prof, agent_kind="hash", agent_seed=7)
+    if len(sys.argv) > 5 and sys.argv[5] == "table":
+        table, _cfr = T.solved_table(game_cls, agent_bets, 4)
+        b = T.BatchedLBR(t_prof, agent_kind="table", agent_seed=7, table=table)
+    else:
+        b = T.BatchedLBR(t_prof, agent_kind="hash", agent_seed=7)
     out = {}
     for seat in (0, 1):
         mean, conf, n, x = b.run_sharded(seat, n_total, deck_seed=seed + seat, device="cpu")

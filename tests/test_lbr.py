@@ -561,10 +561,12 @@ def test_gpu_batched_h2h_vs_reference(tag, tmp_path):
     check_batched_h2h_vs_golden(tag, tmp_path)
 
 
-def test_lbr_hand_split_two_ranks_equals_one_rank_gloo_emu(tmp_path):
+@pytest.mark.parametrize("agent", ["hash", "table"])
+def test_lbr_hand_split_two_ranks_equals_one_rank_gloo_emu(tmp_path, agent):
     """SURVEY 8e, LBR row (LocalLBRMaster.py:53-69: hands split evenly over the workers): BatchedLBR.run_sharded with world_size 2
     over gloo -- every rank plays its half of the same counter-based deck / agent-draw streams -- must give the per-hand winnings
-    of the one-rank run, concatenated in rank order, and the same all-reduced (mean, confidence, n)."""
+    of the one-rank run, concatenated in rank order, and the same all-reduced (mean, confidence, n). "table": against a tabular agent (every rank
+    holds its own copy of the solver's average strategy in its device memory)."""
     import subprocess
     sys.path.insert(0, os.path.join(HERE, "emu"))
     import build_emu
@@ -574,7 +576,7 @@ def test_lbr_hand_split_two_ranks_equals_one_rank_gloo_emu(tmp_path):
 
     def run(world, d):
         port = _free_port()
-        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "lbr_split_worker.py"), lib, str(d), str(n_total), str(seed)],
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "lbr_split_worker.py"), lib, str(d), str(n_total), str(seed), agent],
                                   env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
                  for r in range(world)]
         for p in procs:
