@@ -318,7 +318,12 @@ int32_t prl_solver_create_opts(const prl_tree_t* tree, int32_t variant, int32_t 
  * A class subtree works with reach scaled by mult_c (values are linear in the opponent's reach, strategies do not depend on the scale), so its
  * regrets are mult_c x those of one member board. Summation order: the canonical chance sum over the listed boards, then the orbit sum in ascending
  * hand index, then one correctly rounded division -- oracle/prl_oracle.c restates it (orc_set_board_weights, orc_set_symmetrize).
+ * `symmetrize` is checked, not trusted (the orbit mean is only right for suit classes): every listed board must be the representative of its class
+ * (the lexicographically smallest of its 24 relabellings, cards ascending), board_mult[i] the size of its orbit, and with symmetrize = 1 the list must
+ * cover the game (multiplicities adding up to C(n_cards, k)); PRL_SYMMETRIZE_SUBSET accepts a subset of the classes (tests, partial solves). Any other
+ * weighting of boards (importance-sampled boards ...) is symmetrize = 0. PRL_ERR_ARG otherwise, prl_last_error() naming the board.
  * Single-deal FUSED engine, one GPU (no exchange); flags as prl_solver_create_opts. */
+enum { PRL_SYMMETRIZE_SUBSET = 2 };
 int32_t prl_solver_create_weighted(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t flags, const int32_t* board_mult, int32_t symmetrize,
                                    prl_solver_t** out_solver);
 /* Placement selection. The fused board pass streams within ~15 % of what HBM sustains and its speed depends on WHERE its arrays land
@@ -494,6 +499,26 @@ void prl_policy_table_destroy(prl_policy_table_t* table);
  * of that row (0 without one) -- what the batched engines read, so that a table can be verified where it lives. */
 int32_t prl_policy_table_probe(const prl_policy_table_t* table, int32_t n, const uint32_t* key_lo, const uint32_t* key_hi, const int32_t* action,
                                const int32_t* hand, int32_t* out_row, float* out_prob);
+
+/* The table of a SOLVER's average strategy, built where the strategy lives (no host copy of the columns; the reference's evaluators are pointed at the
+ * trained agent: PokerRL/eval/lbr/LocalLBRWorker.py:316-374, PokerRL/rl/base_cls/EvalAgentBase.py:39-44). `tree` is the tree the solver was created on.
+ * One row per decision node, rows in node order; the row's history key is the chain of prl_policy_table_create over the states on the node's path
+ * (the env replayed along the tree). LEVELS engine and the single-deal FUSED engine (its board columns are expanded from sorted storage to hand order
+ * on the device, a chunk of boards at a time); the average is what prl_solver_get(PRL_SF_AVG) returns, rounded to float32.
+ * A solver made by prl_solver_create_weighted with `symmetrize` (suit classes) yields a SUIT-CANONICAL table: rows exist for the class representatives
+ * only; the evaluators relabel the dealt board to its class representative -- the lexicographically smallest of its 24 relabellings, cards ascending,
+ * taking the FIRST permutation in lexicographic order of (p[0], p[1], p[2], p[3]) that attains it (csrc/prl_policy.h: prl_suit_canon) -- hash THAT
+ * board into the history key and read the table at the hand relabelled by the same permutation: the whole game's 2 598 960 boards through 134 459 x 6
+ * rows (12.8 GB). Errors: PRL_ERR_STATE before the first average exists, PRL_ERR_UNSUPPORTED for the per-street engine / sharded solves. */
+int32_t prl_policy_table_from_solver(prl_solver_t* solver, const prl_tree_t* tree, uint32_t key_seed, prl_policy_table_t** out_table);
+/* out6: n_rows, n_actions, range_size, capacity of the key table, suit_canon (0 / 1), key_seed */
+int32_t prl_policy_table_info(const prl_policy_table_t* table, int64_t* out6);
+/* the key table as it lives on the device: keys[capacity] (0 = empty), rows[capacity] */
+int32_t prl_policy_table_export_keys(const prl_policy_table_t* table, uint64_t* out_keys, int32_t* out_rows);
+/* rows [row_begin, row_begin + n_rows) of the table: out float32 [n_rows][n_actions][range_size] (hands in the table's own labelling) */
+int32_t prl_policy_table_get_rows(const prl_policy_table_t* table, int32_t row_begin, int32_t n_rows, float* out);
+/* host helper (tests, host twins of the evaluators): the canonical form of n boards of k cards each (prl_suit_canon) and the permutation numbers taken */
+int32_t prl_suit_canon_boards(const int8_t* boards, int32_t n, int32_t k, int32_t n_suits, int8_t* out_boards, int32_t* out_perm);
 
 /* prl_lbr_batch_run against a tabular agent: `table` is the agent's policy; agent_seed drives its action draws as for the synthetic agents. */
 int32_t prl_lbr_batch_run_table(const PrlGame* lbr_game, const PrlGame* agent_game, const PrlRules* rules, int32_t n_envs, int32_t agent_seat,

@@ -156,6 +156,8 @@ def _bind_solver(L):
     L.prl_solver_create.argtypes = [vp, i32, i32, ctypes.POINTER(vp)]
     L.prl_solver_create_ex.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp)]
     L.prl_solver_create_ex.restype = i32
+    L.prl_solver_create_weighted.argtypes = [vp, i32, i32, i32, vp, i32, ctypes.POINTER(vp)]
+    L.prl_solver_create_weighted.restype = i32
     L.prl_solver_create_sharded.argtypes = [vp, i32, i32, i32, i32, EXCHANGE_FN, vp, ctypes.POINTER(vp)]
     L.prl_solver_create_sharded.restype = i32
     L.prl_solver_create_sharded_ragged.argtypes = [vp, i32, i32, i32, i32, ctypes.c_int64, ctypes.c_int64, EXCHANGE_FN, vp, ctypes.POINTER(vp)]
@@ -552,7 +554,8 @@ class NativeSolver:
         iterations of each and keeps the fastest (prl_solver_create_placed; .placement_ms / .placement_chosen say what it saw).
         board_mult=int array [n_boards] (+ symmetrize=True): weighted boards / suit isomorphism (prl_solver_create_weighted) -- the listed boards
         stand for board_mult[i] boards each; with symmetrize they are suit-class representatives (pokerrl_amd.game.board_enum.
-        single_deal_board_classes) and the chance node's values are averaged over every hand's suit orbit: the WHOLE game from its classes."""
+        single_deal_board_classes) and the chance node's values are averaged over every hand's suit orbit: the WHOLE game from its classes.
+        The library checks that claim (representatives, orbit sizes, the whole game covered); symmetrize="subset" admits a subset of the classes."""
         self._L = _lib or tree._L
         self.placement_ms, self.placement_chosen = None, None
         if _lib is None and self._L is lib():
@@ -562,6 +565,10 @@ class NativeSolver:
         v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
         e = ENGINES[engine] if isinstance(engine, str) else int(engine)
         self._exchange_cb = None
+        if board_mult is not None and (shard is not None or place is not None):
+            raise ValueError("weighted boards (board_mult=): one GPU, no placement probe -- not with shard= / place=")
+        if symmetrize and board_mult is None:
+            raise ValueError("symmetrize= goes with board_mult= (suit-class representatives and their orbit sizes)")
         if shard is not None and isinstance(shard[0], str):
             # ("rccl", world, rank, unique_id bytes[, shard_boards, total_boards]): the exchange lives in the library (ncclAllGather on
             # the solver's stream, prl_solver_create_sharded_rccl) -- no Python in the iteration loop. pokerrl_amd.dist.rccl_shard builds it.
@@ -595,14 +602,10 @@ class NativeSolver:
                 check(self._L.prl_solver_create_sharded(tree.handle, v, int(delay), int(world), int(rank), self._exchange_cb, None,
                                                         ctypes.byref(self._h)), self._L)
         elif board_mult is not None:
-            assert shard is None and place is None, "weighted boards: one GPU, no placement probe"
             m = np.ascontiguousarray(board_mult, np.int32)
             assert m.shape == (tree.n_boards,), "one multiplicity per listed board"
-            self._L.prl_solver_create_weighted.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
-                                                           ctypes.POINTER(ctypes.c_void_p)]
-            self._L.prl_solver_create_weighted.restype = ctypes.c_int32
-            check(self._L.prl_solver_create_weighted(tree.handle, v, int(delay), 1 if avg_dtype == "f32" else 0, _ptr(m), 1 if symmetrize else 0,
-                                                     ctypes.byref(self._h)), self._L)
+            sym = 2 if symmetrize == "subset" else (1 if symmetrize else 0)  # PRL_SYMMETRIZE_SUBSET: class representatives that do not cover the game
+            check(self._L.prl_solver_create_weighted(tree.handle, v, int(delay), 1 if avg_dtype == "f32" else 0, _ptr(m), sym, ctypes.byref(self._h)), self._L)
         elif not self._h and place is not None:
             # placement selection inside the library (prl_solver_create_placed): `place` candidates built side by side, the fastest kept
             n = int(place)

@@ -54,7 +54,8 @@ class CFRBase:
             raise ValueError("a CFR variant written against the reference's hook methods runs on per-node vectors (LEVELS engine): give it boards= / "
                              "n_boards=; the whole game through its suit classes needs a built-in variant (CFRPlus / LinearCFR / VanillaCFR)")
         self._boards, self._engine = boards, engine
-        self._trees = [PublicTree(env_bldr=b, stack_size=a.starting_stack_sizes_list, stop_at_street=None, boards=boards, engine=engine, board_mult=board_mult)
+        self._trees = [PublicTree(env_bldr=b, stack_size=a.starting_stack_sizes_list, stop_at_street=None, boards=boards, engine=engine, board_mult=board_mult,
+                                  suit_isomorphism=True if board_mult is not None else None)  # (the classes of the whole game, as enumerated above)
                        for b, a in zip(self._env_bldrs, self._env_args)]
         self._eval_trees = None
         for tree in self._trees:

@@ -26,6 +26,7 @@
 #include "prl_env.h"
 #include "prl_host.h"
 #include "prl_lbr.h"
+#include "prl_policy.h"
 #include "prl_rt.h"
 
 extern "C" int32_t prl_device_available(void);
@@ -49,16 +50,6 @@ extern "C" int32_t prl_device_available(void);
 #endif
 #define LBRB_N_STATS 16
 
-// agent kind 2 (see the header comment): the device arrays of one tabular policy
-struct PrlPolicyTable {
-    unsigned long long* keys;     // [mask + 1] 64-bit state keys, 0 = empty slot (linear probing)
-    int32_t* rows;                // [mask + 1] row of the key in the same slot
-    float* probs;                 // [n_rows][n_actions][range_size] P(action | hand); 0 for actions that are not legal in the row's state
-    uint32_t mask, key_seed;
-    int32_t n_rows, n_actions, range_size;
-};
-#define LBRB_KEY_SEED_HI 0x5BD1E995u  // the high word of a state's key is the hash chain under key_seed ^ this
-
 struct PrlLbrBatchParams {
     PrlGame g_lbr, g_agent;
     PrlRules rules;
@@ -71,24 +62,6 @@ struct PrlLbrBatchParams {
     float* eq_scratch;            // [grid][LBRB_MAX_Q][LBRB_MAX_BOARDS_2] when LBR may decide with two cards to come, else NULL
     PrlPolicyTable tab;           // agent kind 2
 };
-
-PRL_HD PRL_INLINE uint32_t lbrb_mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return x;
-}
-
-// hash chain over the public state (tests/lbr_fixture_agent.py: state_key)
-PRL_HD PRL_INLINE uint32_t lbrb_state_key(uint32_t seed, const PrlEnvState& s, const int8_t* board, int n_dealt, int n_board_total, int n_suits) {
-    uint32_t k = seed;
-    const int vals[7] = {s.round, s.main_pot, s.bet[0], s.bet[1], s.stack[0], s.stack[1], (int)s.cur};
-    for (int i = 0; i < 7; ++i) k = lbrb_mix32(k * 31u + (uint32_t)vals[i]);
-    for (int i = 0; i < n_board_total; ++i) {  // 2-D cards (rank, suit); the not-dealt token is -127 in both fields
-        const int r = i < n_dealt ? board[i] / n_suits : -127, su = i < n_dealt ? board[i] % n_suits : -127;
-        k = lbrb_mix32(k * 31u + (uint32_t)(r & 0xFF));
-        k = lbrb_mix32(k * 31u + (uint32_t)(su & 0xFF));
-    }
-    return k;
-}
 
 // P(action `a` | hand h) of the synthetic agent; legal[0..n_legal) ascending. 0 for an illegal action.
 PRL_HD PRL_INLINE float lbrb_agent_prob(int kind, uint32_t key, int h, const int32_t* legal, int n_legal, int a) {
@@ -130,46 +103,23 @@ PRL_HD PRL_INLINE int lbrb_agent_draw(int kind, uint32_t key, int h, const int32
     return legal[n_legal - 1];
 }
 
-// Tabular agent. A policy row belongs to a node of the agent's public TREE, not to a public state (two betting histories can meet in one state), so the
-// key is a chain over the states of the hand so far: key(root) = lbrb_state_key(key_seed, root state), key(next) = lbrb_state_key(key(now), next state)
-// after every env step (with the new board cards on the table when the step ends a round) -- two 32-bit chains make the 64-bit key. States, not action
-// ids: LBR raising by a pot fraction of ITS bet set reaches the agent's node whenever the agent's tree has a raise to the same amount.
-struct LbrbHistKey { uint32_t lo, hi; };
-
-PRL_HD PRL_INLINE LbrbHistKey lbrb_hist_root(uint32_t key_seed) { return LbrbHistKey{key_seed, key_seed ^ LBRB_KEY_SEED_HI}; }
-
-PRL_HD PRL_INLINE LbrbHistKey lbrb_hist_step(const LbrbHistKey& k, const PrlEnvState& s, const int8_t* board, int n_dealt, int n_board_total, int n_suits) {
-    return LbrbHistKey{lbrb_state_key(k.lo, s, board, n_dealt, n_board_total, n_suits), lbrb_state_key(k.hi, s, board, n_dealt, n_board_total, n_suits)};
-}
-
-// the row of a history key in the table, -1 if the table does not hold it (one lane; a handful of dependent HBM reads per agent decision)
-PRL_HD PRL_INLINE int lbrb_table_row(const PrlPolicyTable& T, const LbrbHistKey& hk) {
-    unsigned long long k = ((unsigned long long)hk.hi << 32) | hk.lo;
-    if (k == 0ull) k = 1ull;
-    for (uint32_t i = (hk.lo ^ (hk.hi * 0x9E3779B1u)) & T.mask;; i = (i + 1u) & T.mask) {  // the table is never full: the loop ends at an empty slot
-        const unsigned long long ki = T.keys[i];
-        if (ki == k) return T.rows[i];
-        if (ki == 0ull) return -1;
-    }
-}
-
 // P(a | hand h) of agent `kind` in the state (key, row, legal list); TABLE builds read kind 2 from the table, the others never touch it
 template <bool TABLE>
-PRL_HD PRL_INLINE float lbrb_prob(const PrlPolicyTable& T, int kind, uint32_t key, int row, int h, const int32_t* legal, int n_legal, int a) {
-    if (TABLE && kind == 2) {
-        if (row >= 0) return T.probs[((size_t)row * T.n_actions + a) * T.range_size + h];
+PRL_HD PRL_INLINE float lbrb_prob(const PrlPolicyTable& T, int kind, uint32_t key, int row, int h, int hm, const int32_t* legal, int n_legal, int a) {
+    if (TABLE && kind == 2) {  // hm: the hand's index in the table's labelling (= h unless the table is keyed under suit-canonical boards)
+        if (row >= 0) return T.probs[((size_t)row * T.n_actions + a) * T.range_size + hm];
         kind = 0;
     }
     return lbrb_agent_prob(kind, key, h, legal, n_legal, a);
 }
 
 template <bool TABLE>
-PRL_HD PRL_INLINE int lbrb_draw(const PrlPolicyTable& T, int kind, uint32_t key, int row, int h, const int32_t* legal, int n_legal, float u) {
+PRL_HD PRL_INLINE int lbrb_draw(const PrlPolicyTable& T, int kind, uint32_t key, int row, int h, int hm, const int32_t* legal, int n_legal, float u) {
     if (TABLE && kind == 2) {
         if (row >= 0) {
             float c = 0.f;
             for (int j = 0; j < n_legal; ++j) {
-                c = c + T.probs[((size_t)row * T.n_actions + legal[j]) * T.range_size + h];
+                c = c + T.probs[((size_t)row * T.n_actions + legal[j]) * T.range_size + hm];
                 if (u < c) return legal[j];
             }
             return legal[n_legal - 1];
@@ -194,6 +144,8 @@ struct LbrbShared {
     uint32_t key;
     int32_t row, raise_row[LBRB_MAX_Q];  // tabular agent: the table rows of the state / of the states after LBR's candidate raises
     LbrbHistKey hk;                      // ... and the history key of the hand so far
+    int8_t cboard[5];                    // ... a table keyed under suit-canonical boards: the canonical form of the board on the table (prl_policy.h)
+    int32_t canon_k;                     //     and the number of the suit permutation that makes it
     float total;
     int32_t raise_action[LBRB_MAX_Q], pot_after[LBRB_MAX_Q];
     uint32_t raise_key[LBRB_MAX_Q];
@@ -488,7 +440,7 @@ PRL_HD PRL_INLINE bool nh_is_two(const PrlRules& r) { return r.n_hole_cards == 2
 PRL_HD PRL_INLINE size_t lbrb_smem_bytes(int R) {  // the carve-outs of prl_k_lbr_batch, in its order
     const size_t sizes[] = {(size_t)R * 4, (size_t)LBRB_MAX_Q * R * 4, (size_t)LBRB_MAX_Q * LBRB_MAX_BOARDS * 4, (size_t)R * 2, (size_t)R * 2, sizeof(LbrbShared),
                             sizeof(LbrbLeaves), (size_t)LBRB_MAX_Q * PRL_LBR_MAX_CARDS * 4, (size_t)LBRB_MAX_Q * LBRB_MAX_BOARDS * 4, 3 * sizeof(LbrbLeafMap),
-                            (size_t)LBRB_PART_FLOATS * 4, LBRB_MAX_Q * sizeof(unsigned), (size_t)R * 2};
+                            (size_t)LBRB_PART_FLOATS * 4, LBRB_MAX_Q * sizeof(unsigned), (size_t)R * 2, (size_t)R * 2};
     size_t off = 0;
     for (size_t b : sizes) off = ((off + 15) & ~(size_t)15) + b;
     return off + 16;
@@ -519,6 +471,8 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
     float* part = (float*)carve((size_t)LBRB_PART_FLOATS * 4);       // [LBRB_PART_FLOATS] accumulator slots of lbrb_multi_sum
     unsigned* minpos = (unsigned*)carve(LBRB_MAX_Q * sizeof(unsigned));  // [LBRB_MAX_Q] bits of the smallest non-zero entry of every candidate range
     uint16_t* hl2 = (uint16_t*)carve((size_t)R * 2);                 // [R] c1 | c2 << 8 of the hands the cards on the table leave, 0xFFFF for the others
+    uint16_t* hmap = (uint16_t*)carve((size_t)R * 2);                // [R] tabular agent: hand -> its index in the table's labelling (identity unless suit-canonical)
+    const bool canon = TABLE && P.agent_kind == 2 && P.tab.suit_canon != 0 && nh_is_two(P.rules);
     const bool coop = nh_is_two(P.rules) && R >= 64;  // the cooperative sums (hold'em ranges); tiny ranges keep one lane per sum
     if (tid == 0) lbrb_build_leaves(Lf, R);
     if (tid == 64) lbrb_build_leaf_map(MR, R);
@@ -544,8 +498,9 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
             prl_env_reset(P.g_lbr, S.st);
             S.done = 0; S.n_dealt = 0; S.step_ctr = 0;
             S.lbr_idx = lbrb_hand_idx(P.rules, lbr_hand);
-            if (TABLE) S.hk = lbrb_hist_step(lbrb_hist_root(P.tab.key_seed), S.st, S.board, 0, n_board_total, P.rules.n_suits);
+            if (TABLE) { S.hk = lbrb_hist_step(lbrb_hist_root(P.tab.key_seed), S.st, S.board, 0, n_board_total, P.rules.n_suits); S.canon_k = 0; }
         }
+        if (TABLE) for (int h = tid; h < R; h += LBRB_THREADS) hmap[h] = (uint16_t)h;
         // agent_range.reset(); set_cards_to_zero_prob(lbr_hand) (:73-74, :190-191)
         const float unif = (float)(1.0 / (double)R);
         PrlLbrGame hg;  // only the card geometry is needed for hand_has
@@ -618,7 +573,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                             const int nl2 = prl_legal_actions_to(P.g_agent, s2, put);
                             S.raise_n_legal[q] = nl2;
                             S.raise_key[q] = lbrb_state_key(P.seed, s2, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
-                            if (TABLE) S.raise_row[q] = P.agent_kind == 2 ? lbrb_table_row(P.tab, lbrb_hist_step(S.hk, s2, S.board, S.n_dealt, n_board_total, P.rules.n_suits)) : -1;
+                            if (TABLE) S.raise_row[q] = P.agent_kind == 2 ? lbrb_table_row(P.tab, lbrb_hist_step(S.hk, s2, canon ? S.cboard : S.board, S.n_dealt, n_board_total, P.rules.n_suits)) : -1;
                         }
                         if (tid == 0) {
                             if (P.limit) S.step_ctr += n_raises;  // the limit branch asks get_action(step_env=False): one draw per raise is consumed (:120)
@@ -643,7 +598,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                         const int nl2 = S.raise_n_legal[q];
                         const int32_t* lg2 = S.raise_legal[q];  // read from LDS where it is (the same word for every lane: a broadcast)
                         for (int h = tid; h < R; h += LBRB_THREADS)
-                            cand[(size_t)q * R + h] = lbrb_prob<TABLE>(P.tab, P.agent_kind, S.raise_key[q], TABLE ? S.raise_row[q] : -1, h, lg2, nl2, PRL_FOLD);  // p(fold | hand)
+                            cand[(size_t)q * R + h] = lbrb_prob<TABLE>(P.tab, P.agent_kind, S.raise_key[q], TABLE ? S.raise_row[q] : -1, h, TABLE ? (int)hmap[h] : h, lg2, nl2, PRL_FOLD);  // p(fold | hand)
                     }
                     // first complete board for the classification (see the quirk in prl_lbr_kernels.hip)
                     {
@@ -958,12 +913,12 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     const uint32_t x = lbrb_mix32(P.seed * 0x51ED27u + episode * 0x9E3779B1u + (uint32_t)S.step_ctr);
                     const float u = (float)(x >> 8) / 16777216.0f;
                     S.step_ctr += 1;
-                    S.action = lbrb_draw<TABLE>(P.tab, P.agent_kind, S.key, TABLE ? S.row : -1, hi, S.legal, S.n_legal, u);
+                    S.action = lbrb_draw<TABLE>(P.tab, P.agent_kind, S.key, TABLE ? S.row : -1, hi, TABLE ? (int)hmap[hi] : hi, S.legal, S.n_legal, u);
                     n_agent += 1;
                 }
                 prl_sync();
                 const int a = S.action;
-                for (int h = tid; h < R; h += LBRB_THREADS) rg[h] = rg[h] * lbrb_prob<TABLE>(P.tab, P.agent_kind, S.key, TABLE ? S.row : -1, h, S.legal, S.n_legal, a);
+                for (int h = tid; h < R; h += LBRB_THREADS) rg[h] = rg[h] * lbrb_prob<TABLE>(P.tab, P.agent_kind, S.key, TABLE ? S.row : -1, h, TABLE ? (int)hmap[h] : h, S.legal, S.n_legal, a);
                 if (coop) lbrb_normalize_blocks(rg, R, MR, part, S); else lbrb_normalize(rg, R, Lf, S);
                 if (tid == 0) {
                     PrlEnvState st = S.st;
@@ -1007,9 +962,17 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     const int n_new = P.rules.board_cards_in_round[S.st.round];
                     for (int i = 0; i < n_new; ++i) { S.board[S.n_dealt] = deck_board[S.n_dealt]; S.n_dealt += 1; }
                     S.n_legal = n_new;  // scratch: how many cards are new
-                    if (TABLE) S.hk = lbrb_hist_step(S.hk, S.st, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
+                    if (canon) S.canon_k = prl_suit_canon(S.board, S.n_dealt, P.rules.n_suits, S.cboard);
+                    if (TABLE) S.hk = lbrb_hist_step(S.hk, S.st, canon ? S.cboard : S.board, S.n_dealt, n_board_total, P.rules.n_suits);
                 }
                 prl_sync();
+                if (canon) {  // the hands in the canonical labelling: the same suit permutation applied to both hole cards
+                    const int ck = S.canon_k;
+                    for (int h = tid; h < R; h += LBRB_THREADS) {
+                        const unsigned v = hole_lut[h];
+                        hmap[h] = (uint16_t)prl_suit_perm_hand((int)(v & 0xFFu), (int)(v >> 8), ck, P.rules.n_suits, P.rules.n_cards);
+                    }
+                }
                 // agent_range.update_after_new_round (PokerRange.py:60-65): the new board cards leave the range
                 const int n_new = S.n_legal, nd = S.n_dealt;
                 unsigned long long m = 0ull;
@@ -1017,7 +980,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                 for (int h = tid; h < R; h += LBRB_THREADS)
                     if (prl_lbr_hand_mask(hg, h, hole_lut) & m) rg[h] = 0.f;
                 if (coop) lbrb_normalize_blocks(rg, R, MR, part, S); else lbrb_normalize(rg, R, Lf, S);
-            } else if (TABLE && tid == 0) S.hk = lbrb_hist_step(S.hk, S.st, S.board, S.n_dealt, n_board_total, P.rules.n_suits);
+            } else if (TABLE && tid == 0) S.hk = lbrb_hist_step(S.hk, S.st, canon ? S.cboard : S.board, S.n_dealt, n_board_total, P.rules.n_suits);
             LBRB_TICK(9);  // after the step: dealing / range update / payout
         }
     }
@@ -1031,9 +994,10 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
 
 // ---- tabular policies in HBM (agent kind 2) ---------------------------------------------------------------------------------------------------------
 // keys / rows: the open-addressed key table as the host built it (capacity a power of two, 0 = empty); probs: [n_rows][n_actions][range_size] float32.
-extern "C" PrlPolicyTable* prl_policy_table_create(const uint64_t* keys, const int32_t* rows, uint32_t capacity, const float* probs, int32_t n_rows,
-                                                   int32_t n_actions, int32_t range_size, uint32_t key_seed) {
-    if (!keys || !rows || !probs || capacity < 2 || (capacity & (capacity - 1)) || n_rows <= 0 || (uint32_t)n_rows >= capacity || n_actions < 2 || range_size <= 0) {
+// probs == nullptr: the probabilities are left zeroed for the caller to fill on the device (prl_policy_table_from_solver, prl_solver.hip)
+PrlPolicyTable* prl_policy_table_alloc(const uint64_t* keys, const int32_t* rows, uint32_t capacity, const float* probs, int32_t n_rows, int32_t n_actions,
+                                       int32_t range_size, uint32_t key_seed) {
+    if (!keys || !rows || capacity < 2 || (capacity & (capacity - 1)) || n_rows <= 0 || (uint32_t)n_rows >= capacity || n_actions < 2 || range_size <= 0) {
         prl_set_error("prl_policy_table_create: bad argument (capacity: a power of two above the number of rows)"); return nullptr;
     }
     if (!prl_device_available()) { prl_set_error("no HIP device: policy tables live in HBM"); return nullptr; }
@@ -1043,13 +1007,50 @@ extern "C" PrlPolicyTable* prl_policy_table_create(const uint64_t* keys, const i
     const size_t np = (size_t)n_rows * n_actions * range_size;
     if (hipMalloc((void**)&T->keys, (size_t)capacity * 8) != hipSuccess || hipMalloc((void**)&T->rows, (size_t)capacity * 4) != hipSuccess ||
         hipMalloc((void**)&T->probs, np * 4) != hipSuccess || hipMemcpy(T->keys, keys, (size_t)capacity * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(T->rows, rows, (size_t)capacity * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(T->probs, probs, np * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(T->rows, rows, (size_t)capacity * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        (probs ? hipMemcpy(T->probs, probs, np * 4, hipMemcpyHostToDevice) : hipMemset(T->probs, 0, np * 4)) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(T->keys); (void)hipFree(T->rows); (void)hipFree(T->probs);
         delete T;
-        prl_set_error("prl_policy_table_create: HIP allocation / copy failed"); return nullptr;
+        prl_set_error("policy table: HIP allocation / copy failed (" + std::to_string((np * 4 + (size_t)capacity * 12) >> 20) + " MB)"); return nullptr;
     }
     return T;
+}
+
+extern "C" PrlPolicyTable* prl_policy_table_create(const uint64_t* keys, const int32_t* rows, uint32_t capacity, const float* probs, int32_t n_rows,
+                                                   int32_t n_actions, int32_t range_size, uint32_t key_seed) {
+    if (!probs) { prl_set_error("prl_policy_table_create: bad argument (no probabilities)"); return nullptr; }
+    return prl_policy_table_alloc(keys, rows, capacity, probs, n_rows, n_actions, range_size, key_seed);
+}
+
+extern "C" int32_t prl_policy_table_info(const PrlPolicyTable* T, int64_t* out6) {
+    if (!T || !out6) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    out6[0] = T->n_rows; out6[1] = T->n_actions; out6[2] = T->range_size; out6[3] = (int64_t)T->mask + 1; out6[4] = T->suit_canon; out6[5] = T->key_seed;
+    return PRL_OK;
+}
+
+extern "C" int32_t prl_policy_table_export_keys(const PrlPolicyTable* T, uint64_t* out_keys, int32_t* out_rows) {
+    if (!T || !out_keys || !out_rows) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    const size_t cap = (size_t)T->mask + 1;
+    if (hipMemcpy(out_keys, T->keys, cap * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(out_rows, T->rows, cap * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError(); prl_set_error("HIP error in prl_policy_table_export_keys"); return PRL_ERR_HIP;
+    }
+    return PRL_OK;
+}
+
+extern "C" int32_t prl_policy_table_get_rows(const PrlPolicyTable* T, int32_t row_begin, int32_t n_rows, float* out) {
+    if (!T || !out || row_begin < 0 || n_rows < 0 || (int64_t)row_begin + n_rows > T->n_rows) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    const size_t per_row = (size_t)T->n_actions * T->range_size;
+    if (n_rows && hipMemcpy(out, T->probs + (size_t)row_begin * per_row, (size_t)n_rows * per_row * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError(); prl_set_error("HIP error in prl_policy_table_get_rows"); return PRL_ERR_HIP;
+    }
+    return PRL_OK;
+}
+
+extern "C" int32_t prl_suit_canon_boards(const int8_t* boards, int32_t n, int32_t k, int32_t n_suits, int8_t* out_boards, int32_t* out_perm) {
+    if (!boards || !out_boards || !out_perm || n < 0 || k < 1 || k > 5 || n_suits < 1 || n_suits > 4) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    for (int i = 0; i < n; ++i) out_perm[i] = prl_suit_canon(boards + (size_t)i * k, k, n_suits, out_boards + (size_t)i * k);
+    return PRL_OK;
 }
 
 extern "C" void prl_policy_table_destroy(PrlPolicyTable* T) {
@@ -1245,8 +1246,10 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_h2h_batch(PrlH2hBatchParams P) {
         LbrbHistKey hk[2];         // per tabular agent: the history key of the hand so far under its table's seed
         if (TABLE)
             for (int w = 0; w < 2; ++w) hk[w] = lbrb_hist_step(lbrb_hist_root(P.tab[w].key_seed), st, board, 0, nb, P.rules.n_suits);
-        int hand_idx[2];
-        for (int p = 0; p < 2; ++p) hand_idx[p] = lbrb_hand_idx(P.rules, cards + p * nh);
+        int hand_idx[2], hand_idx_c[2];  // ... _c: in the labelling of a table keyed under suit-canonical boards (prl_policy.h), once the board is out
+        for (int p = 0; p < 2; ++p) hand_idx_c[p] = hand_idx[p] = lbrb_hand_idx(P.rules, cards + p * nh);
+        int8_t cboard[5] = {0, 0, 0, 0, 0};
+        const bool any_canon = TABLE && nh == 2 && ((P.kind[0] == 2 && P.tab[0].suit_canon) || (P.kind[1] == 2 && P.tab[1].suit_canon));
         PrlLbrGame hg;
         hg.n_hole = nh; hg.n_cards = P.rules.n_cards; hg.n_suits = P.rules.n_suits; hg.rank_rule = P.rules.rank_rule; hg.R = P.rules.range_size;
         hg.n_board_total = nb;
@@ -1260,7 +1263,7 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_h2h_batch(PrlH2hBatchParams P) {
             const float u = (float)(x >> 8) / 16777216.0f;
             step_ctr[who] += 1;
             const int row = TABLE && P.kind[who] == 2 ? lbrb_table_row(P.tab[who], hk[who]) : -1;
-            const int a = lbrb_draw<TABLE>(P.tab[who], P.kind[who], key, row, hand_idx[seat], legal, n_legal, u);
+            const int a = lbrb_draw<TABLE>(P.tab[who], P.kind[who], key, row, hand_idx[seat], TABLE && P.tab[who].suit_canon ? hand_idx_c[seat] : hand_idx[seat], legal, n_legal, u);
             PrlStepInfo info;
             if (!P.limit && a >= 2) {  // discretized games step by pot fraction
                 const int amt = prl_fraction_of_pot_raise(st, P.game.bet_fracs[a - 2], st.cur);
@@ -1284,9 +1287,16 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_h2h_batch(PrlH2hBatchParams P) {
             } else if (info.chance_acts) {
                 const int n_new = P.rules.board_cards_in_round[st.round];
                 for (int i = 0; i < n_new; ++i) { board[n_dealt] = deck_board[n_dealt]; n_dealt += 1; }
+                if (any_canon) {
+                    const int ck = prl_suit_canon(board, n_dealt, P.rules.n_suits, cboard);
+                    for (int p = 0; p < 2; ++p) {
+                        const int8_t* hc = cards + p * nh;
+                        hand_idx_c[p] = prl_suit_perm_hand(hc[0], hc[1], ck, P.rules.n_suits, P.rules.n_cards);
+                    }
+                }
             }
             if (TABLE && !info.is_terminal)
-                for (int w = 0; w < 2; ++w) hk[w] = lbrb_hist_step(hk[w], st, board, n_dealt, nb, P.rules.n_suits);
+                for (int w = 0; w < 2; ++w) hk[w] = lbrb_hist_step(hk[w], st, P.tab[w].suit_canon ? cboard : board, n_dealt, nb, P.rules.n_suits);
         }
     }
     // one pair of atomics per wave: butterfly sum of the per-lane counts (each far below 2^31)

@@ -16,7 +16,9 @@
 #include <rccl/rccl.h>  // types only: the library is bound at run time (prl_rccl_api), so that single-GPU users never load it
 #endif
 
+#include <algorithm>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "prl_cards.h"
@@ -24,6 +26,7 @@
 #include "prl_fhp.h"
 #include "prl_host.h"
 #include "prl_kernels.h"
+#include "prl_policy.h"
 #include "prl_rt.h"
 #include "prl_solver_types.h"
 #include "prl_st.h"
@@ -885,6 +888,40 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             mult_sum += board_mult[i];
         }
         if (mult_sum > 0x7fffffffll) { prl_set_error("weighted boards: too many boards in all"); return PRL_ERR_ARG; }
+        if (symmetrize) {
+            // the orbit mean at the chance node equals the whole game's sum only for suit-class representatives with their orbit sizes -- any other
+            // weighting (importance-sampled boards, ...) is `symmetrize` 0. Checked here: every listed board is the canonical member of its class
+            // (prl_policy.h: prl_suit_canon; cards ascending), its multiplicity is the size of its orbit, and -- unless symmetrize is
+            // PRL_SYMMETRIZE_SUBSET -- the list covers the game: the multiplicities add up to C(n_cards, k).
+            if (symmetrize != 1 && symmetrize != PRL_SYMMETRIZE_SUBSET) { prl_set_error("symmetrize: 0, 1 (all suit classes) or 2 (a subset of them)"); return PRL_ERR_ARG; }
+            const int n_perm = prl_n_suit_perms(r.n_suits);
+            for (int i = 0; i < full.n_boards; ++i) {
+                const int8_t* b = full.boards.data() + (size_t)i * full.board_len;
+                int8_t cb[5];
+                prl_suit_canon(b, full.board_len, r.n_suits, cb);
+                int stab = 0;  // relabellings that leave the (canonical) board in place
+                for (int k = 0; k < n_perm; ++k) {
+                    int p[4] = {0, 1, 2, 3};
+                    prl_suit_perm(k, r.n_suits, p);
+                    unsigned long long m0 = 0ull, m1 = 0ull;
+                    for (int c = 0; c < full.board_len; ++c) { m0 |= 1ull << b[c]; m1 |= 1ull << ((b[c] / r.n_suits) * r.n_suits + p[b[c] % r.n_suits]); }
+                    stab += m0 == m1;
+                }
+                bool same = true;
+                for (int c = 0; c < full.board_len; ++c) same = same && cb[c] == b[c];
+                if (!same || board_mult[i] != n_perm / stab) {
+                    prl_set_error("symmetrize: board " + std::to_string(i) + (same ? " carries a multiplicity that is not the size of its suit orbit" :
+                                  " is not the representative of its suit class (the lexicographically smallest relabelling, cards ascending)") +
+                                  " -- weighted boards that are not suit classes go with symmetrize = 0");
+                    return PRL_ERR_ARG;
+                }
+            }
+            if (symmetrize == 1 && mult_sum != prl_comb(r.n_cards, full.board_len)) {
+                prl_set_error("symmetrize: the listed classes do not cover the game (their multiplicities add up to " + std::to_string(mult_sum) + " of " +
+                              std::to_string(prl_comb(r.n_cards, full.board_len)) + " boards); a deliberate subset is symmetrize = 2");
+                return PRL_ERR_ARG;
+            }
+        }
     } else if (symmetrize) { prl_set_error("symmetrize needs board multiplicities"); return PRL_ERR_ARG; }
     if ((flags & PRL_SOLVER_AVG_F32) && (!fused || variant != PRL_CFR_PLUS)) {
         prl_set_error("PRL_SOLVER_AVG_F32: the fused engines (single-deal board pass, per-street passes) with CFR+ only (the variant whose running average the passes blend)");
@@ -2220,3 +2257,180 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
 }
 
 }  // extern "C"
+
+// ---- the policy table of a solver's average strategy (prl_policy.h; include/pokerrl_hip.h section 6) --------------------------------------------------
+namespace {
+// columns [.][R] of `elem` bytes (4: float32, 8: float64) -> rows of the table. Row r of this launch is row row0 + r of the table; rows repeat with
+// `period` (the decision nodes of one board subtree; period = the number of rows when nothing repeats): row r is entry t = r % period of the per-row
+// arrays in repetition rep = r / period, its j-th action column is source column rep * cols_per_rep + col0[t] + j and goes to action col_action[col0[t] + j].
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_table_fill(const void* cols, int elem, int R, int n_rows_here, int period, int cols_per_rep, const int32_t* col0,
+                                                        const int32_t* nch, const int32_t* col_action, int n_actions, long long row0, float* probs) {
+    const long long i = (long long)prl_bid() * prl_nthreads() + prl_tid();
+    if (i >= (long long)n_rows_here * R) return;
+    const int r = (int)(i / R), h = (int)(i - (long long)r * R);
+    const int rep = r / period, t = r - rep * period;
+    for (int j = 0; j < nch[t]; ++j) {
+        const size_t at = ((size_t)rep * cols_per_rep + col0[t] + j) * R + h;
+        const float v = elem == 8 ? (float)((const double*)cols)[at] : ((const float*)cols)[at];
+        probs[((size_t)(row0 + r) * n_actions + col_action[col0[t] + j]) * R + h] = v;
+    }
+}
+
+struct TableReplay {
+    const PrlFlatTree& t;
+    uint32_t seed;
+    std::vector<LbrbHistKey> key_of;  // per node (decision nodes)
+    std::vector<int32_t> twin_of;     // node whose public state and history this node repeats (two bet sizes that the env turns into one amount), else -1
+    std::vector<int32_t> rows;        // decision nodes that get a row, in node order
+    TableReplay(const PrlFlatTree& tree, uint32_t key_seed) : t(tree), seed(key_seed), key_of(tree.n_nodes), twin_of(tree.n_nodes, -1) {}
+    void walk(int id, const PrlEnvState& st, const LbrbHistKey& parent_key) {
+        const int8_t* row = t.board_id[id] >= 0 ? t.boards.data() + (size_t)t.board_id[id] * t.board_len : nullptr;
+        int n_dealt = 0;
+        for (int c = 0; row && c < t.board_len; ++c) n_dealt += row[c] >= 0;
+        int8_t none[PRL_MAX_BOARD_CARDS] = {0, 0, 0, 0, 0};
+        key_of[id] = lbrb_hist_step(parent_key, st, row ? row : none, n_dealt, t.rules.n_board_cards, t.rules.n_suits);
+        if (t.n_children[id] == 0) return;
+        rows.push_back(id);
+        for (int i = 0; i < t.n_children[id]; ++i) {
+            const int c = t.child_list[t.child_start[id] + i];
+            PrlEnvState s2 = st;
+            PrlStepInfo info;
+            prl_env_step(t.game, s2, t.col_action[t.first_col[id] + i], &info);
+            if (info.is_terminal) continue;  // fold / showdown leaves, all-in run-out chains: no decisions below
+            if (t.kind[c] == PRL_NODE_CHANCE) {
+                for (int k = 0; k < t.n_children[c]; ++k) walk(t.child_list[t.child_start[c] + k], s2, key_of[id]);
+            } else walk(c, s2, key_of[id]);
+        }
+    }
+};
+}  // namespace
+
+extern "C" int32_t prl_policy_table_from_solver(prl_solver_t* s, const prl_tree_t* tree, uint32_t key_seed, prl_policy_table_t** out) {
+    if (!s || !tree || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
+    *out = nullptr;
+    const PrlFlatTree& full = *prl_tree_flat(tree);
+    if (full.n_nodes != s->full_nodes || full.n_cols != s->full_cols || full.rules.range_size != s->R) { prl_set_error("prl_policy_table_from_solver: not the tree this solver was created on"); return PRL_ERR_ARG; }
+    if (s->streets || s->world > 1) { prl_set_error("prl_policy_table_from_solver: LEVELS engine or the single-deal fused engine, unsharded"); return PRL_ERR_UNSUPPORTED; }
+    if (s->fused && s->user_strategy_f64 >= 0) { prl_set_error("prl_policy_table_from_solver: an explicit strategy is loaded; the table is made of a CFR run's average"); return PRL_ERR_STATE; }
+    if (s->iter < 1 || (s->variant == PRL_CFR_PLUS && s->iter <= s->delay)) { prl_set_error("prl_policy_table_from_solver: no average strategy yet (iterate first; CFR+ starts averaging after `delay` iterations)"); return PRL_ERR_STATE; }
+    if (s->fused) {  // a run of prl_solver_iterations leaves its last evaluation (and the Vanilla / Linear average update riding on it) pending
+        TRY(ensure_ev(s));
+        if (s->avg_pending[0] >= 0 || s->avg_pending[1] >= 0) { prl_set_error("prl_policy_table_from_solver: iteration not closed"); return PRL_ERR_STATE; }
+    }
+    TRY(ensure_board_avg(s));
+    // rows and their history keys: the env replayed along the tree
+    TableReplay rp(full, key_seed);
+    {
+        PrlEnvState st;
+        prl_env_reset(full.game, st);
+        rp.walk(0, st, lbrb_hist_root(key_seed));
+    }
+    const int n_act = full.game.game_type == PRL_GAME_LIMIT ? 3 : full.game.n_bet_sizes + 2;
+    // two rows with one key: children of one node that the env turns into the same state (a bet size below the minimum raise and the minimum raise
+    // itself) repeat each other node for node -- the first one keeps the rows (no look-up could tell them apart); anything else is a hash collision
+    std::vector<int32_t> rows;
+    {
+        std::unordered_map<unsigned long long, int32_t> first;  // key -> the node that holds it (rp.rows is in node order: parents come first)
+        first.reserve(rp.rows.size() * 2);
+        auto dec_parent = [&](int n) { int p = full.parent[n]; while (p >= 0 && full.kind[p] != PRL_NODE_DECISION) p = full.parent[p]; return p; };
+        auto orig = [&](int n) { return n >= 0 && rp.twin_of[n] >= 0 ? rp.twin_of[n] : n; };
+        for (int32_t b : rp.rows) {
+            auto it = first.emplace(lbrb_key64(rp.key_of[b]), b);
+            if (it.second) { rows.push_back(b); continue; }
+            const int a = it.first->second, pa = dec_parent(a), pb = dec_parent(b);
+            if (!(pa >= 0 && pb >= 0 && orig(pa) == orig(pb) && full.board_id[a] == full.board_id[b])) {
+                prl_set_error("prl_policy_table_from_solver: nodes " + std::to_string(a) + " and " + std::to_string(b) + " share a 64-bit history key; build the table under another key_seed");
+                return PRL_ERR_STATE;
+            }
+            rp.twin_of[b] = orig(a);
+        }
+    }
+    const int n_rows = (int)rows.size();
+    if (n_rows < 1) { prl_set_error("prl_policy_table_from_solver: the tree has no decision node"); return PRL_ERR_ARG; }
+    uint32_t cap = 2;
+    while (cap < 2u * (uint32_t)n_rows) cap *= 2;
+    std::vector<uint64_t> keys(cap, 0);
+    std::vector<int32_t> slot_row(cap, -1);
+    for (int r = 0; r < n_rows; ++r) {
+        const LbrbHistKey& hk = rp.key_of[rows[r]];
+        uint32_t i = lbrb_first_slot(hk, cap - 1);
+        while (keys[i] != 0) i = (i + 1u) & (cap - 1);
+        keys[i] = lbrb_key64(hk); slot_row[i] = r;
+    }
+    PrlPolicyTable* T = prl_policy_table_alloc(keys.data(), slot_row.data(), cap, nullptr, n_rows, n_act, s->R, key_seed);
+    if (!T) return PRL_ERR_OOM;
+    T->suit_canon = s->symmetrize ? 1 : 0;
+    int rc = PRL_OK;
+    int32_t* d_meta = nullptr;
+    auto fail = [&](int code) { prl_policy_table_destroy(T); (void)hipFree(d_meta); return code; };
+#define PT_TRY(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); prl_set_error("HIP error in prl_policy_table_from_solver"); return fail(PRL_ERR_HIP); } } while (0)
+    // rows whose columns lie in hand order ([col][R] float64): every row of the LEVELS engine / an unsorted fused solve, the trunk's rows of the sorted one
+    int n_plain = n_rows;
+    if (s->sorted) {
+        n_plain = 0;
+        while (n_plain < n_rows && full.first_col[rows[n_plain]] < s->col_base) ++n_plain;
+        // the boards' rows: n_dec per board, board after board, columns col_base + b * ncb + the shape's local columns
+        const int n_dec = s->fp.n_dec;
+        bool ok = n_rows - n_plain == s->fp.n_boards * n_dec;
+        for (int b = 0; ok && b < s->fp.n_boards; b += (s->fp.n_boards > 64 ? s->fp.n_boards / 64 : 1))
+            for (int d = 0; d < n_dec; ++d) {
+                const int n = rows[n_plain + b * n_dec + d];
+                ok = ok && full.first_col[n] == s->col_base + b * s->ncb + s->fp.dec_col0[d] && full.n_children[n] == s->fp.dec_nch[d];
+            }
+        if (!ok) { prl_set_error("prl_policy_table_from_solver: the tree's rows do not follow the board pass's layout"); return fail(PRL_ERR_UNSUPPORTED); }
+    }
+    {
+        std::vector<int32_t> meta;  // col0[n_plain], nch[n_plain], col_action[full trunk / all columns]
+        const int n_cols_plain = s->sorted ? s->col_base : s->full_cols;
+        for (int r = 0; r < n_plain; ++r) meta.push_back(full.first_col[rows[r]]);
+        for (int r = 0; r < n_plain; ++r) meta.push_back(full.n_children[rows[r]]);
+        for (int c = 0; c < n_cols_plain; ++c) meta.push_back(full.col_action[c]);
+        if (s->sorted) {  // one board's decision nodes: local col0, nch, the local columns' actions
+            for (int d = 0; d < s->fp.n_dec; ++d) meta.push_back(s->fp.dec_col0[d]);
+            for (int d = 0; d < s->fp.n_dec; ++d) meta.push_back(s->fp.dec_nch[d]);
+            for (int j = 0; j < s->ncb; ++j) meta.push_back(full.col_action[s->col_base + j]);
+        }
+        PT_TRY(hipMalloc((void**)&d_meta, meta.size() * 4 + 16));
+        PT_TRY(hipMemcpy(d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice));
+        PT_TRY(hipStreamSynchronize(s->stream));
+        if (n_plain > 0) {
+            const long long n = (long long)n_plain * s->R;
+            PRL_LAUNCH(prl_k_table_fill, (unsigned)((n + 255) / 256), 256, 0, s->stream, (const void*)s->d_avg, 8, s->R, n_plain, n_plain, 0, (const int32_t*)d_meta,
+                       (const int32_t*)(d_meta + n_plain), (const int32_t*)(d_meta + 2 * n_plain), n_act, 0ll, T->probs);
+            PT_TRY(hipGetLastError());
+        }
+        if (s->sorted) {
+            rc = stage_ready(s);
+            if (rc) return fail(rc);
+            double fill[PRL_FHP_MAX_NODES * 3] = {0.};
+            blocked_avg_fill(s, fill);
+            const int elem = s->avg_f32 ? 4 : 8;
+            const void* region = s->avg_f32 ? (const void*)(s->d_avg32 + s->board_ofs) : (const void*)(s->d_avg + s->board_ofs);
+            {
+                char tmp[PRL_FHP_MAX_NODES * 3 * 8];
+                for (int j = 0; j < s->ncb; ++j) {
+                    if (elem == 4) ((float*)tmp)[j] = (float)fill[j];
+                    else ((double*)tmp)[j] = fill[j];
+                }
+                PT_TRY(hipMemcpyAsync(s->d_fill, tmp, (size_t)s->ncb * elem, hipMemcpyHostToDevice, s->stream));
+                PT_TRY(hipStreamSynchronize(s->stream));
+            }
+            const int32_t* m = d_meta + 2 * n_plain + s->col_base;
+            const int n_dec = s->fp.n_dec;
+            for (int at = 0; at < s->fp.n_boards; at += s->stage_boards) {
+                const int nb = s->fp.n_boards - at < s->stage_boards ? s->fp.n_boards - at : s->stage_boards;
+                prl_launch_fhp_expand(s->fp, region, elem, at, nb, s->d_fill, nullptr, s->d_stage, s->stream);
+                PT_TRY(hipGetLastError());
+                const long long n = (long long)nb * n_dec * s->R;
+                PRL_LAUNCH(prl_k_table_fill, (unsigned)((n + 255) / 256), 256, 0, s->stream, (const void*)s->d_stage, elem, s->R, nb * n_dec, n_dec, s->ncb, m, m + n_dec,
+                           m + 2 * n_dec, n_act, (long long)n_plain + (long long)at * n_dec, T->probs);
+                PT_TRY(hipGetLastError());
+            }
+        }
+        PT_TRY(hipStreamSynchronize(s->stream));
+    }
+#undef PT_TRY
+    (void)hipFree(d_meta);
+    *out = T;
+    return PRL_OK;
+}

@@ -146,7 +146,10 @@ class PublicTree:
         """boards=None: the builder deals the chance outcomes from the deck itself as the reference does (PublicTree.py:188-210) -- every board
         of the game (Leduc: the 6 cards; Flop5Holdem: all C(52,5) five-card boards), or a subset: n_boards= (games that deal once) /
         max_outcomes=(flops, turns, rivers) (games that deal on several streets), the first ones in combinatorial order or, with board_seed=,
-        a seeded choice (pokerrl_amd/game/board_enum.py). boards=[[c1..c5], ...] lists them explicitly (run-outs in deal order)."""
+        a seeded choice (pokerrl_amd/game/board_enum.py). boards=[[c1..c5], ...] lists them explicitly (run-outs in deal order).
+        board_mult= (with explicit boards): weighted boards, board i standing for board_mult[i] boards of the game. They are only treated as SUIT CLASSES
+        (orbit-mean chance values: prl_solver_create_weighted's `symmetrize`) when suit_isomorphism says so -- True: the representatives of ALL classes,
+        "subset": some of them; the library checks either claim. Any other weighting (sampled boards with importance weights ...) leaves it None / False."""
         self._env_bldr = env_bldr
         self._stack_size = stack_size
         self._is_debugging = is_debugging
@@ -202,6 +205,8 @@ class PublicTree:
             boards, self._board_mult = board_enum.default_boards_or_classes(env_cls, n_boards=n_boards, max_outcomes=max_outcomes, seed=seed,
                                                                                 suit_isomorphism=self._suit_iso)
             self._boards = boards
+            if self._board_mult is not None:
+                self._suit_iso = True  # the enumeration above produced every class of the game
         self._native_tree = _native.NativeTree(env_cls.native_game(args), env_cls.native_rules(), boards,
                                                stop_at_round=self._stop_at_street if self._is_partial else None)
         t = self._native_tree
@@ -211,7 +216,7 @@ class PublicTree:
         if self._is_partial:
             self._solver = None
         elif self._board_mult is not None:  # the whole game through its suit classes: fused engine, prl_solver_create_weighted
-            self._solver = _native.NativeSolver(t, variant, delay, board_mult=self._board_mult, symmetrize=True)
+            self._solver = _native.NativeSolver(t, variant, delay, board_mult=self._board_mult, symmetrize=self._suit_iso or False)
         else:
             self._solver = _native.NativeSolver(t, variant, delay, engine=self._engine)
         self.root = self.node(0)

@@ -182,6 +182,34 @@ class Chunked:
         self.hist.append(self.sweep(n_iters, None))
         return np.stack(self.hist)
 
+    def eval_avg(self):
+        """_CFRBase._evaluate_avg_strats (_CFRBase.py:218-262) chunk by chunk, after run(): every instance plays its AVERAGE strategy (float64, the trunk's
+        from the trunk instance, the boards' from disk), reach, EVs, the canonical sum of the board roots into the trunk's chance node (symmetrised there
+        for suit classes) -> exploitability of the average strategy; what orc_eval_avg does in one piece. Leaves the instances' strategies overwritten."""
+        assert self.pending is None, "run() closes with an evaluation that applies the last pending average update"
+        T, groups = self.T, []
+        for c in range(self.n_chunks):
+            O = self._chunk_instance(c)
+            O.strategy[:self.nt] = T.avg[:self.nt]
+            O.strat_f64[:self.first_board] = T.avg_f64[:self.first_board]
+            O.strategy[self.nt:] = O.avg[self.nt:]
+            O.strat_f64[self.first_board:] = O.avg_f64[self.first_board:]
+            O.update_reach()
+            O.compute_ev()
+            roots = self.first_board + NB * np.arange(len(self.boards[c * self.chunk:(c + 1) * self.chunk]))
+            groups.append(group_sums(np.concatenate([O.ev[roots], O.ev_br[roots]], axis=1)))
+            print("  average-strategy evaluation chunk %d/%d" % (c + 1, self.n_chunks), flush=True)
+        g = np.concatenate(groups)
+        total = g[0].copy()
+        for i in range(1, len(g)):
+            total = total + g[i]
+        T.strategy[:self.nt] = T.avg[:self.nt]
+        T.strat_f64[:self.first_board] = T.avg_f64[:self.first_board]
+        T.update_reach()
+        T.set_override(self.chance, total[0:2], total[2:4])
+        T.compute_ev()
+        return np.array(T.exploitability, np.float32)
+
     def state_hashes(self):
         """sha-256 of regret / avg in the flat tree's column order: trunk columns, then every board's, chunk after chunk"""
         out = {}
@@ -219,7 +247,9 @@ def selftest(workdir, variant="plus"):
     assert hs["regret"] == h32(np.asarray(o.regret)) and hs["avg"] == h32(np.asarray(o.avg))
     if variant != "plus":
         assert np.array_equal(full["avg_sum"], np.asarray(o.avg_sum)) and hs["avg_sum"] == h32(np.asarray(o.avg_sum))
-    print("selftest ok: the chunked run equals the one-piece oracle (2048 boards, 2 iterations, %s)" % variant)
+    ea = ch.eval_avg()
+    assert np.array_equal(ea, o.eval_avg()), (ea, o.eval_avg())
+    print("selftest ok: the chunked run equals the one-piece oracle (2048 boards, 2 iterations, %s; average-strategy exploitability %s)" % (variant, ea))
 
 
 def selftest_weighted(workdir, variant="plus"):
@@ -248,7 +278,9 @@ def selftest_weighted(workdir, variant="plus"):
     assert hs["regret"] == h32(np.asarray(o.regret)) and hs["avg"] == h32(np.asarray(o.avg))
     if variant != "plus":
         assert np.array_equal(full["avg_sum"], np.asarray(o.avg_sum)) and hs["avg_sum"] == h32(np.asarray(o.avg_sum))
-    print("selftest ok: the chunked weighted run equals the one-piece oracle (2363 suit classes in chunks of 1024 + 1024 + 315, 3 iterations, %s)" % variant, hist[-1])
+    ea = ch.eval_avg()
+    assert np.array_equal(ea, o.eval_avg()), (ea, o.eval_avg())
+    print("selftest ok: the chunked weighted run equals the one-piece oracle (2363 suit classes in chunks of 1024 + 1024 + 315, 3 iterations, %s)" % variant, hist[-1], "average:", ea)
 
 
 def main_whole_game(n_iters, chunk, workdir, variant="plus"):
@@ -259,10 +291,11 @@ def main_whole_game(n_iters, chunk, workdir, variant="plus"):
     ch = Chunked(reps, chunk, workdir, variant, mult=mult, sym_class=board_enum.hand_suit_classes(G.Flop5Holdem))
     hist = ch.run(n_iters)
     hs = ch.state_hashes()
+    ea = ch.eval_avg()  # (round 6) the average strategy's exploitability at full size: the <EVAL, AVG, AVG> pass over a ragged last chunk + orbit means
     out = os.path.join(HERE, "fhp_whole_game_%s_chunked.npz" % variant)
     np.savez(out, n_classes=len(reps), n_boards=int(mult.sum()), variant=variant, n_iters=n_iters, chunk=chunk, boards_sha256=h32(reps), mult_sha256=h32(mult.astype(np.int32)),
-             expl_history=hist, regret_sha256=hs["regret"], avg_sha256=hs["avg"], avg_sum_sha256=hs.get("avg_sum", ""), numpy=np.__version__)
-    print("wrote", out, hist)
+             expl_history=hist, regret_sha256=hs["regret"], avg_sha256=hs["avg"], avg_sum_sha256=hs.get("avg_sum", ""), eval_avg=ea, numpy=np.__version__)
+    print("wrote", out, hist, "average strategy:", ea)
 
 
 def main(n_boards, n_iters, chunk, workdir, variant="plus", seed=0):

@@ -568,7 +568,7 @@ def check_weighted_vs_oracle(L, n_classes, n_iters, variant="plus", symmetrize=T
     from pokerrl_amd.game import board_enum
     reps, mult = classes if classes is not None else iso_classes(n_classes)
     t = fhp_tree_of(L, reps)
-    s = _native.NativeSolver(t, variant, 0, _lib=L, board_mult=mult, symmetrize=symmetrize)
+    s = _native.NativeSolver(t, variant, 0, _lib=L, board_mult=mult, symmetrize="subset" if symmetrize else False)  # a few classes, not the game
     assert s.engine == "fused"
     o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, 2, 52, 4, 2)
     w = o.set_board_weights(mult)
@@ -612,7 +612,7 @@ def check_weighted_checkpoint(L):
     multiplicities differ (they are part of the fingerprint)"""
     reps, mult = iso_classes(4)
     t = fhp_tree_of(L, reps)
-    mk = lambda m: _native.NativeSolver(t, "plus", 0, _lib=L, board_mult=m, symmetrize=True)  # noqa: E731
+    mk = lambda m: _native.NativeSolver(t, "plus", 0, _lib=L, board_mult=m, symmetrize="subset")  # noqa: E731
     a = mk(mult)
     a.iterations(3)
     b = mk(mult)
@@ -626,8 +626,30 @@ def check_weighted_checkpoint(L):
     assert np.array_equal(a.eval_avg(), c.eval_avg())
     other = mult.copy()
     other[0] = 12 if other[0] != 12 else 24
-    with pytest.raises(Exception):
-        mk(other).load_state(blob)
+    with pytest.raises(_native.NativeError, match="orbit"):  # suit classes are checked, not trusted: a multiplicity that is not the orbit's size
+        mk(other)
+    with pytest.raises(_native.NativeError):  # ... and as plain weighted boards (no orbit means) the problem is another one: the blob does not load
+        _native.NativeSolver(t, "plus", 0, _lib=L, board_mult=other, symmetrize=False).load_state(blob)
+
+
+def check_symmetrize_is_validated(L):
+    """prl_solver_create_weighted with `symmetrize` checks its premise (round 5's advisor finding): every listed board the representative of its suit class,
+    its multiplicity the orbit's size, and -- unless a subset is declared -- the whole game covered. Weighted boards that are not suit classes take symmetrize=False."""
+    reps, mult = iso_classes(4)
+    t = fhp_tree_of(L, reps)
+    mk = lambda tree, m, sym: _native.NativeSolver(tree, "plus", 0, _lib=L, board_mult=m, symmetrize=sym)  # noqa: E731
+    mk(t, mult, "subset")
+    with pytest.raises(_native.NativeError, match="do not cover the game"):
+        mk(t, mult, True)
+    member = np.array(suit_orbit([int(c) for c in reps[1]])[-1], np.int8)  # another member of class 1: not its representative
+    assert not np.array_equal(member, reps[1])
+    boards = reps.copy()
+    boards[1] = member
+    with pytest.raises(_native.NativeError, match="not the representative"):
+        mk(fhp_tree_of(L, boards), mult, "subset")
+    mk(fhp_tree_of(L, boards), mult, False)  # importance-style weights on arbitrary boards: fine without the orbit means
+    with pytest.raises(ValueError):
+        _native.NativeSolver(t, "plus", 0, _lib=L, board_mult=mult, symmetrize="subset", place=2)
 
 
 def check_streets_avg_f32(L, game_cls, stack, runouts, n_iters, max_raises=None, batched=False):

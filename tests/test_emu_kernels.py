@@ -133,6 +133,10 @@ def test_emu_fused_engine_weighted_boards_checkpoint_resume(L):
     pc.check_weighted_checkpoint(L)
 
 
+def test_emu_suit_classes_are_checked_not_trusted(L):
+    pc.check_symmetrize_is_validated(L)
+
+
 def test_emu_fused_engine_float32_running_average_opt_in(L):
     """PRL_SOLVER_AVG_F32: generic and steady-state instantiations of the update passes with the average stored as float32"""
     pc.check_fused_avg_f32(L, 3, 4)

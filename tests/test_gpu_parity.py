@@ -431,7 +431,7 @@ def test_gpu_fused_suit_isomorphism_equals_the_full_board_list(L):
     class S:
         def __init__(self, boards, mult):
             from pokerrl_amd import _native
-            self.s = _native.NativeSolver(pc.fhp_tree_of(L, boards), "plus", 0, engine="fused", _lib=L, board_mult=mult, symmetrize=mult is not None)
+            self.s = _native.NativeSolver(pc.fhp_tree_of(L, boards), "plus", 0, engine="fused", _lib=L, board_mult=mult, symmetrize="subset" if mult is not None else False)
 
         def iteration(self):
             self.s.iteration()

@@ -391,6 +391,207 @@ def test_gpu_lbr_against_the_solvers_average_strategy_is_a_lower_bound_of_its_ex
     assert seen[1][0] < 0.2 * seen[0][0] and seen[1][1] + seen[1][2] < seen[0][1] - seen[0][2], seen  # exploitability and LBR winnings both fell
 
 
+# ---- hold'em-sized tables straight from the fused solver (PolicyTable.from_solver), suit-canonical look-ups -----------------------------------------------
+import contextlib
+
+
+@contextlib.contextmanager
+def forced_deck(deck):
+    """inside: a 52-card deck that is shuffled comes out with `deck` (1d cards) on top, in that order"""
+    deck, shuffle = [int(c) for c in deck], np.random.shuffle
+    order = np.asarray(deck + [c for c in range(52) if c not in deck])
+
+    def forced(arr):
+        if getattr(arr, "shape", None) == (52, 2):
+            arr[:] = np.stack([order // 4, order % 4], axis=1)
+        else:
+            shuffle(arr)
+
+    np.random.shuffle = forced
+    try:
+        yield
+    finally:
+        np.random.shuffle = shuffle
+
+
+class _DealtLBRWorker(LocalLBRWorker):
+    """the host worker on GIVEN decks (seat 0's hole cards, seat 1's, the board in deal order): the env's shuffle of hand k yields deck k"""
+    DECKS, _k = None, 0
+
+    def _reset_episode(self):
+        with forced_deck(self.DECKS[self._k]):
+            ret = self._env.reset()
+        self._k += 1
+        self.agent.reset(deck_state_dict=self._env.cards_state_dict())
+        self.agent_range.reset()
+        return ret
+
+
+def fhp_class_solver(L, n_classes, n_iters, variant="plus"):
+    """CFR on Flop5Holdem over a few suit classes (the whole-game solve in small: representatives x orbit sizes, orbit-mean chance values)"""
+    import parity_cases as pc
+    reps, mult = pc.iso_classes(n_classes)
+    t = pc.fhp_tree_of(L, reps)
+    s = _native.NativeSolver(t, variant, 0, _lib=L, board_mult=mult, symmetrize="subset")
+    s.iterations(n_iters)
+    return s, reps, mult
+
+
+def decks_on_classes(reps, n_hands, seed, stranger_every=0):
+    """hands whose boards are random MEMBERS of the given suit classes (any relabelling, any deal order); every `stranger_every`-th board is from no listed class"""
+    import parity_cases as pc
+    rng = np.random.RandomState(seed)
+    orbits = [pc.suit_orbit([int(c) for c in r]) for r in reps]
+    listed = {b for o in orbits for b in o}
+    decks = []
+    for i in range(n_hands):
+        if stranger_every and i % stranger_every == stranger_every - 1:
+            while True:
+                board = tuple(sorted(int(c) for c in rng.choice(52, 5, replace=False)))
+                if board not in listed:
+                    break
+        else:
+            o = orbits[rng.randint(len(orbits))]
+            board = o[rng.randint(len(o))]
+        board = [board[j] for j in rng.permutation(5)]
+        rest = [c for c in range(52) if c not in board]
+        hole = [rest[j] for j in rng.choice(len(rest), 4, replace=False)]
+        decks.append(hole + board)
+    return np.asarray(decks, np.int8)
+
+
+def check_canon_agrees_with_the_library(L):
+    """the host twin's canonicalisation (rl/tabular_agent.py: suit_canon, hand_perm) was written on its own: equal to the library's (prl_suit_canon /
+    prl_suit_perm_hand through the table look-ups below) on random boards, boards with stabilisers among them; representatives are fixed points"""
+    import ctypes
+    from pokerrl_amd.game import board_enum
+    from pokerrl_amd.rl.tabular_agent import suit_canon
+    rng = np.random.RandomState(1)
+    boards = np.stack([np.sort(rng.choice(52, 5, replace=False)) for _ in range(3000)] + [[0, 4, 8, 12, 16], [0, 1, 2, 3, 7], [3, 7, 11, 50, 51], [1, 5, 9, 13, 18]]).astype(np.int8)
+    out, perm = np.zeros_like(boards), np.zeros(len(boards), np.int32)
+    L.prl_suit_canon_boards.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    L.prl_suit_canon_boards.restype = ctypes.c_int32
+    _native.check(L.prl_suit_canon_boards(boards.ctypes.data_as(ctypes.c_void_p), len(boards), 5, 4, out.ctypes.data_as(ctypes.c_void_p), perm.ctypes.data_as(ctypes.c_void_p)), L)
+    for b, cb, k in zip(boards, out, perm):
+        want, wk = suit_canon(b)
+        assert np.array_equal(cb, want) and k == wk, (b, cb, k, want, wk)
+    import parity_cases as pc
+    reps, _ = pc.iso_classes(40)
+    r2, k2 = np.zeros_like(reps), np.zeros(len(reps), np.int32)
+    _native.check(L.prl_suit_canon_boards(np.ascontiguousarray(reps).ctypes.data_as(ctypes.c_void_p), len(reps), 5, 4, r2.ctypes.data_as(ctypes.c_void_p), k2.ctypes.data_as(ctypes.c_void_p)), L)
+    assert np.array_equal(r2, reps) and np.all(k2 == 0)  # a representative is its own canonical form under the identity
+    assert board_enum is not None
+
+
+def check_solver_table_vs_host(L, tmp_path, n_classes, n_iters, n_hands, variant="plus"):
+    """PolicyTable.from_solver on a suit-class solve of Flop5Holdem = the solver's average strategy (row for row against prl_solver_get), and BatchedLBR
+    against it = the host LocalLBRWorker playing the same table, hand for hand, on boards that are arbitrary members of the classes (relabelled, shuffled
+    deal order: the device and the host twin each canonicalise on their own) and on boards of no listed class (uniform play on both sides)"""
+    from pokerrl_amd.game.games import Flop5Holdem
+    from pokerrl_amd.rl.tabular_agent import PolicyTable, make_table_agent_cls
+    s, reps, mult = fhp_class_solver(L, n_classes, n_iters, variant)
+    table = PolicyTable.from_solver(s)
+    assert table.suit_canon and table.n_actions == 3 and table.range_size == 1326
+    t = s.tree
+    kind, first_col, nch, col_action = t.field("kind"), t.field("first_col"), t.field("n_children"), t.field("col_action")
+    dec = [i for i in range(t.n_nodes) if kind[i] == 0]
+    assert table.n_rows == len(dec) == 2 + 6 * len(reps)
+    avg = s.get("avg")
+    for r in (0, 1, 2, 5, 8, table.n_rows - 1):  # rows are the decision nodes in node order: the table holds float32(average), 0 for actions a node lacks
+        want = np.zeros((3, 1326), np.float32)
+        for j in range(nch[dec[r]]):
+            want[col_action[first_col[dec[r]] + j]] = avg[first_col[dec[r]] + j].astype(np.float32)
+        assert np.array_equal(table.row_probs(r), want), r
+    t_prof = make_t_prof(Flop5Holdem, None, dict(lbr_check_to_round=Poker.FLOP), n_hands, tmp_path)
+    b = BatchedLBR(t_prof, agent_kind="table", agent_seed=7, table=table)
+    total_misses = 0
+    for seat in (0, 1):
+        decks = decks_on_classes(reps, n_hands, seed=11 + seat, stranger_every=5)
+        w = _DealtLBRWorker(t_prof=t_prof, chief_handle=None, eval_agent_cls=make_table_agent_cls(EvalAgentBase, table, seed=7))
+        w.DECKS = decks
+        misses, lookup = [], table.row_of
+        table.row_of = lambda hk, _f=lookup: (misses.append(1) if _f(hk) < 0 else None, _f(hk))[1]
+        try:
+            want = w.run(agent_seat_id=seat, n_iterations=n_hands, mode="TABLE", stack_size=[Flop5Holdem.DEFAULT_STACK_SIZE] * 2)
+        finally:
+            del table.row_of
+        got = b.run(agent_seat_id=seat, n_hands=n_hands, decks=decks)
+        assert np.array_equal(got, want), "seat %d: %d of %d hands differ (first at %s): %s vs %s" % (seat, int(np.sum(got != want)), n_hands, np.flatnonzero(got != want)[:5], got[:8], want[:8])
+        total_misses += len(misses)
+        if seat == 0:  # the agent (seat 0) raises or folds before the flop; LBR (the big blind) calls and plays the flop: the table is in use there
+            assert len(np.unique(got)) > 2, got  # (with the agent in seat 1, LBR's forced pre-flop "call" is a fold of the small blind: -500 every hand)
+            uni = BatchedLBR(t_prof, agent_kind="uniform").run(agent_seat_id=seat, n_hands=n_hands, decks=decks)
+            assert not np.array_equal(uni, got)
+            assert b.last_stats["lbr_lookaheads"] > 0
+    assert total_misses > 0  # the strangers' boards were met (and played uniformly on both sides)
+    table.close()
+    return s
+
+
+def check_solver_table_h2h_vs_host(L, tmp_path, n_classes, n_iters, n_hands):
+    """head-to-head on Flop5Holdem: the class solve's average strategy (mode "TABLE", a suit-canonical table built on the device) against the hash agent
+    -- BatchedHead2Head = the host LocalHead2HeadMaster on the same decks, hand for hand"""
+    from pokerrl_amd.eval.head_to_head import BatchedHead2Head, H2HArgs, LocalHead2HeadMaster
+    from pokerrl_amd.game.games import Flop5Holdem
+    from pokerrl_amd.rl.tabular_agent import PolicyTable, make_table_agent_cls
+    s, reps, _mult = fhp_class_solver(L, n_classes, n_iters)
+    table = PolicyTable.from_solver(s)
+    t_prof = TrainingProfileBase(
+        name="h2h_fhp", log_verbose=False, log_export_freq=1, checkpoint_freq=10 ** 9, eval_agent_export_freq=10 ** 9, game_cls=Flop5Holdem,
+        env_bldr_cls=HistoryEnvBuilder, start_chips=None, eval_modes_of_algo=("TABLE", "HASH2"), eval_stack_sizes=None,
+        module_args={"env": Flop5Holdem.ARGS_CLS(n_seats=2), "h2h": H2HArgs(n_hands=n_hands)}, path_data=str(tmp_path))
+    decks = decks_on_classes(reps, 2 * n_hands, seed=23, stranger_every=7)
+    m = LocalHead2HeadMaster(t_prof=t_prof, chief_handle=_Chief(), eval_agent_cls=make_table_agent_cls(EvalAgentBase, table, seed=11))
+    m.set_modes(["TABLE", "HASH2"])
+    get_env, dealt = m._eval_env_bldr.get_new_env, [0]
+
+    def get_dealt_env(**kw):  # the master's own env deals deck k for hand k (the agents' envs take their cards from it)
+        env = get_env(**kw)
+        reset = env.reset
+
+        def dealt_reset(deck_state_dict=None):
+            with forced_deck(decks[dealt[0]]):
+                out = reset(deck_state_dict=deck_state_dict)
+            dealt[0] += 1
+            return out
+
+        env.reset = dealt_reset
+        return env
+
+    m._eval_env_bldr.get_new_env = get_dealt_env
+    want = m.play(stack_size=t_prof.eval_stack_sizes[0])
+    assert dealt[0] == 2 * n_hands
+    b = BatchedHead2Head(t_prof, kinds=("table", "hash"), seeds=(11, 12), tables=(table, None))
+    got = b.play(n_hands=n_hands, decks=decks)
+    assert np.array_equal(got, want), "%d of %d hands differ (first at %s)" % (int(np.sum(got != want)), 2 * n_hands, np.flatnonzero(got != want)[:5])
+    assert len(np.unique(got)) > 4
+    table.close()
+
+
+def test_host_canonicalisation_equals_the_librarys(emu_lib):
+    check_canon_agrees_with_the_library(emu_lib)
+
+
+def test_batched_lbr_solver_table_flop5holdem_vs_host_worker_emu(emu_lib, tmp_path):
+    check_solver_table_vs_host(emu_lib, tmp_path, 3, 2, 10)
+
+
+def test_batched_h2h_solver_table_flop5holdem_vs_host_master_emu(emu_lib, tmp_path):
+    check_solver_table_h2h_vs_host(emu_lib, tmp_path, 3, 2, 14)
+
+
+@pytest.mark.gpu
+def test_gpu_batched_h2h_solver_table_flop5holdem_vs_host_master(tmp_path):
+    check_solver_table_h2h_vs_host(_native.lib(), tmp_path, 12, 4, 300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["plus", "linear"])
+def test_gpu_batched_lbr_solver_table_flop5holdem_vs_host_worker(variant, tmp_path):
+    check_canon_agrees_with_the_library(_native.lib())
+    check_solver_table_vs_host(_native.lib(), tmp_path, 12, 4, 160, variant)
+
+
 def check_master_drives_batched_worker(tmp_path, n_hands):
     """LocalLBRMaster with a BatchedLBRWorker: the chief hands the solver's table over through update_weights, the master logs mean and confidence of
     exactly the hands BatchedLBR plays for those deck / episode numbers"""
