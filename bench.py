@@ -116,22 +116,89 @@ def fixed_problem_check(total, iters, world, rank, how, lib, emu_lib):
     patterns. The sharded solve is bit-identical to the one-GPU solve by construction (canonical chance sum): the driver's N = 1, 2, 4, 8
     lines carry this object, so the claim is checked by the scaling run itself -- equal hex strings in every line."""
     from pokerrl_amd import _native
+
+    def all_ok(ok, what):
+        """the ranks agree before they enter the next collective phase: one rank that failed locally (out of memory, a tree that does not build) must
+        not leave the others waiting inside an all-gather -- every rank raises instead (round 5's advisor finding)"""
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if emu_lib else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = ok and bool(int(flag.item()))
+        if not ok:
+            raise RuntimeError("fixed_problem_check: %s failed on this or another rank" % what)
+
     per, mine = shard_geometry(total, world, rank)
-    tree = fhp_tree(seeded_boards(mine, 0, offset=rank * per), lib)
-    if world == 1:
-        solver = _native.NativeSolver(tree, "plus", 0, engine="fused", _lib=lib)
-    elif how == "rccl":
-        from pokerrl_amd.dist import rccl_shard
-        solver = _native.NativeSolver(tree, "plus", 0, shard=rccl_shard(world, rank, per, total, lib=lib), _lib=lib)
-    else:
-        from pokerrl_amd.dist import TorchExchange
-        solver = _native.NativeSolver(tree, "plus", 0, shard=(world, rank, TorchExchange("cpu" if emu_lib else "cuda"), per, total), _lib=lib)
+    tree, solver, err = None, None, None
+    try:
+        tree = fhp_tree(seeded_boards(mine, 0, offset=rank * per), lib)
+    except Exception as e:  # noqa: BLE001
+        err = e
+    all_ok(tree is not None, "the tree build (%s)" % err)
+    try:  # (creating a sharded solver is itself collective -- ncclCommInitRank, rccl_shard's own pre-flight agreement: every rank gets here)
+        if world == 1:
+            solver = _native.NativeSolver(tree, "plus", 0, engine="fused", _lib=lib)
+        elif how == "rccl":
+            from pokerrl_amd.dist import rccl_shard
+            solver = _native.NativeSolver(tree, "plus", 0, shard=rccl_shard(world, rank, per, total, lib=lib), _lib=lib)
+        else:
+            from pokerrl_amd.dist import TorchExchange
+            solver = _native.NativeSolver(tree, "plus", 0, shard=(world, rank, TorchExchange("cpu" if emu_lib else "cuda"), per, total), _lib=lib)
+    except Exception as e:  # noqa: BLE001
+        err = e
+    all_ok(solver is not None, "the solver (%s)" % err)
     solver.iterations(iters)
     e = np.asarray(solver.exploitability(), np.float32)
     a = np.asarray(solver.eval_avg(), np.float32)
     return {"total_boards": total, "iterations": iters, "world": world, "exchange": how if world > 1 else None,
             "exploitability_f32_hex": [x.tobytes().hex() for x in e], "avg_strategy_exploitability_f32_hex": [x.tobytes().hex() for x in a],
             "exploitability_mbb_per_g": float(np.mean(e) * 10.0)}
+
+
+def whole_game_lines(lib, steps, warmup):
+    """BASELINE config 3 exactly as stated -- "LinearCFR on Flop Hold'em Poker (1326-combo ranges, full public tree), 1 MI355X" -- and CFR+ on the same tree,
+    as two short HIP-event-timed regions inside the default line (round 5's verdict: the driver should see them): ALL 2 598 960 boards of Flop5Holdem
+    through their 134 459 suit classes on this one GPU (prl_solver_create_weighted, ~30 GB). Per variant: ms per iteration (device, HIP events on the
+    solver's stream), the board pass's share, whole-game iterations/s, the roofline fraction on the class tree's algorithmic bytes, the node-updates/s
+    of the class tree and of the full tree it stands for; the average strategy's exploitability after the timed iterations (bit-exact to the oracle's
+    chunked run of the same classes for the first four: tests/golden/fhp_whole_game_*_chunked.npz)."""
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import board_enum
+    from pokerrl_amd.game import games as G
+    t0 = time.perf_counter()
+    reps, mult = board_enum.single_deal_board_classes(G.Flop5Holdem)
+    tree = fhp_tree(reps, lib)
+    setup_s = time.perf_counter() - t0
+    R, sum_a, n_classes = tree.range_size, tree.n_cols, len(reps)
+    bytes_iter = 20.0 * R * sum_a + 8.0 * R * n_classes
+    full_nodes = int(mult.sum()) * 15 + (tree.n_nodes - n_classes * 15)
+    out = {"workload": "full-width iterations on the WHOLE Flop5Holdem public tree (blinds 50/100, stacks 20000, pot-size raises, 1326-hand ranges): all %d boards "
+                       "through their %d suit classes, one GPU" % (int(mult.sum()), n_classes),
+           "suit_classes": n_classes, "boards_represented": int(mult.sum()), "class_tree_nodes": tree.n_nodes, "full_tree_nodes_represented": full_nodes,
+           "class_enumeration_and_tree_build_s": setup_s, "bytes_per_iteration_algorithmic": bytes_iter, "steps": steps, "warmup": warmup}
+    for variant in ("plus", "linear"):
+        s = _native.NativeSolver(tree, variant, 0, _lib=lib, board_mult=mult, symmetrize=True)
+        s.iterations(warmup)
+        s.sync()
+        t1 = time.perf_counter()
+        dev_ms, pass_ms, n_pass = s.time_iterations_ex(steps)
+        s.sync()
+        wall = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        avg = s.eval_avg()
+        eval_ms = (time.perf_counter() - t2) * 1e3
+        k_ms = pass_ms if n_pass else dev_ms
+        out[{"plus": "cfr_plus", "linear": "linear_cfr"}[variant]] = {
+            "ms_per_iteration": wall * 1e3 / steps, "device_ms_per_iteration": dev_ms / steps, "board_pass_kernel_ms_per_iteration": k_ms / steps,
+            "whole_game_iterations_per_s": steps / wall, "class_tree_node_updates_per_s": tree.n_nodes * steps / wall,
+            "equivalent_full_tree_node_updates_per_s": full_nodes * steps / wall,
+            "roofline_frac": bytes_iter * steps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "achieved_gbps": bytes_iter * steps / (k_ms * 1e-3) / 1e9,
+            "iterations_done": s.iter, "exploitability_mbb_per_g": float(np.mean(s.exploitability()) * 10.0),
+            "avg_strategy_exploitability_mbb_per_g": float(np.mean(avg) * 10.0), "avg_strategy_evaluation_ms": eval_ms,
+            "hbm_bytes_allocated": int(s.get("bytes_allocated")[0])}
+        del s
+    return out
 
 
 def launch_ranks(n, argv):
@@ -175,6 +242,9 @@ def main():
     ap.add_argument("--fixed-check-boards", type=int, default=-1,
                     help="after the timed region: one list of this many boards solved by all ranks together for 3 iterations, exploitability bits in "
                          "config.fixed_problem_check -- the same in the N = 1, 2, 4, 8 lines (default 8192; 0 = off; the emulator runs of the CPU suite: off unless given)")
+    ap.add_argument("--no-whole-game-lines", dest="whole_game_lines", action="store_false",
+                    help="N = 1: skip config.whole_game (CFR+ and Linear CFR on the whole game through its suit classes, two short timed regions after the headline)")
+    ap.add_argument("--whole-game-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-boards", type=int, default=384)
     ap.add_argument("--cpu-iters", type=int, default=24)
@@ -331,6 +401,15 @@ def main():
         except Exception as e:  # noqa: BLE001
             fixed = {"error": "%s: %s" % (type(e).__name__, e)}
         barrier()
+    whole = None
+    hbm_allocated, iterations_done, engine_name, n_exchanges = int(solver.get("bytes_allocated")[0]), solver.iter, solver.engine, int(solver.get("exchanges")[0])
+    expl = solver.exploitability()
+    if args.whole_game_lines and not os.environ.get("PRL_BENCH_NO_WHOLE_GAME") and world == 1 and not emu_lib and not args.whole_game and not sharded and not total and args.engine != "levels":
+        solver = None  # the headline's 58 GB go back before the whole game's 30 GB come (both would fit; the pass's speed depends on placement)
+        try:  # (after the timed region: it must not cost the line)
+            whole = whole_game_lines(lib, args.whole_game_steps, 2)
+        except Exception as e:  # noqa: BLE001
+            whole = {"error": "%s: %s" % (type(e).__name__, e)}
     n_board_nodes = args.boards * 15
     n_nodes_total = (tree.n_nodes - n_board_nodes) + (total * 15 if total else n_board_nodes * world)  # one trunk + every rank's board subtrees
     value = n_nodes_total * args.steps / dt
@@ -338,12 +417,11 @@ def main():
     bytes_iter = 20.0 * R * sum_a + 8.0 * R * args.boards  # per GPU
     kernel_ms = pass_ms if n_pass else dev_ms
     achieved = bytes_iter * args.steps / (kernel_ms * 1e-3) / 1e9
-    pmc_ok = solver.engine == "fused" and args.variant in ("plus", "linear")
+    pmc_ok = engine_name == "fused" and args.variant in ("plus", "linear")
     pmc_per_board = None
     if pmc_ok:
         pmc_per_board = (PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_LINEAR if args.variant == "linear" else
                          PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_AVG_F32 if args.avg_f32 else PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION)
-    expl = solver.exploitability()
     out = {
         "metric": "CFR+ node-updates/sec on FHP public tree" if args.variant == "plus" else "%s CFR node-updates/sec on FHP public tree" % args.variant,
         "value": value, "unit": "node-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -364,9 +442,9 @@ def main():
             "full_tree_nodes_represented": (int(board_mult.sum()) * 15 + (tree.n_nodes - n_board_nodes)) if board_mult is not None else None,
             "equivalent_full_tree_node_updates_per_s": ((int(board_mult.sum()) * 15 + (tree.n_nodes - n_board_nodes)) * args.steps / dt) if board_mult is not None else None,
             "boards_per_gpu": args.boards, "nodes_per_gpu": tree.n_nodes, "action_columns_per_gpu": sum_a,
-            "engine": solver.engine, "avg_dtype": "f32 (opt-in: PRL_SOLVER_AVG_F32; the reference's average is float64)" if args.avg_f32 else "f64", "avg_f32_check": avg_check,
+            "engine": engine_name, "avg_dtype": "f32 (opt-in: PRL_SOLVER_AVG_F32; the reference's average is float64)" if args.avg_f32 else "f64", "avg_f32_check": avg_check,
             "parallelism": "boards sharded over %d GPU(s), trunk replicated, 1 all-gather of chance-node partial sums per EV pass" % world,
-            "nodes_whole_tree": n_nodes_total, "exchanges": int(solver.get("exchanges")[0]), "exchange": (how if sharded else None),
+            "nodes_whole_tree": n_nodes_total, "exchanges": n_exchanges, "exchange": (how if sharded else None),
             "exchange_ms_mean": (exchange.seconds * 1e3 / max(exchange.calls, 1)) if exchange else None,
             # per rank: wall ms per step, device ms per iteration (HIP events on the solver's stream), board-pass kernel ms per iteration
             "per_rank_ms_per_step": [r[0] * 1e3 / args.steps for r in per_rank] if per_rank else None,
@@ -376,11 +454,13 @@ def main():
             "exchange_bytes_per_pass_per_rank_upper": (int(-(-args.boards // 1024)) if args.boards % 1024 == 0 else int(-(-args.boards // 32)) if args.boards % 32 == 0 else args.boards) * 3 * tree.range_size * 4 if sharded else None,
             "rccl_library": rccl_path,
             "fixed_problem_check": fixed,
-            "iterations_done": solver.iter, "exploitability_mbb_per_g": float(np.mean(expl) * 10.0),
+            # BASELINE config 3 as stated (Linear CFR, full public tree, one GPU) and CFR+ on the same whole game: whole_game_lines above
+            "whole_game": whole,
+            "iterations_done": iterations_done, "exploitability_mbb_per_g": float(np.mean(expl) * 10.0),
             "exploitability_pinned_to": "oracle/ (C restatement of the reference with an explicit float32 summation order; the reference cannot build 2-hole-card trees)",
             "avg_strategy_exploitability_mbb_per_g": float(np.mean(avg_expl) * 10.0), "avg_strategy_evaluation_ms": avg_eval_ms,
             "ms_per_step_with_avg_strategy_evaluation": dt * 1e3 / args.steps + avg_eval_ms,
-            "hbm_bytes_allocated": int(solver.get("bytes_allocated")[0]),
+            "hbm_bytes_allocated": hbm_allocated,
             "placement_probe_ms_per_iteration": placement,  # one entry per candidate allocation, built by the library (prl_solver_create_placed): the fastest was kept (None: not probed)
             "placement_chosen": placement_chosen, "first_allocation_probe_ms_per_iteration": placement[0] if placement else None,
             # the same number under the name it deserves since round 5: device ms per STEADY iteration (3 warm-up iterations, then `steps` timed ones) of

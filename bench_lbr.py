@@ -5,6 +5,9 @@ lbr_check_to_round = TURN (LBRArgs.py:16-18,31-35), 2^20 hands per agent seat, s
 by (seed, hand id).
 
     python bench_lbr.py [--gpus N] [--hands H] [--agent hash|uniform] [--cpu-hands M]
+    python bench_lbr.py --game Flop5Holdem --agent table [--solver-iters 100]      LBR against the WHOLE-GAME solution of Flop5Holdem: CFR+ over all
+        2 598 960 boards (134 459 suit classes, bench.py --whole-game), its average strategy as a suit-canonical policy table built on the device
+        (PolicyTable.from_solver, 12.8 GB), LBR acting from the flop; the line carries the solver's exact exploitability beside LBR's winnings
 
 N > 1 GPUs (`--gpus N` starts the ranks itself; or torch.distributed.run): hands are independent (LocalLBRMaster.py:53-69 splits
 them over workers the same way); rank r plays hands [r * H/N, (r + 1) * H/N) of the same deck / agent-draw streams and
@@ -32,7 +35,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--hands", type=int, default=1 << 20, help="hands per agent seat (whole job)")
-    ap.add_argument("--agent", default="hash")
+    ap.add_argument("--agent", default="hash", help="hash | uniform | table (--game Flop5Holdem: the whole-game CFR+ average strategy)")
+    ap.add_argument("--game", default="DiscretizedNLHoldem", help="DiscretizedNLHoldem (config 5) | Flop5Holdem")
+    ap.add_argument("--solver-iters", type=int, default=100, help="--agent table: CFR+ iterations of the whole-game solve the table is made of")
+    ap.add_argument("--no-warmup", action="store_true", help="profiling runs: exactly one launch per seat")
     ap.add_argument("--cpu-hands", type=int, default=200, help="hands of the host LocalLBRWorker timed as the baseline (0 = skip)")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -55,19 +61,49 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from pokerrl_amd.eval.lbr import BatchedLBR, LBRArgs, LocalLBRWorker
     from pokerrl_amd.game import bet_sets
-    from pokerrl_amd.game.games import DiscretizedNLHoldem
+    from pokerrl_amd.game.games import DiscretizedNLHoldem, Flop5Holdem
     from pokerrl_amd.game.Poker import Poker
     from pokerrl_amd.game.wrappers import HistoryEnvBuilder
     from pokerrl_amd.rl.base_cls.TrainingProfileBase import TrainingProfileBase
 
+    fhp = args.game == "Flop5Holdem"
+    assert fhp or args.game == "DiscretizedNLHoldem"
+    assert args.agent != "table" or fhp, "--agent table: the whole-game solution of Flop5Holdem (--game Flop5Holdem)"
+    if fhp:  # the fixed-limit env with pot-size raises (games.py:222-254); LBR acts from the flop on: the board is complete there
+        env_args, lbr_args = Flop5Holdem.ARGS_CLS(n_seats=2), LBRArgs(n_lbr_hands_per_seat=args.hands, lbr_check_to_round=Poker.FLOP)
+    else:
+        env_args = DiscretizedNLHoldem.ARGS_CLS(n_seats=2, bet_sizes_list_as_frac_of_pot=bet_sets.B_5)
+        lbr_args = LBRArgs(lbr_bet_set=bet_sets.OFF_TREE_11, n_lbr_hands_per_seat=args.hands, lbr_check_to_round=Poker.TURN)
+    game_cls = Flop5Holdem if fhp else DiscretizedNLHoldem
     t_prof = TrainingProfileBase(
         name="lbr_bench", log_verbose=False, log_export_freq=1, checkpoint_freq=10 ** 9, eval_agent_export_freq=10 ** 9,
-        game_cls=DiscretizedNLHoldem, env_bldr_cls=HistoryEnvBuilder, start_chips=None, eval_modes_of_algo=("HASH",), eval_stack_sizes=None,
-        module_args={"env": DiscretizedNLHoldem.ARGS_CLS(n_seats=2, bet_sizes_list_as_frac_of_pot=bet_sets.B_5),
-                     "lbr": LBRArgs(lbr_bet_set=bet_sets.OFF_TREE_11, n_lbr_hands_per_seat=args.hands, lbr_check_to_round=Poker.TURN)},
-        path_data=tempfile.mkdtemp())
-    b = BatchedLBR(t_prof, agent_kind=args.agent, agent_seed=7)
-    b.run(agent_seat_id=0, n_hands=4096, deck_seed=99)  # warm-up
+        game_cls=game_cls, env_bldr_cls=HistoryEnvBuilder, start_chips=None, eval_modes_of_algo=("HASH",), eval_stack_sizes=None,
+        module_args={"env": env_args, "lbr": lbr_args}, path_data=tempfile.mkdtemp())
+    table, solve = None, None
+    if args.agent == "table":
+        from pokerrl_amd.game import board_enum
+        from pokerrl_amd.rl.tabular_agent import PolicyTable
+        t0 = time.perf_counter()
+        reps, mult = board_enum.single_deal_board_classes(Flop5Holdem)
+        tree = _native.NativeTree.for_game(Flop5Holdem, 20000, bet_sets.POT_ONLY, reps)
+        solver = _native.NativeSolver(tree, "plus", 0, engine="fused", board_mult=mult, symmetrize=True)
+        t1 = time.perf_counter()
+        solver.iterations(args.solver_iters)
+        solver.sync()
+        t2 = time.perf_counter()
+        expl = [float(x) * float(Flop5Holdem.EV_NORMALIZER) for x in solver.eval_avg()]
+        t3 = time.perf_counter()
+        table = PolicyTable.from_solver(solver)
+        t4 = time.perf_counter()
+        solve = {"cfr_plus_iterations": args.solver_iters, "suit_classes": int(len(reps)), "boards_represented": int(mult.sum()),
+                 "tree_and_solver_build_s": t1 - t0, "iterations_s": t2 - t1, "average_strategy_exploitability_mbb_per_g": expl,
+                 "average_strategy_exploitability_mean_mbb_per_g": sum(expl) / 2.0, "evaluation_s": t3 - t2, "policy_table_build_s": t4 - t3,
+                 "policy_table_rows": table.n_rows, "policy_table_gb": table.n_rows * table.n_actions * table.range_size * 4 / 1e9,
+                 "solver_gb": float(solver.get("bytes_allocated")[0]) / 1e9}
+        del solver  # the table is a copy: the solver's 30 GB are not needed any more
+    b = BatchedLBR(t_prof, agent_kind=args.agent, agent_seed=7, table=table)
+    if not args.no_warmup:
+        b.run(agent_seat_id=0, n_hands=4096, deck_seed=99)  # warm-up
 
     def barrier():
         torch.cuda.synchronize()
@@ -90,16 +126,19 @@ def main():
     # both seats pooled (LocalLBRMaster.py:61-69 concatenates the seats' scores before _get_95confidence)
     mean = sum(r[0] * r[2] for r in res) / n
     dev_s = sum(s["device_ms"] for s in stats) * 1e-3
-    out = {"metric": "LBR hands/s (DiscretizedNLHoldem, batched rollouts on the GPU)", "value": n / dt, "unit": "hands/s", "n_gpus": world,
+    out = {"metric": "LBR hands/s (%s, batched rollouts on the GPU)" % args.game, "value": n / dt, "unit": "hands/s", "n_gpus": world,
            "steps": 1, "warmup": 1, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
-           "config": {"workload": "LBR vs a synthetic tabular agent on DiscretizedNLHoldem (agent bets B_5, LBR bets OFF_TREE_11, LBR acts from the "
-                                  "turn on), %d hands per agent seat over %d GPU(s), every hand played start to finish by one workgroup" % (args.hands, world),
+           "config": {"workload": ("LBR vs the WHOLE-GAME CFR+ average strategy of Flop5Holdem (policy table in HBM, suit-canonical look-ups; LBR acts from the flop on), "
+                                   if args.agent == "table" else "LBR vs a synthetic tabular agent on Flop5Holdem (LBR acts from the flop on), " if fhp else
+                                   "LBR vs a synthetic tabular agent on DiscretizedNLHoldem (agent bets B_5, LBR bets OFF_TREE_11, LBR acts from the turn on), ") +
+                                  "%d hands per agent seat over %d GPU(s), every hand played start to finish by one workgroup" % (args.hands, world),
                       "hands_total": int(n), "device_seconds_rank0": dev_s, "agent": args.agent,
                       "env_steps_per_s_rank0": sum(s["env_steps"] for s in stats) / dev_s,
                       "lbr_lookaheads_per_s_rank0": sum(s["lbr_lookaheads"] for s in stats) / dev_s,
                       "hand_evals_per_s_rank0": sum(s["range_board_equities"] for s in stats) * 1326 / dev_s,
-                      "lbr_winnings_mbb_per_g": mean, "conf95_per_seat": [r[1] for r in res]}}
+                      "lbr_winnings_mbb_per_g": mean, "lbr_winnings_per_agent_seat_mbb_per_g": [r[0] for r in res], "conf95_per_seat": [r[1] for r in res],
+                      "whole_game_solve": solve}}
     # The batch kernel keeps a hand's whole state in LDS / registers: HBM moves the decks in and the winnings out (bytes per hand in the
     # tens), and nothing in it is a contraction: neither the HBM nor the MFMA roofline says anything about it. It is bound by VECTOR
     # INSTRUCTION ISSUE, integer and float32 alike, and the model counts what the kernel executes for the dominant step, the (range, board)
@@ -119,28 +158,41 @@ def main():
     peak = 256 * 4 * 32 * 2.4e9 / 1e12
     out["config"]["hand_rank_evaluations_per_s_rank0"] = sum(s["lbr_lookaheads"] for s in stats) * (R_ + 1) / dev_s
     del out["config"]["hand_evals_per_s_rank0"]
-    # HEADLINE of this object since round 5: the MEASURED vector-issue occupancy of the kernel (SQ counters, below) -- `frac` is that; the
-    # operation-count model of rounds 3-4 (a yardstick chosen by the author, which the kernel beats by executing fewer operations) stays beside
-    # it as `model_*`
-    # (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on CDNA4's 32-lane SIMDs -- `peak` above is exactly that rate. Rounds 3-4
-    # priced an instruction at 4 clocks (the GCN / CDNA3 figure) and quoted 0.467; at the guide's 2 clocks the same counters say 0.234.)
-    VALU_BUSY = 1.765e10 * 2.0 / (1024 * 61.45e-3 * 2.4e9)
-    out["roofline"] = {"bound": "valu-issue (int + fp32)", "achieved": VALU_BUSY * peak, "peak": peak, "unit": "T lane-ops/s", "frac": VALU_BUSY, "traffic": None,
+    # HEADLINE of this object since round 5: the MEASURED vector-issue occupancy of the kernel (SQ counters) -- `frac` is that; the operation-count
+    # model of rounds 3-4 (a yardstick chosen by the author, which the kernel beats by executing fewer operations) stays beside it as `model_*`.
+    # (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on CDNA4's 32-lane SIMDs -- `peak` above is exactly that rate.)
+    # The occupancy comes from a FILE written by a profiling run of this bench (scripts/gpu_r6_lbr.sh -> scripts/lbr_counters.py -> profiles/lbr_counters.json:
+    # rocprofv3 --pmc SQ_INSTS_VALU ... and the --stats launch duration of the same command), not from a literal: no file, no figure.
+    ctr = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "lbr_counters.json")) as f:
+            ctr = json.load(f)
+        valu, k_us = float(ctr["counters"]["SQ_INSTS_VALU"]), float(ctr["kernel_us_mean"])
+        VALU_BUSY = valu * 2.0 / (1024 * k_us * 1e-6 * 2.4e9)
+    except (OSError, ValueError, KeyError, TypeError):
+        ctr, VALU_BUSY = None, None
+    cnt = (ctr or {}).get("counters", {})
+    ratio = lambda a, b: (cnt[a] / cnt[b]) if (a in cnt and b in cnt and cnt[b]) else None  # noqa: E731
+    applies = ctr is not None and not fhp and args.agent != "table"  # the counters are those of config 5's kernel and workload
+    out["roofline"] = {"bound": "valu-issue (int + fp32)", "achieved": VALU_BUSY * peak if (applies and VALU_BUSY) else None, "peak": peak, "unit": "T lane-ops/s",
+                       "frac": VALU_BUSY if applies else None, "traffic": None,
                        "frac_is": "SQ_INSTS_VALU x 2 clocks (wave64 on a 32-lane SIMD) / (1024 SIMDs x kernel clocks): the share of the vector ALUs' issue slots the "
-                                  "kernel fills, measured -- the kernel is bound by dependent chains (LDS gathers -> compare -> divide -> add) and barriers, not by issue",
-                       "valu_issue_busy_at_4_clocks_per_instruction_as_quoted_in_rounds_3_4": 0.467,
+                                  "kernel fills, MEASURED by the profiling run named in `counters_source` -- the kernel is bound by dependent chains (LDS gathers -> "
+                                  "compare -> divide -> add) and barriers, not by issue" + ("" if applies else "; not quoted for this workload (the counters are config 5's)"),
+                       "counters_source": None if ctr is None else "profiles/lbr_counters.json (checkpoint %s: rocprofv3 --pmc / --stats -- %s; %d hands per launch, %.2f ms per launch)"
+                                          % (ctr.get("checkpoint"), ctr.get("command"), ctr.get("hands_per_launch") or 0, float(ctr.get("kernel_us_mean", 0.0)) / 1e3),
+                       "counters_kernel": (ctr or {}).get("kernel"),
+                       "sq_wait_any_over_wave_cycles": ratio("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"),
+                       "lds_bank_conflict_over_idx_active": ratio("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"),
                        "model_achieved": achieved, "model_frac": achieved / peak,
-                       "kernel": "prl_k_lbr_batch", "lane_ops_per_range_board_equity": ops_eq,
+                       "kernel": "prl_k_lbr_batch<%s>" % ("true" if args.agent == "table" else "false"), "lane_ops_per_range_board_equity": ops_eq,
                        "range_board_equities_per_hand": n_eq_tot / max(float(n), 1.0), "range_board_equities_per_s_rank0": n_eq_tot / dev_s,
-                       # the hardware's own figure, from the SQ counters of the final kernel (profiles/r21_lbr_pmc_sq.txt, r21_lbr_kernel_stats.txt):
-                       # SQ_INSTS_VALU 1.765e10 wave-instructions per launch x 4 clocks / (1024 SIMDs x 61.45 ms x 2.4 GHz)
-                       "valu_issue_busy_measured": VALU_BUSY, "valu_issue_busy_source": "profiles/r21_lbr_pmc_sq.txt (rocprofv3 --pmc SQ_INSTS_VALU, 131072 hands per launch)",
                        "note": "not an HBM- or MFMA-bound kernel: state on chip, no contraction. Modelled: the (range, board) equities only (the betting "
                                "engine, the agent's draws and the range updates are not counted: the model is a lower bound of the work done). The "
                                "operation counts are ALGORITHMIC ones, read off round 3's kernel (generic float32 division, 64-bit blocker test) and "
-                               "kept as the yardstick; round 4's kernel executes fewer per equity (shared-reciprocal division, byte compares), so "
-                               "'model_frac' is modelled work delivered per peak; 'frac' = valu_issue_busy_measured is what the vector ALUs were actually busy with"}
-    if rank == 0 and args.cpu_hands > 0 and world == 1:
+                               "kept as the yardstick; the present kernel executes fewer per equity (shared-reciprocal division, byte compares), so "
+                               "'model_frac' is modelled work delivered per peak; 'frac' is what the vector ALUs were actually busy with"}
+    if rank == 0 and args.cpu_hands > 0 and world == 1 and not fhp:
         # cpu_baseline: the SAME episode loop (pokerrl_amd.eval.lbr.LocalLBRWorker = the reference's LocalLBRWorker.run) with the check-down
         # equity of every decision computed ON THE HOST by the NumPy restatement of the reference's rollout manager (oracle/lbr.py, pinned to
         # the reference bit for bit) -- no device call in the timed region. (Round 3 timed the host worker with its equity queries on the GPU

@@ -440,6 +440,14 @@ enum {
                                                          strategy is loaded (prl_solver_set_strategy), 1 an explicit float64 one; LEVELS: -1 */
 };
 int32_t prl_solver_get(prl_solver_t* solver, int32_t field, void* out);
+/* The strategy of every decision node from a DEVICE array -- PublicTree.fill_with_agent_policy (StrategyFiller.py:88-116) without the host in between:
+ * d_probs float32 [n_decision_nodes][range_size][n_actions] in HBM (decision nodes in node order = the order the reference visits them in; the agent's
+ * probabilities over ALL action ints, e.g. the output tensor of one batched network forward); column first_col[node] + j takes
+ * d_probs[k][:][col_action[first_col[node] + j]]. Equal, bit for bit, to prl_solver_set_strategy with the same float32 values gathered on the host
+ * (float32 strategy: float32 arithmetic at every node); the fused engines scatter into their own storage (sorted board columns: through the staging
+ * buffer, a chunk of boards at a time). `tree`: the tree the solver was created on. Ends with the reach pass, like prl_solver_set_strategy. The caller
+ * synchronises whatever produced d_probs before the call (the solver works on its own stream). */
+int32_t prl_solver_set_strategy_device(prl_solver_t* solver, const prl_tree_t* tree, const float* d_probs, int32_t n_actions);
 /* n_cols action columns of a per-action-column field (REGRET, AVG, AVG_SUM) starting at flat-tree column col_begin: what lets a caller
  * stream a 20-60 GB array through a small host buffer (hashing, checkpoints to disk). Trees on the per-street engine keep their columns
  * in another order internally: the call gathers them (one copy per run of columns that are neighbours in both orders). */

@@ -668,6 +668,14 @@ class NativeSolver:
         assert a.shape == (self.n_cols, self.R), (a.shape, (self.n_cols, self.R))
         self._call("prl_solver_set_strategy", _ptr(a), int(a.dtype == np.float64))
 
+    def set_strategy_device(self, device_ptr, n_actions):
+        """float32 [n_decision_nodes, R, n_actions] ALREADY IN HBM (e.g. a torch tensor's data_ptr(): a batched network forward's output; decision nodes
+        in node order) -> the solver's strategy, scattered on the GPU (prl_solver_set_strategy_device): no host copy. The caller synchronises the
+        producer first (torch.cuda.synchronize())."""
+        self._L.prl_solver_set_strategy_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+        self._L.prl_solver_set_strategy_device.restype = ctypes.c_int32
+        self._call("prl_solver_set_strategy_device", self.tree.handle, ctypes.c_void_p(int(device_ptr)), int(n_actions))
+
     def set_strategy_mixed(self, strategy_cols_f64, node_is_f64):
         """float64 [n_cols, R] + uint8 [n_nodes]: 1 where the node's strategy is float64 in the reference's sense (else the stored
         values are float32-representable and the node's arithmetic is float32)"""

@@ -2305,6 +2305,79 @@ struct TableReplay {
 };
 }  // namespace
 
+// ---- an agent's strategy from a DEVICE array (StrategyFiller.py:88-116 without the host in between) -----------------------------------------------------
+namespace {
+// probs [n_dec][R][A] float32 (decision nodes in node order, every action int) -> action columns. Column c of this launch is entry c of the maps:
+// node ordinal col_k[c], action col_a[c]; dst32 / dst64 (either may be null) take it at dst_col0 + c.
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_cols_from_node_probs(const float* probs, int R, int A, const int32_t* col_k, const int32_t* col_a, long long n_cols_here,
+                                                                  float* dst32, double* dst64) {
+    const long long i = (long long)prl_bid() * prl_nthreads() + prl_tid();
+    if (i >= n_cols_here * R) return;
+    const long long c = i / R;
+    const int h = (int)(i - c * R);
+    const float v = probs[((size_t)col_k[c] * R + h) * A + col_a[c]];
+    if (dst32) dst32[(size_t)c * R + h] = v;
+    if (dst64) dst64[(size_t)c * R + h] = (double)v;
+}
+}  // namespace
+
+extern "C" int32_t prl_solver_set_strategy_device(prl_solver_t* s, const prl_tree_t* tree, const float* d_probs, int32_t n_actions) {
+    if (!s || !tree || !d_probs || n_actions < 2) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    const PrlFlatTree& full = *prl_tree_flat(tree);
+    if (full.n_nodes != s->full_nodes || full.n_cols != s->full_cols || full.rules.range_size != s->R) { prl_set_error("prl_solver_set_strategy_device: not the tree this solver was created on"); return PRL_ERR_ARG; }
+    // per column (in the engine's internal column order): the ordinal of its decision node among the decision nodes, its action int
+    std::vector<int32_t> ord(full.n_nodes, -1), maps((size_t)2 * s->full_cols);
+    int n_dec = 0;
+    for (int n = 0; n < full.n_nodes; ++n)
+        if (full.kind[n] == PRL_NODE_DECISION) ord[n] = n_dec++;
+    for (int ci = 0; ci < s->full_cols; ++ci) {
+        const int c = s->col_dfs.empty() ? ci : s->col_dfs[ci];
+        if (full.col_action[c] < 0 || full.col_action[c] >= n_actions) { prl_set_error("prl_solver_set_strategy_device: the tree has an action outside [0, n_actions)"); return PRL_ERR_ARG; }
+        maps[ci] = ord[full.col_node[c]];
+        maps[(size_t)s->full_cols + ci] = full.col_action[c];
+    }
+    int32_t* d_maps = nullptr;
+    PRL_HIP_TRY(hipMalloc((void**)&d_maps, maps.size() * sizeof(int32_t)));
+    auto fail = [&](int code) { (void)hipFree(d_maps); return code; };
+#define SD_TRY(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); prl_set_error("HIP error in prl_solver_set_strategy_device"); return fail(PRL_ERR_HIP); } } while (0)
+    SD_TRY(hipMemcpy(d_maps, maps.data(), maps.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    const int32_t *d_k = d_maps, *d_a = d_maps + s->full_cols;
+    const int R = s->R;
+    auto launch = [&](long long c0, long long n, float* d32, double* d64) {
+        if (n <= 0) return;
+        PRL_LAUNCH(prl_k_cols_from_node_probs, (unsigned)((n * R + 255) / 256), 256, 0, s->stream, d_probs, R, (int)n_actions, d_k + c0, d_a + c0, n, d32, d64);
+    };
+    const long long tc = s->T.n_cols;  // LEVELS: every column; FUSED: the trunk's (they precede the others)
+    launch(0, tc, nullptr, s->S.strategy);
+    if (s->sorted) {
+        const size_t ne = col_array_elems(s), nblk = (size_t)s->fp.n_boards * s->ncb * PRL_FHP_NBLOCKED;
+        int rc = PRL_OK;
+        if (!s->d_user_strategy32) rc = dev_alloc(s, &s->d_user_strategy32, ne);
+        if (!rc && !s->d_user_blocked32) rc = dev_alloc(s, &s->d_user_blocked32, nblk);
+        if (!rc) rc = stage_ready(s);
+        if (rc) return fail(rc);
+        launch(0, tc, s->d_user_strategy32, nullptr);
+        for (int at = 0; at < s->fp.n_boards; at += s->stage_boards) {  // the boards' columns: hand order in the staging buffer, then into sorted storage
+            const int nb = s->fp.n_boards - at < s->stage_boards ? s->fp.n_boards - at : s->stage_boards;
+            launch((long long)s->col_base + (long long)at * s->ncb, (long long)nb * s->ncb, (float*)s->d_stage, nullptr);
+            prl_launch_fhp_compact(s->fp, s->d_stage, 4, at, nb, s->d_user_strategy32 + s->board_ofs, s->d_user_blocked32, s->stream);
+            SD_TRY(hipGetLastError());
+        }
+        s->user_strategy_f64 = 0;
+    } else if (s->fused) {
+        if (!s->d_user_strategy32) { const int rc = dev_alloc(s, &s->d_user_strategy32, (size_t)s->full_cols * R); if (rc) return fail(rc); }
+        launch(0, s->full_cols, s->d_user_strategy32, nullptr);
+        s->user_strategy_f64 = 0;
+    }
+    SD_TRY(hipGetLastError());
+    SD_TRY(hipMemsetAsync(s->S.strat_f64, 0, (size_t)s->T.n_nodes, s->stream));  // a float32 strategy: float32 arithmetic at every node
+    SD_TRY(hipStreamSynchronize(s->stream));
+#undef SD_TRY
+    (void)hipFree(d_maps);
+    s->ev_valid = false;
+    return do_update_reach(s, s->S);
+}
+
 extern "C" int32_t prl_policy_table_from_solver(prl_solver_t* s, const prl_tree_t* tree, uint32_t key_seed, prl_policy_table_t** out) {
     if (!s || !tree || !out) { prl_set_error("NULL argument"); return PRL_ERR_ARG; }
     *out = nullptr;

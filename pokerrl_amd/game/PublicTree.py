@@ -268,13 +268,26 @@ class PublicTree:
     def fill_with_agent_policy(self, agent):
         """one query per decision node (StrategyFiller.py:88-116): strategy = agent probs restricted to the legal actions.
 
+        An agent that defines ``get_a_probs_for_each_hand_in_nodes_device(nodes)`` -> a float32 device tensor ``[len(nodes), RANGE_SIZE, N_ACTIONS]``
+        (or None to decline) keeps the probabilities in HBM: no host copy of the strategy at all (prl_solver_set_strategy_device).
         SURVEY section 8f-1 (batched agent querying): an agent that defines
         ``get_a_probs_for_each_hand_in_nodes(nodes) -> [len(nodes), RANGE_SIZE, N_ACTIONS]`` is asked ONCE for all decision
         nodes (DFS pre-order, the order the reference visits them in) instead of once per node, so a neural agent can run
         one batched forward; it positions its own env copies from ``node.env_state`` / the node's action history."""
         t = self._native_tree
-        strat, dtype = np.zeros((t.n_cols, t.range_size), np.float64), None
         decision = np.where(self._kind == KIND_DECISION)[0]
+        on_device = getattr(agent, "get_a_probs_for_each_hand_in_nodes_device", None)
+        if callable(on_device):
+            # round 6: the probabilities never leave HBM -- a float32 tensor [n_decision_nodes, R, N_ACTIONS] on the GPU (the network's output) is
+            # scattered into the solver's columns by the library (prl_solver_set_strategy_device); equal to the host path below bit for bit
+            probs = on_device([self.node(int(n)) for n in decision])
+            if probs is not None:
+                assert tuple(probs.shape) == (len(decision), t.range_size, int(self._env_bldr.N_ACTIONS)) and probs.is_contiguous(), tuple(probs.shape)
+                self._staged.clear()
+                self.solver.set_strategy_device(probs.data_ptr(), int(self._env_bldr.N_ACTIONS))
+                self._invalidate()
+                return
+        strat, dtype = np.zeros((t.n_cols, t.range_size), np.float64), None
         batched = getattr(agent, "get_a_probs_for_each_hand_in_nodes", None)
         if callable(batched):
             nodes = [self.node(int(n)) for n in decision]

@@ -80,10 +80,14 @@ class TorchPolicyAgent(EvalAgentBase):
         return m.to(self.device)
 
     @torch.no_grad()
-    def _forward(self, pub_obs, legal_lists):
+    def _forward_t(self, pub_obs, legal_lists):
+        """the forward's output where it is computed: float32 tensor [B, R, A] on self.device"""
         self.n_forwards += 1
         pub = torch.as_tensor(np.ascontiguousarray(pub_obs, dtype=np.float32)).to(self.device)
-        return self._net(pub, self._priv, self._legal_mask(legal_lists)).float().cpu().numpy()
+        return self._net(pub, self._priv, self._legal_mask(legal_lists)).float()
+
+    def _forward(self, pub_obs, legal_lists):
+        return self._forward_t(pub_obs, legal_lists).cpu().numpy()
 
     def get_a_probs_for_each_hand(self):
         """reference protocol: the internal wrapper has been positioned (set_to_public_tree_node_state / steps)"""
@@ -105,12 +109,36 @@ class TorchPolicyAgent(EvalAgentBase):
         return action, (all_p if need_probs else None)
 
     # ---- batched protocol (PublicTree.fill_with_agent_policy) -----------------------------------------------------------
+    DEVICE_RESIDENT_FILL = True  # PublicTree.fill_with_agent_policy keeps this agent's probabilities in HBM (False: the host path, for comparison)
+
+    def get_a_probs_for_each_hand_in_nodes_device(self, nodes):
+        """the same numbers as get_a_probs_for_each_hand_in_nodes, left where the network put them: a float32 tensor [len(nodes), R, A] on self.device
+        (one forward per history length writes its rows of the output tensor), synchronised -- PublicTree hands its address to the solver, which
+        scatters it into its strategy columns on the GPU. None (declined) when the agent is told to use the host path."""
+        if not self.DEVICE_RESIDENT_FILL or not nodes:
+            return None
+        R, A = self.env_bldr.rules.RANGE_SIZE, self.env_bldr.N_ACTIONS
+        out = torch.zeros((len(nodes), R, A), dtype=torch.float32, device=self.device)
+        self._fill_nodes(nodes, lambda part, probs: out.index_copy_(0, torch.as_tensor(part, device=self.device), probs), self._forward_t)
+        if out.is_cuda:
+            torch.cuda.synchronize(out.device)
+        return out
+
     def get_a_probs_for_each_hand_in_nodes(self, nodes):
         """float32 [len(nodes), RANGE_SIZE, N_ACTIONS] for decision nodes of one PublicTree: one forward per history length"""
         R, A = self.env_bldr.rules.RANGE_SIZE, self.env_bldr.N_ACTIONS
         out = np.zeros((len(nodes), R, A), dtype=np.float32)
         if not nodes:
             return out
+
+        def put(part, probs):
+            out[part] = probs
+
+        self._fill_nodes(nodes, put, self._forward)
+        return out
+
+    def _fill_nodes(self, nodes, put, forward):
+        R = self.env_bldr.rules.RANGE_SIZE
         hist = W.history_of_nodes(self.env_bldr, nodes, stack_size=list(nodes[0].tree.stack_size))
         groups = {}
         for i, h in enumerate(hist):
@@ -119,5 +147,4 @@ class TorchPolicyAgent(EvalAgentBase):
         for idxs in groups.values():
             for lo in range(0, len(idxs), chunk):
                 part = idxs[lo:lo + chunk]
-                out[part] = self._forward(np.stack([hist[i] for i in part]), [nodes[i].allowed_actions for i in part])
-        return out
+                put(part, forward(np.stack([hist[i] for i in part]), [nodes[i].allowed_actions for i in part]))

@@ -14,7 +14,7 @@ timeout 600 python bench.py --variant linear --no-cpu-baseline > gpurun_out/${TA
 timeout 600 python bench.py --avg-f32 --no-cpu-baseline > gpurun_out/${TAG}_bench_avg_f32.json 2>> gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --whole-game --no-cpu-baseline > gpurun_out/${TAG}_bench_whole_game.json 2>> gpurun_out/${TAG}_bench.err
 pushd /tmp > /dev/null; export TMPDIR=/tmp
-B="python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-placement-probe --fixed-check-boards 0"
+B="python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-placement-probe --fixed-check-boards 0 --no-whole-game-lines"
 BR="python $R/bench_br.py --steps 4 --warmup 1 --no-cpu-baseline"
 WG="python $R/bench.py --whole-game --steps 4 --warmup 1 --no-cpu-baseline --fixed-check-boards 0"
 for nv in "bench=$B" "br=$BR" "whole_game=$WG"; do

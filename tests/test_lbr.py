@@ -592,6 +592,59 @@ def test_gpu_batched_lbr_solver_table_flop5holdem_vs_host_worker(variant, tmp_pa
     check_solver_table_vs_host(_native.lib(), tmp_path, 12, 4, 160, variant)
 
 
+@pytest.mark.gpu
+def test_gpu_lbr_and_self_play_on_the_whole_game_flop5holdem_solution(tmp_path):
+    """The evaluators pointed at the headline solver's own output, the WHOLE Flop5Holdem game (2 598 960 boards as 134 459 suit classes, 30 GB), with no
+    oracle in the loop: after 10 and after 100 CFR+ iterations the average strategy goes into a suit-canonical policy table on the device (806 758 rows,
+    12.8 GB); batched LBR plays 2^20 hands per seat against it (LBR acts from the flop on: as the big blind it calls the raise and plays the flop; as the
+    small blind its forced pre-flop call IS a fold in this game -- FIRST_ACTION_NO_CALL -- and loses the 50-chip blind every hand, on the host worker
+    alike); batched self-play of the table against itself gives the game value of the big blind. Three engines have to agree:
+      * LBR is a strategy, so the big blind's LBR winnings stay below its exact best-response value = the solver's own exploitability[seat 1] + the
+        game value of seat 1 (self-play), and LBR's mean over both seats below the mean exploitability (Lisy & Bowling 2017);
+      * exploitability and LBR's edge over the game value both fall from 10 to 100 iterations."""
+    import parity_cases as pc
+    from pokerrl_amd.eval.head_to_head import BatchedHead2Head, H2HArgs
+    from pokerrl_amd.game import bet_sets, board_enum
+    from pokerrl_amd.game.games import Flop5Holdem
+    from pokerrl_amd.rl.tabular_agent import PolicyTable
+    n = 1 << 20
+    reps, mult = board_enum.single_deal_board_classes(Flop5Holdem)
+    t = _native.NativeTree.for_game(Flop5Holdem, 20000, bet_sets.POT_ONLY, reps)
+    s = _native.NativeSolver(t, "plus", 0, engine="fused", board_mult=mult, symmetrize=True)
+    t_prof = TrainingProfileBase(
+        name="whole", log_verbose=False, log_export_freq=1, checkpoint_freq=10 ** 9, eval_agent_export_freq=10 ** 9, game_cls=Flop5Holdem,
+        env_bldr_cls=HistoryEnvBuilder, start_chips=None, eval_modes_of_algo=("TABLE",), eval_stack_sizes=None,
+        module_args={"env": Flop5Holdem.ARGS_CLS(n_seats=2), "lbr": LBRArgs(n_lbr_hands_per_seat=n, lbr_check_to_round=Poker.FLOP), "h2h": H2HArgs(n_hands=n)},
+        path_data=str(tmp_path))
+    seen = []
+    for n_iters in (10, 100):
+        s.iterations(n_iters - s.iter)
+        expl = s.eval_avg().astype(np.float64) * float(Flop5Holdem.EV_NORMALIZER)  # per seat, mbb per game
+        table = PolicyTable.from_solver(s)
+        assert table.suit_canon and table.n_rows == 2 + 6 * len(reps)
+        b = BatchedLBR(t_prof, agent_kind="table", agent_seed=7, table=table)
+        w_bb = b.run(agent_seat_id=0, n_hands=n, deck_seed=5).astype(np.float64)                        # LBR in the big blind
+        w_sb = b.run(agent_seat_id=1, n_hands=n, deck_seed=5, first_hand=n, episode_base=n).astype(np.float64)
+        assert np.all(w_sb == -500.0)  # 50 chips = half a big blind, every hand (see above)
+        h = BatchedHead2Head(t_prof, kinds=("table", "table"), seeds=(11, 12), tables=(table, table))
+        v = h.play(n_hands=n, deck_seed=9).astype(np.float64)  # [2n]: the reference copy's winnings in seat 0, then in seat 1
+        v1 = 0.5 * (v[n:].mean() - v[:n].mean())               # game value of seat 1 under the average strategy (zero-sum: V1 = -V0)
+        ci = lambda x: 1.96 * x.std() / np.sqrt(x.size)        # noqa: E731
+        ci_v = 0.5 * np.hypot(ci(v[:n]), ci(v[n:]))
+        edge, ci_e = w_bb.mean() - v1, np.hypot(ci(w_bb), ci_v)
+        # LBR's winnings in the big blind <= the exact best-response value of seat 1 = exploitability[1] + V1
+        assert edge - ci_e <= expl[1], (n_iters, w_bb.mean(), v1, expl, ci_e)
+        assert 0.5 * (w_bb.mean() + w_sb.mean()) - 0.5 * ci(w_bb) <= expl.mean(), (n_iters, w_bb.mean(), expl)
+        assert abs(v[:n].mean() + v[n:].mean()) <= 2.0 * np.hypot(ci(v[:n]), ci(v[n:])) + 1e-9  # self-play is zero-sum up to the two halves' noise
+        seen.append((expl.mean(), edge, ci_e, expl[1]))
+        print("whole game, %d CFR+ iterations: exploitability %s mbb/g, LBR (big blind) %.2f, game value of the big blind %.2f +- %.2f, LBR's edge %.2f +- %.2f of "
+              "the exact %.2f" % (n_iters, expl, w_bb.mean(), v1, ci_v, edge, ci_e, expl[1]))
+        table.close()
+    assert seen[1][0] < 0.5 * seen[0][0], seen                      # the exact exploitability fell
+    assert seen[1][1] + seen[1][2] < seen[0][1] - seen[0][2], seen  # and so did what LBR finds
+    assert pc is not None
+
+
 def check_master_drives_batched_worker(tmp_path, n_hands):
     """LocalLBRMaster with a BatchedLBRWorker: the chief hands the solver's table over through update_weights, the master logs mean and confidence of
     exactly the hands BatchedLBR plays for those deck / episode numbers"""
