@@ -775,6 +775,36 @@ class NativeSolver:
             h.update(np.ascontiguousarray(a + a.dtype.type(0)).tobytes())
         return h.hexdigest()
 
+    def sha256_of_many(self, names, cols_per_piece=32768):
+        """{name: SHA-256} of several per-action-column arrays at once: the pieces are fetched in turn (one staging buffer, one stream) while one hasher
+        thread per array digests them -- a 60-80 GB state is hashed in the time of its biggest array instead of the sum (hashlib releases the GIL)"""
+        import hashlib
+        import queue
+        import threading
+        hs = {n: hashlib.sha256() for n in names}
+        qs = {n: queue.Queue(maxsize=3) for n in names}
+
+        def work(n):
+            while True:
+                a = qs[n].get()
+                if a is None:
+                    return
+                hs[n].update(np.ascontiguousarray(a + a.dtype.type(0)).tobytes())
+
+        th = [threading.Thread(target=work, args=(n,), daemon=True) for n in names]
+        for t in th:
+            t.start()
+        try:
+            for c0 in range(0, self.n_cols, cols_per_piece):
+                for n in names:
+                    qs[n].put(self.get_cols(n, c0, min(cols_per_piece, self.n_cols - c0)))
+        finally:
+            for n in names:
+                qs[n].put(None)
+            for t in th:
+                t.join()
+        return {n: h.hexdigest() for n, h in hs.items()}
+
     def get(self, name):
         n, c, R = self.n_nodes, self.n_cols, self.R
         shape, dtype = {

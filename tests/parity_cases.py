@@ -136,7 +136,36 @@ def check_multistreet_vs_oracle(L, game_cls, stack, bets, runouts, variant, n_it
     """public trees of games that deal on several streets (one chance level per street, children = the distinct prefixes
     of the listed run-outs), incl. all-in run-outs dealt as chance chains: every per-node vector, regrets, averages and the
     exploitability of the level-synchronous engine against the oracle, bit for bit, plus the structural invariants."""
-    t, s, o = make_pair(L, game_cls, stack, bets, runouts, variant, max_raises=max_raises)
+    from oracle_tape import digest, same
+    tape = _tape("multistreet", L, game_cls.__name__, stack, bets, np.asarray(runouts), variant, n_iters, max_raises)
+    rec, live = tape is not None and tape.recording, tape is None or tape.live
+    take = (lambda tag, fn: fn()) if tape is None else tape.take
+    big = (lambda a: a) if (tape is None or (tape.live and not tape.recording)) else digest
+    if rec or not live:  # the oracle alone (recording, no GPU) / the solver alone (replay)
+        args = env_args(game_cls, stack, bets)
+        game = game_cls.native_game(args)
+        if max_raises is not None:
+            for i, v in enumerate(max_raises):
+                game.max_raises[i] = v
+        t = _native.NativeTree(game, game_cls.native_rules(), runouts, _lib=L)
+        s = o = None
+        if rec:
+            o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, game_cls.RULES.N_HOLE_CARDS, game_cls.RULES.N_CARDS_IN_DECK,
+                              game_cls.RULES.N_SUITS, game_cls.RULES._RANK_RULE)
+            o.cfr_reset(_native.VARIANTS[variant], 0)
+        else:
+            s = _native.NativeSolver(t, variant, 0, engine="levels", _lib=L)
+    else:
+        t, s, o = make_pair(L, game_cls, stack, bets, runouts, variant, max_raises=max_raises)
+
+    def state(tag):
+        for k in STATE_FIELDS:
+            want = take("%s/%s" % (tag, k), lambda: big(np.asarray(getattr(o, k))))
+            if s is not None:
+                same(s.get(k), want, "%s: %s" % (tag, k))
+        want = take(tag + "/expl", lambda: np.array(o.exploitability, np.float32))
+        if s is not None:
+            assert np.array_equal(s.exploitability(), want), (tag, s.exploitability(), want)
     kind, bid, rnd, par = t.field("kind"), t.field("board_id"), t.field("round"), t.field("parent")
     n_chance_levels = len({int(np.sum(t.board_rows[bid[c]] >= 0)) for c in np.where(par >= 0)[0] if kind[par[c]] == 1})
     assert n_chance_levels == sum(1 for k in game_cls.native_rules().board_cards_in_round[1:game_cls.native_rules().n_rounds] if k > 0)
@@ -145,13 +174,21 @@ def check_multistreet_vs_oracle(L, game_cls, stack, bets, runouts, variant, n_it
     assert np.all(np.sum(t.board_rows[bid[sd]] >= 0, axis=1) == t.board_len)  # every showdown sits on a complete board
     if expect_runout_chain:
         assert np.any((kind == 1) & (kind[np.maximum(par, 0)] == 1))      # a chance node below a chance node: the all-in run-out
-    assert s.engine == "levels"
-    assert_state_equal(s, o, "multistreet it0")
+    assert s is None or s.engine == "levels"
+    state("multistreet it0")
     for it in range(1, n_iters + 1):
-        s.iteration()
-        o.cfr_iteration()
-        assert_state_equal(s, o, "multistreet it%d" % it)
-        assert np.array_equal(s.eval_avg(), o.eval_avg())
+        if s is not None:
+            s.iteration()
+        if live:
+            o.cfr_iteration()
+        state("multistreet it%d" % it)
+        want = take("it%d/eval_avg" % it, lambda: np.array(o.eval_avg(), np.float32))
+        if s is not None:
+            assert np.array_equal(s.eval_avg(), want)
+    if tape is not None:
+        tape.close()
+    if s is None:
+        return t, s, o
     # ValueFiller.py:98: zero-sum at every node (float64 accumulation of the float32 products)
     ev, reach = s.get("ev"), s.get("reach")
     zs = np.sum(ev.astype(np.float64) * reach.astype(np.float64), axis=(1, 2))
@@ -408,27 +445,50 @@ def check_iterations_many(L, n_iters=5):
     assert_state_equal(s, o, "many[0] + 2")
 
 
-def make_streets_pair(L, game_cls, stack, runouts, variant, delay=0, max_raises=None):
-    """(tree, fused solver on the per-street engine, oracle) on one multi-street flat tree (csrc/prl_st.h)"""
+def make_streets_pair(L, game_cls, stack, runouts, variant, delay=0, max_raises=None, tape=None, **solver_kw):
+    """(tree, fused solver on the per-street engine, oracle) on one multi-street flat tree (csrc/prl_st.h). With an oracle tape (tests/oracle_tape.py):
+    no oracle when the tape is replayed, no solver when it is being recorded (the generator runs without a GPU)."""
     args = env_args(game_cls, stack, None)
     game = game_cls.native_game(args)
     if max_raises is not None:
         for i, v in enumerate(max_raises):
             game.max_raises[i] = v
     t = _native.NativeTree(game, game_cls.native_rules(), runouts, _lib=L)
-    s = _native.NativeSolver(t, variant, delay, engine="auto", _lib=L)
-    assert s.engine == "fused", "engine=auto must take the per-street fused engine for a multi-street tree of registered street shapes"
-    r = game_cls.RULES
-    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS, r._RANK_RULE)
-    o.cfr_reset(_native.VARIANTS[variant], delay)
+    s = None
+    if tape is None or not tape.recording:
+        s = _native.NativeSolver(t, variant, delay, engine="auto", _lib=L, **solver_kw)
+        assert s.engine == "fused", "engine=auto must take the per-street fused engine for a multi-street tree of registered street shapes"
+    o = None
+    if tape is None or tape.live:
+        r = game_cls.RULES
+        o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS, r._RANK_RULE)
+        o.cfr_reset(_native.VARIANTS[variant], delay)
     return t, s, o
+
+
+def _tape(kind, L, *parts):
+    """an oracle tape for the GPU suite's checks (the emulator suite of the container keeps the oracle live: its problems are small)"""
+    import oracle_tape
+    if L is not None and L is not _native_product_lib():
+        return None
+    return oracle_tape.Tape(kind, *parts)
+
+
+def _native_product_lib():
+    try:
+        return _native.lib()
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def check_streets_br_vs_oracle(L, game_cls, stack, runouts, max_raises=None, seed=5):
     """Exact best response of an explicit strategy on a multi-street tree, per-street engine (LocalBRMaster.py:67-80): a seeded strategy given as
     float32 (played as float32 from the engine's internal column order) and as float64 columns in the flat tree's DFS order; exploitability
     against the oracle, the strategy read back unchanged; iterating again after reset()"""
-    t, s, o = make_streets_pair(L, game_cls, stack, runouts, "plus", 0, max_raises)
+    tape = _tape("streets_br", L, game_cls.__name__, stack, np.asarray(runouts), max_raises, seed)
+    t, s, o = make_streets_pair(L, game_cls, stack, runouts, "plus", 0, max_raises, tape=tape)
+    live = tape is None or tape.live
+    take = (lambda tag, fn: fn()) if tape is None else tape.take
     kind, nch, fc = t.field("kind"), t.field("n_children"), t.field("first_col")
     rng = np.random.RandomState(seed)
     strat = np.empty((t.n_cols, t.range_size), np.float32)
@@ -437,50 +497,86 @@ def check_streets_br_vs_oracle(L, game_cls, stack, runouts, max_raises=None, see
         strat[fc[n]:fc[n] + nch[n]] = x / x.sum(axis=0, keepdims=True)
     for f64 in (False, True):
         st = strat.astype(np.float64) * (1.0 + 1e-9 * rng.random_sample(strat.shape)) if f64 else strat
-        s.set_strategy(st)
-        o.set_strategy(np.asarray(st, dtype=np.float64), f64)
-        s.compute_ev()
-        o.compute_ev()
-        assert np.array_equal(s.exploitability(), o.exploitability), (f64, s.exploitability(), o.exploitability)
-        assert np.array_equal(s.get("strategy"), np.asarray(st, dtype=np.float64))
-    s.reset()
-    o.cfr_reset(1, 0)
-    s.iterations(2)
-    o.cfr_iteration(); o.cfr_iteration()
-    assert np.array_equal(s.exploitability(), o.exploitability)
+        if live:
+            o.set_strategy(np.asarray(st, dtype=np.float64), f64)
+            o.compute_ev()
+        want = take("br/f64=%d" % f64, lambda: np.array(o.exploitability, np.float32))
+        if s is not None:
+            s.set_strategy(st)
+            s.compute_ev()
+            assert np.array_equal(s.exploitability(), want), (f64, s.exploitability(), want)
+            assert np.array_equal(s.get("strategy"), np.asarray(st, dtype=np.float64))
+    if live:
+        o.cfr_reset(1, 0)
+        o.cfr_iteration(); o.cfr_iteration()
+    want = take("after reset/expl", lambda: np.array(o.exploitability, np.float32))
+    if s is not None:
+        s.reset()
+        s.iterations(2)
+        assert np.array_equal(s.exploitability(), want)
+    if tape is not None:
+        tape.close()
     return t
 
 
 def check_streets_vs_oracle(L, game_cls, stack, runouts, variant, n_iters, delay=0, max_raises=None, batched=False):
     """SURVEY 8f-4 on the per-street fused engine (csrc/prl_st.h): regrets, averages, the strategy implied by the regrets, current- and
     average-strategy exploitability after every iteration (batched: the exploitability history of prl_solver_iterations(n) and the
-    final state), bit for bit against the oracle -- in the flat tree's DFS column order, which the engine does not use internally."""
-    t, s, o = make_streets_pair(L, game_cls, stack, runouts, variant, delay, max_raises)
-    assert np.array_equal(s.exploitability(), o.exploitability), (s.exploitability(), o.exploitability)
+    final state), bit for bit against the oracle -- in the flat tree's DFS column order, which the engine does not use internally.
+    On the GPU box the oracle's side comes from a tape (tests/oracle_tape.py) when one was recorded for exactly this problem."""
+    from oracle_tape import digest, same
+    tape = _tape("streets", L, game_cls.__name__, stack, np.asarray(runouts), variant, n_iters, delay, max_raises, batched)
+    t, s, o = make_streets_pair(L, game_cls, stack, runouts, variant, delay, max_raises, tape=tape)
+    live = tape is None or tape.live
+    take = (lambda tag, fn: fn()) if tape is None else tape.take
+    big = (lambda a: a) if (tape is None or (tape.live and not tape.recording)) else digest  # arrays entry by entry when the oracle is here, digests on tape
+
+    def expl(tag):
+        want = take(tag, lambda: np.array(o.exploitability, np.float32))
+        if s is not None:
+            assert np.array_equal(s.exploitability(), want), (tag, s.exploitability(), want)
+
+    def eval_avg(tag):
+        want = take(tag, lambda: np.array(o.eval_avg(), np.float32))
+        if s is not None:
+            assert np.array_equal(s.eval_avg(), want), (tag, s.eval_avg(), want)
+
+    expl("reset/expl")
     fields = FUSED_FIELDS + ("strategy",) + (() if variant == "plus" else ("avg_sum",))
 
     def same_state(tag):
         for k in fields:
-            a, b = s.get(k), np.asarray(getattr(o, k))
-            assert np.array_equal(a, b), "streets %s: %s differs in %d entries, first %s" % (tag, k, int(np.sum(a != b)), np.argwhere(a != b)[:3].tolist())
+            want = take("%s/%s" % (tag, k), lambda: big(np.asarray(getattr(o, k))))
+            if s is not None:
+                same(s.get(k), want, "streets %s: %s" % (tag, k))
     if batched:
-        want = [np.array(o.exploitability, np.float32)]
-        for _ in range(n_iters):
-            o.cfr_iteration()
-            want.append(np.array(o.exploitability, np.float32))
-        s.iterations(n_iters - 1)
-        s.iterations(1)
-        assert np.array_equal(s.get("expl_history"), np.stack(want)), (s.get("expl_history"), np.stack(want))
+        def run():
+            want = [np.array(o.exploitability, np.float32)]
+            for _ in range(n_iters):
+                o.cfr_iteration()
+                want.append(np.array(o.exploitability, np.float32))
+            return np.stack(want)
+        want = take("batched/expl_history", run)
+        if s is not None:
+            s.iterations(n_iters - 1)
+            s.iterations(1)
+            assert np.array_equal(s.get("expl_history"), want), (s.get("expl_history"), want)
         same_state("batched")
-        assert np.array_equal(s.eval_avg(), o.eval_avg())
+        eval_avg("batched/eval_avg")
     else:
         for it in range(1, n_iters + 1):
-            s.iteration()
-            o.cfr_iteration()
+            if s is not None:
+                s.iteration()
+            if live:
+                o.cfr_iteration()
             same_state("it%d" % it)
-            assert np.array_equal(s.exploitability(), o.exploitability), (it, s.exploitability(), o.exploitability)
+            expl("it%d/expl" % it)
             if it > delay:
-                assert np.array_equal(s.eval_avg(), o.eval_avg()), it
+                eval_avg("it%d/eval_avg" % it)
+    if tape is not None:
+        tape.close()
+    if s is None:
+        return t, s, o
     # prl_solver_get_cols on this engine: any window of flat-tree columns, gathered from the internal order
     nc = t.n_cols
     for name in ("regret", "avg") + (() if variant == "plus" else ("avg_sum",)):
@@ -657,45 +753,52 @@ def check_streets_avg_f32(L, game_cls, stack, runouts, n_iters, max_raises=None,
     average stored as float32 -- regrets, current-strategy exploitability history: bit-exact to the oracle; the average = the reference's
     recurrence with one float32 rounding per iteration, restated here from the oracle's strategies; the trunk's columns stay float64 = the
     oracle's; average-strategy exploitability within 1e-5 relative of the float64 one."""
-    args = env_args(game_cls, stack, None)
-    game = game_cls.native_game(args)
-    if max_raises is not None:
-        for i, v in enumerate(max_raises):
-            game.max_raises[i] = v
-    t = _native.NativeTree(game, game_cls.native_rules(), runouts, _lib=L)
-    s = _native.NativeSolver(t, "plus", 0, engine="auto", _lib=L, avg_dtype="f32")
-    assert s.engine == "fused"
-    r = game_cls.RULES
-    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS, r._RANK_RULE)
-    o.cfr_reset(1, 0)
+    from oracle_tape import digest, same
+    tape = _tape("streets_avg_f32", L, game_cls.__name__, stack, np.asarray(runouts), n_iters, max_raises, batched)
+    t, s, o = make_streets_pair(L, game_cls, stack, runouts, "plus", 0, max_raises, tape=tape, avg_dtype="f32")
+    live = tape is None or tape.live
+    take = (lambda tag, fn: fn()) if tape is None else tape.take
+    big = (lambda a: a) if (tape is None or (tape.live and not tape.recording)) else digest
     kind, rnd, first_col, n_ch = t.field("kind"), t.field("round"), t.field("first_col"), t.field("n_children")
     trunk = np.zeros(t.n_cols, bool)
     for n in np.where(kind == 0)[0]:
         if rnd[n] == 0:  # the betting before the first deal: the trunk (LEVELS kernels, float64 average as the reference)
             trunk[first_col[n]:first_col[n] + n_ch[n]] = True
     a32 = None
-    hist = [np.array(o.exploitability, np.float32)]
+    hist = [take("reset/expl", lambda: np.array(o.exploitability, np.float32))]
     for it in range(n_iters):
-        o.cfr_iteration()
-        hist.append(np.array(o.exploitability, np.float32))
-        strat = np.asarray(o.strategy)
-        if it == 0:
-            a32 = strat.astype(np.float32)
-        else:
-            cw, nw = sum(range(1, it + 1)), it + 1
-            a32 = (cw / (cw + nw) * a32.astype(np.float64) + nw / (cw + nw) * strat).astype(np.float32)
+        if live:
+            o.cfr_iteration()
+            strat = np.asarray(o.strategy)
+            if it == 0:
+                a32 = strat.astype(np.float32)
+            else:
+                cw, nw = sum(range(1, it + 1)), it + 1
+                a32 = (cw / (cw + nw) * a32.astype(np.float64) + nw / (cw + nw) * strat).astype(np.float32)
+        hist.append(take("it%d/expl" % it, lambda: np.array(o.exploitability, np.float32)))
         if not batched:
-            s.iteration()
-            assert np.array_equal(s.get("regret"), np.asarray(o.regret)), it
-            assert np.array_equal(s.exploitability(), o.exploitability), it
+            want = take("it%d/regret" % it, lambda: big(np.asarray(o.regret)))
+            if s is not None:
+                s.iteration()
+                same(s.get("regret"), want, "regret it%d" % it)
+                assert np.array_equal(s.exploitability(), hist[-1]), it
     if batched:
-        s.iterations(n_iters)
-        assert np.array_equal(s.get("regret"), np.asarray(o.regret))
+        want = take("batched/regret", lambda: big(np.asarray(o.regret)))
+        if s is not None:
+            s.iterations(n_iters)
+            same(s.get("regret"), want, "regret")
+    want_trunk = take("avg/trunk", lambda: big(np.asarray(o.avg)[trunk]))
+    want_rest = take("avg/streets", lambda: big(a32.astype(np.float64)[~trunk]))
+    e64 = take("eval_avg", lambda: np.array(o.eval_avg(), np.float32))
+    if tape is not None:
+        tape.close()
+    if s is None:
+        return
     assert np.array_equal(s.get("expl_history"), np.stack(hist))
     avg = s.get("avg")
-    assert np.array_equal(avg[trunk], np.asarray(o.avg)[trunk]), "trunk average"
-    assert np.array_equal(avg[~trunk], a32.astype(np.float64)[~trunk]), "street columns: the float32 recurrence"
-    e32, e64 = s.eval_avg(), o.eval_avg()
+    same(avg[trunk], want_trunk, "trunk average")
+    same(avg[~trunk], want_rest, "street columns: the float32 recurrence")
+    e32 = s.eval_avg()
     assert np.allclose(e32, e64, rtol=1e-5, atol=0), (e32, e64)
     with pytest.raises(Exception):
         s.get_cols("avg", 0, 1)  # float32 storage: prl_solver_get translates, get_cols does not

@@ -142,7 +142,7 @@ def test_batched_forward_equals_per_node_queries_emu(emu_lib, tmp_path, bldr_cls
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("game_cls,bldr_cls,bets", [(StandardLeduc, HistoryEnvBuilder, None), (StandardLeduc, FlatLimitPokerEnvBuilder, None),
-                                                    (DiscretizedNLLeduc, HistoryEnvBuilder, bet_sets.B_3)])
+                                                    (DiscretizedNLLeduc, HistoryEnvBuilder, bet_sets.B_2)])
 def test_gpu_batched_forward_equals_per_node_queries(tmp_path, game_cls, bldr_cls, bets):
     """the network runs on the GPU too (PyTorch-ROCm): device_inference = cuda"""
     check_batched_vs_per_node(game_cls, bldr_cls, tmp_path, bets, device="cuda")

@@ -475,6 +475,28 @@ def test_gpu_fhp_properties_at_scale(L):
         assert np.allclose(strat[fc[n]:fc[n] + nc[n]].sum(axis=0), 1, atol=1e-5)
 
 
+_BIG_TREES = {}
+
+
+def _big_tree(key, make_boards):
+    """the bench-size / whole-game trees are built once per test session (three variants each walk the same one)"""
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    from helpers import native_tree
+    if key not in _BIG_TREES:
+        boards = make_boards()
+        _BIG_TREES[key] = (boards, native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards[0] if isinstance(boards, tuple) else boards))
+    return _BIG_TREES[key]
+
+
+def _check_state_hashes(s, g, variant):
+    """SHA-256 of every regret / average (/ average-sum) column against the fixture; the arrays are hashed side by side while they stream off the GPU"""
+    names = ("regret",) + (() if variant == "plus" else ("avg_sum",)) + ("avg",)  # (avg after avg_sum: the last average update rode on the closing evaluation)
+    got = s.sha256_of_many(names)
+    for n in names:
+        assert got[n] == str(g[n + "_sha256"]), n
+
+
 @pytest.mark.parametrize("variant", ["plus", "linear", "vanilla"])
 def test_gpu_fused_bench_size_vs_oracle_fixture(L, variant):
     """bench.py's workload at full size (262144 boards, the board list of rank 0) against the ORACLE: two CFR+ (Linear CFR: BASELINE config 3)
@@ -493,25 +515,24 @@ def test_gpu_fused_bench_size_vs_oracle_fixture(L, variant):
         pytest.skip("fixture not generated (an hour of oracle time: tests/golden/make_fhp_golden_chunked.py)")
     g = np.load(path)
     assert str(g["variant"]) == variant
-    boards = bench.seeded_boards(int(g["n_boards"]), int(g["seed"]))
+    boards, t = _big_tree(("bench", int(g["n_boards"]), int(g["seed"])), lambda: bench.seeded_boards(int(g["n_boards"]), int(g["seed"])))
     assert h32(boards) == str(g["boards_sha256"])
-    t = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, boards)
     s = _native.NativeSolver(t, variant, 0, engine="fused")
     s.iterations(int(g["n_iters"]))
     assert np.array_equal(s.get("expl_history"), g["expl_history"]), (s.get("expl_history"), g["expl_history"])
-    assert s.sha256_of("regret") == str(g["regret_sha256"])
-    if variant != "plus":  # (the average updates of the last iteration rode on its closing evaluation)
-        assert s.sha256_of("avg_sum") == str(g["avg_sum_sha256"])
-    assert s.sha256_of("avg") == str(g["avg_sha256"])
+    _check_state_hashes(s, g, variant)
+    assert bet_sets is not None and G is not None and native_tree is not None
 
 
-@pytest.mark.parametrize("variant", ["plus", "linear"])
+@pytest.mark.parametrize("variant", ["plus", "linear", "vanilla"])
 def test_gpu_whole_game_vs_oracle_fixture(L, variant):
     """The WHOLE Flop5Holdem game on the GPU -- all 2 598 960 boards through their 134 459 suit classes (prl_solver_create_weighted: multiplicities in
     the chance weights, orbit-mean chance values) -- against the ORACLE: four iterations of CFR+ and of Linear CFR (BASELINE config 3: "LinearCFR, full
     public tree, 1 MI355X"), exploitability history and SHA-256 of all 1.88 M regret / average (/ average-sum) columns. The fixtures come from the
     oracle's chunked run (make_fhp_golden_chunked.py --whole-game: 8 chunks of 16384 classes + one of 3387, the trunk's chance node fed the canonical
-    weighted sum and symmetrised; equal to the one-piece oracle on 2363 classes in ragged chunks, `--selftest <dir> weighted [variant]`)."""
+    weighted sum and symmetrised; equal to the one-piece oracle on 2363 classes in ragged chunks, `--selftest <dir> weighted [variant]`).
+    Round 6: all three variants, and the AVERAGE strategy's exploitability at full size (the two-seat evaluation pass over the float64 averages with the
+    ragged last chunk and the orbit means: `eval_avg` of the chunked oracle)."""
     import os
     from pokerrl_amd import _native
     from pokerrl_amd.game import bet_sets, board_enum
@@ -522,17 +543,16 @@ def test_gpu_whole_game_vs_oracle_fixture(L, variant):
         pytest.skip("fixture not generated (an hour of oracle time: tests/golden/make_fhp_golden_chunked.py --whole-game)")
     g = np.load(path)
     assert str(g["variant"]) == variant
-    reps, mult = board_enum.single_deal_board_classes(G.Flop5Holdem)
+    (reps, mult), t = _big_tree("whole", lambda: board_enum.single_deal_board_classes(G.Flop5Holdem))
     assert len(reps) == int(g["n_classes"]) and int(mult.sum()) == int(g["n_boards"]) == 2598960
     assert h32(reps) == str(g["boards_sha256"]) and h32(mult.astype(np.int32)) == str(g["mult_sha256"])
-    t = native_tree(G.Flop5Holdem, 20000, bet_sets.POT_ONLY, reps)
     s = _native.NativeSolver(t, variant, 0, engine="fused", board_mult=mult, symmetrize=True)
     s.iterations(int(g["n_iters"]))
     assert np.array_equal(s.get("expl_history"), g["expl_history"]), (s.get("expl_history"), g["expl_history"])
-    assert s.sha256_of("regret") == str(g["regret_sha256"])
-    if variant != "plus":  # (the average updates of the last iteration rode on its closing evaluation)
-        assert s.sha256_of("avg_sum") == str(g["avg_sum_sha256"])
-    assert s.sha256_of("avg") == str(g["avg_sha256"])
+    _check_state_hashes(s, g, variant)
+    if "eval_avg" in g.files:  # (fixtures regenerated in round 6 carry it)
+        assert np.array_equal(s.eval_avg(), g["eval_avg"]), (s.eval_avg(), g["eval_avg"])
+    assert bet_sets is not None and native_tree is not None
 
 
 def test_gpu_fused_br_bench_size_vs_oracle_fixture(L):
