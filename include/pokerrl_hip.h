@@ -474,8 +474,13 @@ int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t* board_deal
  *   check_to_round: -1 = None; agent_kind 0 uniform, 1 seeded hash policy (csrc/prl_lbr_batch.hip); episode_base: hand e
  *   draws the agent's actions as episode episode_base + e + 1; reward_scalar / ev_normalizer: env.REWARD_SCALAR, EV_NORMALIZER.
  *   out_winnings[n_envs] float32 = reward[lbr_seat] * REWARD_SCALAR * EV_NORMALIZER; out_stats4: env steps, LBR look-ahead
- *   decisions, (range, board) equities, agent actions; out_device_ms: kernel time (HIP events). LBR may only decide with at
- *   most two board cards to come (hold'em: lbr_check_to_round >= FLOP). */
+ *   decisions, (range, board) equities, agent actions; out_device_ms: kernel time (HIP events, summed over the rounds below).
+ *   LBR decisions with at most two board cards to come are evaluated inside the kernel. Decisions with more -- hold'em BEFORE THE FLOP, i.e.
+ *   lbr_check_to_round = None, the reference's default (LBRArgs.py:18; enumeration LocalLBRWorker.py:388-425) -- need C(50, 5) boards per candidate
+ *   range, which are a function of the public history and LBR's hand only: they are cached per (history key, LBR hand) in HBM. A hand that misses
+ *   files a request and stops; the call computes the requested equities with prl_lbr_checkdown_equity (the host worker's own call at that decision),
+ *   fills the cache and plays the stopped hands again from the start (counter-based decks and draws: a replay reaches the same decision with the
+ *   same ranges) -- rounds of launches until no hand waits; the counters include the replays. Same per-hand winnings as the host worker. */
 int32_t prl_lbr_batch_run(const PrlGame* lbr_game, const PrlGame* agent_game, const PrlRules* rules, int32_t n_envs, int32_t agent_seat,
                           int32_t check_to_round, int32_t agent_kind, uint32_t agent_seed, uint32_t episode_base, double reward_scalar,
                           double ev_normalizer, const int8_t* cards, float* out_winnings, uint64_t* out_stats4, float* out_device_ms);

@@ -12,6 +12,7 @@ inline void prl_atomic_add_u64(unsigned long long* p, unsigned long long v) { *p
 inline void prl_lds_add_i(int* p, int v) { *p += v; }
 inline void prl_lds_min_u(unsigned* p, unsigned v) { if (v < *p) *p = v; }
 inline int prl_atomic_add_i(int* p, int v) { int o = *p; *p += v; return o; }
+inline unsigned long long prl_atomic_cas_u64(unsigned long long* p, unsigned long long expect, unsigned long long v) { const unsigned long long o = *p; if (o == expect) *p = v; return o; }
 #else
 #include <hip/hip_runtime.h>
 
@@ -27,6 +28,7 @@ PRL_DEV PRL_INLINE void prl_atomic_add_u64(unsigned long long* p, unsigned long 
 PRL_DEV PRL_INLINE void prl_lds_add_i(int* p, int v) { atomicAdd(p, v); }  // integer add on an LDS word (order-free)
 PRL_DEV PRL_INLINE void prl_lds_min_u(unsigned* p, unsigned v) { atomicMin(p, v); }  // unsigned minimum on an LDS word (order-free)
 PRL_DEV PRL_INLINE int prl_atomic_add_i(int* p, int v) { return atomicAdd(p, v); }  // returns the value before the add
+PRL_DEV PRL_INLINE unsigned long long prl_atomic_cas_u64(unsigned long long* p, unsigned long long expect, unsigned long long v) { return atomicCAS(p, expect, v); }  // returns the value before
 PRL_DEV PRL_INLINE unsigned prl_tid() { return threadIdx.x; }
 PRL_DEV PRL_INLINE unsigned prl_bid() { return blockIdx.x; }
 PRL_DEV PRL_INLINE unsigned prl_bid_y() { return blockIdx.y; }

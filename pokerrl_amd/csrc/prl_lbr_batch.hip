@@ -61,7 +61,31 @@ struct PrlLbrBatchParams {
     unsigned long long* stats;    // [4] env steps, LBR look-ahead decisions, (range, board) equities, agent actions
     float* eq_scratch;            // [grid][LBRB_MAX_Q][LBRB_MAX_BOARDS_2] when LBR may decide with two cards to come, else NULL
     PrlPolicyTable tab;           // agent kind 2
+    // PRE builds: LBR decisions with more than two board cards to come (hold'em before the flop: lbr_check_to_round = None, the reference's default,
+    // LBRArgs.py:18). Such a check-down equity is C(50, 5) = 2 118 760 boards per candidate range -- no hand can afford it, and no hand has to: the
+    // candidate ranges are a function of the PUBLIC history and of LBR's hand only, so the equities are cached per (history key, LBR hand) in HBM. A
+    // hand that misses files a request (its candidate ranges) and stops; the host computes the requested equities with the stand-alone kernel
+    // (prl_lbr_checkdown_equity: what the host worker calls at the same decision), puts them into the cache and plays the stopped hands AGAIN from
+    // the start -- decks and agent draws are counter-based, so a replay reaches the same decision with the same ranges, and hits.
+    const int32_t* env_list;      // [n_envs] the hands this launch plays (nullptr: 0 .. n_envs - 1)
+    int32_t* status;              // [all hands] 1 = stopped at a missing equity
+    const unsigned long long* pf_keys;  // [pf_mask + 1] cache: key of (history, LBR hand), 0 = empty
+    const float* pf_wp;                 // [pf_mask + 1][LBRB_MAX_Q]
+    unsigned long long* req_keys;       // [req_mask + 1] keys requested in this launch (claimed by atomicCAS: one request per key)
+    int32_t* n_req;                     // requests filed
+    int32_t* req_meta;                  // [max_req][8]: LBR's hand index, n_q, n_dealt, the cards on the table (5)
+    unsigned long long* req_key_of;     // [max_req]
+    float* req_ranges;                  // [max_req][LBRB_MAX_Q][R]
+    uint32_t pf_mask, req_mask;
+    int32_t max_req, pf_min_to_deal;
 };
+#define LBRB_PF_SEED 0x9E3779u  // history keys of a PRE build without a table
+
+PRL_HD PRL_INLINE unsigned long long lbrb_pf_key(const LbrbHistKey& hk, int lbr_idx) {
+    unsigned long long k = (((unsigned long long)hk.hi << 32) | hk.lo) ^ ((unsigned long long)(lbr_idx + 1) * 0x9E3779B97F4A7C15ull);
+    k ^= k >> 29; k *= 0xBF58476D1CE4E5B9ull; k ^= k >> 32;
+    return k == 0ull ? 1ull : k;
+}
 
 // P(action `a` | hand h) of the synthetic agent; legal[0..n_legal) ascending. 0 for an illegal action.
 PRL_HD PRL_INLINE float lbrb_agent_prob(int kind, uint32_t key, int h, const int32_t* legal, int n_legal, int a) {
@@ -144,6 +168,7 @@ struct LbrbShared {
     uint32_t key;
     int32_t row, raise_row[LBRB_MAX_Q];  // tabular agent: the table rows of the state / of the states after LBR's candidate raises
     LbrbHistKey hk;                      // ... and the history key of the hand so far
+    int32_t pf_slot, pf_req;             // PRE builds: the cache slot of this decision's equities (-1: a miss), the request it filed (-1: another hand did)
     int8_t cboard[5];                    // ... a table keyed under suit-canonical boards: the canonical form of the board on the table (prl_policy.h)
     int32_t canon_k;                     //     and the number of the suit permutation that makes it
     float total;
@@ -445,8 +470,11 @@ PRL_HD PRL_INLINE size_t lbrb_smem_bytes(int R) {  // the carve-outs of prl_k_lb
     for (size_t b : sizes) off = ((off + 15) & ~(size_t)15) + b;
     return off + 16;
 }
-template <bool TABLE>  // TABLE: the agent may be a tabular one (kind 2); the synthetic agents' kernel carries no table code
+// TABLE: the agent may be a tabular one (kind 2); the synthetic agents' kernel carries no table code. PRE: look-aheads with many cards to come go
+// through the equity cache (see PrlLbrBatchParams); the kernels of the timed configurations carry none of it.
+template <bool TABLE, bool PRE>
 PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
+    constexpr bool HK = TABLE || PRE;  // the history key of the hand so far is kept
     char* lbrb_smem = prl_smem();
     const int R = P.rules.range_size, tid = (int)prl_tid();
     // Every array is the LDS base plus a BYTE OFFSET (no pointer -> integer -> pointer round trips): the compiler has to see that these are LDS
@@ -487,7 +515,8 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
         hole_lut[h] = (uint16_t)(c1 | (c2 << 8));
     }
 
-    for (int e = (int)prl_bid(); e < P.n_envs; e += (int)prl_nblocks()) {
+    for (int e_at = (int)prl_bid(); e_at < P.n_envs; e_at += (int)prl_nblocks()) {
+        const int e = PRE && P.env_list ? P.env_list[e_at] : e_at;
         const int8_t* cards = P.cards + (size_t)e * P.n_deal;
         const int8_t* lbr_hand = cards + lbr_seat * nh;
         const int8_t* agent_hand = cards + P.agent_seat * nh;
@@ -498,7 +527,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
             prl_env_reset(P.g_lbr, S.st);
             S.done = 0; S.n_dealt = 0; S.step_ctr = 0;
             S.lbr_idx = lbrb_hand_idx(P.rules, lbr_hand);
-            if (TABLE) { S.hk = lbrb_hist_step(lbrb_hist_root(P.tab.key_seed), S.st, S.board, 0, n_board_total, P.rules.n_suits); S.canon_k = 0; }
+            if (HK) { S.hk = lbrb_hist_step(lbrb_hist_root(TABLE && P.agent_kind == 2 ? P.tab.key_seed : LBRB_PF_SEED), S.st, S.board, 0, n_board_total, P.rules.n_suits); S.canon_k = 0; }
         }
         if (TABLE) for (int h = tid; h < R; h += LBRB_THREADS) hmap[h] = (uint16_t)h;
         // agent_range.reset(); set_cards_to_zero_prob(lbr_hand) (:73-74, :190-191)
@@ -588,7 +617,8 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     float* eq = big ? P.eq_scratch + (size_t)prl_bid() * 2 * LBRB_MAX_Q * LBRB_MAX_BOARDS_2 : eq_lds;
                     float* eqb = big ? eq + (size_t)LBRB_MAX_Q * LBRB_MAX_BOARDS_2 : eq_b;
                     const int eq_stride = big ? LBRB_MAX_BOARDS_2 : LBRB_MAX_BOARDS;
-                    if (g.n_to_deal > 2 || n_boards > LBRB_MAX_BOARDS_2 || (big && !P.eq_scratch)) {  // run() rejects configurations that get here
+                    const bool cached = PRE && g.n_to_deal >= P.pf_min_to_deal;  // this decision's equities come from the cache (or stop the hand)
+                    if (!cached && (g.n_to_deal > 2 || n_boards > LBRB_MAX_BOARDS_2 || (big && !P.eq_scratch))) {  // run() rejects configurations that get here
                         if (tid == 0) S.done = 1;
                         continue;
                     }
@@ -601,7 +631,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                             cand[(size_t)q * R + h] = lbrb_prob<TABLE>(P.tab, P.agent_kind, S.raise_key[q], TABLE ? S.raise_row[q] : -1, h, TABLE ? (int)hmap[h] : h, lg2, nl2, PRL_FOLD);  // p(fold | hand)
                     }
                     // first complete board for the classification (see the quirk in prl_lbr_kernels.hip)
-                    {
+                    if (!cached) {
                         int8_t fb0[5];
                         prl_lbr_board_at(g, S.pc, S.n_pc, 0, fb0);
                         if (tid == 0) { S.n_big = 0; S.n_eq = 0; }
@@ -621,9 +651,9 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     prl_sync();
                     // the two classes as ascending index lists (stable compaction by one wave: ballot + popcount of the lanes below), so that
                     // the sums over a class read element i directly instead of scanning the class bytes (prl_lbr_board_equity_lists)
-                    if (tid == 64) lbrb_build_leaf_map(MB, S.n_big);
-                    if (tid == 128) lbrb_build_leaf_map(ME, S.n_eq);
-                    if (tid < 64) {
+                    if (!cached && tid == 64) lbrb_build_leaf_map(MB, S.n_big);
+                    if (!cached && tid == 128) lbrb_build_leaf_map(ME, S.n_eq);
+                    if (!cached && tid < 64) {
                         int at_big = 0, at_eq = S.n_big;
                         for (int base = 0; base < R; base += 64) {
                             const int h = base + tid;
@@ -680,6 +710,49 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     }
                     prl_sync();
                     LBRB_TICK(4);  // candidate ranges
+                    if (cached) {
+                        // the equities of (this public history, LBR's hand): from the cache -- or the hand files a request and stops
+                        if (tid == 0) {
+                            const unsigned long long k = lbrb_pf_key(S.hk, S.lbr_idx);
+                            int slot = -1;
+                            for (uint32_t i = (uint32_t)k & P.pf_mask;; i = (i + 1u) & P.pf_mask) {
+                                const unsigned long long ki = P.pf_keys[i];
+                                if (ki == k) { slot = (int)i; break; }
+                                if (ki == 0ull) break;
+                            }
+                            S.pf_slot = slot;
+                            S.pf_req = -1;
+                            if (slot < 0) {
+                                for (uint32_t i = (uint32_t)(k >> 20) & P.req_mask, tries = 0; tries <= P.req_mask; i = (i + 1u) & P.req_mask, ++tries) {
+                                    const unsigned long long was = prl_atomic_cas_u64(P.req_keys + i, 0ull, k);
+                                    if (was == 0ull) {  // this hand files the request
+                                        const int r = prl_atomic_add_i(P.n_req, 1);
+                                        if (r < P.max_req) S.pf_req = r;
+                                        break;
+                                    }
+                                    if (was == k) break;  // another hand did
+                                }
+                                P.status[e] = 1;
+                                S.done = 1;
+                            }
+                        }
+                        prl_sync();
+                        if (S.pf_slot < 0) {
+                            const int r = S.pf_req;
+                            if (r >= 0) {
+                                float* dst = P.req_ranges + (size_t)r * LBRB_MAX_Q * R;
+                                for (int i = tid; i < n_q * R; i += LBRB_THREADS) dst[i] = cand[i];
+                                if (tid == 0) {
+                                    int32_t* m = P.req_meta + (size_t)r * 8;
+                                    m[0] = S.lbr_idx; m[1] = n_q; m[2] = g.n_dealt;
+                                    for (int i = 0; i < 5; ++i) m[3 + i] = i < g.n_dealt ? (int)g.board[i] : -1;
+                                    P.req_key_of[r] = lbrb_pf_key(S.hk, S.lbr_idx);
+                                }
+                            }
+                            continue;  // the hand is over for this launch (S.done): the host fills the cache and plays it again
+                        }
+                        if (tid < n_q) S.wp[tid] = P.pf_wp[(size_t)S.pf_slot * LBRB_MAX_Q + tid];
+                    } else {
                     if (coop) {
                         // pair p = (candidate q, board b). Three rounds of sums: the pair's normaliser (the range without the board's hands) into eq,
                         // its tie sum into eqb, its win sum -- and with it the equity -- into eq (prl_lbr_board_equity_lists, term for term).
@@ -853,6 +926,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                         }
                     } else if (tid < n_q) S.wp[tid] = prl_lbr_reduce_range_cp(g, eq + tid * eq_stride, cpw + tid * PRL_LBR_MAX_CARDS, eq_lds + tid * LBRB_MAX_BOARDS,
                                                                               S.pc, S.n_pc);
+                    }  // !cached
                     prl_sync();
                     LBRB_TICK(6);  // board probabilities + reduction (one lane per candidate)
                     // one lane per candidate computes its utility; lane 0 takes the arg-max in action order. Candidate 0 is check / call (action 1), the
@@ -963,7 +1037,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                     for (int i = 0; i < n_new; ++i) { S.board[S.n_dealt] = deck_board[S.n_dealt]; S.n_dealt += 1; }
                     S.n_legal = n_new;  // scratch: how many cards are new
                     if (canon) S.canon_k = prl_suit_canon(S.board, S.n_dealt, P.rules.n_suits, S.cboard);
-                    if (TABLE) S.hk = lbrb_hist_step(S.hk, S.st, canon ? S.cboard : S.board, S.n_dealt, n_board_total, P.rules.n_suits);
+                    if (HK) S.hk = lbrb_hist_step(S.hk, S.st, canon ? S.cboard : S.board, S.n_dealt, n_board_total, P.rules.n_suits);
                 }
                 prl_sync();
                 if (canon) {  // the hands in the canonical labelling: the same suit permutation applied to both hole cards
@@ -980,7 +1054,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                 for (int h = tid; h < R; h += LBRB_THREADS)
                     if (prl_lbr_hand_mask(hg, h, hole_lut) & m) rg[h] = 0.f;
                 if (coop) lbrb_normalize_blocks(rg, R, MR, part, S); else lbrb_normalize(rg, R, Lf, S);
-            } else if (TABLE && tid == 0) S.hk = lbrb_hist_step(S.hk, S.st, canon ? S.cboard : S.board, S.n_dealt, n_board_total, P.rules.n_suits);
+            } else if (HK && tid == 0) S.hk = lbrb_hist_step(S.hk, S.st, canon ? S.cboard : S.board, S.n_dealt, n_board_total, P.rules.n_suits);
             LBRB_TICK(9);  // after the step: dealing / range update / payout
         }
     }
@@ -1114,26 +1188,42 @@ static int32_t lbr_batch_run_impl(const PrlGame* lbr_game, const PrlGame* agent_
     if (lbr_game->game_type == PRL_GAME_NOLIMIT || agent_game->game_type != lbr_game->game_type) { prl_set_error("batched LBR: fixed-limit or discretized games"); return PRL_ERR_UNSUPPORTED; }
     if (lbr_game->n_bet_sizes + 2 > LBRB_MAX_LEGAL || agent_game->n_bet_sizes + 2 > LBRB_MAX_LEGAL) { prl_set_error("batched LBR: at most 14 bet sizes per player"); return PRL_ERR_UNSUPPORTED; }
     if (lbr_game->game_type == PRL_GAME_DISCRETIZED && lbr_game->n_bet_sizes + 1 > LBRB_MAX_Q) { prl_set_error("batched LBR: at most 11 LBR bet sizes"); return PRL_ERR_UNSUPPORTED; }
-    // the look-ahead equity handles at most two board cards to come where LBR decides
-    int to_deal_max = 0;
+    // Look-aheads with at most two board cards to come are evaluated inside the kernel; with more (hold'em before the flop: lbr_check_to_round = None)
+    // the equities come from the per-(history, LBR hand) cache and the request / replay rounds below (PrlLbrBatchParams). PRL_LBRB_PF_MIN (tests)
+    // lowers the threshold so that small games walk the same machinery.
+    int to_deal_max = 0, pf_min = 3;
     {
         int dealt_before_first_decision = 0;
         const int first_round = check_to_round >= 0 ? check_to_round : 0;
         for (int r = 0; r <= first_round && r < 4; ++r) dealt_before_first_decision += rules->board_cards_in_round[r];
         to_deal_max = nb - dealt_before_first_decision;
-        if (to_deal_max > 2) { prl_set_error("batched LBR: LBR may only decide with at most two board cards to come (lbr_check_to_round)"); return PRL_ERR_UNSUPPORTED; }
+        if (const char* ev = getenv("PRL_LBRB_PF_MIN")) { pf_min = atoi(ev); if (pf_min < 0) pf_min = 0; }
     }
+    const bool pre = to_deal_max >= pf_min;
     PrlLbrBatchParams P;
     memset(&P, 0, sizeof(P));
     P.g_lbr = *lbr_game; P.g_agent = *agent_game; P.rules = *rules;
     P.n_envs = n_envs; P.agent_seat = agent_seat; P.check_to_round = check_to_round; P.agent_kind = agent_kind;
     P.n_deal = 2 * nh + nb; P.limit = lbr_game->game_type == PRL_GAME_LIMIT;
     P.seed = agent_seed; P.episode_base = episode_base; P.reward_scalar = reward_scalar; P.ev_normalizer = ev_normalizer;
+    P.pf_min_to_deal = pf_min;
     if (agent_kind == 2) P.tab = *table;
     const int R = rules->range_size;
     const size_t smem = lbrb_smem_bytes(R);
     int8_t* d_cards = nullptr; float* d_win = nullptr; unsigned long long* d_stats = nullptr; float* d_eq = nullptr;
+    // PRE: the cache, the requests of a round, the hands of a round
+    const int max_req = 1024;
+    const uint32_t req_cap = 4096;
+    int32_t *d_list = nullptr, *d_status = nullptr, *d_n_req = nullptr, *d_req_meta = nullptr;
+    unsigned long long *d_pf_keys = nullptr, *d_req_keys = nullptr, *d_req_key_of = nullptr;
+    float *d_pf_wp = nullptr, *d_req_ranges = nullptr;
+    std::vector<unsigned long long> c_keys;
+    std::vector<float> c_wp;
+    uint32_t c_cap = 0, c_used = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    float total_ms = 0.f;
+    int n_rounds = 0;
+    long long n_requests = 0;
     int rc = PRL_OK;
 #define LB_TRY(x) do { if ((x) != hipSuccess) { prl_set_error("HIP error in prl_lbr_batch_run"); rc = PRL_ERR_HIP; goto done; } } while (0)
     LB_TRY(hipMalloc((void**)&d_cards, (size_t)n_envs * P.n_deal));
@@ -1148,29 +1238,124 @@ static int32_t lbr_batch_run_impl(const PrlGame* lbr_game, const PrlGame* agent_
     {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const int grid = n_envs < cus * 8 ? n_envs : cus * 8;  // persistent workgroups; every one plays its hands start to finish
-        if (to_deal_max == 2) {
+        const int grid_max = cus * 8;  // persistent workgroups; every one plays its hands start to finish
+        if (to_deal_max >= 2 && pf_min > 2) {
+            const int grid = n_envs < grid_max ? n_envs : grid_max;
             LB_TRY(hipMalloc((void**)&d_eq, (size_t)grid * 2 * LBRB_MAX_Q * LBRB_MAX_BOARDS_2 * sizeof(float)));  // equities + the tie sums under way
             P.eq_scratch = d_eq;
         }
 #if !defined(PRL_EMU)
         if (getenv("PRL_LBRB_DEBUG")) {
             int nb = -1;
-            hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, prl_k_lbr_batch<false>, LBRB_THREADS, smem);
+            hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, prl_k_lbr_batch<false, false>, LBRB_THREADS, smem);
             hipFuncAttributes fa;
             memset(&fa, 0, sizeof(fa));
-            hipError_t fe = hipFuncGetAttributes(&fa, (const void*)prl_k_lbr_batch<false>);
+            hipError_t fe = hipFuncGetAttributes(&fa, (const void*)prl_k_lbr_batch<false, false>);
             fprintf(stderr, "lbrb: smem %zu, occupancy %d workgroups per CU (err %d); regs %d, static smem %zu, local %zu, maxDyn %d (err %d)\n", smem, nb, (int)oe,
                     fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fa.maxDynamicSharedSizeBytes, (int)fe);
         }
 #endif
-        LB_TRY(hipEventRecord(e0, nullptr));
-        if (agent_kind == 2) PRL_LAUNCH(prl_k_lbr_batch<true>, grid, LBRB_THREADS, smem, nullptr, P);
-        else PRL_LAUNCH(prl_k_lbr_batch<false>, grid, LBRB_THREADS, smem, nullptr, P);
-        LB_TRY(hipEventRecord(e1, nullptr));
+        if (!pre) {
+            const int grid = n_envs < grid_max ? n_envs : grid_max;
+            LB_TRY(hipEventRecord(e0, nullptr));
+            if (agent_kind == 2) PRL_LAUNCH((prl_k_lbr_batch<true, false>), grid, LBRB_THREADS, smem, nullptr, P);
+            else PRL_LAUNCH((prl_k_lbr_batch<false, false>), grid, LBRB_THREADS, smem, nullptr, P);
+            LB_TRY(hipEventRecord(e1, nullptr));
+            LB_TRY(hipDeviceSynchronize());
+            LB_TRY(hipEventElapsedTime(&total_ms, e0, e1));
+        } else {
+            // rounds: play the hands that are left; compute what they asked for; play the stopped ones again
+            std::vector<int32_t> list((size_t)n_envs), status((size_t)n_envs), meta((size_t)max_req * 8);
+            std::vector<unsigned long long> key_of((size_t)max_req);
+            std::vector<float> ranges;
+            for (int i = 0; i < n_envs; ++i) list[i] = i;
+            LB_TRY(hipMalloc((void**)&d_list, (size_t)n_envs * 4));
+            LB_TRY(hipMalloc((void**)&d_status, (size_t)n_envs * 4));
+            LB_TRY(hipMalloc((void**)&d_n_req, 4));
+            LB_TRY(hipMalloc((void**)&d_req_meta, (size_t)max_req * 8 * 4));
+            LB_TRY(hipMalloc((void**)&d_req_keys, (size_t)req_cap * 8));
+            LB_TRY(hipMalloc((void**)&d_req_key_of, (size_t)max_req * 8));
+            LB_TRY(hipMalloc((void**)&d_req_ranges, (size_t)max_req * LBRB_MAX_Q * R * sizeof(float)));
+            c_cap = 1u << 12;
+            c_keys.assign(c_cap, 0ull);
+            c_wp.assign((size_t)c_cap * LBRB_MAX_Q, 0.f);
+            auto insert = [&](unsigned long long k, const float* wp) {
+                for (uint32_t i = (uint32_t)k & (c_cap - 1);; i = (i + 1u) & (c_cap - 1)) {
+                    if (c_keys[i] == k) return;
+                    if (c_keys[i] == 0ull) { c_keys[i] = k; memcpy(&c_wp[(size_t)i * LBRB_MAX_Q], wp, LBRB_MAX_Q * sizeof(float)); ++c_used; return; }
+                }
+            };
+            uint32_t d_cap = 0;
+            while (!list.empty()) {
+                if (2 * c_used + 2 * (uint32_t)max_req > c_cap) {  // keep the table at most half full after this round's insertions
+                    std::vector<unsigned long long> ok;
+                    std::vector<float> ow;
+                    ok.swap(c_keys); ow.swap(c_wp);
+                    const uint32_t old = c_cap;
+                    while (2 * c_used + 2 * (uint32_t)max_req > c_cap) c_cap *= 2;
+                    c_keys.assign(c_cap, 0ull); c_wp.assign((size_t)c_cap * LBRB_MAX_Q, 0.f); c_used = 0;
+                    for (uint32_t i = 0; i < old; ++i) if (ok[i]) insert(ok[i], &ow[(size_t)i * LBRB_MAX_Q]);
+                }
+                if (d_cap != c_cap) {
+                    (void)hipFree(d_pf_keys); (void)hipFree(d_pf_wp); d_pf_keys = nullptr; d_pf_wp = nullptr;
+                    LB_TRY(hipMalloc((void**)&d_pf_keys, (size_t)c_cap * 8));
+                    LB_TRY(hipMalloc((void**)&d_pf_wp, (size_t)c_cap * LBRB_MAX_Q * sizeof(float)));
+                    d_cap = c_cap;
+                }
+                LB_TRY(hipMemcpy(d_pf_keys, c_keys.data(), (size_t)c_cap * 8, hipMemcpyHostToDevice));
+                LB_TRY(hipMemcpy(d_pf_wp, c_wp.data(), (size_t)c_cap * LBRB_MAX_Q * sizeof(float), hipMemcpyHostToDevice));
+                LB_TRY(hipMemcpy(d_list, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+                LB_TRY(hipMemset(d_status, 0, (size_t)n_envs * 4));
+                LB_TRY(hipMemset(d_n_req, 0, 4));
+                LB_TRY(hipMemset(d_req_keys, 0, (size_t)req_cap * 8));
+                P.n_envs = (int)list.size(); P.env_list = d_list; P.status = d_status;
+                P.pf_keys = d_pf_keys; P.pf_wp = d_pf_wp; P.pf_mask = c_cap - 1;
+                P.req_keys = d_req_keys; P.req_mask = req_cap - 1; P.n_req = d_n_req; P.req_meta = d_req_meta; P.req_key_of = d_req_key_of; P.req_ranges = d_req_ranges;
+                P.max_req = max_req;
+                const int grid = P.n_envs < grid_max ? P.n_envs : grid_max;
+                LB_TRY(hipEventRecord(e0, nullptr));
+                if (agent_kind == 2) PRL_LAUNCH((prl_k_lbr_batch<true, true>), grid, LBRB_THREADS, smem, nullptr, P);
+                else PRL_LAUNCH((prl_k_lbr_batch<false, true>), grid, LBRB_THREADS, smem, nullptr, P);
+                LB_TRY(hipEventRecord(e1, nullptr));
+                LB_TRY(hipDeviceSynchronize());
+                float ms = 0.f;
+                LB_TRY(hipEventElapsedTime(&ms, e0, e1));
+                total_ms += ms;
+                ++n_rounds;
+                int n_req = 0;
+                LB_TRY(hipMemcpy(&n_req, d_n_req, 4, hipMemcpyDeviceToHost));
+                if (n_req > max_req) n_req = max_req;
+                LB_TRY(hipMemcpy(status.data(), d_status, (size_t)n_envs * 4, hipMemcpyDeviceToHost));
+                std::vector<int32_t> next;
+                for (int32_t e : list) if (status[e]) next.push_back(e);
+                if (!next.empty() && n_req == 0) { prl_set_error("batched LBR: hands wait for an equity nobody requested"); rc = PRL_ERR_STATE; goto done; }
+                if (n_req > 0) {
+                    LB_TRY(hipMemcpy(meta.data(), d_req_meta, (size_t)n_req * 8 * 4, hipMemcpyDeviceToHost));
+                    LB_TRY(hipMemcpy(key_of.data(), d_req_key_of, (size_t)n_req * 8, hipMemcpyDeviceToHost));
+                    ranges.resize((size_t)n_req * LBRB_MAX_Q * R);
+                    LB_TRY(hipMemcpy(ranges.data(), d_req_ranges, ranges.size() * sizeof(float), hipMemcpyDeviceToHost));
+                    for (int r = 0; r < n_req; ++r) {
+                        const int32_t* m = &meta[(size_t)r * 8];
+                        int c1 = m[0], c2 = 0;
+                        if (nh == 2) prl_hole_cards_2(m[0], rules->n_cards, &c1, &c2);
+                        const int8_t hand[2] = {(int8_t)c1, (int8_t)c2};
+                        int8_t board[5];
+                        for (int i = 0; i < 5; ++i) board[i] = (int8_t)(m[3 + i] < 0 ? 0 : m[3 + i]);
+                        float wp[LBRB_MAX_Q];
+                        memset(wp, 0, sizeof(wp));
+                        // the stand-alone equity of the host worker's own call at this decision (LocalLBRWorker._checkdown_equity -> prl_lbr_checkdown_equity)
+                        rc = prl_lbr_checkdown_equity(rules, board, m[2], hand, &ranges[(size_t)r * LBRB_MAX_Q * R], m[1], wp);
+                        if (rc != PRL_OK) goto done;
+                        insert(key_of[r], wp);
+                    }
+                    n_requests += n_req;
+                }
+                list.swap(next);
+            }
+            if (getenv("PRL_LBRB_DEBUG")) fprintf(stderr, "lbrb: %d rounds, %lld equity requests, %u cached keys\n", n_rounds, n_requests, c_used);
+        }
     }
-    LB_TRY(hipDeviceSynchronize());
-    if (out_device_ms) LB_TRY(hipEventElapsedTime(out_device_ms, e0, e1));
+    if (out_device_ms) *out_device_ms = total_ms;
     LB_TRY(hipMemcpy(out_winnings, d_win, (size_t)n_envs * sizeof(float), hipMemcpyDeviceToHost));
     if (out_stats4) LB_TRY(hipMemcpy(out_stats4, d_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 #ifdef PRL_LBRB_TIMING
@@ -1189,6 +1374,8 @@ done:
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(d_cards); (void)hipFree(d_win); (void)hipFree(d_stats); (void)hipFree(d_eq);
+    (void)hipFree(d_list); (void)hipFree(d_status); (void)hipFree(d_n_req); (void)hipFree(d_req_meta); (void)hipFree(d_req_keys); (void)hipFree(d_req_key_of);
+    (void)hipFree(d_req_ranges); (void)hipFree(d_pf_keys); (void)hipFree(d_pf_wp);
     return rc;
 }
 

@@ -264,6 +264,40 @@ def test_batched_lbr_nl_leduc_vs_reference_emu(emu_lib, tmp_path):
     check_batched_vs_golden("DiscretizedNLLeduc", tmp_path, max_hands=40)
 
 
+@pytest.mark.parametrize("tag", ["StandardLeduc", "DiscretizedNLLeduc"])
+def test_batched_lbr_equity_cache_and_replay_rounds_emu(emu_lib, monkeypatch, tag, tmp_path):
+    """the machinery of LBR decisions with many board cards to come (hold'em before the flop: the equities cached per (public history, LBR hand), hands that
+    miss stop, file a request and are played again) walked by the Leduc games: PRL_LBRB_PF_MIN=1 sends their one-card-to-come decisions through it.
+    Same per-hand winnings as the reference's worker (tests/golden/lbr_*.npz)."""
+    monkeypatch.setenv("PRL_LBRB_PF_MIN", "1")
+    check_batched_vs_golden(tag, tmp_path, max_hands=60)
+
+
+def check_batched_before_the_flop_vs_host(tmp_path, n_hands):
+    """lbr_check_to_round = None on DiscretizedNLHoldem (the reference's default, LBRArgs.py:18): LBR decides before the flop too, C(50, 5) run-outs per
+    candidate range. BatchedLBR (equity cache + request / replay rounds) against the host LocalLBRWorker (one prl_lbr_checkdown_equity call per such
+    decision), the same decks and agent draws, hand for hand"""
+    game_cls, agent_bets, lbr_kwargs = DiscretizedNLHoldem, bet_sets.B_2, dict(lbr_bet_set=bet_sets.B_2, lbr_check_to_round=None)
+    t_prof = make_t_prof(game_cls, agent_bets, lbr_kwargs, n_hands, tmp_path)
+    record = []
+    w = LocalLBRWorker(t_prof=t_prof, chief_handle=None, eval_agent_cls=fx.make_agent_cls(EvalAgentBase, seed=7, record=record))
+    b = BatchedLBR(t_prof, agent_kind="hash", agent_seed=7)
+    lut = game_cls.get_lut_holder()
+    for seat in (0, 1):
+        np.random.seed(300 + seat)
+        n0 = len(record)
+        host = w.run(agent_seat_id=seat, n_iterations=n_hands, mode="HASH", stack_size=[game_cls.DEFAULT_STACK_SIZE] * 2)
+        decks = decks_from_record(record[n0:], lut, b.n_deal - 2 * b._rules.n_hole_cards)
+        got = b.run(agent_seat_id=seat, n_hands=n_hands, decks=decks)
+        assert np.array_equal(got, host), "seat %d: %d of %d hands differ (first at %s): %s vs %s" % (seat, int(np.sum(got != host)), n_hands, np.flatnonzero(got != host)[:5], got[:6], host[:6])
+        assert b.last_stats["lbr_lookaheads"] >= n_hands  # every hand opens with a decision of LBR or reaches one
+
+
+@pytest.mark.gpu
+def test_gpu_batched_lbr_before_the_flop_vs_host_worker(tmp_path):
+    check_batched_before_the_flop_vs_host(tmp_path, int(os.environ.get("PRL_LBR_PREFLOP_HANDS", "16")))
+
+
 def test_batched_lbr_holdem_vs_reference_emu(emu_lib, tmp_path):
     """1326-hand ranges through the emulator: every inter-lane hand-off of the kernel is exercised with the fibers run strictly
     one after another (this is how a missing barrier before lane 0's env step was found)."""
