@@ -156,8 +156,9 @@ def _bind_solver(L):
     L.prl_solver_create.argtypes = [vp, i32, i32, ctypes.POINTER(vp)]
     L.prl_solver_create_ex.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp)]
     L.prl_solver_create_ex.restype = i32
-    L.prl_solver_create_weighted.argtypes = [vp, i32, i32, i32, vp, i32, ctypes.POINTER(vp)]
-    L.prl_solver_create_weighted.restype = i32
+    if hasattr(L, "prl_solver_create_weighted"):  # (A/B runs bind older builds of the library)
+        L.prl_solver_create_weighted.argtypes = [vp, i32, i32, i32, vp, i32, ctypes.POINTER(vp)]
+        L.prl_solver_create_weighted.restype = i32
     L.prl_solver_create_sharded.argtypes = [vp, i32, i32, i32, i32, EXCHANGE_FN, vp, ctypes.POINTER(vp)]
     L.prl_solver_create_sharded.restype = i32
     L.prl_solver_create_sharded_ragged.argtypes = [vp, i32, i32, i32, i32, ctypes.c_int64, ctypes.c_int64, EXCHANGE_FN, vp, ctypes.POINTER(vp)]

@@ -43,6 +43,109 @@ PRL_GLOBAL void prl_k_lbr_reduce(PrlLbrGame g, int n_boards, const float* __rest
         out[q] = prl_lbr_reduce_range(g, ranges + (size_t)q * g.R, eq + (size_t)q * n_boards);
 }
 
+// ---- more than two cards to come (hold'em before the flop: C(50, 5) = 2 118 760 boards per range) ---------------------------------------------------------
+// prl_lbr_reduce_range_deep (prl_lbr.h) is _calc_eq's recursion (LocalLBRWorker.py:470-512) as ONE sequential walk: per interior node of the deal tree the
+// card probabilities re-normalised, per board the product of the dealt cards' probabilities times the board's equity, added to a running float32 sum.
+// One lane doing that is 230 300 re-normalisations of 52 entries in private memory and 2.1 M dependent global reads: 1.5 s per call (round 6: the batched
+// engine's pre-flop rounds and the host worker both pay it per decision). The VALUES do not need the walk: a board's term depends on its own path only.
+//   prl_k_lbr_deep_terms: one lane per (range, prefix of the first k - 1 cards to come): the chain of re-normalised card probabilities down ITS path
+//                         (the same operations on the same numbers as the walk), then x[b] = e[b] * reach for the boards below the prefix -- they are
+//                         consecutive in the enumeration order -- written over e[b];
+//   prl_k_lbr_deep_sum:   per range the running float32 sum of the terms in board order (the one step that IS sequential): the workgroup streams the
+//                         terms through LDS, one lane adds.
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_lbr_deep_terms(PrlLbrGame g, const float* __restrict__ ranges, int n_q, int n_boards, int n_prefix, float* __restrict__ eq) {
+    float* cp_all = (float*)prl_smem();  // [n_cards][blockDim]: a lane's card probabilities, lane index fastest (no bank conflicts)
+    const int nt = (int)prl_nthreads(), tid = (int)prl_tid();
+    const long long t = (long long)prl_bid() * nt + tid;
+    if (t >= (long long)n_q * n_prefix) return;
+    const int q = (int)(t / n_prefix);
+    int pr = (int)(t - (long long)q * n_prefix);
+    const int k = g.n_to_deal, nc = g.n_cards;
+    int8_t pc[PRL_LBR_MAX_CARDS];
+    const int n_pc = prl_lbr_possible_cards(g, pc);
+    auto cp = [&](int c) -> float& { return cp_all[(size_t)c * nt + tid]; };
+    // the prefix: combination number `pr` of k - 1 of the first n_pc - 1 possible cards, lexicographic (the walk's order of interior paths)
+    int idx[PRL_LBR_MAX_DEAL];
+    {
+        int v = 0;
+        for (int j = 0; j < k - 1; ++j) {
+            for (;; ++v) {
+                const int below = (int)prl_comb(n_pc - 1 - (v + 1), k - 2 - j);  // prefixes that continue with card v at position j
+                if (pr < below) break;
+                pr -= below;
+            }
+            idx[j] = v++;
+        }
+    }
+    // rank of the first board below the prefix among all boards (lexicographic k-combinations of n_pc cards)
+    long long b0 = 0;
+    {
+        int prev = -1;
+        for (int j = 0; j < k - 1; ++j) {
+            for (int v = prev + 1; v < idx[j]; ++v) b0 += prl_comb(n_pc - 1 - v, k - 1 - j);
+            prev = idx[j];
+        }
+    }
+    // the chain of card probabilities down the path (prl_lbr_reduce_range_deep, level by level; one array, rewritten in place)
+    const float* rg = ranges + (size_t)q * g.R;
+    for (int c = 0; c < nc; ++c) cp(c) = prl_lbr_card_not_held(g, rg, c);
+    for (int i = 0; i < g.n_hole; ++i) cp(g.lbr_hand[i]) = 0.f;
+    for (int i = 0; i < g.n_dealt; ++i) cp(g.board[i]) = 0.f;
+    {
+        int j = 0;
+        auto nx = [&]() { return cp(j++); };
+        const float s = prl_np_sum_stream<0>(nc, nx);
+        if (s > 0.f)
+            for (int c = 0; c < nc; ++c) cp(c) = cp(c) / s;
+    }
+    float reach = 1.f;
+    for (int l = 0; l < k - 1; ++l) {
+        const int card = pc[idx[l]];
+        reach = l == 0 ? cp(card) : reach * cp(card);  // 1.0 * p at depth 0
+        cp(card) = 0.f;
+        int j = 0;
+        auto nx = [&]() { return cp(j++); };
+        const float s = prl_np_sum_stream<0>(nc, nx);
+        for (int c = 0; c < nc; ++c) cp(c) = cp(c) / s;
+    }
+    float* e = eq + (size_t)q * n_boards + b0;
+    int b = 0;
+    for (int i = idx[k - 2] + 1; i < n_pc; ++i, ++b) {
+        const float r = k == 1 ? cp(pc[i]) : reach * cp(pc[i]);
+        e[b] = e[b] * r;
+    }
+}
+
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_lbr_deep_sum(int k, int n_boards, const float* __restrict__ terms, float* __restrict__ out) {
+    float* buf = (float*)prl_smem();  // [2048]
+    const int q = (int)prl_bid(), tid = (int)prl_tid(), nt = (int)prl_nthreads();
+    const float* x = terms + (size_t)q * n_boards;
+    float win = 0.f;
+    for (int b0 = 0; b0 < n_boards; b0 += 2048) {
+        const int n = n_boards - b0 < 2048 ? n_boards - b0 : 2048;
+        prl_sync();
+        for (int i = tid; i < n; i += nt) buf[i] = x[b0 + i];
+        prl_sync();
+        if (tid == 0) {
+            int i = 0;
+            if (b0 == 0) { win = buf[0]; i = 1; }  // 0.0 (Python float) + float32 -> float32
+            for (; i + 8 <= n; i += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = buf[i + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) win = win + v[j];
+            }
+            for (; i < n; ++i) win = win + buf[i];
+        }
+    }
+    if (tid == 0) {
+        float fact = 1.f;
+        for (int m = 2; m <= k; ++m) fact = fact * (float)m;
+        out[q] = win * fact;
+    }
+}
+
 extern "C" int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t* board_dealt, int32_t n_dealt, const int8_t* lbr_hand,
                                             const float* ranges, int32_t n_q, float* out_wp) {
     if (!rules || !lbr_hand || !ranges || !out_wp || n_q <= 0 || n_dealt < 0 || (n_dealt > 0 && !board_dealt)) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
@@ -103,7 +206,13 @@ extern "C" int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t*
         const long long items_eq = (long long)n_q * n_boards;
         PRL_LAUNCH(prl_k_lbr_board_eq, (int)((items_eq + 63) / 64 < 262144 ? (items_eq + 63) / 64 : 262144), 64, 0, nullptr, g, (const int8_t*)d_boards, n_boards, (const uint8_t*)d_cls,
                    (const float*)d_rg, n_q, d_eq, hole_lut);
-        PRL_LAUNCH(prl_k_lbr_reduce, (n_q + 63) / 64, 64, 0, nullptr, g, n_boards, (const float*)d_rg, n_q, (const float*)d_eq, d_out);
+        if (g.n_to_deal > 2) {  // the deal tree's terms in parallel, then the running sum in board order
+            const int n_pc = (int)pc.size(), n_prefix = (int)prl_comb(n_pc - 1, g.n_to_deal - 1);
+            const long long items = (long long)n_q * n_prefix;
+            PRL_LAUNCH(prl_k_lbr_deep_terms, (int)((items + 255) / 256), 256, (size_t)g.n_cards * 256 * sizeof(float), nullptr, g, (const float*)d_rg, n_q, n_boards, n_prefix, d_eq);
+            PRL_LAUNCH(prl_k_lbr_deep_sum, n_q, 256, 2048 * sizeof(float), nullptr, (int)g.n_to_deal, n_boards, (const float*)d_eq, d_out);
+        } else
+            PRL_LAUNCH(prl_k_lbr_reduce, (n_q + 63) / 64, 64, 0, nullptr, g, n_boards, (const float*)d_rg, n_q, (const float*)d_eq, d_out);
     }
     LB_TRY(hipDeviceSynchronize());
     LB_TRY(hipMemcpy(out_wp, d_out, (size_t)n_q * sizeof(float), hipMemcpyDeviceToHost));
