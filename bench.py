@@ -156,7 +156,7 @@ def fixed_problem_check(total, iters, world, rank, how, lib, emu_lib):
             "exploitability_mbb_per_g": float(np.mean(e) * 10.0)}
 
 
-def whole_game_lines(lib, steps, warmup):
+def whole_game_lines(lib, steps, warmup, candidates=1):
     """BASELINE config 3 exactly as stated -- "LinearCFR on Flop Hold'em Poker (1326-combo ranges, full public tree), 1 MI355X" -- and CFR+ on the same tree,
     as two short HIP-event-timed regions inside the default line (round 5's verdict: the driver should see them): ALL 2 598 960 boards of Flop5Holdem
     through their 134 459 suit classes on this one GPU (prl_solver_create_weighted, ~30 GB). Per variant: ms per iteration (device, HIP events on the
@@ -178,7 +178,9 @@ def whole_game_lines(lib, steps, warmup):
            "suit_classes": n_classes, "boards_represented": int(mult.sum()), "class_tree_nodes": tree.n_nodes, "full_tree_nodes_represented": full_nodes,
            "class_enumeration_and_tree_build_s": setup_s, "bytes_per_iteration_algorithmic": bytes_iter, "steps": steps, "warmup": warmup}
     for variant in ("plus", "linear"):
-        s = _native.NativeSolver(tree, variant, 0, _lib=lib, board_mult=mult, symmetrize=True)
+        # the same placement selection as the headline's (the pass's speed depends on where the arrays land: DESIGN.md section 4 "Spread"): candidates
+        # built side by side by the library, each timed on `steps` steady iterations, the fastest kept; every candidate's figure is reported
+        s = _native.NativeSolver(tree, variant, 0, _lib=lib, board_mult=mult, symmetrize=True, place=candidates if candidates > 1 else None, probe_iters=max(4, steps))
         s.iterations(warmup)
         s.sync()
         t1 = time.perf_counter()
@@ -196,7 +198,8 @@ def whole_game_lines(lib, steps, warmup):
             "roofline_frac": bytes_iter * steps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "achieved_gbps": bytes_iter * steps / (k_ms * 1e-3) / 1e9,
             "iterations_done": s.iter, "exploitability_mbb_per_g": float(np.mean(s.exploitability()) * 10.0),
             "avg_strategy_exploitability_mbb_per_g": float(np.mean(avg) * 10.0), "avg_strategy_evaluation_ms": eval_ms,
-            "hbm_bytes_allocated": int(s.get("bytes_allocated")[0])}
+            "hbm_bytes_allocated": int(s.get("bytes_allocated")[0]),
+            "placement_probe_ms_per_iteration": [x for x in s.placement_ms if x > 0.0] if s.placement_ms else None, "placement_chosen": s.placement_chosen}
         del s
     return out
 
@@ -407,7 +410,7 @@ def main():
     if args.whole_game_lines and not os.environ.get("PRL_BENCH_NO_WHOLE_GAME") and world == 1 and not emu_lib and not args.whole_game and not sharded and not total and args.engine != "levels":
         solver = None  # the headline's 58 GB go back before the whole game's 30 GB come (both would fit; the pass's speed depends on placement)
         try:  # (after the timed region: it must not cost the line)
-            whole = whole_game_lines(lib, args.whole_game_steps, 2)
+            whole = whole_game_lines(lib, args.whole_game_steps, 2, args.placement_candidates if args.placement_probe else 1)
         except Exception as e:  # noqa: BLE001
             whole = {"error": "%s: %s" % (type(e).__name__, e)}
     n_board_nodes = args.boards * 15

@@ -336,6 +336,10 @@ int32_t prl_solver_create_weighted(const prl_tree_t* tree, int32_t variant, int3
  * reference: the solver object of PokerRL/cfr/_CFRBase.py:18-62 (what CFRPlus(...) builds), which has no such concern on the CPU. */
 int32_t prl_solver_create_placed(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t flags, int32_t n_candidates,
                                  int32_t probe_iters, float* out_ms, int32_t* out_chosen, prl_solver_t** out_solver);
+/* The same for weighted boards / suit classes (prl_solver_create_weighted's arguments, then prl_solver_create_placed's): the whole Flop5Holdem game is
+ * 30 GB, three candidates fit side by side. */
+int32_t prl_solver_create_weighted_placed(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t flags, const int32_t* board_mult, int32_t symmetrize,
+                                          int32_t n_candidates, int32_t probe_iters, float* out_ms, int32_t* out_chosen, prl_solver_t** out_solver);
 /* Sharded solve over `world_size` GPUs, one process per GPU: the tree handed to rank r holds the
  * r-th contiguous block of the global board list (every rank the same number of boards; see _ragged below); the pre-chance trunk is
  * replicated; regrets / averages of a board live on its owner only. The one exchange per EV pass is the pull-up of the

@@ -148,10 +148,26 @@ def bind(path):
     return L
 
 
+class _Lenient:
+    """prototype declarations on a library that may lack newer symbols (same-box A/B runs bind older builds through POKERRL_AMD_LIB): a missing symbol's
+    declaration goes to a throw-away object; CALLING it still fails loudly on the CDLL itself"""
+
+    class _Missing:
+        argtypes = restype = None
+
+    def __init__(self, lib):
+        object.__setattr__(self, "_lib", lib)
+
+    def __getattr__(self, name):
+        lib = object.__getattribute__(self, "_lib")
+        return getattr(lib, name) if hasattr(lib, name) else _Lenient._Missing()
+
+
 def _bind_solver(L):
     """Device-side solver entry points (declared in include/pokerrl_hip.h section 5)."""
     if not hasattr(L, "prl_solver_create"):
         return
+    L = _Lenient(L)
     vp, i32, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_double
     L.prl_solver_create.argtypes = [vp, i32, i32, ctypes.POINTER(vp)]
     L.prl_solver_create_ex.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp)]
@@ -566,8 +582,8 @@ class NativeSolver:
         v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
         e = ENGINES[engine] if isinstance(engine, str) else int(engine)
         self._exchange_cb = None
-        if board_mult is not None and (shard is not None or place is not None):
-            raise ValueError("weighted boards (board_mult=): one GPU, no placement probe -- not with shard= / place=")
+        if board_mult is not None and shard is not None:
+            raise ValueError("weighted boards (board_mult=): one GPU -- not with shard=")
         if symmetrize and board_mult is None:
             raise ValueError("symmetrize= goes with board_mult= (suit-class representatives and their orbit sizes)")
         if shard is not None and isinstance(shard[0], str):
@@ -606,7 +622,18 @@ class NativeSolver:
             m = np.ascontiguousarray(board_mult, np.int32)
             assert m.shape == (tree.n_boards,), "one multiplicity per listed board"
             sym = 2 if symmetrize == "subset" else (1 if symmetrize else 0)  # PRL_SYMMETRIZE_SUBSET: class representatives that do not cover the game
-            check(self._L.prl_solver_create_weighted(tree.handle, v, int(delay), 1 if avg_dtype == "f32" else 0, _ptr(m), sym, ctypes.byref(self._h)), self._L)
+            if place is not None:  # placement selection among `place` candidates built side by side (prl_solver_create_weighted_placed)
+                n = int(place)
+                ms, chosen = (ctypes.c_float * n)(), ctypes.c_int32(0)
+                self._L.prl_solver_create_weighted_placed.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                                                      ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32),
+                                                                      ctypes.POINTER(ctypes.c_void_p)]
+                self._L.prl_solver_create_weighted_placed.restype = ctypes.c_int32
+                check(self._L.prl_solver_create_weighted_placed(tree.handle, v, int(delay), 1 if avg_dtype == "f32" else 0, _ptr(m), sym, n, int(probe_iters), ms,
+                                                                ctypes.byref(chosen), ctypes.byref(self._h)), self._L)
+                self.placement_ms, self.placement_chosen = [float(x) for x in ms], int(chosen.value)
+            else:
+                check(self._L.prl_solver_create_weighted(tree.handle, v, int(delay), 1 if avg_dtype == "f32" else 0, _ptr(m), sym, ctypes.byref(self._h)), self._L)
         elif not self._h and place is not None:
             # placement selection inside the library (prl_solver_create_placed): `place` candidates built side by side, the fastest kept
             n = int(place)

@@ -1331,8 +1331,23 @@ int32_t prl_solver_create_weighted(const prl_tree_t* tree, int32_t variant, int3
     return solver_create_impl(tree, variant, delay, PRL_ENGINE_FUSED, 1, 0, nullptr, nullptr, out, 0, 0, nullptr, flags, board_mult, symmetrize);
 }
 
+static int32_t create_placed_impl(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t flags, int32_t n_candidates,
+                                  int32_t probe_iters, float* out_ms, int32_t* out_chosen, prl_solver_t** out, const int32_t* board_mult, int32_t symmetrize);
+
 int32_t prl_solver_create_placed(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t flags, int32_t n_candidates,
                                  int32_t probe_iters, float* out_ms, int32_t* out_chosen, prl_solver_t** out) {
+    return create_placed_impl(tree, variant, delay, engine, flags, n_candidates, probe_iters, out_ms, out_chosen, out, nullptr, 0);
+}
+
+// placement selection for weighted boards / suit classes (the whole game is 30 GB: three candidates fit beside one another)
+int32_t prl_solver_create_weighted_placed(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t flags, const int32_t* board_mult, int32_t symmetrize,
+                                          int32_t n_candidates, int32_t probe_iters, float* out_ms, int32_t* out_chosen, prl_solver_t** out) {
+    if (!board_mult) { prl_set_error("prl_solver_create_weighted_placed: board multiplicities"); return PRL_ERR_ARG; }
+    return create_placed_impl(tree, variant, delay, PRL_ENGINE_FUSED, flags, n_candidates, probe_iters, out_ms, out_chosen, out, board_mult, symmetrize);
+}
+
+static int32_t create_placed_impl(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, int32_t flags, int32_t n_candidates,
+                                  int32_t probe_iters, float* out_ms, int32_t* out_chosen, prl_solver_t** out, const int32_t* board_mult, int32_t symmetrize) {
     if (!out || n_candidates < 1 || n_candidates > 8 || probe_iters < 1) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
     if (out_ms) for (int i = 0; i < n_candidates; ++i) out_ms[i] = 0.f;
     if (out_chosen) *out_chosen = 0;
@@ -1341,7 +1356,7 @@ int32_t prl_solver_create_placed(const prl_tree_t* tree, int32_t variant, int32_
     int rc = PRL_OK;
     for (int i = 0; i < n_candidates; ++i) {
         prl_solver* s = nullptr;
-        rc = prl_solver_create_opts(tree, variant, delay, engine, flags, &s);
+        rc = board_mult ? prl_solver_create_weighted(tree, variant, delay, flags, board_mult, symmetrize, &s) : prl_solver_create_opts(tree, variant, delay, engine, flags, &s);
         if (rc != PRL_OK) {
             if (rc == PRL_ERR_OOM && !cand.empty()) {  // no room for another set of arrays: choose among those there are
                 (void)hipGetLastError();  // the tolerated hipMalloc failure must not be what the survivor's next PRL_HIP_TRY(hipGetLastError()) reports

@@ -745,7 +745,7 @@ def check_symmetrize_is_validated(L):
         mk(fhp_tree_of(L, boards), mult, "subset")
     mk(fhp_tree_of(L, boards), mult, False)  # importance-style weights on arbitrary boards: fine without the orbit means
     with pytest.raises(ValueError):
-        _native.NativeSolver(t, "plus", 0, _lib=L, board_mult=mult, symmetrize="subset", place=2)
+        _native.NativeSolver(t, "plus", 0, _lib=L, board_mult=mult, symmetrize="subset", shard=(2, 0, None))
 
 
 def check_streets_avg_f32(L, game_cls, stack, runouts, n_iters, max_raises=None, batched=False):

@@ -295,8 +295,8 @@ def check_batched_before_the_flop_vs_host(tmp_path, n_hands):
 
 @pytest.mark.gpu
 def test_gpu_batched_lbr_before_the_flop_vs_host_worker(tmp_path):
-    # (r71: 16 hands per seat, 67 s -- every pre-flop decision is a 2.1 M-board call on either side; the suite's default is smaller)
-    check_batched_before_the_flop_vs_host(tmp_path, int(os.environ.get("PRL_LBR_PREFLOP_HANDS", "5")))
+    # (r71: 16 hands per seat took 67 s with the one-lane walk of the deal tree; r73, terms in parallel: 2.5 s)
+    check_batched_before_the_flop_vs_host(tmp_path, int(os.environ.get("PRL_LBR_PREFLOP_HANDS", "64")))
 
 
 def test_batched_lbr_holdem_vs_reference_emu(emu_lib, tmp_path):
