@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--game", default="DiscretizedNLHoldem", help="DiscretizedNLHoldem (config 5) | Flop5Holdem")
     ap.add_argument("--solver-iters", type=int, default=100, help="--agent table: CFR+ iterations of the whole-game solve the table is made of")
     ap.add_argument("--no-warmup", action="store_true", help="profiling runs: exactly one launch per seat")
+    ap.add_argument("--lbr-from-the-start", action="store_true",
+                    help="lbr_check_to_round = None (the reference's default): LBR also decides BEFORE the flop -- C(50, 5) run-outs per candidate range, cached per "
+                         "(public history, LBR hand) and computed on request between replay rounds (DESIGN.md section 6); the line then times rounds AND requests")
     ap.add_argument("--cpu-hands", type=int, default=200, help="hands of the host LocalLBRWorker timed as the baseline (0 = skip)")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -70,10 +73,11 @@ def main():
     assert fhp or args.game == "DiscretizedNLHoldem"
     assert args.agent != "table" or fhp, "--agent table: the whole-game solution of Flop5Holdem (--game Flop5Holdem)"
     if fhp:  # the fixed-limit env with pot-size raises (games.py:222-254); LBR acts from the flop on: the board is complete there
-        env_args, lbr_args = Flop5Holdem.ARGS_CLS(n_seats=2), LBRArgs(n_lbr_hands_per_seat=args.hands, lbr_check_to_round=Poker.FLOP)
+        env_args = Flop5Holdem.ARGS_CLS(n_seats=2)
+        lbr_args = LBRArgs(n_lbr_hands_per_seat=args.hands, lbr_check_to_round=None if args.lbr_from_the_start else Poker.FLOP)
     else:
         env_args = DiscretizedNLHoldem.ARGS_CLS(n_seats=2, bet_sizes_list_as_frac_of_pot=bet_sets.B_5)
-        lbr_args = LBRArgs(lbr_bet_set=bet_sets.OFF_TREE_11, n_lbr_hands_per_seat=args.hands, lbr_check_to_round=Poker.TURN)
+        lbr_args = LBRArgs(lbr_bet_set=bet_sets.OFF_TREE_11, n_lbr_hands_per_seat=args.hands, lbr_check_to_round=None if args.lbr_from_the_start else Poker.TURN)
     game_cls = Flop5Holdem if fhp else DiscretizedNLHoldem
     t_prof = TrainingProfileBase(
         name="lbr_bench", log_verbose=False, log_export_freq=1, checkpoint_freq=10 ** 9, eval_agent_export_freq=10 ** 9,
@@ -134,6 +138,7 @@ def main():
                                    "LBR vs a synthetic tabular agent on DiscretizedNLHoldem (agent bets B_5, LBR bets OFF_TREE_11, LBR acts from the turn on), ") +
                                   "%d hands per agent seat over %d GPU(s), every hand played start to finish by one workgroup" % (args.hands, world),
                       "hands_total": int(n), "device_seconds_rank0": dev_s, "agent": args.agent,
+                      "lbr_check_to_round": "None (LBR decides before the flop too: equity cache + request / replay rounds)" if args.lbr_from_the_start else ("FLOP" if fhp else "TURN"),
                       "env_steps_per_s_rank0": sum(s["env_steps"] for s in stats) / dev_s,
                       "lbr_lookaheads_per_s_rank0": sum(s["lbr_lookaheads"] for s in stats) / dev_s,
                       "hand_evals_per_s_rank0": sum(s["range_board_equities"] for s in stats) * 1326 / dev_s,

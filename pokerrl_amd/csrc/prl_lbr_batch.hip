@@ -959,7 +959,7 @@ PRL_GLOBAL void LBRB_LB prl_k_lbr_batch(PrlLbrBatchParams P) {
                             if (q < n_q && uq[q] > best) { best = uq[q]; best_a = aq[q]; }  // np.argmax: the first maximum
                         S.action = best_a;
                         n_look += 1;
-                        n_eq += (unsigned long long)n_q * n_boards;
+                        if (!cached) n_eq += (unsigned long long)n_q * n_boards;  // (cached equities were computed by the request that filled the cache)
                     }
                     prl_sync();
                     action = S.action;
