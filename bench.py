@@ -50,7 +50,7 @@ PMC_TRAFFIC_BYTES_PER_BOARD_ITERATION_LINEAR = 87.4e9 / 262144
 # the two-seat evaluation pass over the float64 averages (prl_k_fhp_pass<EVAL, AVG, AVG>): 2 * 18.16 GB read + 0.17 GB written (profiles/r50_bench_pmc.txt;
 # round 4: 2 * 17.65 + 0.17)
 PMC_TRAFFIC_BYTES_PER_BOARD_AVG_EVALUATION = 36.49e9 / 262144
-PMC_TRAFFIC_SOURCE = ("profiles/r06_pmc.txt, re-measured on round 5's pass in r50_bench_pmc.txt: 2 * 17.72 GB read + 24.3 GB written per launch = 119.5 GB (CFR+), "
+PMC_TRAFFIC_SOURCE = ("profiles/r06_pmc.txt, re-measured on round 5's pass in r50_bench_pmc.txt and on round 6's final build in r76_bench_pmc.txt: 2 * 17.72 GB read + 24.2-24.3 GB written per launch = 119.4 GB (CFR+), "
                       "r30_avg_f32_pmc_traffic.txt (--avg-f32), r30_linear_pmc_traffic.txt (--variant linear): "
                       "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md")
 
