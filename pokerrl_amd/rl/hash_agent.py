@@ -24,7 +24,7 @@ def state_key(env, seed):
             env.seats[1].stack, env.current_player.seat_id]
     vals += [int(c) & 0xFF for c in np.asarray(env.board).reshape(-1)]
     for v in vals:
-        k = mix32(k * np.uint64(31) + (np.uint64(int(v)) & M32))
+        k = mix32(k * np.uint64(31) + np.uint64(int(v) & 0xFFFFFFFF))
     return k
 
 

@@ -481,6 +481,31 @@ def _native_product_lib():
         return None
 
 
+def check_set_strategy_device(L, t, make_solver, to_device=None, seed=9):
+    """prl_solver_set_strategy_device (the agent's probabilities [n_decision_nodes][R][A] float32 already in device memory, scattered into the solver's
+    columns on the device) = prl_solver_set_strategy with the same numbers gathered into [n_cols][R] on the host: strategy read back, exploitability.
+    to_device: array -> (object that keeps the device copy alive, its address); None: the emulator, where host memory IS device memory"""
+    kind, nch, fc, col_action = t.field("kind"), t.field("n_children"), t.field("first_col"), t.field("col_action")
+    dec = np.flatnonzero(kind == 0)
+    n_act = int(col_action.max()) + 1
+    rng = np.random.RandomState(seed)
+    probs = rng.random_sample((len(dec), t.range_size, n_act)).astype(np.float32)
+    probs /= probs.sum(axis=2, keepdims=True)
+    cols = np.zeros((t.n_cols, t.range_size), np.float32)
+    for k, n in enumerate(dec):
+        for j in range(nch[n]):
+            cols[fc[n] + j] = probs[k, :, col_action[fc[n] + j]]
+    a, b = make_solver(), make_solver()
+    a.set_strategy(cols)
+    keep, ptr = (probs, probs.ctypes.data) if to_device is None else to_device(probs)
+    b.set_strategy_device(ptr, n_act)
+    assert np.array_equal(a.get("strategy"), b.get("strategy"))
+    a.compute_ev(); b.compute_ev()
+    assert np.array_equal(a.exploitability(), b.exploitability()) and np.all(a.exploitability() > 0)
+    del keep
+    return a.engine
+
+
 def check_streets_br_vs_oracle(L, game_cls, stack, runouts, max_raises=None, seed=5):
     """Exact best response of an explicit strategy on a multi-street tree, per-street engine (LocalBRMaster.py:67-80): a seeded strategy given as
     float32 (played as float32 from the engine's internal column order) and as float64 columns in the flat tree's DFS order; exploitability

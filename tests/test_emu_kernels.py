@@ -133,6 +133,21 @@ def test_emu_fused_engine_weighted_boards_checkpoint_resume(L):
     pc.check_weighted_checkpoint(L)
 
 
+def test_emu_set_strategy_device_on_every_engine(L):
+    """the device-side scatter of an agent's probabilities into the solver's columns: LEVELS (hand-order columns), the single-deal fused engine (sorted
+    board storage, through the staging buffer) and the per-street engine (internal column order)"""
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import games as G
+    t = pc.fhp_tree_of(L, pc.fhp_boards(3))
+    assert pc.check_set_strategy_device(L, t, lambda: _native.NativeSolver(t, "plus", 0, engine="levels", _lib=L)) == "levels"
+    assert pc.check_set_strategy_device(L, t, lambda: _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)) == "fused"
+    game = G.LimitHoldem.native_game(pc.env_args(G.LimitHoldem, 48, None))
+    for i, v in enumerate((1, 2, 1, 1)):
+        game.max_raises[i] = v
+    t2 = _native.NativeTree(game, G.LimitHoldem.native_rules(), pc.multistreet_runouts(1, 2, 1), _lib=L)
+    assert pc.check_set_strategy_device(L, t2, lambda: _native.NativeSolver(t2, "plus", 0, engine="auto", _lib=L)) == "fused"
+
+
 def test_emu_suit_classes_are_checked_not_trusted(L):
     pc.check_symmetrize_is_validated(L)
 

@@ -126,6 +126,16 @@ def test_device_resident_agent_fill_equals_host_fill_emu(emu_lib, tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpu_device_resident_agent_fill_on_the_per_street_engine(tmp_path):
+    """a multi-street tree (LimitHoldem, one run-out, full betting: 17 221 nodes) on the per-street fused engine, whose columns live in an internal order
+    (trunk, then street by street, instance by instance): the device-side scatter goes through that order's column map"""
+    import parity_cases as pc
+    from pokerrl_amd.game.games import LimitHoldem
+    _e, eng = check_device_fill_equals_host_fill(LimitHoldem, HistoryEnvBuilder, tmp_path, device="cuda", boards=pc.multistreet_runouts(1, 1, 1), engine="auto")
+    assert eng == "fused"
+
+
+@pytest.mark.gpu
 def test_gpu_device_resident_agent_fill_on_a_4096_board_tree(tmp_path):
     """best response against a neural agent on Flop5Holdem x 4096 boards (24 578 decision nodes, a 391 MB probability tensor): the strategy never visits
     the host -- and equals the host path bit for bit"""

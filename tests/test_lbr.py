@@ -603,6 +603,54 @@ def check_solver_table_h2h_vs_host(L, tmp_path, n_classes, n_iters, n_hands):
     table.close()
 
 
+def check_solver_table_equals_tree_table(game_cls, agent_bets, n_iters, variant="plus", expect_twins=False, **cfr_kw):
+    """prl_policy_table_from_solver on the LEVELS engine (columns already in hand order) = the host path PolicyTable.from_cfr: the same rows in the same
+    order under the same keys, the same float32 probabilities; node keys by path = node keys by index; and on the device the look-ups hit.
+    expect_twins: a bet set whose sizes the env turns into ONE amount (a size below the minimum raise is raised to it, the next size IS the minimum raise):
+    such siblings repeat each other node for node under one history key -- both builders keep the first and drop the rest (round 5's advisor finding)"""
+    from pokerrl_amd.cfr.CFRPlus import CFRPlus
+    from pokerrl_amd.cfr.LinearCFR import LinearCFR
+    from pokerrl_amd.cfr.VanillaCFR import VanillaCFR
+    from pokerrl_amd.rl.tabular_agent import PolicyTable
+    cls = {"plus": CFRPlus, "linear": LinearCFR, "vanilla": VanillaCFR}[variant]
+    kw = dict(delay=0) if variant == "plus" else {}
+    cfr = cls(name="tab", chief_handle=_Chief(), game_cls=game_cls, agent_bet_set=agent_bets, **kw, **cfr_kw)
+    cfr.reset()
+    for _ in range(n_iters):
+        cfr.iteration()
+    host, dev = PolicyTable.from_cfr(cfr), PolicyTable.from_solver(cfr)
+    n_dec = int(np.sum(cfr._trees[0]._kind == 0))
+    assert (host.n_rows < n_dec) == expect_twins, (host.n_rows, n_dec)
+    assert (dev.n_rows, dev.n_actions, dev.range_size, dev.suit_canon) == (host.n_rows, host.n_actions, host.range_size, False)
+    assert np.array_equal(dev.keys, host.keys) and np.array_equal(dev.rows, host.rows)  # the same open-addressed table, slot for slot
+    for r in range(host.n_rows):
+        assert np.array_equal(dev.row_probs(r), host.probs[r]), r
+    tree = cfr._trees[0]
+    for i in np.flatnonzero(tree._kind == 0)[::7]:
+        assert dev.key_of_node(tree.node(int(i))) == host.node_keys[int(i)]
+    keys = [hk for hk in host.node_keys.values() if host.row_of(hk) >= 0][:64]
+    rng = np.random.RandomState(0)
+    a, h = rng.randint(0, host.n_actions, len(keys)), rng.randint(0, host.range_size, len(keys))
+    rows, probs = dev.probe(keys, a, h)
+    want = np.array([host.row_of(k) for k in keys])
+    assert np.array_equal(rows, want) and np.array_equal(probs, host.probs[want, a, h])
+    host.close(), dev.close()
+
+
+@pytest.mark.parametrize("game,bets,variant", [("StandardLeduc", None, "plus"), ("StandardLeduc", None, "linear"), ("DiscretizedNLLeduc", "B_3", "vanilla")])
+def test_solver_table_on_the_levels_engine_equals_the_tree_table_emu(emu_lib, game, bets, variant):
+    check_solver_table_equals_tree_table({"StandardLeduc": StandardLeduc, "DiscretizedNLLeduc": DiscretizedNLLeduc}[game], getattr(bet_sets, bets) if bets else None, 4, variant)
+
+
+def test_solver_table_merges_children_the_env_turns_into_one_state_emu(emu_lib):
+    check_solver_table_equals_tree_table(DiscretizedNLLeduc, [0.3, 0.34, 1.0], 2, "plus", expect_twins=True, starting_stack_sizes=[1000])
+
+
+@pytest.mark.gpu
+def test_gpu_solver_table_on_the_levels_engine_equals_the_tree_table():
+    check_solver_table_equals_tree_table(DiscretizedNLLeduc, bet_sets.B_3, 6, "plus")
+
+
 def test_host_canonicalisation_equals_the_librarys(emu_lib):
     check_canon_agrees_with_the_library(emu_lib)
 
