@@ -37,6 +37,36 @@ PRL_GLOBAL void prl_k_lbr_board_eq(PrlLbrGame g, const int8_t* __restrict__ boar
     }
 }
 
+// the b-th board of the enumeration, any number of cards to come: the lexicographic k-combination number b of the possible cards (what the host
+// used to enumerate and upload: 10.6 MB per pre-flop call)
+PRL_HD PRL_INLINE void prl_lbr_board_unrank(const PrlLbrGame& g, const int8_t* pc, int n_pc, long long b, int8_t* fb) {
+    const int k = g.n_to_deal;
+    for (int i = 0; i < 5; ++i) fb[i] = i < g.n_dealt ? g.board[i] : (int8_t)0;
+    int v = 0;
+    for (int j = 0; j < k; ++j) {
+        for (;; ++v) {
+            const long long below = prl_comb(n_pc - 1 - v, k - 1 - j);  // boards that continue with card v at position j
+            if (b < below) break;
+            b -= below;
+        }
+        const int8_t c = pc[v++];
+        for (int i = 0; i < 5; ++i) fb[i] = i == g.n_dealt + j ? c : fb[i];  // (selects: a write at a run-time position would push the board into private memory)
+    }
+}
+
+PRL_GLOBAL void prl_k_lbr_board_eq_deep(PrlLbrGame g, int n_boards, const uint8_t* __restrict__ cls, const float* __restrict__ ranges, int n_q,
+                                        float* __restrict__ eq, const uint16_t* __restrict__ hole_lut) {
+    int8_t pc[PRL_LBR_MAX_CARDS];
+    const int n_pc = prl_lbr_possible_cards(g, pc);
+    const long long total = (long long)n_q * n_boards;
+    for (long long t = (long long)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (long long)prl_nblocks() * prl_nthreads()) {
+        const int q = (int)(t / n_boards), b = (int)(t - (long long)q * n_boards);
+        int8_t fb[5];
+        prl_lbr_board_unrank(g, pc, n_pc, b, fb);
+        eq[t] = prl_lbr_board_equity(g, fb, cls, ranges + (size_t)q * g.R, hole_lut);
+    }
+}
+
 PRL_GLOBAL void prl_k_lbr_reduce(PrlLbrGame g, int n_boards, const float* __restrict__ ranges, int n_q, const float* __restrict__ eq,
                                  float* __restrict__ out) {
     for (int q = (int)(prl_bid() * prl_nthreads() + prl_tid()); q < n_q; q += (int)(prl_nblocks() * prl_nthreads()))
@@ -116,30 +146,39 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_lbr_deep_terms(PrlLbrGame g, const 
     }
 }
 
-PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_lbr_deep_sum(int k, int n_boards, const float* __restrict__ terms, float* __restrict__ out) {
-    float* buf = (float*)prl_smem();  // [2048]
-    const int q = (int)prl_bid(), tid = (int)prl_tid(), nt = (int)prl_nthreads();
+// One WAVE per range. The sum is a strictly sequential float32 chain (that is the reference's order); what can be taken off the chain is everything but
+// the add itself: the wave loads 64 terms per register (coalesced, eight registers in flight), and every lane runs the same chain taking term j of a
+// register by a lane broadcast (v_readlane: a scalar operand, independent of the chain) -- the chain is one dependent v_add per term.
+#if defined(PRL_EMU)
+#define PRL_LANE_BCAST(v, j) prl_shfl((v), (j))
+#else
+PRL_DEV PRL_INLINE float prl_lane_bcast_(float v, int j) { int i; __builtin_memcpy(&i, &v, 4); i = __builtin_amdgcn_readlane(i, j); float o; __builtin_memcpy(&o, &i, 4); return o; }
+#define PRL_LANE_BCAST(v, j) prl_lane_bcast_((v), (j))
+#endif
+PRL_GLOBAL void PRL_LAUNCH_BOUNDS(64) prl_k_lbr_deep_sum(int k, int n_boards, const float* __restrict__ terms, float* __restrict__ out) {
+    const int q = (int)prl_bid(), lane = (int)prl_tid();
     const float* x = terms + (size_t)q * n_boards;
     float win = 0.f;
-    for (int b0 = 0; b0 < n_boards; b0 += 2048) {
-        const int n = n_boards - b0 < 2048 ? n_boards - b0 : 2048;
-        prl_sync();
-        for (int i = tid; i < n; i += nt) buf[i] = x[b0 + i];
-        prl_sync();
-        if (tid == 0) {
-            int i = 0;
-            if (b0 == 0) { win = buf[0]; i = 1; }  // 0.0 (Python float) + float32 -> float32
-            for (; i + 8 <= n; i += 8) {
-                float v[8];
+    bool first = true;
+    for (int b0 = 0; b0 < n_boards; b0 += 8 * 64) {
+        float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = buf[i + j];
+        for (int r = 0; r < 8; ++r) { const int i = b0 + r * 64 + lane; v[r] = i < n_boards ? x[i] : 0.f; }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) win = win + v[j];
+        for (int r = 0; r < 8; ++r) {
+            const int left = n_boards - (b0 + r * 64);
+            if (left >= 64 && !first) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) win = win + PRL_LANE_BCAST(v[r], j);
+            } else {
+                for (int j = 0; j < 64; ++j) {
+                    const float t = PRL_LANE_BCAST(v[r], j);
+                    if (j < left) { win = first ? t : win + t; first = false; }  // 0.0 (Python float) + float32 -> float32
+                }
             }
-            for (; i < n; ++i) win = win + buf[i];
         }
     }
-    if (tid == 0) {
+    if (lane == 0) {
         float fact = 1.f;
         for (int m = 2; m <= k; ++m) fact = fact * (float)m;
         out[q] = win * fact;
@@ -170,7 +209,13 @@ extern "C" int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t*
         if (!used) pc.push_back((int8_t)c);
     }
     std::vector<int8_t> boards;
-    {   // every combination of n_to_deal of the possible cards, lexicographic (what the nested loops of :408-417 produce)
+    const bool deep = g.n_to_deal > 2;  // the kernels number the boards themselves (prl_lbr_board_unrank); only the first one is needed here (classification)
+    if (deep) {
+        int8_t fb[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < n_dealt; ++i) fb[i] = g.board[i];
+        for (int i = 0; i < g.n_to_deal; ++i) fb[n_dealt + i] = pc[i];
+        boards.insert(boards.end(), fb, fb + 5);
+    } else {   // every combination of n_to_deal of the possible cards, lexicographic (what the nested loops of :408-417 produce)
         const int k = g.n_to_deal, m = (int)pc.size();
         boards.reserve((size_t)prl_comb(m, k) * 5);
         int idx[PRL_LBR_MAX_DEAL + 1];
@@ -186,8 +231,9 @@ extern "C" int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t*
             else { ++idx[i]; for (int j = i + 1; j < k; ++j) idx[j] = idx[j - 1] + 1; }
         }
     }
-    const int n_boards = (int)(boards.size() / 5);
-    if ((long long)n_q * n_boards > 0x7FFFFFFFll) { prl_set_error("LBR equity: too many (range, board) pairs in one call"); return PRL_ERR_ARG; }
+    const long long n_boards_ll = deep ? prl_comb((int)pc.size(), g.n_to_deal) : (long long)(boards.size() / 5);
+    const int n_boards = (int)n_boards_ll;
+    if (n_boards_ll <= 0 || n_q * n_boards_ll > 0x7FFFFFFFll) { prl_set_error("LBR equity: too many (range, board) pairs in one call"); return PRL_ERR_ARG; }
     const uint16_t* hole_lut = nullptr;  // hold'em: the process-wide (c1, c2) table of the hand evaluator
     if (g.n_hole == 2 && prl_hole_lut_device(&hole_lut) != PRL_OK) return PRL_ERR_HIP;
     int8_t* d_boards = nullptr; uint8_t* d_cls = nullptr; float *d_rg = nullptr, *d_eq = nullptr, *d_out = nullptr;
@@ -204,13 +250,15 @@ extern "C" int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t*
         const size_t items = (size_t)g.R;  // first board only
         PRL_LAUNCH(prl_k_lbr_classify, (int)((items + 255) / 256), 256, 0, nullptr, g, (const int8_t*)d_boards, 1, d_cls);
         const long long items_eq = (long long)n_q * n_boards;
-        PRL_LAUNCH(prl_k_lbr_board_eq, (int)((items_eq + 63) / 64 < 262144 ? (items_eq + 63) / 64 : 262144), 64, 0, nullptr, g, (const int8_t*)d_boards, n_boards, (const uint8_t*)d_cls,
+        if (deep) PRL_LAUNCH(prl_k_lbr_board_eq_deep, (int)((items_eq + 63) / 64 < 262144 ? (items_eq + 63) / 64 : 262144), 64, 0, nullptr, g, n_boards, (const uint8_t*)d_cls,
+                             (const float*)d_rg, n_q, d_eq, hole_lut);
+        else PRL_LAUNCH(prl_k_lbr_board_eq, (int)((items_eq + 63) / 64 < 262144 ? (items_eq + 63) / 64 : 262144), 64, 0, nullptr, g, (const int8_t*)d_boards, n_boards, (const uint8_t*)d_cls,
                    (const float*)d_rg, n_q, d_eq, hole_lut);
         if (g.n_to_deal > 2) {  // the deal tree's terms in parallel, then the running sum in board order
             const int n_pc = (int)pc.size(), n_prefix = (int)prl_comb(n_pc - 1, g.n_to_deal - 1);
             const long long items = (long long)n_q * n_prefix;
             PRL_LAUNCH(prl_k_lbr_deep_terms, (int)((items + 255) / 256), 256, (size_t)g.n_cards * 256 * sizeof(float), nullptr, g, (const float*)d_rg, n_q, n_boards, n_prefix, d_eq);
-            PRL_LAUNCH(prl_k_lbr_deep_sum, n_q, 256, 2048 * sizeof(float), nullptr, (int)g.n_to_deal, n_boards, (const float*)d_eq, d_out);
+            PRL_LAUNCH(prl_k_lbr_deep_sum, n_q, 64, 0, nullptr, (int)g.n_to_deal, n_boards, (const float*)d_eq, d_out);
         } else
             PRL_LAUNCH(prl_k_lbr_reduce, (n_q + 63) / 64, 64, 0, nullptr, g, n_boards, (const float*)d_rg, n_q, (const float*)d_eq, d_out);
     }
