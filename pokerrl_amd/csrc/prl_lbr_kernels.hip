@@ -54,7 +54,9 @@ PRL_HD PRL_INLINE void prl_lbr_board_unrank(const PrlLbrGame& g, const int8_t* p
     }
 }
 
-PRL_GLOBAL void prl_k_lbr_board_eq_deep(PrlLbrGame g, int n_boards, const uint8_t* __restrict__ cls, const float* __restrict__ ranges, int n_q,
+// (the classes as ascending index lists -- prl_lbr_board_equity_lists: element i of a class sum is a pure function of i, so NumPy's eight accumulator chains run
+// side by side instead of scanning the class bytes; the same values in the same order)
+PRL_GLOBAL void prl_k_lbr_board_eq_deep(PrlLbrGame g, int n_boards, const uint16_t* __restrict__ cls_list, int n_big, int n_eq, const float* __restrict__ ranges, int n_q,
                                         float* __restrict__ eq, const uint16_t* __restrict__ hole_lut) {
     int8_t pc[PRL_LBR_MAX_CARDS];
     const int n_pc = prl_lbr_possible_cards(g, pc);
@@ -63,7 +65,7 @@ PRL_GLOBAL void prl_k_lbr_board_eq_deep(PrlLbrGame g, int n_boards, const uint8_
         const int q = (int)(t / n_boards), b = (int)(t - (long long)q * n_boards);
         int8_t fb[5];
         prl_lbr_board_unrank(g, pc, n_pc, b, fb);
-        eq[t] = prl_lbr_board_equity(g, fb, cls, ranges + (size_t)q * g.R, hole_lut);
+        eq[t] = prl_lbr_board_equity_lists(g, fb, cls_list, n_big, n_eq, ranges + (size_t)q * g.R, hole_lut);
     }
 }
 
@@ -236,7 +238,7 @@ extern "C" int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t*
     if (n_boards_ll <= 0 || n_q * n_boards_ll > 0x7FFFFFFFll) { prl_set_error("LBR equity: too many (range, board) pairs in one call"); return PRL_ERR_ARG; }
     const uint16_t* hole_lut = nullptr;  // hold'em: the process-wide (c1, c2) table of the hand evaluator
     if (g.n_hole == 2 && prl_hole_lut_device(&hole_lut) != PRL_OK) return PRL_ERR_HIP;
-    int8_t* d_boards = nullptr; uint8_t* d_cls = nullptr; float *d_rg = nullptr, *d_eq = nullptr, *d_out = nullptr;
+    int8_t* d_boards = nullptr; uint8_t* d_cls = nullptr; float *d_rg = nullptr, *d_eq = nullptr, *d_out = nullptr; uint16_t* d_list = nullptr;
     int rc = PRL_OK;
 #define LB_TRY(x) do { if ((x) != hipSuccess) { prl_set_error("HIP error in prl_lbr_checkdown_equity"); rc = PRL_ERR_HIP; goto done; } } while (0)
     LB_TRY(hipMalloc((void**)&d_boards, boards.size()));
@@ -250,8 +252,20 @@ extern "C" int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t*
         const size_t items = (size_t)g.R;  // first board only
         PRL_LAUNCH(prl_k_lbr_classify, (int)((items + 255) / 256), 256, 0, nullptr, g, (const int8_t*)d_boards, 1, d_cls);
         const long long items_eq = (long long)n_q * n_boards;
-        if (deep) PRL_LAUNCH(prl_k_lbr_board_eq_deep, (int)((items_eq + 63) / 64 < 262144 ? (items_eq + 63) / 64 : 262144), 64, 0, nullptr, g, n_boards, (const uint8_t*)d_cls,
-                             (const float*)d_rg, n_q, d_eq, hole_lut);
+        if (deep) {
+            // the first board's classes as index lists: the hands LBR beats (ascending), then the ones it ties with
+            std::vector<uint8_t> cls((size_t)g.R);
+            LB_TRY(hipMemcpy(cls.data(), d_cls, (size_t)g.R, hipMemcpyDeviceToHost));
+            std::vector<uint16_t> lst;
+            int n_big = 0, n_eq = 0;
+            for (int h = 0; h < g.R; ++h) if (cls[h] == 1) { lst.push_back((uint16_t)h); ++n_big; }
+            for (int h = 0; h < g.R; ++h) if (cls[h] == 2) { lst.push_back((uint16_t)h); ++n_eq; }
+            lst.resize((size_t)g.R + 8, 0);  // (the streams fetch eight entries at a time)
+            LB_TRY(hipMalloc((void**)&d_list, lst.size() * sizeof(uint16_t)));
+            LB_TRY(hipMemcpy(d_list, lst.data(), lst.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            PRL_LAUNCH(prl_k_lbr_board_eq_deep, (int)((items_eq + 63) / 64 < 262144 ? (items_eq + 63) / 64 : 262144), 64, 0, nullptr, g, n_boards, (const uint16_t*)d_list, n_big, n_eq,
+                       (const float*)d_rg, n_q, d_eq, hole_lut);
+        }
         else PRL_LAUNCH(prl_k_lbr_board_eq, (int)((items_eq + 63) / 64 < 262144 ? (items_eq + 63) / 64 : 262144), 64, 0, nullptr, g, (const int8_t*)d_boards, n_boards, (const uint8_t*)d_cls,
                    (const float*)d_rg, n_q, d_eq, hole_lut);
         if (g.n_to_deal > 2) {  // the deal tree's terms in parallel, then the running sum in board order
@@ -266,6 +280,6 @@ extern "C" int32_t prl_lbr_checkdown_equity(const PrlRules* rules, const int8_t*
     LB_TRY(hipMemcpy(out_wp, d_out, (size_t)n_q * sizeof(float), hipMemcpyDeviceToHost));
 #undef LB_TRY
 done:
-    (void)hipFree(d_boards); (void)hipFree(d_cls); (void)hipFree(d_rg); (void)hipFree(d_eq); (void)hipFree(d_out);
+    (void)hipFree(d_boards); (void)hipFree(d_cls); (void)hipFree(d_rg); (void)hipFree(d_eq); (void)hipFree(d_out); (void)hipFree(d_list);
     return rc;
 }
