@@ -153,7 +153,9 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_lbr_deep_terms(PrlLbrGame g, const 
 // register by a lane broadcast (v_readlane: a scalar operand, independent of the chain) -- the chain is one dependent v_add per term.
 #if defined(PRL_EMU)
 #define PRL_LANE_BCAST(v, j) prl_shfl((v), (j))
+#define PRL_SCHED_FENCE() do { } while (0)
 #else
+#define PRL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 PRL_DEV PRL_INLINE float prl_lane_bcast_(float v, int j) { int i; __builtin_memcpy(&i, &v, 4); i = __builtin_amdgcn_readlane(i, j); float o; __builtin_memcpy(&o, &i, 4); return o; }
 #define PRL_LANE_BCAST(v, j) prl_lane_bcast_((v), (j))
 #endif
@@ -170,8 +172,18 @@ PRL_GLOBAL void PRL_LAUNCH_BOUNDS(64) prl_k_lbr_deep_sum(int k, int n_boards, co
         for (int r = 0; r < 8; ++r) {
             const int left = n_boards - (b0 + r * 64);
             if (left >= 64 && !first) {
+                // sixteen broadcasts, a scheduling fence, sixteen adds: left to itself the compiler reads every lane into ONE scalar register right before
+                // its add (v_readlane, s_nop 1, v_add: 19 clocks per term); sixteen live scalars take the broadcasts off the chain
 #pragma unroll
-                for (int j = 0; j < 64; ++j) win = win + PRL_LANE_BCAST(v[r], j);
+                for (int j0 = 0; j0 < 64; j0 += 16) {
+                    float t[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) t[j] = PRL_LANE_BCAST(v[r], j0 + j);
+                    PRL_SCHED_FENCE();
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) win = win + t[j];
+                    PRL_SCHED_FENCE();
+                }
             } else {
                 for (int j = 0; j < 64; ++j) {
                     const float t = PRL_LANE_BCAST(v[r], j);
