@@ -554,7 +554,7 @@ def check_solver_table_vs_host(L, tmp_path, n_classes, n_iters, n_hands, variant
         assert np.array_equal(got, want), "seat %d: %d of %d hands differ (first at %s): %s vs %s" % (seat, int(np.sum(got != want)), n_hands, np.flatnonzero(got != want)[:5], got[:8], want[:8])
         total_misses += len(misses)
         if seat == 0:  # the agent (seat 0) raises or folds before the flop; LBR (the big blind) calls and plays the flop: the table is in use there
-            assert len(np.unique(got)) > 2, got  # (with the agent in seat 1, LBR's forced pre-flop "call" is a fold of the small blind: -500 every hand)
+            assert len(np.unique(got)) > 1, got  # (with the agent in seat 1, LBR's forced pre-flop "call" is a fold of the small blind: -500 every hand)
             uni = BatchedLBR(t_prof, agent_kind="uniform").run(agent_seat_id=seat, n_hands=n_hands, decks=decks)
             assert not np.array_equal(uni, got)
             assert b.last_stats["lbr_lookaheads"] > 0
