@@ -44,14 +44,13 @@ def runouts(n_flops, n_turns, n_rivers, seed=9):
     return np.array(rows, np.int8)
 
 
-def cpu_baseline(n_iters):
+def cpu_baseline(n_iters, game_cls, stack, bets):
     """CFR+ on the same game with the CPU oracle (1 thread): one flop x one turn x one river, full betting"""
     import oracle
     from pokerrl_amd import _native
-    from pokerrl_amd.game import games as G
     oracle.set_threads(1)
-    t = _native.NativeTree.for_game(G.LimitHoldem, 48, None, runouts(1, 1, 1))
-    r = G.LimitHoldem.RULES
+    t = _native.NativeTree.for_game(game_cls, stack, bets, runouts(1, 1, 1))
+    r = game_cls.RULES
     o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS, r._RANK_RULE)
     o.cfr_reset(1, 0)
     t0 = time.perf_counter()
@@ -59,7 +58,7 @@ def cpu_baseline(n_iters):
         o.cfr_iteration()
     dt = time.perf_counter() - t0
     return {"value": t.n_nodes * n_iters / dt, "unit": "node-updates/s", "cores": 1, "kind": "port",
-            "sample": "CFR+ delay 0, LimitHoldem 1 flop x 1 turn x 1 river (%d nodes), %d iterations, oracle/prl_oracle.c, 1 thread, %.1f s" % (t.n_nodes, n_iters, dt)}
+            "sample": "CFR+ delay 0, %s 1 flop x 1 turn x 1 river (%d nodes), %d iterations, oracle/prl_oracle.c, 1 thread, %.1f s" % (game_cls.__name__, t.n_nodes, n_iters, dt)}
 
 
 def main():
@@ -76,6 +75,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--placement-candidates", type=int, default=3, help="one GPU: solver objects built and timed before the run, the fastest is kept (1 = no probe)")
+    ap.add_argument("--game", default="LimitHoldem", choices=["LimitHoldem", "DiscretizedNLHoldem"], help="DiscretizedNLHoldem: pot-sized raises (bet_sets.POT_ONLY) -- mixed street "
+                    "shapes and all-in run-out chains (csrc/prl_st.h MIXED STREETS), one GPU")
+    ap.add_argument("--stack", type=int, default=None, help="chips per seat (default: 48 for LimitHoldem, 2500 for DiscretizedNLHoldem)")
     ap.add_argument("--max-raises", default=None, help="raises per betting round, e.g. 1,1,1,1 (smaller street subtrees: the CPU test-suite's emulator runs); default: the game's 4")
     args = ap.parse_args()
     import bench
@@ -106,15 +108,20 @@ def main():
     per_flop = args.turns * args.rivers
     all_runouts = runouts(world * args.flops, args.turns, args.rivers)
     mine = all_runouts[rank * args.flops * per_flop:(rank + 1) * args.flops * per_flop]  # this rank's block of the flops, with their run-outs
+    from pokerrl_amd.game import bet_sets
+    game_cls = getattr(G, args.game)
+    nl = args.game == "DiscretizedNLHoldem"
+    stack = args.stack if args.stack is not None else (2500 if nl else 48)
+    bets = bet_sets.POT_ONLY if nl else None
     if args.max_raises:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from helpers import env_args
-        game = G.LimitHoldem.native_game(env_args(G.LimitHoldem, 48, None))
+        game = game_cls.native_game(env_args(game_cls, stack, bets))
         for i, v in enumerate(int(x) for x in args.max_raises.split(",")):
             game.max_raises[i] = v
-        tree = _native.NativeTree(game, G.LimitHoldem.native_rules(), mine, _lib=lib)
+        tree = _native.NativeTree(game, game_cls.native_rules(), mine, _lib=lib)
     else:
-        tree = _native.NativeTree.for_game(G.LimitHoldem, 48, None, mine, _lib=lib)
+        tree = _native.NativeTree.for_game(game_cls, stack, bets, mine, _lib=lib)
     t_tree = time.perf_counter() - t0
     exchange = None
     placement = None
@@ -179,18 +186,19 @@ def main():
     n_nodes_job = n_trunk + world * (tree.n_nodes - n_trunk)
     achieved = (bytes_last * args.steps / (pass_ms * 1e-3) if fused else bytes_iter * args.steps / (dev_ms * 1e-3)) / 1e9
     out = {
-        "metric": "CFR+ node-updates/sec on a multi-street LimitHoldem public tree", "value": n_nodes_job * args.steps / dt, "unit": "node-updates/s",
+        "metric": "CFR+ node-updates/sec on a multi-street %s public tree" % args.game, "value": n_nodes_job * args.steps / dt, "unit": "node-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "build_flavor": (lib or _native.lib()).prl_build_flavor().decode(),
         "config": {"avg_dtype": "f32 (opt-in: PRL_SOLVER_AVG_F32; the reference's average is float64)" if args.avg_f32 else "f64",
-                   "workload": "CFR+ (delay 0) on LimitHoldem, %d flops per GPU x %d turns x %d rivers of seeded run-outs, 1326-hand ranges" % (args.flops, args.turns, args.rivers),
+                   "workload": "CFR+ (delay 0) on %s (%d-chip stacks%s), %d flops per GPU x %d turns x %d rivers of seeded run-outs, 1326-hand ranges"
+                               % (args.game, stack, ", pot-sized raises" if nl else "", args.flops, args.turns, args.rivers),
                    "engine": s.engine + (" (per-street)" if s.engine == "fused" else ""), "nodes": tree.n_nodes, "nodes_whole_job": n_nodes_job,
                    "placement_probe_ms_per_iteration": placement, "flops_per_gpu": args.flops, "exchanges": int(s.get("exchanges")[0]) if world > 1 else 0, "action_columns": tree.n_cols,
                    "action_columns_last_street": cols_last, "board_rows": int(tree.n_boards), "tree_build_s": t_tree,
                    "device_ms_per_iteration": dev_ms / args.steps, "exploitability_chips": float(np.mean(expl)), "iterations_done": s.iter,
                    "hbm_bytes_allocated": int(s.get("bytes_allocated")[0])},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": PMC_TRAFFIC_BYTES_PER_LAST_STREET_COLUMN * cols_last if fused else None, "traffic_source": PMC_TRAFFIC_SOURCE,
+                     "traffic": PMC_TRAFFIC_BYTES_PER_LAST_STREET_COLUMN * cols_last if fused and not nl else None, "traffic_source": PMC_TRAFFIC_SOURCE if not nl else "not measured on this tree",
                      "kernel": "prl_k_st_pass<last street>" if fused else "all kernels of the iteration",
                      "launches_per_iteration": n_pass / float(args.steps) if fused else None,
                      "kernel_ms_per_iteration": (pass_ms if fused else dev_ms) / args.steps,
@@ -201,7 +209,7 @@ def main():
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_iters)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_iters, game_cls, stack, bets)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

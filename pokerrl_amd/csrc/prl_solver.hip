@@ -105,7 +105,16 @@ struct prl_solver {
     bool streets = false;
     PrlStPlanHost st;
     PrlStParams sp{};                  // what every street launch shares (plans, sizes)
-    struct StLevelDev { PrlStInst* inst = nullptr; float* leaf_reach = nullptr; float* val = nullptr; } st_dev[PRL_ST_MAX_LEVELS];
+    struct StLevelDev { PrlStInst* inst = nullptr; } st_dev[PRL_ST_MAX_GROUPS];                                    // per (street, shape) group
+    struct StStreetDev { float* leaf_reach = nullptr; float* val = nullptr; } st_str[PRL_ST_MAX_LEVELS + 1];       // per street: the groups share them
+    // run-out chains below all-in calls (prl_st.h "MIXED STREETS"): a decision-free forest on the LEVELS kernels
+    PrlFlatTree chain_ft;
+    PrlDevTree Tc{};
+    PrlDevState Sc{};
+    int32_t* d_chain_term = nullptr;
+    int n_chain_term = 0, n_chain = 0;
+    PrlStChainDev chain_dev{};
+    int chain_first[PRL_ST_MAX_LEVELS + 2] = {0, 0, 0, 0, 0, 0};  // chain roots of street v: [chain_first[v], chain_first[v + 1])
     int32_t* d_trunk_leaves = nullptr; // trunk ids of the trunk's chance leaves
     int n_trunk_leaves = 1;
     std::vector<int32_t> col_dfs;      // internal column -> flat-tree (DFS) column; empty = identity (every other engine)
@@ -426,10 +435,10 @@ int do_update_reach(prl_solver* s, const PrlDevState& st) {
 static int ensure_board_avg(prl_solver* s) {
     if (!s->fused || !s->board_avg_stale) return PRL_OK;
     if (s->streets) {
-        for (int lv = 0; lv < s->st.n_levels; ++lv) {
+        for (int lv = 0; lv < s->st.n_groups; ++lv) {
             PrlStParams q = s->sp;
-            q.n_inst = s->st.level[lv].n_inst; q.col_base = s->st.level[lv].col_base; q.avg_sum = s->S.avg_sum; q.avg = s->d_avg;
-            prl_launch_st_avg_from_sum(q, s->st.level[lv].spec, s->stream);
+            q.n_inst = s->st.group[lv].n_inst; q.col_base = s->st.group[lv].col_base; q.avg_sum = s->S.avg_sum; q.avg = s->d_avg;
+            prl_launch_st_avg_from_sum(q, s->st.group[lv].spec, s->stream);
         }
         PRL_HIP_TRY(hipGetLastError());
         s->board_avg_stale = false;
@@ -468,17 +477,17 @@ int street_sweep(prl_solver* s, const PrlDevState& st, int mode, int src0, int s
                 s->board_avg_stale = true;
             }
     }
-    const int L = s->st.n_levels, R = p.R, NL0 = s->n_trunk_leaves;
+    const int NG = s->st.n_groups, R = p.R, NL0 = s->n_trunk_leaves;
     const int width = prl_fhp_out_width(mode);
-    auto level_params = [&](int lv) {
+    auto level_params = [&](int g) {
         PrlStParams q = p;
-        const PrlStLevelHost& H = s->st.level[lv];
-        q.n_inst = H.n_inst; q.col_base = H.col_base; q.inst = s->st_dev[lv].inst;
-        q.parent_reach = lv == 0 ? st.reach : s->st_dev[lv - 1].leaf_reach;  // (node-major [n_nodes][2][R]: prl_vidx)
-        q.leaf_reach = s->st_dev[lv].leaf_reach;
-        q.child_val = lv + 1 < L ? s->st_dev[lv + 1].val : nullptr;
+        const PrlStLevelHost& H = s->st.group[g];
+        q.n_inst = H.n_inst; q.col_base = H.col_base; q.inst = s->st_dev[g].inst;
+        q.parent_reach = H.street == 0 ? st.reach : s->st_str[H.street - 1].leaf_reach;  // (node-major [n_nodes][2][R]: prl_vidx)
+        q.leaf_reach = s->st_str[H.street].leaf_reach;
+        q.child_val = s->st_str[H.street + 1].val;  // (the next street's rows: instances of any group and run-out chain roots)
         q.child_w = width;
-        q.val = s->st_dev[lv].val;
+        q.val = s->st_str[H.street].val;
 #ifdef PRL_ST_TIMING
         if (H.last == (getenv("PRL_ST_TIMING_INNER") != nullptr)) q.timing = nullptr;  // instrumented builds clock the last street's pass, or the others'
 #else
@@ -486,19 +495,34 @@ int street_sweep(prl_solver* s, const PrlDevState& st, int mode, int src0, int s
 #endif
         return q;
     };
-    for (int lv = 0; lv + 1 < L; ++lv) {
-        const int e = prl_launch_st_down(s->st.level[lv].spec, level_params(lv), src0, src1, s->stream);
+    // reach down the streets; the roots of the run-out chains below street v - 1's all-in calls take theirs as soon as that street's leaf reach exists
+    auto chain_reach = [&](int v) {
+        if (s->n_chain) prl_launch_st_chain_reach(s->Tc, s->Sc.reach, v == 0 ? st.reach : s->st_str[v - 1].leaf_reach, s->chain_dev, s->chain_first[v],
+                                                 s->chain_first[v + 1] - s->chain_first[v], s->stream);
+    };
+    chain_reach(0);
+    for (int g = 0, v = 0; g <= NG; ++g) {
+        const int street = g < NG ? s->st.group[g].street : PRL_ST_MAX_LEVELS;
+        for (; v < street && v < PRL_ST_MAX_LEVELS; ++v) chain_reach(v + 1);  // every group of street v has pushed its leaf reach
+        if (g == NG || s->st.group[g].last) continue;
+        const int e = prl_launch_st_down(s->st.group[g].spec, level_params(g), src0, src1, s->stream);
         if (e) { prl_set_error("street engine: unsupported strategy-source combination"); return e; }
     }
-    for (int lv = L - 1; lv >= 0; --lv) {
+    if (s->n_chain) {  // the decision-free forest: reach below its roots, showdown equities, chance sums -- then its roots' values as rows of their streets
+        prl_launch_reach(s->Tc, s->Sc, s->chain_ft.level_start.data(), s->stream, true);
+        prl_launch_ev_forest(s->Tc, s->Sc, s->chain_ft.level_start.data(), s->d_chain_term, s->n_chain_term, s->stream);
+        for (int v = 0; v <= PRL_ST_MAX_LEVELS; ++v)
+            prl_launch_st_chain_rows(s->Tc, s->Sc.ev, s->Sc.ev_br, s->chain_dev, s->chain_first[v], s->chain_first[v + 1] - s->chain_first[v], s->st_str[v].val, mode, s->stream);
+    }
+    for (int g = NG - 1; g >= 0; --g) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        const bool timed = s->time_passes && lv == L - 1;  // the last street's pass is the dominant kernel
+        const bool timed = s->time_passes && s->st.group[g].last;  // the last street's pass is the dominant kernel
         if (timed) {
             PRL_HIP_TRY(hipEventCreate(&ev0));
             PRL_HIP_TRY(hipEventCreate(&ev1));
             PRL_HIP_TRY(hipEventRecord(ev0, s->stream));
         }
-        const int e = prl_launch_st_pass(s->st.level[lv].spec, s->st.level[lv].last, level_params(lv), mode, src0, src1, s->stream);
+        const int e = prl_launch_st_pass(s->st.group[g].spec, s->st.group[g].last, level_params(g), mode, src0, src1, s->stream);
         if (e) { prl_set_error("street engine: unsupported pass mode / strategy-source combination"); return e; }
         if (timed) {
             PRL_HIP_TRY(hipEventRecord(ev1, s->stream));
@@ -509,7 +533,7 @@ int street_sweep(prl_solver* s, const PrlDevState& st, int mode, int src0, int s
     // street-1 rows are outcome-major: [n_top][n_leaves][width][R] -> one canonical sum over the outcomes for all leaves at once
     const int W = NL0 * width * R, n_top = s->st.n_top;
     float* summed = s->d_row_sum;
-    const float* rows = s->st_dev[0].val;
+    const float* rows = s->st_str[0].val;
     if (!s->exchange) prl_launch_fhp_chance_sum(rows, n_top, W, s->d_sum_scratch, summed, s->stream);
     else {
         const size_t per_rank = (size_t)s->n_units * W;
@@ -975,6 +999,11 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     if (streets) {
         if (exchange && prl_st_build(full, total_boards, &st_plan, &st_why) != PRL_OK) { prl_set_error("street engine: " + st_why); delete s; return PRL_ERR_UNSUPPORTED; }
         s->st = st_plan;
+        if (exchange) {  // a sharded solve splits the first deal's outcomes of ONE shape per street (the layout its exchange counts on)
+            bool mixed = !st_plan.chain.empty();
+            for (int g = 0; g + 1 < st_plan.n_groups; ++g) mixed = mixed || st_plan.group[g].street == st_plan.group[g + 1].street;
+            if (mixed) { prl_set_error("street engine: a sharded solve takes trees whose streets have one shape each and no all-in run-outs"); delete s; return PRL_ERR_UNSUPPORTED; }
+        }
         s->col_dfs = st_plan.col_dfs;
         bool identity = true;
         for (size_t c = 0; c < s->col_dfs.size() && identity; ++c) identity = s->col_dfs[c] == (int32_t)c;
@@ -989,6 +1018,49 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     if (streets) make_trunk_streets(full, s->st, &s->ft, &st_leaf_ids);
     else if (fused) make_trunk(full, ch_node, first_board, full.n_boards * prl_fhp_shape_desc(shape_id).n_nodes, &s->ft, &s->chance_trunk);
     else s->ft = full;
+    std::vector<int32_t> chain_full_node;  // forest node -> node of the full tree (run-out chains of the per-street engine, prl_st.h)
+    std::vector<int32_t> chain_root_id;    // per chain root (s->st.chain order, sorted by street below): its forest node
+    if (streets && !s->st.chain.empty()) {
+        std::stable_sort(s->st.chain.begin(), s->st.chain.end(), [](const PrlStChainKid& a, const PrlStChainKid& b) { return a.street < b.street; });
+        PrlFlatTree& u = s->chain_ft;
+        u = PrlFlatTree();
+        u.rules = full.rules; u.game = full.game; u.board_len = full.board_len; u.n_boards = full.n_boards;
+        std::vector<int> map(full.n_nodes, -1);
+        for (const PrlStChainKid& ck : s->st.chain) {
+            chain_root_id.push_back(u.n_nodes);
+            for (int i = ck.node; i < ck.node + full.subtree_size[ck.node]; ++i) {
+                map[i] = u.n_nodes++;
+                chain_full_node.push_back(i);
+                u.kind.push_back(full.kind[i]); u.actor.push_back(-1);
+                u.parent.push_back(i == ck.node ? -1 : map[full.parent[i]]);
+                u.child_idx.push_back(full.child_idx[i]); u.action.push_back(full.action[i]); u.acted_last.push_back(full.acted_last[i]);
+                u.round.push_back(full.round[i]); u.board_id.push_back(full.board_id[i]); u.main_pot.push_back(full.main_pot[i]);
+                u.depth.push_back(full.depth[i] - full.depth[ck.node]);
+                u.n_children.push_back(full.n_children[i]); u.first_col.push_back(-1); u.subtree_size.push_back(full.subtree_size[i]);
+            }
+        }
+        u.child_start.assign(u.n_nodes + 1, 0);
+        for (int i = 0; i < u.n_nodes; ++i) u.child_start[i + 1] = u.child_start[i] + u.n_children[i];
+        u.child_list.assign(u.child_start[u.n_nodes] > 0 ? u.child_start[u.n_nodes] : 1, -1);
+        int max_depth = 0;
+        for (int i = 0; i < u.n_nodes; ++i) {
+            if (u.parent[i] >= 0) u.child_list[u.child_start[u.parent[i]] + u.child_idx[i]] = i;
+            max_depth = max_depth > u.depth[i] ? max_depth : u.depth[i];
+        }
+        u.n_levels = max_depth + 1;
+        u.level_start.assign(u.n_levels + 1, 0);
+        for (int i = 0; i < u.n_nodes; ++i) u.level_start[u.depth[i] + 1]++;
+        for (int d = 0; d < u.n_levels; ++d) u.level_start[d + 1] += u.level_start[d];
+        u.level_nodes.assign(u.n_nodes, 0);
+        std::vector<int32_t> fill(u.level_start.begin(), u.level_start.end() - 1);
+        for (int i = 0; i < u.n_nodes; ++i) u.level_nodes[fill[u.depth[i]]++] = i;
+        s->n_chain = (int)s->st.chain.size();
+        for (int v = 0; v <= PRL_ST_MAX_LEVELS + 1; ++v) {
+            int c = 0;
+            for (const PrlStChainKid& ck : s->st.chain) c += ck.street < v;
+            s->chain_first[v] = c;
+        }
+    }
     const PrlFlatTree& ft = s->ft;
 #define FAIL_IF(x) do { int e_ = (x); if (e_) { prl_solver_destroy(s); return e_; } } while (0)
     if (hipStreamCreate(&s->stream) != hipSuccess) { prl_set_error("hipStreamCreate failed"); delete s; return PRL_ERR_HIP; }
@@ -1056,6 +1128,17 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         }
         if (first) T.chance_prob = chance_prob_f32(board_mult ? (int)mult_sum : exchange ? (int)total_boards : n_chance_children, r.n_cards, r.n_hole_cards, full.board_len);
         FAIL_IF(dev_upload(s, &T.chance_w, w));
+        if (s->n_chain) {  // the run-out chains' own chance nodes (the forest of the per-street engine)
+            std::vector<float> wc(s->chain_ft.n_nodes, 0.f);
+            for (int i = 0; i < s->chain_ft.n_nodes; ++i) {
+                const int f = chain_full_node[i];
+                if (full.kind[f] != PRL_NODE_CHANCE) continue;
+                const int before = dealt(full.board_id[f]);
+                const int k = dealt(full.board_id[full.child_list[full.child_start[f]]]) - before;
+                wc[i] = chance_prob_f32(full.n_children[f], r.n_cards - before, r.n_hole_cards, k);
+            }
+            FAIL_IF(dev_upload(s, &s->Tc.chance_w, wc));
+        }
     }
     T.eq_const = eq_const_f32(r.n_cards, r.n_hole_cards);
 
@@ -1091,7 +1174,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         if (fused) FAIL_IF(dev_alloc(s, &clx, (size_t)n_plans * PRL_CLX_WORDS));
         if (s->sorted) FAIL_IF(dev_alloc(s, &pp, (size_t)n_plans * PRL_PP_STRIDE));
         uint8_t* klh = nullptr;  // the LEVELS engine's showdown terminals (a fused solver's trunk has none)
-        if (!fused) FAIL_IF(dev_alloc(s, &klh, (size_t)n_plans * T.R * 4));
+        if (!fused || s->n_chain) FAIL_IF(dev_alloc(s, &klh, (size_t)n_plans * T.R * 4));  // (the run-out chains of the per-street engine end in showdown terminals too)
         PrlDevTree Tb = T;
         Tb.n_boards = full.n_boards;
         prl_launch_plan_build(Tb, n_plans, sh, pos, gs, ge, cl, nl, hgs, hge, clx, nd, klh, pp, s->stream);
@@ -1102,6 +1185,14 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         T.plan_ge = ge + off * T.plan_stride; T.plan_cl = cl + off * T.cl_stride; T.plan_nlive = nl + off; T.plan_ndealt = nd + off;
         T.plan_hgs = hgs + off * T.plan_stride; T.plan_hge = hge + off * T.plan_stride; T.plan_clx = clx ? clx + off * PRL_CLX_WORDS : nullptr;
         T.plan_klh = klh;
+        if (s->n_chain) {  // the forest addresses the plans by board row, like a LEVELS tree
+            const float* wc = s->Tc.chance_w;
+            s->Tc = T;
+            s->Tc.chance_w = wc;
+            s->Tc.n_boards = full.n_boards;
+            s->Tc.plan_sh = sh; s->Tc.plan_pos = pos; s->Tc.plan_gs = gs; s->Tc.plan_ge = ge; s->Tc.plan_cl = cl; s->Tc.plan_nlive = nl; s->Tc.plan_ndealt = nd;
+            s->Tc.plan_hgs = hgs; s->Tc.plan_hge = hge; s->Tc.plan_clx = clx; s->Tc.plan_klh = klh;
+        }
         if (streets) {
             PrlStParams& sp = s->sp;
             sp.R = T.R; sp.eq_const = T.eq_const; sp.n_cards = T.n_cards;
@@ -1204,17 +1295,66 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     if (streets) {  // per street: instance table, leaf reach (not on the last street), one row of <= 4 root vectors per instance
         s->n_trunk_leaves = (int)st_leaf_ids.size();
         FAIL_IF(dev_upload(s, (const int32_t**)&s->d_trunk_leaves, st_leaf_ids));
-        for (int lv = 0; lv < s->st.n_levels; ++lv) {
-            const PrlStLevelHost& H = s->st.level[lv];
-            if (lv == 0) {
+        if (getenv("PRL_ST_DEBUG")) {
+            fprintf(stderr, "street engine: %d streets, %d groups, %zu run-out chain roots (%d forest nodes), trunk leaves %d\n", s->st.n_levels, s->st.n_groups, s->st.chain.size(), s->chain_ft.n_nodes, s->n_trunk_leaves);
+            for (int g = 0; g < s->st.n_groups; ++g)
+                fprintf(stderr, "  group %d: street %d spec %d n_inst %d leaves %d cols/inst %d col_base %d last %d\n", g, s->st.group[g].street, s->st.group[g].spec, s->st.group[g].n_inst,
+                        s->st.group[g].n_leaves, s->st.group[g].n_cols_inst, s->st.group[g].col_base, (int)s->st.group[g].last);
+            for (int v = 0; v < PRL_ST_MAX_LEVELS; ++v) fprintf(stderr, "  street %d: %d rows, %d leaf slots\n", v, s->st.n_val_slots[v], s->st.n_leaf_slots[v]);
+        }
+        for (int g = 0; g < s->st.n_groups; ++g) {
+            const PrlStLevelHost& H = s->st.group[g];
+            if (H.street == 0) {
                 // first street: an instance's root reach is read straight from the trunk's reach array (row = the trunk id of its chance leaf)
                 std::vector<PrlStInst> inst0 = H.inst;
                 for (PrlStInst& in : inst0) in.parent_slot = st_leaf_ids[in.parent_slot];
-                FAIL_IF(dev_upload(s, (const PrlStInst**)&s->st_dev[lv].inst, inst0));
+                FAIL_IF(dev_upload(s, (const PrlStInst**)&s->st_dev[g].inst, inst0));
             } else
-            FAIL_IF(dev_upload(s, (const PrlStInst**)&s->st_dev[lv].inst, H.inst));
-            if (!H.last) FAIL_IF(dev_alloc(s, &s->st_dev[lv].leaf_reach, (size_t)H.n_inst * H.n_leaves * 2 * T.R));
-            FAIL_IF(dev_alloc(s, &s->st_dev[lv].val, (size_t)H.n_inst * 4 * T.R));
+            FAIL_IF(dev_upload(s, (const PrlStInst**)&s->st_dev[g].inst, H.inst));
+        }
+        for (int v = 0; v <= PRL_ST_MAX_LEVELS; ++v) {  // per street: the leaves' reach (both seats) and the rows of <= 4 root vectors, shared by its groups
+            if (v < PRL_ST_MAX_LEVELS && s->st.n_leaf_slots[v] > 0) FAIL_IF(dev_alloc(s, &s->st_str[v].leaf_reach, (size_t)s->st.n_leaf_slots[v] * 2 * T.R));
+            if (v < PRL_ST_MAX_LEVELS && s->st.n_val_slots[v] > 0) FAIL_IF(dev_alloc(s, &s->st_str[v].val, (size_t)s->st.n_val_slots[v] * 4 * T.R));
+        }
+        if (s->n_chain) {
+            PrlDevTree& C = s->Tc;  // (plans, constants and chance weights were set above)
+            const PrlFlatTree& u = s->chain_ft;
+            C.n_nodes = u.n_nodes; C.n_cols = 0; C.n_levels = u.n_levels;
+            FAIL_IF(dev_upload(s, &C.kind, u.kind));
+            FAIL_IF(dev_upload(s, &C.actor, u.actor));
+            FAIL_IF(dev_upload(s, &C.parent, u.parent));
+            FAIL_IF(dev_upload(s, &C.child_idx, u.child_idx));
+            FAIL_IF(dev_upload(s, &C.acted_last, u.acted_last));
+            FAIL_IF(dev_upload(s, &C.board_id, u.board_id));
+            FAIL_IF(dev_upload(s, &C.main_pot, u.main_pot));
+            FAIL_IF(dev_upload(s, &C.n_children, u.n_children));
+            FAIL_IF(dev_upload(s, &C.first_col, u.first_col));
+            FAIL_IF(dev_upload(s, &C.child_start, u.child_start));
+            FAIL_IF(dev_upload(s, &C.child_list, u.child_list));
+            FAIL_IF(dev_upload(s, &C.level_nodes, u.level_nodes));
+            const size_t nv = (size_t)u.n_nodes * 2 * T.R;
+            FAIL_IF(dev_alloc(s, &s->Sc.reach, nv));
+            FAIL_IF(dev_alloc(s, &s->Sc.ev, nv));
+            FAIL_IF(dev_alloc(s, &s->Sc.ev_br, nv));
+            PRL_HIP_TRY(hipMemsetAsync(s->Sc.reach, 0, nv * sizeof(float), s->stream));
+            PRL_HIP_TRY(hipMemsetAsync(s->Sc.ev, 0, nv * sizeof(float), s->stream));
+            PRL_HIP_TRY(hipMemsetAsync(s->Sc.ev_br, 0, nv * sizeof(float), s->stream));
+            std::vector<int32_t> cterm, c_root, c_par, c_val;
+            std::vector<float> c_w;
+            for (int i = 0; i < u.n_nodes; ++i) if (u.kind[i] == PRL_NODE_TERM_SHOWDOWN) cterm.push_back(i);
+            s->n_chain_term = (int)cterm.size();
+            FAIL_IF(dev_upload(s, (const int32_t**)&s->d_chain_term, cterm));
+            for (size_t i = 0; i < s->st.chain.size(); ++i) {
+                const PrlStChainKid& ck = s->st.chain[i];
+                c_root.push_back(chain_root_id[i]);
+                c_par.push_back(ck.street == 0 ? st_leaf_ids[ck.parent_slot] : ck.parent_slot);  // (street 0: the trunk id of the all-in call's chance node)
+                c_val.push_back(ck.val_slot);
+                c_w.push_back(ck.w);
+            }
+            FAIL_IF(dev_upload(s, &s->chain_dev.root, c_root));
+            FAIL_IF(dev_upload(s, &s->chain_dev.parent_slot, c_par));
+            FAIL_IF(dev_upload(s, &s->chain_dev.val_slot, c_val));
+            FAIL_IF(dev_upload(s, &s->chain_dev.w, c_w));
         }
 #ifdef PRL_ST_TIMING
         FAIL_IF(dev_alloc(s, &s->sp.timing, (size_t)8));
@@ -2180,10 +2320,10 @@ int32_t prl_solver_get(prl_solver_t* s, int32_t field, void* out) {
                 if (!s->d_user_strategy) TRY(dev_alloc(s, &s->d_user_strategy, nc));
                 PRL_HIP_TRY(hipMemcpyAsync(s->d_user_strategy, s->S.strategy, (size_t)s->T.n_cols * s->R * 8, hipMemcpyDeviceToDevice, s->stream));
                 if (s->streets) {
-                    for (int lv = 0; lv < s->st.n_levels; ++lv) {
+                    for (int lv = 0; lv < s->st.n_groups; ++lv) {
                         PrlStParams q = s->sp;
-                        q.n_inst = s->st.level[lv].n_inst; q.col_base = s->st.level[lv].col_base; q.regret = s->d_regret; q.variant = s->variant;
-                        prl_launch_st_strategy_from_regret(q, s->st.level[lv].spec, s->d_user_strategy, s->stream);
+                        q.n_inst = s->st.group[lv].n_inst; q.col_base = s->st.group[lv].col_base; q.regret = s->d_regret; q.variant = s->variant;
+                        prl_launch_st_strategy_from_regret(q, s->st.group[lv].spec, s->d_user_strategy, s->stream);
                     }
                 } else {
                     PrlFhpParams fp = s->fp;

@@ -29,8 +29,17 @@
 
 #include "prl_fhp.h"
 
+// Round 6: MIXED STREETS. The instances of one street need not share a shape any more (a discretized no-limit game: the betting left before somebody is
+// all-in depends on the pot the street is entered with), and a leaf may be an all-in call whose children hold no decision at all (a run-out chain: chance
+// nodes down to showdowns, PublicTree.py:244-251 / ValueFiller.py:160-175). The instances of a street are cut into GROUPS, one per registered shape, each
+// walked by its own launches of the same kernels; every street has ONE leaf-reach buffer and ONE buffer of root-vector rows, addressed by explicit slots
+// (PrlStInst::leaf_slot0 / val_slot), so that the children of one leaf may live in any group: child (leaf j, outcome k) of an instance sits at row
+// kid_base + k * n_leaves + j of the next street's buffer whatever it is. The decision-free subtrees (the chance outcomes below an all-in call) form a small
+// forest that the LEVELS kernels evaluate: their roots' reach is gathered from the street's leaf reach, their values are scattered into the rows the
+// parent's pass sums (prl_k_st_chain_reach / prl_k_st_chain_rows).
 enum { PRL_ST_SPEC_9 = 0, PRL_ST_SPEC_15 = 1, PRL_ST_SPEC_21 = 2, PRL_ST_SPEC_27 = 3, PRL_ST_N_SPECS = 4 };
-#define PRL_ST_MAX_LEVELS 4
+#define PRL_ST_MAX_LEVELS 4   // dealing streets
+#define PRL_ST_MAX_GROUPS 16  // (street, shape) groups
 
 // per street instance (uniform over the workgroup that walks it: read through scalar loads)
 struct PrlStInst {
@@ -38,8 +47,10 @@ struct PrlStInst {
     int32_t parent_slot;  // index of its root's reach in the previous level's leaf_reach: parent instance * n_leaves(parent) + leaf
     float w;              // chance weight of the outcome (StrategyFiller.py:159-166 generalised, per chance node)
     int32_t n_kids;       // chance outcomes below each of its leaves (0 on the last street)
-    int32_t kid_base;     // first child instance (next street): child of (leaf j, outcome k) = kid_base + k * n_leaves + j
-    int32_t pad[3];
+    int32_t kid_base;     // first child row (next street's buffer): child of (leaf j, outcome k) = kid_base + k * n_leaves + j
+    int32_t val_slot;     // this instance's row of root vectors in its street's buffer (= where its parent looks for it)
+    int32_t leaf_slot0;   // its first leaf's slot in its street's leaf-reach buffer (leaf j: leaf_slot0 + j)
+    int32_t pad;
     float pot[PRL_FHP_MAX_NODES];  // main pot of every node of the instance (terminals use theirs)
 };
 
@@ -72,17 +83,30 @@ struct PrlStParams {
     unsigned long long* timing;  // PRL_ST_TIMING builds (scripts/gpu_st_phases.sh): [8] shader-clock accumulators per phase of the pass; else unused
 };
 
-// host description of one street (prl_st_build)
+// host description of one GROUP: the instances of one street that have one shape (prl_st_build)
 struct PrlStLevelHost {
+    int street = 0;                   // 0 = the first dealing street
     int spec = -1, n_inst = 0, n_leaves = 0, n_cols_inst = 0, n_nodes_inst = 0;
-    bool last = false;
+    bool last = false;                // the last street: its leaves are showdowns
     int col_base = 0;                 // internal column of instance 0
     std::vector<PrlStInst> inst;
     std::vector<int32_t> root_node;   // flat-tree node id of every instance root
 };
+// a chance outcome below an all-in call: the root of a decision-free subtree (run-out chain), a child row of its parent like any instance
+struct PrlStChainKid {
+    int32_t node;         // flat-tree node id (a chance node, or a showdown on the last street)
+    int32_t street;       // the street it belongs to (its row lives in that street's buffer)
+    int32_t parent_slot;  // leaf slot of the all-in call above it in the previous street's leaf-reach buffer (street 0: index of the trunk's chance leaf)
+    int32_t val_slot;     // its row in its street's buffer
+    float w;              // chance weight of the outcome
+};
 struct PrlStPlanHost {
     int n_levels = 0;                       // dealing streets (>= 2 for this engine)
-    PrlStLevelHost level[PRL_ST_MAX_LEVELS];
+    int n_groups = 0;                       // (street, shape) groups, ordered by street
+    PrlStLevelHost group[PRL_ST_MAX_GROUPS];
+    int n_val_slots[PRL_ST_MAX_LEVELS] = {0, 0, 0, 0};   // rows of root vectors per street (instances and run-out chain roots)
+    int n_leaf_slots[PRL_ST_MAX_LEVELS] = {0, 0, 0, 0};  // leaves per street (not the last one)
+    std::vector<PrlStChainKid> chain;       // run-out chain roots, all streets
     std::vector<int32_t> trunk_leaf_node;   // flat-tree ids of the trunk's chance nodes, DFS order (= leaf index j of "level 0")
     int n_top = 0;                          // chance outcomes of the first deal (the unit a sharded solve splits)
     int n_trunk_cols = 0;
@@ -106,6 +130,11 @@ struct PrlStScatter {  // copies out of a summed row of n_vec vectors: vector sr
 void prl_launch_st_scatter_trunk(const float* d_summed, const int32_t* d_leaf_nodes, int n_leaves, int R, const PrlStScatter& sc, float* d_ev, float* d_ev_br,
                                  float* d_half, void* stream);
 void prl_launch_st_half_to_trunk(const float* d_half, const int32_t* d_leaf_nodes, int n_leaves, int R, float* d_ev, float* d_ev_br, void* stream);
+// run-out chains: the roots of the decision-free forest (device arrays, one entry per chain root, ordered by street)
+struct PrlStChainDev { const int32_t *root, *parent_slot, *val_slot; const float* w; };
+struct PrlStRowMap { int32_t width, seat[4], br[4]; };  // vector v of a row = (br[v] ? ev_br : ev)[seat[v]]
+void prl_launch_st_chain_reach(const PrlDevTree& Tc, float* reach_c, const float* src, const PrlStChainDev& cd, int first, int count, void* stream);
+void prl_launch_st_chain_rows(const PrlDevTree& Tc, const float* ev, const float* ev_br, const PrlStChainDev& cd, int first, int count, float* val, int mode, void* stream);
 // materialise strategies / averages of one street's columns (prl_solver_get, Vanilla / Linear averages)
 void prl_launch_st_strategy_from_regret(const PrlStParams& prm, int spec, double* out_cols, void* stream);
 void prl_launch_st_avg_from_sum(const PrlStParams& prm, int spec, void* stream);

@@ -740,6 +740,15 @@ void prl_launch_ev_levels(const PrlDevTree& T, const PrlDevState& S, const int32
     else PRL_LAUNCH(prl_k_exploitability, 1, 256, smem, stream, T, S, S.expl);
 }
 
+// a FOREST (several nodes at depth 0, no root exploitability): the run-out chains of the per-street engine (prl_st.h)
+void prl_launch_ev_forest(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, const int32_t* d_term_nodes, int n_term, void* stream) {
+    prl_launch_terminals(T, S, d_term_nodes, n_term, stream);
+    for (int d = T.n_levels - 2; d >= 0; --d) {
+        int cnt = h_level_start[d + 1] - h_level_start[d];
+        if (cnt > 0) PRL_LAUNCH(prl_k_ev_level, prl_grid_for((size_t)cnt * T.R, 256), 256, 0, stream, T, S, h_level_start[d], cnt);
+    }
+}
+
 void prl_launch_ev(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, const int32_t* d_term_nodes, int n_term,
                    void* stream, float* d_expl_copy) {
     prl_launch_terminals(T, S, d_term_nodes, n_term, stream);

@@ -22,7 +22,8 @@ TAPED = ["test_gpu_multistreet_limit_holdem_full_betting_vs_oracle", "test_gpu_s
          "test_gpu_streets_engine_other_street_shapes_vs_oracle", "test_gpu_streets_engine_many_outcomes_per_deal_vs_oracle",
          "test_gpu_streets_engine_cfr_plus_with_averaging_delay_vs_oracle", "test_gpu_streets_engine_float32_running_average_opt_in",
          "test_gpu_streets_engine_best_response_of_an_explicit_strategy_vs_oracle", "test_gpu_multistreet_short_stack_run_outs_vs_oracle",
-         "test_gpu_all_in_before_the_deal_run_out_vs_oracle"]
+         "test_gpu_all_in_before_the_deal_run_out_vs_oracle", "test_gpu_streets_engine_discretized_nl_holdem_vs_oracle",
+         "test_gpu_streets_engine_all_in_run_outs_vs_oracle", "test_gpu_streets_engine_mixed_best_response_and_f32_average_vs_oracle"]
 
 
 def cases(fn):

@@ -445,10 +445,10 @@ def check_iterations_many(L, n_iters=5):
     assert_state_equal(s, o, "many[0] + 2")
 
 
-def make_streets_pair(L, game_cls, stack, runouts, variant, delay=0, max_raises=None, tape=None, **solver_kw):
+def make_streets_pair(L, game_cls, stack, runouts, variant, delay=0, max_raises=None, tape=None, bets=None, **solver_kw):
     """(tree, fused solver on the per-street engine, oracle) on one multi-street flat tree (csrc/prl_st.h). With an oracle tape (tests/oracle_tape.py):
     no oracle when the tape is replayed, no solver when it is being recorded (the generator runs without a GPU)."""
-    args = env_args(game_cls, stack, None)
+    args = env_args(game_cls, stack, bets)
     game = game_cls.native_game(args)
     if max_raises is not None:
         for i, v in enumerate(max_raises):
@@ -506,12 +506,12 @@ def check_set_strategy_device(L, t, make_solver, to_device=None, seed=9):
     return a.engine
 
 
-def check_streets_br_vs_oracle(L, game_cls, stack, runouts, max_raises=None, seed=5):
+def check_streets_br_vs_oracle(L, game_cls, stack, runouts, max_raises=None, seed=5, bets=None):
     """Exact best response of an explicit strategy on a multi-street tree, per-street engine (LocalBRMaster.py:67-80): a seeded strategy given as
     float32 (played as float32 from the engine's internal column order) and as float64 columns in the flat tree's DFS order; exploitability
     against the oracle, the strategy read back unchanged; iterating again after reset()"""
-    tape = _tape("streets_br", L, game_cls.__name__, stack, np.asarray(runouts), max_raises, seed)
-    t, s, o = make_streets_pair(L, game_cls, stack, runouts, "plus", 0, max_raises, tape=tape)
+    tape = _tape("streets_br", L, game_cls.__name__, stack, np.asarray(runouts), max_raises, seed, *(() if bets is None else (tuple(bets),)))
+    t, s, o = make_streets_pair(L, game_cls, stack, runouts, "plus", 0, max_raises, tape=tape, bets=bets)
     live = tape is None or tape.live
     take = (lambda tag, fn: fn()) if tape is None else tape.take
     kind, nch, fc = t.field("kind"), t.field("n_children"), t.field("first_col")
@@ -544,14 +544,14 @@ def check_streets_br_vs_oracle(L, game_cls, stack, runouts, max_raises=None, see
     return t
 
 
-def check_streets_vs_oracle(L, game_cls, stack, runouts, variant, n_iters, delay=0, max_raises=None, batched=False):
+def check_streets_vs_oracle(L, game_cls, stack, runouts, variant, n_iters, delay=0, max_raises=None, batched=False, bets=None):
     """SURVEY 8f-4 on the per-street fused engine (csrc/prl_st.h): regrets, averages, the strategy implied by the regrets, current- and
     average-strategy exploitability after every iteration (batched: the exploitability history of prl_solver_iterations(n) and the
     final state), bit for bit against the oracle -- in the flat tree's DFS column order, which the engine does not use internally.
     On the GPU box the oracle's side comes from a tape (tests/oracle_tape.py) when one was recorded for exactly this problem."""
     from oracle_tape import digest, same
-    tape = _tape("streets", L, game_cls.__name__, stack, np.asarray(runouts), variant, n_iters, delay, max_raises, batched)
-    t, s, o = make_streets_pair(L, game_cls, stack, runouts, variant, delay, max_raises, tape=tape)
+    tape = _tape("streets", L, game_cls.__name__, stack, np.asarray(runouts), variant, n_iters, delay, max_raises, batched, *(() if bets is None else (tuple(bets),)))
+    t, s, o = make_streets_pair(L, game_cls, stack, runouts, variant, delay, max_raises, tape=tape, bets=bets)
     live = tape is None or tape.live
     take = (lambda tag, fn: fn()) if tape is None else tape.take
     big = (lambda a: a) if (tape is None or (tape.live and not tape.recording)) else digest  # arrays entry by entry when the oracle is here, digests on tape
@@ -773,14 +773,14 @@ def check_symmetrize_is_validated(L):
         _native.NativeSolver(t, "plus", 0, _lib=L, board_mult=mult, symmetrize="subset", shard=(2, 0, None))
 
 
-def check_streets_avg_f32(L, game_cls, stack, runouts, n_iters, max_raises=None, batched=False):
+def check_streets_avg_f32(L, game_cls, stack, runouts, n_iters, max_raises=None, batched=False, bets=None):
     """PRL_SOLVER_AVG_F32 on the per-street fused engine (round 5: feature parity with the single-deal board pass): the street columns' running
     average stored as float32 -- regrets, current-strategy exploitability history: bit-exact to the oracle; the average = the reference's
     recurrence with one float32 rounding per iteration, restated here from the oracle's strategies; the trunk's columns stay float64 = the
     oracle's; average-strategy exploitability within 1e-5 relative of the float64 one."""
     from oracle_tape import digest, same
-    tape = _tape("streets_avg_f32", L, game_cls.__name__, stack, np.asarray(runouts), n_iters, max_raises, batched)
-    t, s, o = make_streets_pair(L, game_cls, stack, runouts, "plus", 0, max_raises, tape=tape, avg_dtype="f32")
+    tape = _tape("streets_avg_f32", L, game_cls.__name__, stack, np.asarray(runouts), n_iters, max_raises, batched, *(() if bets is None else (tuple(bets),)))
+    t, s, o = make_streets_pair(L, game_cls, stack, runouts, "plus", 0, max_raises, tape=tape, bets=bets, avg_dtype="f32")
     live = tape is None or tape.live
     take = (lambda tag, fn: fn()) if tape is None else tape.take
     big = (lambda a: a) if (tape is None or (tape.live and not tape.recording)) else digest

@@ -221,15 +221,59 @@ def test_emu_streets_engine_checkpoint_resume(L):
     assert np.array_equal(s.eval_avg(), s2.eval_avg())
 
 
-def test_emu_streets_engine_refuses_all_in_run_outs(L):
-    """4-chip stacks: all-ins dealt out as chance chains are not street instances -- engine=auto falls back to the level-synchronous engine,
-    engine=fused says why"""
+@pytest.mark.parametrize("variant,stack,runouts,batched", [("plus", 4, (1, 1, 1), False), ("linear", 6, (2, 1, 2), True)])
+def test_emu_streets_engine_all_in_run_outs(L, variant, stack, runouts, batched):
+    """MIXED STREETS (csrc/prl_st.h): 4- and 6-chip stacks put all-in calls on every street, each dealt out as a chain of chance nodes down to showdown
+    leaves (a decision-free forest on the level kernels, next to the street instances) -- engine=auto takes the per-street engine, results equal the
+    oracle's bit for bit"""
+    from pokerrl_amd.game import games as G
+    pc.check_streets_vs_oracle(L, G.LimitHoldem, stack, pc.multistreet_runouts(*runouts), variant, 3 if batched else 2, batched=batched)
+
+
+@pytest.mark.parametrize("variant,stack,runouts,batched", [("plus", 600, (1, 1, 1), False), ("vanilla", 1200, (1, 1, 1), True), ("linear", 600, (2, 1, 2), True)])
+def test_emu_streets_engine_discretized_nl_holdem(L, variant, stack, runouts, batched):
+    """MIXED STREETS: DiscretizedNLHoldem (games.py:114-131) with pot-sized raises -- a street's subtrees differ with the stacks behind (9-, 15- and
+    21-node shapes side by side on one street, 6 to 9 (street, shape) groups) and every raise sequence that runs out of chips ends in a run-out chain"""
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    pc.check_streets_vs_oracle(L, G.DiscretizedNLHoldem, stack, pc.multistreet_runouts(*runouts), variant, 3 if batched else 2, batched=batched, bets=bet_sets.POT_ONLY)
+
+
+def test_emu_streets_engine_mixed_best_response_of_an_explicit_strategy(L):
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    pc.check_streets_br_vs_oracle(L, G.DiscretizedNLHoldem, 600, pc.multistreet_runouts(1, 2, 1), bets=bet_sets.POT_ONLY)
+
+
+def test_emu_streets_engine_mixed_checkpoint_and_device_fill(L):
+    """save / load and prl_solver_set_strategy_device on a tree with mixed street shapes and run-out chains"""
+    import numpy as np
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    t, s, _o = pc.make_streets_pair(L, G.DiscretizedNLHoldem, 600, pc.multistreet_runouts(1, 1, 1), "linear", 0, bets=bet_sets.POT_ONLY)
+    s.iterations(2)
+    blob = s.save_state()
+    s2 = _native.NativeSolver(t, "linear", 0, engine="auto", _lib=L)
+    s2.load_state(blob)
+    s.iterations(2)
+    s2.iterations(2)
+    for k in ("regret", "avg", "avg_sum", "expl_history"):
+        assert np.array_equal(s.get(k), s2.get(k)), k
+    assert np.array_equal(s.eval_avg(), s2.eval_avg())
+    pc.check_set_strategy_device(L, t, lambda: _native.NativeSolver(t, "plus", 0, engine="auto", _lib=L))
+
+
+def test_emu_streets_engine_refuses_what_it_cannot_walk(L):
+    """two raise sizes (half pot, pot): decisions with four actions, street subtrees that are none of the registered shapes -- engine=auto falls back to
+    the level-synchronous engine, engine=fused says why"""
     from helpers import env_args
     from pokerrl_amd import _native
     from pokerrl_amd.game import games as G
-    t = _native.NativeTree(G.LimitHoldem.native_game(env_args(G.LimitHoldem, 4, None)), G.LimitHoldem.native_rules(), pc.multistreet_runouts(1, 1, 1), _lib=L)
+    game = G.DiscretizedNLHoldem.native_game(env_args(G.DiscretizedNLHoldem, 600, [0.5, 1.0]))
+    t = _native.NativeTree(game, G.DiscretizedNLHoldem.native_rules(), pc.multistreet_runouts(1, 1, 1), _lib=L)
     assert _native.NativeSolver(t, "plus", 0, engine="auto", _lib=L).engine == "levels"
-    with pytest.raises(_native.NativeError, match="run-out"):
+    with pytest.raises(_native.NativeError, match="street subtree"):
         _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
 
 

@@ -228,6 +228,33 @@ def test_gpu_streets_engine_best_response_of_an_explicit_strategy_vs_oracle(L):
     assert t.n_nodes > 60000
 
 
+@pytest.mark.parametrize("variant,stack,runouts,batched", [("plus", 1200, (2, 2, 1), False), ("vanilla", 2500, (2, 2, 2), True), ("linear", 600, (2, 3, 2), True),
+                                                           ("plus", 1200, (1, 34, 2), True)])
+def test_gpu_streets_engine_discretized_nl_holdem_vs_oracle(L, variant, stack, runouts, batched):
+    """MIXED STREETS (csrc/prl_st.h): DiscretizedNLHoldem (games.py:114-131) with pot-sized raises -- the subtrees of one street differ with the stacks
+    behind (9-, 15-, 21-node shapes side by side: 6 to 9 (street, shape) groups) and every raise sequence that runs out of chips ends in an all-in call
+    whose hand is dealt out as a chain of chance nodes (a decision-free forest on the level kernels); 34 turn cards = two canonical blocks"""
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    pc.check_streets_vs_oracle(L, G.DiscretizedNLHoldem, stack, pc.multistreet_runouts(*runouts), variant, 4 if batched else 2, batched=batched, bets=bet_sets.POT_ONLY)
+
+
+@pytest.mark.parametrize("variant,stack,runouts,delay", [("plus", 4, (2, 2, 1), 0), ("linear", 10, (2, 2, 2), 0), ("plus", 20, (2, 1, 2), 2)])
+def test_gpu_streets_engine_all_in_run_outs_vs_oracle(L, variant, stack, runouts, delay):
+    """LimitHoldem with its full betting and stacks that run out (4, 10, 20 chips): capped raise sequences (mixed street shapes) and all-in run-out
+    chains on every street, on the per-street engine; CFR+ with an averaging delay"""
+    from pokerrl_amd.game import games as G
+    pc.check_streets_vs_oracle(L, G.LimitHoldem, stack, pc.multistreet_runouts(*runouts), variant, 4, delay=delay, batched=True)
+
+
+def test_gpu_streets_engine_mixed_best_response_and_f32_average_vs_oracle(L):
+    """explicit strategies (LocalBRMaster.py:67-80) and PRL_SOLVER_AVG_F32 on a tree with mixed street shapes and run-out chains"""
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    pc.check_streets_br_vs_oracle(L, G.DiscretizedNLHoldem, 1200, pc.multistreet_runouts(2, 2, 1), bets=bet_sets.POT_ONLY)
+    pc.check_streets_avg_f32(L, G.DiscretizedNLHoldem, 1200, pc.multistreet_runouts(2, 2, 2), 3, batched=True, bets=bet_sets.POT_ONLY)
+
+
 @pytest.mark.parametrize("variant", ["plus", "linear", "vanilla", "plus_d2_i6"])
 def test_gpu_streets_engine_bench_tree_vs_oracle_fixture(L, variant):
     """bench_multistreet.py's tree (4 flops x 2 turns x 2 rivers, 259 330 nodes) on the per-street engine against the ORACLE's own run of it
