@@ -5,6 +5,10 @@ fused engine (csrc/prl_st.h); --engine levels is the level-synchronous engine th
 tree, profiles/r04p_bench_multistreet.json).
 
     python bench_multistreet.py [--gpus N] [--flops F] [--turns T] [--rivers R] [--steps K] [--warmup W] [--engine auto|levels] [--no-cpu-baseline]
+                                [--game DiscretizedNLHoldem [--stack S]]
+
+--game DiscretizedNLHoldem (round 6): pot-sized raises with finite stacks -- the streets' subtrees differ in shape and all-in calls are dealt out as
+run-out chains ("mixed streets", csrc/prl_st.h); one GPU (a sharded solve takes one shape per street).
 
 N > 1 GPUs: the flops (first-deal outcomes) are sharded, F per GPU (weak scaling: N x F flops in all), the betting before the flop replicated,
 one all-gather of the first street's root rows per EV pass (inside the library over RCCL; `--gpus N` starts the ranks itself as bench.py does).

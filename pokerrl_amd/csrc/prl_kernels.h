@@ -12,7 +12,6 @@ void prl_launch_fill_uniform(const PrlDevTree& T, const PrlDevState& S, const in
 void prl_launch_reach(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, void* stream, bool root_is_set = false);
 void prl_launch_terminals(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_term_nodes, int n_term, void* stream);
 void prl_launch_ev_levels(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, void* stream, float* d_expl_copy = nullptr);
-void prl_launch_ev_forest(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, const int32_t* d_term_nodes, int n_term, void* stream);
 void prl_launch_ev(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, const int32_t* d_term_nodes, int n_term,
                    void* stream, float* d_expl_copy = nullptr);
 void prl_launch_regret_strategy(const PrlDevTree& T, const PrlDevState& S, const int32_t* d_nodes, int n, int p, int variant, int iter,

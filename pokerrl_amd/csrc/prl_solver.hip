@@ -110,11 +110,12 @@ struct prl_solver {
     // run-out chains below all-in calls (prl_st.h "MIXED STREETS"): a decision-free forest on the LEVELS kernels
     PrlFlatTree chain_ft;
     PrlDevTree Tc{};
-    PrlDevState Sc{};
-    int32_t* d_chain_term = nullptr;
-    int n_chain_term = 0, n_chain = 0;
+    float* d_chain_ev = nullptr;       // [forest nodes][2][R]: values of the forest's inner nodes (its roots' values go straight to their streets' rows)
+    PrlStChainTerm* d_chain_terms = nullptr;
+    PrlStChainBundle* d_chain_bundles = nullptr;
+    std::vector<int32_t> chain_level_start;  // the forest's chance nodes by level (Tc.level_nodes lists them, not the showdowns)
+    int n_chain_term = 0, n_chain_bundles = 0, n_chain = 0;
     PrlStChainDev chain_dev{};
-    int chain_first[PRL_ST_MAX_LEVELS + 2] = {0, 0, 0, 0, 0, 0};  // chain roots of street v: [chain_first[v], chain_first[v + 1])
     int32_t* d_trunk_leaves = nullptr; // trunk ids of the trunk's chance leaves
     int n_trunk_leaves = 1;
     std::vector<int32_t> col_dfs;      // internal column -> flat-tree (DFS) column; empty = identity (every other engine)
@@ -495,24 +496,18 @@ int street_sweep(prl_solver* s, const PrlDevState& st, int mode, int src0, int s
 #endif
         return q;
     };
-    // reach down the streets; the roots of the run-out chains below street v - 1's all-in calls take theirs as soon as that street's leaf reach exists
-    auto chain_reach = [&](int v) {
-        if (s->n_chain) prl_launch_st_chain_reach(s->Tc, s->Sc.reach, v == 0 ? st.reach : s->st_str[v - 1].leaf_reach, s->chain_dev, s->chain_first[v],
-                                                 s->chain_first[v + 1] - s->chain_first[v], s->stream);
-    };
-    chain_reach(0);
-    for (int g = 0, v = 0; g <= NG; ++g) {
-        const int street = g < NG ? s->st.group[g].street : PRL_ST_MAX_LEVELS;
-        for (; v < street && v < PRL_ST_MAX_LEVELS; ++v) chain_reach(v + 1);  // every group of street v has pushed its leaf reach
-        if (g == NG || s->st.group[g].last) continue;
+    for (int g = 0; g < NG; ++g) {  // reach down the streets
+        if (s->st.group[g].last) continue;
         const int e = prl_launch_st_down(s->st.group[g].spec, level_params(g), src0, src1, s->stream);
         if (e) { prl_set_error("street engine: unsupported strategy-source combination"); return e; }
     }
-    if (s->n_chain) {  // the decision-free forest: reach below its roots, showdown equities, chance sums -- then its roots' values as rows of their streets
-        prl_launch_reach(s->Tc, s->Sc, s->chain_ft.level_start.data(), s->stream, true);
-        prl_launch_ev_forest(s->Tc, s->Sc, s->chain_ft.level_start.data(), s->d_chain_term, s->n_chain_term, s->stream);
-        for (int v = 0; v <= PRL_ST_MAX_LEVELS; ++v)
-            prl_launch_st_chain_rows(s->Tc, s->Sc.ev, s->Sc.ev_br, s->chain_dev, s->chain_first[v], s->chain_first[v + 1] - s->chain_first[v], s->st_str[v].val, mode, s->stream);
+    if (s->n_chain) {  // the run-out chains below the all-in calls (prl_st.h): their values become rows of their streets before the passes read them
+        PrlStChainIo io = {};
+        for (int v = 0; v <= PRL_ST_MAX_LEVELS; ++v) {
+            io.src[v] = v == 0 ? st.reach : s->st_str[v - 1].leaf_reach;
+            io.val[v] = s->st_str[v].val;
+        }
+        prl_launch_st_chain_eval(s->Tc, s->d_chain_terms, s->d_chain_bundles, s->n_chain_bundles, io, s->chain_dev, s->d_chain_ev, s->chain_level_start.data(), mode, s->stream);
     }
     for (int g = NG - 1; g >= 0; --g) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1020,6 +1015,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     else s->ft = full;
     std::vector<int32_t> chain_full_node;  // forest node -> node of the full tree (run-out chains of the per-street engine, prl_st.h)
     std::vector<int32_t> chain_root_id;    // per chain root (s->st.chain order, sorted by street below): its forest node
+    std::vector<float> chain_w;            // forest node -> the weight of each of its outcomes (chance nodes)
     if (streets && !s->st.chain.empty()) {
         std::stable_sort(s->st.chain.begin(), s->st.chain.end(), [](const PrlStChainKid& a, const PrlStChainKid& b) { return a.street < b.street; });
         PrlFlatTree& u = s->chain_ft;
@@ -1055,11 +1051,6 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
         std::vector<int32_t> fill(u.level_start.begin(), u.level_start.end() - 1);
         for (int i = 0; i < u.n_nodes; ++i) u.level_nodes[fill[u.depth[i]]++] = i;
         s->n_chain = (int)s->st.chain.size();
-        for (int v = 0; v <= PRL_ST_MAX_LEVELS + 1; ++v) {
-            int c = 0;
-            for (const PrlStChainKid& ck : s->st.chain) c += ck.street < v;
-            s->chain_first[v] = c;
-        }
     }
     const PrlFlatTree& ft = s->ft;
 #define FAIL_IF(x) do { int e_ = (x); if (e_) { prl_solver_destroy(s); return e_; } } while (0)
@@ -1138,6 +1129,7 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
                 wc[i] = chance_prob_f32(full.n_children[f], r.n_cards - before, r.n_hole_cards, k);
             }
             FAIL_IF(dev_upload(s, &s->Tc.chance_w, wc));
+            chain_w = wc;
         }
     }
     T.eq_const = eq_const_f32(r.n_cards, r.n_hole_cards);
@@ -1331,30 +1323,61 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             FAIL_IF(dev_upload(s, &C.first_col, u.first_col));
             FAIL_IF(dev_upload(s, &C.child_start, u.child_start));
             FAIL_IF(dev_upload(s, &C.child_list, u.child_list));
-            FAIL_IF(dev_upload(s, &C.level_nodes, u.level_nodes));
-            const size_t nv = (size_t)u.n_nodes * 2 * T.R;
-            FAIL_IF(dev_alloc(s, &s->Sc.reach, nv));
-            FAIL_IF(dev_alloc(s, &s->Sc.ev, nv));
-            FAIL_IF(dev_alloc(s, &s->Sc.ev_br, nv));
-            PRL_HIP_TRY(hipMemsetAsync(s->Sc.reach, 0, nv * sizeof(float), s->stream));
-            PRL_HIP_TRY(hipMemsetAsync(s->Sc.ev, 0, nv * sizeof(float), s->stream));
-            PRL_HIP_TRY(hipMemsetAsync(s->Sc.ev_br, 0, nv * sizeof(float), s->stream));
-            std::vector<int32_t> cterm, c_root, c_par, c_val;
-            std::vector<float> c_w;
-            for (int i = 0; i < u.n_nodes; ++i) if (u.kind[i] == PRL_NODE_TERM_SHOWDOWN) cterm.push_back(i);
-            s->n_chain_term = (int)cterm.size();
-            FAIL_IF(dev_upload(s, (const int32_t**)&s->d_chain_term, cterm));
-            for (size_t i = 0; i < s->st.chain.size(); ++i) {
-                const PrlStChainKid& ck = s->st.chain[i];
-                c_root.push_back(chain_root_id[i]);
-                c_par.push_back(ck.street == 0 ? st_leaf_ids[ck.parent_slot] : ck.parent_slot);  // (street 0: the trunk id of the all-in call's chance node)
-                c_val.push_back(ck.val_slot);
-                c_w.push_back(ck.w);
+            {   // the levels as the forest's own sum kernel walks them: chance nodes only (most roots are showdowns)
+                std::vector<int32_t> ln;
+                s->chain_level_start.assign(u.n_levels + 1, 0);
+                for (int d = 0; d < u.n_levels; ++d) {
+                    s->chain_level_start[d] = (int32_t)ln.size();
+                    for (int k = u.level_start[d]; k < u.level_start[d + 1]; ++k)
+                        if (u.kind[u.level_nodes[k]] == PRL_NODE_CHANCE) ln.push_back(u.level_nodes[k]);
+                }
+                s->chain_level_start[u.n_levels] = (int32_t)ln.size();
+                if (ln.empty()) ln.push_back(0);
+                FAIL_IF(dev_upload(s, &C.level_nodes, ln));
             }
-            FAIL_IF(dev_upload(s, &s->chain_dev.root, c_root));
-            FAIL_IF(dev_upload(s, &s->chain_dev.parent_slot, c_par));
-            FAIL_IF(dev_upload(s, &s->chain_dev.val_slot, c_val));
-            FAIL_IF(dev_upload(s, &s->chain_dev.w, c_w));
+            FAIL_IF(dev_alloc(s, &s->d_chain_ev, (size_t)u.n_nodes * 2 * T.R));
+            PRL_HIP_TRY(hipMemsetAsync(s->d_chain_ev, 0, (size_t)u.n_nodes * 2 * T.R * sizeof(float), s->stream));
+            std::vector<int32_t> node_kid(u.n_nodes, -1), root_of(u.n_nodes, -1), k_street, k_val;
+            for (size_t i = 0; i < s->st.chain.size(); ++i) {
+                node_kid[chain_root_id[i]] = (int32_t)i;
+                k_street.push_back(s->st.chain[i].street);
+                k_val.push_back(s->st.chain[i].val_slot);
+            }
+            std::vector<PrlStChainTerm> terms;
+            for (int i = 0; i < u.n_nodes; ++i) {  // (parents come before their children: the forest keeps the flat tree's DFS order)
+                root_of[i] = u.parent[i] < 0 ? node_kid[i] : root_of[u.parent[i]];
+                if (u.kind[i] != PRL_NODE_TERM_SHOWDOWN) continue;
+                const PrlStChainKid& ck = s->st.chain[root_of[i]];
+                PrlStChainTerm tm = {};
+                tm.node = i;
+                tm.src_street = ck.street;
+                tm.src_slot = ck.street == 0 ? st_leaf_ids[ck.parent_slot] : ck.parent_slot;  // (street 0: the trunk id of the all-in call's chance node)
+                tm.kid = node_kid[i];
+                std::vector<int> path;  // the chance nodes above it, bottom-up
+                for (int a = u.parent[i]; a >= 0; a = u.parent[a]) path.push_back(a);
+                FAIL_IF(path.size() + 1 > 3 ? (prl_set_error("street engine: a run-out chain deeper than three deals"), PRL_ERR_UNSUPPORTED) : PRL_OK);
+                tm.w[tm.n_w++] = ck.w;
+                for (size_t k = path.size(); k-- > 0;) tm.w[tm.n_w++] = chain_w[path[k]];
+                terms.push_back(tm);
+            }
+            s->n_chain_term = (int)terms.size();
+            // bundles: showdowns on one board share their workgroup's plan registers; short enough that the launch still fills the device
+            std::stable_sort(terms.begin(), terms.end(), [&](const PrlStChainTerm& a, const PrlStChainTerm& b) { return u.board_id[a.node] < u.board_id[b.node]; });
+            int per_bundle = (int)std::min<size_t>(8, std::max<size_t>(1, terms.size() / 8192));
+            if (const char* e = getenv("PRL_ST_CHAIN_BUNDLE")) per_bundle = std::max(1, atoi(e));  // (tests: bundles on trees too small to form them)
+            std::vector<PrlStChainBundle> bundles;
+            for (size_t i = 0; i < terms.size();) {
+                size_t j = i;
+                while (j < terms.size() && j - i < (size_t)per_bundle && u.board_id[terms[j].node] == u.board_id[terms[i].node]) ++j;
+                bundles.push_back(PrlStChainBundle{u.board_id[terms[i].node], (int32_t)i, (int32_t)(j - i)});
+                i = j;
+            }
+            s->n_chain_bundles = (int)bundles.size();
+            FAIL_IF(dev_upload(s, (const PrlStChainBundle**)&s->d_chain_bundles, bundles));
+            FAIL_IF(dev_upload(s, (const PrlStChainTerm**)&s->d_chain_terms, terms));
+            FAIL_IF(dev_upload(s, &s->chain_dev.street, k_street));
+            FAIL_IF(dev_upload(s, &s->chain_dev.val_slot, k_val));
+            FAIL_IF(dev_upload(s, &s->chain_dev.node_kid, node_kid));
         }
 #ifdef PRL_ST_TIMING
         FAIL_IF(dev_alloc(s, &s->sp.timing, (size_t)8));

@@ -130,11 +130,26 @@ struct PrlStScatter {  // copies out of a summed row of n_vec vectors: vector sr
 void prl_launch_st_scatter_trunk(const float* d_summed, const int32_t* d_leaf_nodes, int n_leaves, int R, const PrlStScatter& sc, float* d_ev, float* d_ev_br,
                                  float* d_half, void* stream);
 void prl_launch_st_half_to_trunk(const float* d_half, const int32_t* d_leaf_nodes, int n_leaves, int R, float* d_ev, float* d_ev_br, void* stream);
-// run-out chains: the roots of the decision-free forest (device arrays, one entry per chain root, ordered by street)
-struct PrlStChainDev { const int32_t *root, *parent_slot, *val_slot; const float* w; };
-struct PrlStRowMap { int32_t width, seat[4], br[4]; };  // vector v of a row = (br[v] ? ev_br : ev)[seat[v]]
-void prl_launch_st_chain_reach(const PrlDevTree& Tc, float* reach_c, const float* src, const PrlStChainDev& cd, int first, int count, void* stream);
-void prl_launch_st_chain_rows(const PrlDevTree& Tc, const float* ev, const float* ev_br, const PrlStChainDev& cd, int first, int count, float* val, int mode, void* stream);
+// run-out chains: the decision-free forest below the all-in calls, evaluated by two kernels of its own (prl_tree_kernels.hip: they share the showdown
+// arithmetic of the level kernels). A showdown of the forest reads the opponent's reach straight from the leaf of the all-in call above its chain (the
+// trunk's reach array or a street's leaf-reach buffer), multiplies the outcome weights of the chain in (the products the level kernels' reach walk would
+// make, in its order) and writes its value where it is read next: the street's row buffer if the showdown is itself a chain root (an all-in call on the
+// turn: most of them), the forest's value array otherwise; the chance nodes of the forest then sum their children level by level (canonical chance sum).
+struct PrlStChainDev {             // per chain root (device arrays), and per forest node the root it is (or -1)
+    const int32_t *street, *val_slot, *node_kid;
+};
+struct PrlStChainTerm {            // per showdown of the forest
+    int32_t node;                  // forest node (board row, pot)
+    int32_t src_street, src_slot;  // where the reach above its chain lives: PrlStChainIo::src[src_street] + src_slot * 2 R
+    int32_t kid;                   // the chain root it is, or -1
+    int32_t n_w;                   // weights of the chain above it: the root's outcome weight, then one per chance node on the way down
+    float w[3];
+};
+struct PrlStChainBundle { int32_t plan, first, count; };  // showdowns [first, first + count) of the list (sorted by board) sit on board row `plan`: one workgroup's work
+struct PrlStChainIo { const float* src[PRL_ST_MAX_LEVELS + 1]; float* val[PRL_ST_MAX_LEVELS + 1]; };
+struct PrlStRowMap { int32_t width, seat[4]; };  // vector v of a row holds seat[v]'s value (value = best response where nothing is decided)
+void prl_launch_st_chain_eval(const PrlDevTree& Tc, const PrlStChainTerm* d_terms, const PrlStChainBundle* d_bundles, int n_bundles, const PrlStChainIo& io,
+                              const PrlStChainDev& cd, float* ev_c, const int32_t* h_level_start, int mode, void* stream);
 // materialise strategies / averages of one street's columns (prl_solver_get, Vanilla / Linear averages)
 void prl_launch_st_strategy_from_regret(const PrlStParams& prm, int spec, double* out_cols, void* stream);
 void prl_launch_st_avg_from_sum(const PrlStParams& prm, int spec, void* stream);

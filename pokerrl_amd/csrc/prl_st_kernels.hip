@@ -72,57 +72,6 @@ void prl_launch_st_half_to_trunk(const float* d_half, const int32_t* d_leaf_node
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// run-out chains (prl_st.h "MIXED STREETS"): the decision-free subtrees below all-in calls are a forest the LEVELS kernels evaluate; these two kernels are
-// its borders. The same arithmetic as the level kernels' chance step (prl_reach_level_body: reach x the outcome's weight, 0 for the hands its cards block).
-// ---------------------------------------------------------------------------------------------------------------------------------
-PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_st_chain_reach(PrlDevTree Tc, float* __restrict__ reach_c, const float* __restrict__ src, PrlStChainDev cd, int first, int count) {
-    const size_t total = (size_t)count * Tc.R;
-    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
-        const int kid = first + (int)(t / Tc.R), h = (int)(t % Tc.R);
-        const int node = cd.root[kid];
-        const float w = prl_hand_blocked(Tc, h, Tc.board_id[node]) ? 0.f : cd.w[kid];
-        const float* rp = src + (size_t)cd.parent_slot[kid] * 2 * Tc.R;
-        float* rc = reach_c + prl_vidx(Tc, node, 0);
-        rc[h] = rp[h] * w;
-        rc[(size_t)Tc.R + h] = rp[(size_t)Tc.R + h] * w;
-    }
-}
-// the chain roots' values as rows of their street's buffer, in the layout the street passes write (prl_k_st_pass: rowv)
-PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_st_chain_rows(PrlDevTree Tc, const float* __restrict__ ev, const float* __restrict__ ev_br, PrlStChainDev cd, int first, int count,
-                                                        float* __restrict__ val, PrlStRowMap map) {
-    const size_t total = (size_t)count * map.width * Tc.R;
-    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
-        const int h = (int)(t % Tc.R), v = (int)((t / Tc.R) % map.width), kid = first + (int)(t / ((size_t)Tc.R * map.width));
-        const int node = cd.root[kid];
-        const float* a = map.br[v] ? ev_br : ev;
-        val[((size_t)cd.val_slot[kid] * map.width + v) * Tc.R + h] = a[prl_vidx(Tc, node, map.seat[v]) + h];
-    }
-}
-void prl_launch_st_chain_reach(const PrlDevTree& Tc, float* reach_c, const float* src, const PrlStChainDev& cd, int first, int count, void* stream) {
-    if (count <= 0) return;
-    const size_t items = (size_t)count * Tc.R;
-    PRL_LAUNCH(prl_k_st_chain_reach, (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096), 256, 0, stream, Tc, reach_c, src, cd, first, count);
-}
-void prl_launch_st_chain_rows(const PrlDevTree& Tc, const float* ev, const float* ev_br, const PrlStChainDev& cd, int first, int count, float* val, int mode, void* stream) {
-    if (count <= 0) return;
-    PrlStRowMap map = {};
-    const bool both = prl_fhp_runs_seat(mode, 0) && prl_fhp_runs_seat(mode, 1), with_br = prl_fhp_with_br(mode);
-    const int seat = prl_fhp_runs_seat(mode, 0) ? 0 : 1;
-    map.width = prl_fhp_out_width(mode);
-    if (both) {
-        map.seat[0] = 0; map.seat[1] = 1;
-        if (with_br) { map.seat[2] = 0; map.br[2] = 1; map.seat[3] = 1; map.br[3] = 1; }
-    } else if (mode == PRL_FHP_UPDATE1_EVAL1) {  // seat 1's value, its value under its new strategy (nothing of seat 1 is decided below an all-in call: the same), its best response
-        map.seat[0] = 1; map.seat[1] = 1; map.seat[2] = 1; map.br[2] = 1;
-    } else {
-        map.seat[0] = seat;
-        if (with_br) { map.seat[1] = seat; map.br[1] = 1; }
-    }
-    const size_t items = (size_t)count * map.width * Tc.R;
-    PRL_LAUNCH(prl_k_st_chain_rows, (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096), 256, 0, stream, Tc, ev, ev_br, cd, first, count, val, map);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
 // strategies / averages of one street's columns on demand (prl_solver_get(strategy); Vanilla / Linear averages from their sums)
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct PrlStDecTable { int32_t n_dec, n_cols, nch[PRL_FHP_MAX_DEC], col0[PRL_FHP_MAX_DEC]; };

@@ -21,6 +21,7 @@
 
 #include "prl_kernels.h"
 #include "prl_solver_types.h"
+#include "prl_st.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // summation helpers
@@ -66,7 +67,18 @@ PRL_DEV PRL_INLINE void prl_block_prefix(const float* y, int n, float* P, float*
         if (lane == 63) tot[k] = v;
     }
     prl_sync();
-    if (prl_tid() == 0) {
+    if (n_chunks < 64) {  // the sequential chain of chunk carries in wave 0's registers: lane k holds tot[k], one lane broadcast and one dependent add per chunk
+        if (wave == 0) {
+            const float tv = lane < n_chunks ? tot[lane] : 0.f;
+            float c = 0.f, mine = 0.f;
+            for (int k = 0; k < n_chunks; ++k) {
+                if (lane == k) mine = c;
+                c = c + prl_readlane(tv, k);
+            }
+            if (lane == n_chunks) mine = c;
+            if (lane <= n_chunks) carry[lane] = mine;
+        }
+    } else if (prl_tid() == 0) {
         float c = 0.f;
         for (int k = 0; k < n_chunks; ++k) {
             carry[k] = c;
@@ -284,6 +296,188 @@ PRL_GLOBAL void prl_k_terminal_2card(PrlDevTree T, PrlDevState S, const int32_t*
     }
 }
 
+// the run-out chains of the per-street engine (prl_st.h): a workgroup of 256 lanes takes a BUNDLE of showdowns on one complete board for one seat. What
+// prl_terminal_equity_2card reads of the board's plan per showdown -- the sorted order, the per-card position lists, a hand's tie group and its cards' bounds --
+// it holds in registers across the bundle, so a showdown costs one gather of the opponent's reach (from the leaf of the all-in call above its chain, times
+// the chain's outcome weights) and the scans; the arithmetic is that function's, statement for statement.
+#define PRL_CT_NT 256
+#define PRL_CT_K ((PRL_T2_YPAD + PRL_CT_NT - 1) / PRL_CT_NT)  // hands per lane (6)
+#if defined(PRL_EMU)
+#define PRL_CT_LB
+#define PRL_CT_KEEP_PACKED(x) do { } while (0)
+#else
+#ifndef PRL_CT_WAVES
+#define PRL_CT_WAVES 5
+#endif
+#define PRL_CT_LB __launch_bounds__(PRL_CT_NT, PRL_CT_WAVES)  // 6 waves per SIMD = the 6 workgroups per CU the 24.8 KB of LDS admit: the kernel is a chain of latencies
+// the plan words stay packed across the bundle's loop: without this the compiler hoists every address it can derive from them out of the loop (48 registers)
+#define PRL_CT_KEEP_PACKED(x) asm volatile("" : "+v"(x))
+#endif
+struct PrlCtTree {  // what this kernel reads of the forest's PrlDevTree (the whole struct by value costs ~100 scalar registers)
+    const int16_t *plan_sh, *plan_pos, *plan_gs, *plan_ge, *plan_cl, *hole;
+    const uint8_t* plan_klh;
+    const int32_t *plan_nlive, *plan_ndealt, *main_pot;
+    int32_t plan_stride, cl_stride, R, n_cards;
+    float eq_const;
+};
+PRL_GLOBAL void PRL_CT_LB prl_k_st_chain_terminals(PrlCtTree T, const PrlStChainTerm* __restrict__ terms, const PrlStChainBundle* __restrict__ bundles,
+                                                   int n_bundles, PrlStChainIo io, PrlStChainDev cd, float* __restrict__ ev, PrlStRowMap map, int seat_mask) {
+    float* y = (float*)prl_smem();
+    float* P = y + PRL_T2_YPAD;
+    float* tot = P + PRL_T2_YPAD + 8;
+    float* carry = tot + 64;
+    float* Q = carry + 64;  // [n_cards][65]
+    const int tid = (int)prl_tid(), wave = tid >> 6, lane = tid & 63, row = lane >> 4, l16 = lane & 15;
+    const int n_seats = seat_mask == 3 ? 2 : 1;
+    for (int bi = (int)prl_bid(); bi < n_seats * n_bundles; bi += (int)prl_nblocks()) {
+        const PrlStChainBundle bd = bundles[bi / n_seats];
+        const int p = n_seats == 2 ? bi % 2 : (seat_mask == 1 ? 0 : 1);
+        const int plan = bd.plan;
+        const int16_t* sh = T.plan_sh + (size_t)plan * T.plan_stride;
+        const int16_t* pos = T.plan_pos + (size_t)plan * T.plan_stride;
+        const int16_t* gs = T.plan_gs + (size_t)plan * T.plan_stride;
+        const int16_t* ge = T.plan_ge + (size_t)plan * T.plan_stride;
+        const int16_t* cl = T.plan_cl + (size_t)plan * T.cl_stride;
+        const uint8_t* klh = T.plan_klh + (size_t)plan * T.R * 4;
+        const int n = T.plan_nlive[plan];
+        const int n_t = T.n_cards - 1 - T.plan_ndealt[plan];
+        const int E = (n_t + 15) >> 4;  // entries per lane of a card's list, <= 4
+        // ---- the plan's share of this lane, once per bundle (packed: the kernel wants 6 waves per SIMD) ----
+        uint32_t shr[PRL_CT_K / 2];  // two 16-bit sorted-order entries per word, 0xFFFF = none
+#pragma unroll
+        for (int k = 0; k < PRL_CT_K / 2; ++k) {
+            const int i0 = tid + (2 * k) * PRL_CT_NT, i1 = tid + (2 * k + 1) * PRL_CT_NT;
+            shr[k] = (i0 < n ? (uint32_t)(uint16_t)sh[i0] : 0xFFFFu) | ((i1 < n ? (uint32_t)(uint16_t)sh[i1] : 0xFFFFu) << 16);
+        }
+        uint32_t lq[4][2];  // the lane's <= 4 entries of its card's position list per round, 0xFFFF = none
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 4 * wave + 16 * r + row;
+            const bool okc = c < T.n_cards;
+            const int16_t* lst = cl + (size_t)(okc ? c : 0) * (T.n_cards - 1);
+            uint32_t q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = l16 * E + k;
+                q[k] = (okc && k < E && e < n_t) ? (uint32_t)(uint16_t)lst[e] : 0xFFFFu;
+            }
+            lq[r][0] = q[0] | (q[1] << 16);
+            lq[r][1] = q[2] | (q[3] << 16);
+        }
+        uint32_t f_g[PRL_CT_K], f_c[PRL_CT_K], f_k[PRL_CT_K];  // tie group (begin | end << 16); cards (c1 | c2 << 8 | live << 16); the cards' list bounds
+#pragma unroll
+        for (int k = 0; k < PRL_CT_K; ++k) {
+            const int h = tid + k * PRL_CT_NT;
+            f_g[k] = 0u; f_c[k] = 0u; f_k[k] = 0u;
+            if (h < T.R) {
+                const int i = pos[h];
+                if (i >= 0) {
+                    f_g[k] = (uint32_t)(uint16_t)gs[i] | ((uint32_t)(uint16_t)ge[i] << 16);
+                    f_c[k] = (uint32_t)T.hole[2 * h] | ((uint32_t)T.hole[2 * h + 1] << 8) | (1u << 16);
+                    f_k[k] = (uint32_t)klh[4 * h] | ((uint32_t)klh[4 * h + 1] << 8) | ((uint32_t)klh[4 * h + 2] << 16) | ((uint32_t)klh[4 * h + 3] << 24);
+                }
+            }
+        }
+        // ---- the bundle's showdowns; the next one's reach is on its way while this one is scanned ----
+        PrlStChainTerm tm = terms[bd.first];
+        float xr[PRL_CT_K];
+        {
+            const float* x = io.src[tm.src_street] + ((size_t)tm.src_slot * 2 + (1 - p)) * T.R;
+#pragma unroll
+            for (int k = 0; k < PRL_CT_K; ++k) {
+                const uint32_t q = (shr[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                xr[k] = q != 0xFFFFu ? x[q] : 0.f;
+            }
+        }
+        for (int t = 0; t < bd.count; ++t) {
+#pragma unroll
+            for (int k = 0; k < PRL_CT_K; ++k) { PRL_CT_KEEP_PACKED(f_g[k]); PRL_CT_KEEP_PACKED(f_c[k]); PRL_CT_KEEP_PACKED(f_k[k]); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { PRL_CT_KEEP_PACKED(lq[r][0]); PRL_CT_KEEP_PACKED(lq[r][1]); }
+#pragma unroll
+            for (int k = 0; k < PRL_CT_K / 2; ++k) PRL_CT_KEEP_PACKED(shr[k]);
+            float* out = ev + ((size_t)tm.node * 2 + p) * T.R;  // (prl_vidx)
+            int vec_mask = 1;
+            if (tm.kid >= 0) {  // a chain root: its value is a row of its street (every vector of the row that is seat p's)
+                out = io.val[cd.street[tm.kid]] + (size_t)cd.val_slot[tm.kid] * map.width * T.R;
+                vec_mask = 0;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (v < map.width && map.seat[v] == p) vec_mask |= 1 << v;
+            }
+            const float pot = (float)T.main_pot[tm.node];
+            const int n_w = tm.n_w;
+            const float w0 = tm.w[0], w1 = tm.w[1], w2 = tm.w[2];
+#pragma unroll
+            for (int k = 0; k < PRL_CT_K; ++k) {
+                if (((shr[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) == 0xFFFFu) continue;
+                float v = xr[k];
+                if (n_w > 0) v = v * w0;  // (the level kernels' reach walk: the root's outcome weight, then one chance node after the other)
+                if (n_w > 1) v = v * w1;
+                if (n_w > 2) v = v * w2;
+                y[tid + k * PRL_CT_NT] = v;
+            }
+            if (t + 1 < bd.count) {
+                tm = terms[bd.first + t + 1];
+                const float* x = io.src[tm.src_street] + ((size_t)tm.src_slot * 2 + (1 - p)) * T.R;
+#pragma unroll
+                for (int k = 0; k < PRL_CT_K; ++k) {
+                    const uint32_t q = (shr[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                    xr[k] = q != 0xFFFFu ? x[q] : 0.f;
+                }
+            }
+            prl_sync();
+            prl_block_prefix(y, n, P, tot, carry);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // per-card scans in the row16 order: a wave takes four cards at a time, one per row of 16 lanes
+                if (4 * wave + 16 * r >= T.n_cards) continue;
+                const int c = 4 * wave + 16 * r + row;
+                const bool okc = c < T.n_cards;
+                float l[4] = {0.f, 0.f, 0.f, 0.f};
+                float run = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k >= E) continue;
+                    const uint32_t q = (lq[r][k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                    const float v = q != 0xFFFFu ? y[q] : 0.f;
+                    run = k == 0 ? v : run + v;
+                    l[k] = run;
+                }
+                const float tt = prl_row16_scan(run);
+                const float cy = prl_dpp_row_shr<1>(tt);
+                if (okc) {
+                    if (l16 == 0) Q[c * 65] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < E) Q[c * 65 + l16 * E + k + 1] = cy + l[k];
+                }
+            }
+            prl_sync();
+            const float Tsum = P[n];
+#pragma unroll
+            for (int k = 0; k < PRL_CT_K; ++k) {
+                const int h = tid + k * PRL_CT_NT;
+                if (h >= T.R) continue;
+                float e = 0.f;
+                if ((f_c[k] >> 16) & 1u) {
+                    const int g0 = (int)(f_g[k] & 0xFFFFu), g1 = (int)(f_g[k] >> 16);
+                    const float G = P[g0] - (Tsum - P[g1]);
+                    const int c1 = (int)(f_c[k] & 0xFFu), c2 = (int)((f_c[k] >> 8) & 0xFFu);
+                    const int lo1 = (int)(f_k[k] & 0xFFu), hi1 = (int)((f_k[k] >> 8) & 0xFFu), lo2 = (int)((f_k[k] >> 16) & 0xFFu), hi2 = (int)(f_k[k] >> 24);
+                    const float K0 = Q[c1 * 65 + lo1] - (Q[c1 * 65 + n_t] - Q[c1 * 65 + hi1]);
+                    const float K1 = Q[c2 * 65 + lo2] - (Q[c2 * 65 + n_t] - Q[c2 * 65 + hi2]);
+                    e = G - (K0 + K1);
+                    e = e * T.eq_const;
+                }
+                const float v = (e * pot) / 2.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if ((vec_mask >> u) & 1) out[(size_t)u * T.R + h] = v;
+            }
+            prl_sync();
+        }
+    }
+}
 // ---------------------------------------------------------------------------------------------------------------------
 // EV / best-response pull-up
 // ---------------------------------------------------------------------------------------------------------------------
@@ -460,6 +654,26 @@ PRL_GLOBAL void prl_k_terminal_1card(PrlDevTree T, PrlDevState S, const int32_t*
     prl_terminal_1card_body(T, S, term_nodes, n_term);
 }
 PRL_GLOBAL void prl_k_ev_level(PrlDevTree T, PrlDevState S, int level_begin, int level_count) { prl_ev_level_body(T, S, level_begin, level_count); }
+// one level of the run-out forest: its chance nodes sum their children (the seats the pass wants); a chain root's sum is also a row of its street
+PRL_GLOBAL void prl_k_st_chain_sum(PrlDevTree T, float* __restrict__ ev, int level_begin, int level_count, PrlStChainDev cd, PrlStChainIo io, PrlStRowMap map, int seat_mask) {
+    const size_t total = (size_t)level_count * T.R;
+    for (size_t t = (size_t)prl_bid() * prl_nthreads() + prl_tid(); t < total; t += (size_t)prl_nblocks() * prl_nthreads()) {
+        const int node = T.level_nodes[level_begin + (int)(t / T.R)];
+        const int h = (int)(t % T.R);
+        if (T.kind[node] != PRL_NODE_CHANCE) continue;
+        const int kid = cd.node_kid[node];
+        for (int p = 0; p < 2; ++p) {
+            if (!((seat_mask >> p) & 1)) continue;
+            const float v = prl_chance_sum(T, ev, node, p, h);
+            ev[prl_vidx(T, node, p) + h] = v;
+            if (kid >= 0) {
+                float* row = io.val[cd.street[kid]] + (size_t)cd.val_slot[kid] * map.width * T.R;
+                for (int k = 0; k < map.width; ++k)
+                    if (map.seat[k] == p) row[(size_t)k * T.R + h] = v;
+            }
+        }
+    }
+}
 PRL_GLOBAL void prl_k_exploitability(PrlDevTree T, PrlDevState S, float* out2) { prl_exploitability_body(T, S, out2); }
 // the same, the result also to a second place (the solver's history slot: no separate 8-byte copy on a launch-bound trunk)
 PRL_GLOBAL void prl_k_exploitability2(PrlDevTree T, PrlDevState S, float* out2, float* out2b) {
@@ -740,12 +954,34 @@ void prl_launch_ev_levels(const PrlDevTree& T, const PrlDevState& S, const int32
     else PRL_LAUNCH(prl_k_exploitability, 1, 256, smem, stream, T, S, S.expl);
 }
 
-// a FOREST (several nodes at depth 0, no root exploitability): the run-out chains of the per-street engine (prl_st.h)
-void prl_launch_ev_forest(const PrlDevTree& T, const PrlDevState& S, const int32_t* h_level_start, const int32_t* d_term_nodes, int n_term, void* stream) {
-    prl_launch_terminals(T, S, d_term_nodes, n_term, stream);
-    for (int d = T.n_levels - 2; d >= 0; --d) {
-        int cnt = h_level_start[d + 1] - h_level_start[d];
-        if (cnt > 0) PRL_LAUNCH(prl_k_ev_level, prl_grid_for((size_t)cnt * T.R, 256), 256, 0, stream, T, S, h_level_start[d], cnt);
+// the run-out forest of the per-street engine (prl_st.h): its showdowns, then its chance levels bottom-up
+void prl_launch_st_chain_eval(const PrlDevTree& Tc, const PrlStChainTerm* d_terms, const PrlStChainBundle* d_bundles, int n_bundles, const PrlStChainIo& io,
+                              const PrlStChainDev& cd, float* ev_c, const int32_t* h_level_start, int mode, void* stream) {
+    if (n_bundles <= 0) return;
+    PrlStRowMap map = {};
+    const bool both = prl_fhp_runs_seat(mode, 0) && prl_fhp_runs_seat(mode, 1), with_br = prl_fhp_with_br(mode);
+    const int seat = prl_fhp_runs_seat(mode, 0) ? 0 : 1;
+    map.width = prl_fhp_out_width(mode);
+    if (both) {  // (ev0, ev1[, br0, br1])
+        map.seat[0] = 0; map.seat[1] = 1;
+        if (with_br) { map.seat[2] = 0; map.seat[3] = 1; }
+    } else if (mode == PRL_FHP_UPDATE1_EVAL1) {  // seat 1's value, its value under its new strategy (nothing of seat 1 is decided below an all-in call: the same), its best response
+        map.seat[0] = 1; map.seat[1] = 1; map.seat[2] = 1;
+    } else {
+        map.seat[0] = seat;
+        if (with_br) map.seat[1] = seat;
+    }
+    const int seat_mask = both ? 3 : (mode == PRL_FHP_UPDATE1_EVAL1 ? 2 : 1 << seat);
+    const int n_items = (seat_mask == 3 ? 2 : 1) * n_bundles;
+    const size_t smem = ((size_t)PRL_T2_YPAD + (PRL_T2_YPAD + 8) + 64 + 64 + (size_t)Tc.n_cards * 65) * sizeof(float);
+    PrlCtTree ct = {};
+    ct.plan_sh = Tc.plan_sh; ct.plan_pos = Tc.plan_pos; ct.plan_gs = Tc.plan_gs; ct.plan_ge = Tc.plan_ge; ct.plan_cl = Tc.plan_cl; ct.plan_klh = Tc.plan_klh;
+    ct.hole = Tc.hole; ct.plan_nlive = Tc.plan_nlive; ct.plan_ndealt = Tc.plan_ndealt; ct.main_pot = Tc.main_pot;
+    ct.plan_stride = Tc.plan_stride; ct.cl_stride = Tc.cl_stride; ct.R = Tc.R; ct.n_cards = Tc.n_cards; ct.eq_const = Tc.eq_const;
+    PRL_LAUNCH(prl_k_st_chain_terminals, n_items < 65536 ? n_items : 65536, PRL_CT_NT, smem, stream, ct, d_terms, d_bundles, n_bundles, io, cd, ev_c, map, seat_mask);
+    for (int d = Tc.n_levels - 2; d >= 0; --d) {
+        const int cnt = h_level_start[d + 1] - h_level_start[d];
+        if (cnt > 0) PRL_LAUNCH(prl_k_st_chain_sum, prl_grid_for((size_t)cnt * Tc.R, 256), 256, 0, stream, Tc, ev_c, h_level_start[d], cnt, cd, io, map, seat_mask);
     }
 }
 

@@ -230,11 +230,14 @@ def test_emu_streets_engine_all_in_run_outs(L, variant, stack, runouts, batched)
     pc.check_streets_vs_oracle(L, G.LimitHoldem, stack, pc.multistreet_runouts(*runouts), variant, 3 if batched else 2, batched=batched)
 
 
-@pytest.mark.parametrize("variant,stack,runouts,batched", [("plus", 600, (1, 1, 1), False), ("vanilla", 1200, (1, 1, 1), True), ("linear", 600, (2, 1, 2), True)])
-def test_emu_streets_engine_discretized_nl_holdem(L, variant, stack, runouts, batched):
+@pytest.mark.parametrize("variant,stack,runouts,batched,bundle", [("plus", 600, (1, 1, 1), False, 3), ("vanilla", 1200, (1, 1, 1), True, 0), ("linear", 600, (2, 1, 2), True, 2)])
+def test_emu_streets_engine_discretized_nl_holdem(L, monkeypatch, variant, stack, runouts, batched, bundle):
     """MIXED STREETS: DiscretizedNLHoldem (games.py:114-131) with pot-sized raises -- a street's subtrees differ with the stacks behind (9-, 15- and
-    21-node shapes side by side on one street, 6 to 9 (street, shape) groups) and every raise sequence that runs out of chips ends in a run-out chain"""
+    21-node shapes side by side on one street, 6 to 9 (street, shape) groups) and every raise sequence that runs out of chips ends in a run-out chain;
+    bundle: showdowns of the run-out forest per workgroup (PRL_ST_CHAIN_BUNDLE; trees this small would form none by themselves)"""
     from pokerrl_amd.game import bet_sets
+    if bundle:
+        monkeypatch.setenv("PRL_ST_CHAIN_BUNDLE", str(bundle))
     from pokerrl_amd.game import games as G
     pc.check_streets_vs_oracle(L, G.DiscretizedNLHoldem, stack, pc.multistreet_runouts(*runouts), variant, 3 if batched else 2, batched=batched, bets=bet_sets.POT_ONLY)
 
