@@ -8,7 +8,7 @@ tree, profiles/r04p_bench_multistreet.json).
                                 [--game DiscretizedNLHoldem [--stack S]]
 
 --game DiscretizedNLHoldem (round 6): pot-sized raises with finite stacks -- the streets' subtrees differ in shape and all-in calls are dealt out as
-run-out chains ("mixed streets", csrc/prl_st.h); one GPU (a sharded solve takes one shape per street).
+run-out chains ("mixed streets", csrc/prl_st.h).
 
 N > 1 GPUs: the flops (first-deal outcomes) are sharded, F per GPU (weak scaling: N x F flops in all), the betting before the flop replicated,
 one all-gather of the first street's root rows per EV pass (inside the library over RCCL; `--gpus N` starts the ranks itself as bench.py does).
@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--placement-candidates", type=int, default=3, help="one GPU: solver objects built and timed before the run, the fastest is kept (1 = no probe)")
     ap.add_argument("--game", default="LimitHoldem", choices=["LimitHoldem", "DiscretizedNLHoldem"], help="DiscretizedNLHoldem: pot-sized raises (bet_sets.POT_ONLY) -- mixed street "
-                    "shapes and all-in run-out chains (csrc/prl_st.h MIXED STREETS), one GPU")
+                    "shapes and all-in run-out chains (csrc/prl_st.h MIXED STREETS)")
     ap.add_argument("--stack", type=int, default=None, help="chips per seat (default: 48 for LimitHoldem, 2500 for DiscretizedNLHoldem)")
     ap.add_argument("--max-raises", default=None, help="raises per betting round, e.g. 1,1,1,1 (smaller street subtrees: the CPU test-suite's emulator runs); default: the game's 4")
     args = ap.parse_args()

@@ -994,11 +994,6 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
     if (streets) {
         if (exchange && prl_st_build(full, total_boards, &st_plan, &st_why) != PRL_OK) { prl_set_error("street engine: " + st_why); delete s; return PRL_ERR_UNSUPPORTED; }
         s->st = st_plan;
-        if (exchange) {  // a sharded solve splits the first deal's outcomes of ONE shape per street (the layout its exchange counts on)
-            bool mixed = !st_plan.chain.empty();
-            for (int g = 0; g + 1 < st_plan.n_groups; ++g) mixed = mixed || st_plan.group[g].street == st_plan.group[g + 1].street;
-            if (mixed) { prl_set_error("street engine: a sharded solve takes trees whose streets have one shape each and no all-in run-outs"); delete s; return PRL_ERR_UNSUPPORTED; }
-        }
         s->col_dfs = st_plan.col_dfs;
         bool identity = true;
         for (size_t c = 0; c < s->col_dfs.size() && identity; ++c) identity = s->col_dfs[c] == (int32_t)c;

@@ -35,8 +35,8 @@
 // walked by its own launches of the same kernels; every street has ONE leaf-reach buffer and ONE buffer of root-vector rows, addressed by explicit slots
 // (PrlStInst::leaf_slot0 / val_slot), so that the children of one leaf may live in any group: child (leaf j, outcome k) of an instance sits at row
 // kid_base + k * n_leaves + j of the next street's buffer whatever it is. The decision-free subtrees (the chance outcomes below an all-in call) form a small
-// forest that the LEVELS kernels evaluate: their roots' reach is gathered from the street's leaf reach, their values are scattered into the rows the
-// parent's pass sums (prl_k_st_chain_reach / prl_k_st_chain_rows).
+// forest with two kernels of its own (prl_launch_st_chain_eval below): its showdowns read the reach of the all-in leaf in place and write their values into
+// the rows the parent's pass sums.
 enum { PRL_ST_SPEC_9 = 0, PRL_ST_SPEC_15 = 1, PRL_ST_SPEC_21 = 2, PRL_ST_SPEC_27 = 3, PRL_ST_N_SPECS = 4 };
 #define PRL_ST_MAX_LEVELS 4   // dealing streets
 #define PRL_ST_MAX_GROUPS 16  // (street, shape) groups
@@ -44,7 +44,7 @@ enum { PRL_ST_SPEC_9 = 0, PRL_ST_SPEC_15 = 1, PRL_ST_SPEC_21 = 2, PRL_ST_SPEC_27
 // per street instance (uniform over the workgroup that walks it: read through scalar loads)
 struct PrlStInst {
     int32_t row;          // row of the board table = showdown plan of this instance
-    int32_t parent_slot;  // index of its root's reach in the previous level's leaf_reach: parent instance * n_leaves(parent) + leaf
+    int32_t parent_slot;  // slot of its root's reach in the previous street's leaf-reach buffer (street 0: the trunk id of its chance node)
     float w;              // chance weight of the outcome (StrategyFiller.py:159-166 generalised, per chance node)
     int32_t n_kids;       // chance outcomes below each of its leaves (0 on the last street)
     int32_t kid_base;     // first child row (next street's buffer): child of (leaf j, outcome k) = kid_base + k * n_leaves + j

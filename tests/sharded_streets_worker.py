@@ -1,7 +1,7 @@
 """One rank of the sharded multi-street tests (spawned by tests/test_sharded.py).
 
 argv: lib_path device out_dir json   (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the env)
-json: {"n_local": flops per rank, "n_turns":, "n_rivers":, "n_iters":, "seed":, "max_raises": [..] or null, "variant":}
+json: {"n_local": flops per rank, "n_turns":, "n_rivers":, "n_iters":, "seed":, "max_raises": [..] or null, "variant":, "game": (LimitHoldem), "stack": (48), "bets": (null)}
 Rank r solves the r-th block of n_local flops (with all their turn / river run-outs) of pc.multistreet_runouts(world * n_local, ...) on the
 per-street fused engine through NativeSolver(shard=...) and writes its state to out_dir/rank<r>.npz."""
 import json
@@ -32,11 +32,12 @@ def main():
     n_local, per_flop = cfg["n_local"], cfg["n_turns"] * cfg["n_rivers"]
     runouts = pc.multistreet_runouts(world * n_local, cfg["n_turns"], cfg["n_rivers"], seed=cfg["seed"])
     mine = runouts[rank * n_local * per_flop:(rank + 1) * n_local * per_flop]
-    game = G.LimitHoldem.native_game(env_args(G.LimitHoldem, 48, None))
+    game_cls = getattr(G, cfg.get("game", "LimitHoldem"))
+    game = game_cls.native_game(env_args(game_cls, cfg.get("stack", 48), cfg.get("bets")))
     if cfg.get("max_raises"):
         for i, v in enumerate(cfg["max_raises"]):
             game.max_raises[i] = v
-    t = _native.NativeTree(game, G.LimitHoldem.native_rules(), mine, _lib=L)
+    t = _native.NativeTree(game, game_cls.native_rules(), mine, _lib=L)
     ex = TorchExchange(device)
     s = _native.NativeSolver(t, cfg.get("variant", "plus"), 0, _lib=L, shard=(world, rank, ex))
     assert s.engine == "fused"

@@ -303,16 +303,17 @@ def check_streets_against_union(L, ranks, world, cfg):
     and every street instance's; exploitability history; average-strategy exploitability)"""
     n_local, per_flop = cfg["n_local"], cfg["n_turns"] * cfg["n_rivers"]
     runouts = pc.multistreet_runouts(world * n_local, cfg["n_turns"], cfg["n_rivers"], seed=cfg["seed"])
-    game = G.LimitHoldem.native_game(env_args(G.LimitHoldem, 48, None))
+    game_cls = getattr(G, cfg.get("game", "LimitHoldem"))
+    game = game_cls.native_game(env_args(game_cls, cfg.get("stack", 48), cfg.get("bets")))
     for i, v in enumerate(cfg.get("max_raises") or []):
         game.max_raises[i] = v
-    t = _native.NativeTree(game, G.LimitHoldem.native_rules(), runouts, _lib=L)
+    t = _native.NativeTree(game, game_cls.native_rules(), runouts, _lib=L)
     s = _native.NativeSolver(t, cfg.get("variant", "plus"), 0, engine="fused", _lib=L)
     s.iterations(cfg["n_iters"])
     hist, regret, avg, ev_avg = s.get("expl_history"), s.get("regret"), s.get("avg"), s.eval_avg()
     trunk_u, blocks_u = _top_blocks(t)
     for r, out in enumerate(ranks):
-        tl = _native.NativeTree(game, G.LimitHoldem.native_rules(), runouts[r * n_local * per_flop:(r + 1) * n_local * per_flop], _lib=L)
+        tl = _native.NativeTree(game, game_cls.native_rules(), runouts[r * n_local * per_flop:(r + 1) * n_local * per_flop], _lib=L)
         trunk_l, blocks_l = _top_blocks(tl)
         assert np.array_equal(out["expl_history"], hist), "rank %d: exploitability history" % r
         assert np.array_equal(out["eval_avg"], ev_avg), "rank %d: average-strategy exploitability" % r
@@ -331,12 +332,32 @@ def test_streets_sharded_world2_gloo_emu(EMU):
     check_streets_against_union(_native.bind(EMU), ranks, 2, cfg)
 
 
+@pytest.mark.parametrize("game,stack,bets", [("LimitHoldem", 6, None), ("DiscretizedNLHoldem", 600, [1.0])])
+def test_streets_sharded_mixed_streets_world2_gloo_emu(EMU, game, stack, bets):
+    """MIXED STREETS sharded (csrc/prl_st.h): short-stacked LimitHoldem / DiscretizedNLHoldem with pot-sized raises -- several street shapes per street
+    and all-in run-out chains, some of them directly below the trunk (rows of the first street that the ranks exchange like any instance's) --
+    2 flops x 2 turns x 1 river, one flop per rank, equals the one-rank solve of both flops"""
+    cfg = dict(n_local=1, n_turns=2, n_rivers=1, n_iters=2, seed=13, game=game, stack=stack, bets=bets, variant="linear" if bets else "plus")
+    ranks = run_sharded_streets(EMU, "cpu", 2, cfg, timeout=1500)
+    check_streets_against_union(_native.bind(EMU), ranks, 2, cfg)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_local,max_raises", [(1, None), (32, [1, 1, 1, 1])])  # flops / blocks of 32 flops are exchanged
 def test_gpu_streets_sharded_world2_matches_unsharded(n_local, max_raises):
     """two processes on the one GPU: LimitHoldem with its full betting (27-node street subtrees) one flop per rank; a 9-node betting tree
     with 32 flops per rank (whole 32-flop blocks are what the ranks exchange)"""
     cfg = dict(n_local=n_local, n_turns=2, n_rivers=2 if n_local == 1 else 1, n_iters=3, seed=17, max_raises=max_raises)
+    ranks = run_sharded_streets(_native.LIB_PATH, "cuda", 2, cfg, timeout=900)
+    check_streets_against_union(_native.lib(), ranks, 2, cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game,stack,bets,n_local", [("DiscretizedNLHoldem", 2500, [1.0], 2), ("LimitHoldem", 10, None, 32)])
+def test_gpu_streets_sharded_mixed_streets_world2_matches_unsharded(game, stack, bets, n_local):
+    """two processes on the one GPU, mixed street shapes and all-in run-out chains (DiscretizedNLHoldem with pot-sized raises; LimitHoldem with 10-chip
+    stacks, 32 flops per rank = whole blocks are exchanged): every rank's state = its part of the one-rank solve"""
+    cfg = dict(n_local=n_local, n_turns=2, n_rivers=2 if n_local < 32 else 1, n_iters=3, seed=19, game=game, stack=stack, bets=bets, variant="plus")
     ranks = run_sharded_streets(_native.LIB_PATH, "cuda", 2, cfg, timeout=900)
     check_streets_against_union(_native.lib(), ranks, 2, cfg)
 
