@@ -29,11 +29,23 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes of the last street's two steady-state passes per CFR+ iteration and action column, from the PMC counters on the default tree (235 872
-# last-street columns): (2 x 1.267e6 + 2.047e6) + (2 x 1.496e6 + 2.042e6) KB per launch pair = 9.615 GB
-PMC_TRAFFIC_BYTES_PER_LAST_STREET_COLUMN = 9.615e9 / 235872
-PMC_TRAFFIC_SOURCE = ("profiles/r05k_multistreet_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per "
-                      "MI355X_MICROARCH.md), scaled by the last street's action columns")
+def pmc_traffic(game, flops, turns, rivers):
+    """HBM bytes per last-street action column and CFR+ iteration from profiles/multistreet_counters.json (written by scripts/gpu_r6_ms_traffic.sh: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md) -- (bytes per column, source text), or (None, why). The
+    LimitHoldem figure scales to other run-out counts of the same game (one shape per street); a mixed-streets tree only has its own measurement."""
+    path = os.path.join(ROOT, "profiles", "multistreet_counters.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, "profiles/multistreet_counters.json not found"
+    key = "%s_%dx%dx%d" % (game, flops, turns, rivers)
+    if key not in d and game == "LimitHoldem":
+        key = next((k for k in d if k.startswith("LimitHoldem_")), key)
+    if key not in d:
+        return None, "not measured on this tree (profiles/multistreet_counters.json has %s)" % ", ".join(sorted(d))
+    e = d[key]
+    return e["hbm_bytes_per_last_street_column"], "profiles/multistreet_counters.json [%s], checkpoint %s: %s" % (key, e.get("checkpoint"), e.get("command"))
 
 
 def runouts(n_flops, n_turns, n_rivers, seed=9):
@@ -189,6 +201,7 @@ def main():
     n_trunk = int(np.sum(rnd == int(rnd.min())))  # the betting before the first deal: replicated on every rank, counted once
     n_nodes_job = n_trunk + world * (tree.n_nodes - n_trunk)
     achieved = (bytes_last * args.steps / (pass_ms * 1e-3) if fused else bytes_iter * args.steps / (dev_ms * 1e-3)) / 1e9
+    per_col, traffic_src = pmc_traffic(args.game, args.flops, args.turns, args.rivers)
     out = {
         "metric": "CFR+ node-updates/sec on a multi-street %s public tree" % args.game, "value": n_nodes_job * args.steps / dt, "unit": "node-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -202,7 +215,7 @@ def main():
                    "device_ms_per_iteration": dev_ms / args.steps, "exploitability_chips": float(np.mean(expl)), "iterations_done": s.iter,
                    "hbm_bytes_allocated": int(s.get("bytes_allocated")[0])},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": PMC_TRAFFIC_BYTES_PER_LAST_STREET_COLUMN * cols_last if fused and not nl else None, "traffic_source": PMC_TRAFFIC_SOURCE if not nl else "not measured on this tree",
+                     "traffic": per_col * cols_last if fused and per_col and not args.avg_f32 and not args.max_raises else None, "traffic_source": traffic_src,
                      "kernel": "prl_k_st_pass<last street>" if fused else "all kernels of the iteration",
                      "launches_per_iteration": n_pass / float(args.steps) if fused else None,
                      "kernel_ms_per_iteration": (pass_ms if fused else dev_ms) / args.steps,

@@ -363,6 +363,28 @@ def test_gpu_cfr_plus_on_limit_holdem_builder_dealt_run_outs_on_the_street_engin
     assert series[0] == series[1] and len(series[0]) == 5 and series[0][-1][1] < series[0][0][1]
 
 
+def test_gpu_cfr_plus_on_discretized_nl_holdem_on_the_street_engine(L):
+    """CFRPlus(game_cls=DiscretizedNLHoldem, agent_bet_set=POT_ONLY, starting_stack_sizes=[600, 2500], max_outcomes=(2, 2, 2)) through the reference's
+    class (CFRBase.py:13-75: one public tree per stack size): mixed street shapes and all-in run-out chains -- engine=auto takes the per-street fused
+    engine for both trees; the logged exploitability series of each stack equals the level-synchronous engine's on the same tree"""
+    from pokerrl_amd.cfr.CFRPlus import CFRPlus
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    from pokerrl_amd.rl.base_cls.workers.ChiefBase import ChiefBase
+    series = []
+    for engine in ("auto", "levels"):
+        chief = ChiefBase(t_prof=None)
+        cfr = CFRPlus(name="nl_" + engine, chief_handle=chief, game_cls=G.DiscretizedNLHoldem, agent_bet_set=bet_sets.POT_ONLY, starting_stack_sizes=[600, 2500],
+                      delay=0, max_outcomes=(2, 2, 2), engine=engine)
+        assert [t.solver.engine for t in cfr._trees] == ["fused" if engine == "auto" else "levels"] * 2
+        cfr.iterations(4)
+        vals, _ = chief.get_new_values()
+        series.append([[v for k, v in vals.items() if "_Curr_S%d" % st in k][0]["Evaluation/" + G.DiscretizedNLHoldem.WIN_METRIC] for st in (600, 2500)])
+    assert series[0] == series[1]
+    for one in series[0]:
+        assert len(one) == 5 and one[-1][1] < one[0][1]
+
+
 def test_gpu_bench_total_boards_one_gpu_smoke():
     """bench.py --total-boards T on one GPU: ONE board list (strong-scaling mode; the shape of --all-boards, which needs 4-8 GPUs), the
     builder's own seeded enumeration; the JSON says so"""
