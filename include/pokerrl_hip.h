@@ -520,13 +520,14 @@ int32_t prl_policy_table_probe(const prl_policy_table_t* table, int32_t n, const
 /* The table of a SOLVER's average strategy, built where the strategy lives (no host copy of the columns; the reference's evaluators are pointed at the
  * trained agent: PokerRL/eval/lbr/LocalLBRWorker.py:316-374, PokerRL/rl/base_cls/EvalAgentBase.py:39-44). `tree` is the tree the solver was created on.
  * One row per decision node, rows in node order; the row's history key is the chain of prl_policy_table_create over the states on the node's path
- * (the env replayed along the tree). LEVELS engine and the single-deal FUSED engine (its board columns are expanded from sorted storage to hand order
- * on the device, a chunk of boards at a time); the average is what prl_solver_get(PRL_SF_AVG) returns, rounded to float32.
+ * (the env replayed along the tree). Every engine: LEVELS; the single-deal FUSED engine (its board columns are expanded from sorted storage to hand
+ * order on the device, a chunk of boards at a time); the per-street FUSED engine (its internal column order, mixed street shapes included: no decision
+ * below an all-in call, so run-out chains have no rows). The average is what prl_solver_get(PRL_SF_AVG) returns, rounded to float32.
  * A solver made by prl_solver_create_weighted with `symmetrize` (suit classes) yields a SUIT-CANONICAL table: rows exist for the class representatives
  * only; the evaluators relabel the dealt board to its class representative -- the lexicographically smallest of its 24 relabellings, cards ascending,
  * taking the FIRST permutation in lexicographic order of (p[0], p[1], p[2], p[3]) that attains it (csrc/prl_policy.h: prl_suit_canon) -- hash THAT
  * board into the history key and read the table at the hand relabelled by the same permutation: the whole game's 2 598 960 boards through 134 459 x 6
- * rows (12.8 GB). Errors: PRL_ERR_STATE before the first average exists, PRL_ERR_UNSUPPORTED for the per-street engine / sharded solves. */
+ * rows (12.8 GB). Errors: PRL_ERR_STATE before the first average exists, PRL_ERR_UNSUPPORTED for a rank of a sharded solve. */
 int32_t prl_policy_table_from_solver(prl_solver_t* solver, const prl_tree_t* tree, uint32_t key_seed, prl_policy_table_t** out_table);
 /* out6: n_rows, n_actions, range_size, capacity of the key table, suit_canon (0 / 1), key_seed */
 int32_t prl_policy_table_info(const prl_policy_table_t* table, int64_t* out6);

@@ -2436,16 +2436,18 @@ namespace {
 // columns [.][R] of `elem` bytes (4: float32, 8: float64) -> rows of the table. Row r of this launch is row row0 + r of the table; rows repeat with
 // `period` (the decision nodes of one board subtree; period = the number of rows when nothing repeats): row r is entry t = r % period of the per-row
 // arrays in repetition rep = r / period, its j-th action column is source column rep * cols_per_rep + col0[t] + j and goes to action col_action[col0[t] + j].
+// row_id (may be null): the table row of entry r is row0 + row_id[r] instead of row0 + r (a subset of the rows: the per-street engine's trunk / street rows).
 PRL_GLOBAL void PRL_LAUNCH_BOUNDS(256) prl_k_table_fill(const void* cols, int elem, int R, int n_rows_here, int period, int cols_per_rep, const int32_t* col0,
-                                                        const int32_t* nch, const int32_t* col_action, int n_actions, long long row0, float* probs) {
+                                                        const int32_t* nch, const int32_t* col_action, int n_actions, long long row0, float* probs, const int32_t* row_id) {
     const long long i = (long long)prl_bid() * prl_nthreads() + prl_tid();
     if (i >= (long long)n_rows_here * R) return;
     const int r = (int)(i / R), h = (int)(i - (long long)r * R);
     const int rep = r / period, t = r - rep * period;
+    const long long row = row0 + (row_id ? row_id[r] : r);
     for (int j = 0; j < nch[t]; ++j) {
         const size_t at = ((size_t)rep * cols_per_rep + col0[t] + j) * R + h;
         const float v = elem == 8 ? (float)((const double*)cols)[at] : ((const float*)cols)[at];
-        probs[((size_t)(row0 + r) * n_actions + col_action[col0[t] + j]) * R + h] = v;
+        probs[((size_t)row * n_actions + col_action[col0[t] + j]) * R + h] = v;
     }
 }
 
@@ -2556,7 +2558,7 @@ extern "C" int32_t prl_policy_table_from_solver(prl_solver_t* s, const prl_tree_
     *out = nullptr;
     const PrlFlatTree& full = *prl_tree_flat(tree);
     if (full.n_nodes != s->full_nodes || full.n_cols != s->full_cols || full.rules.range_size != s->R) { prl_set_error("prl_policy_table_from_solver: not the tree this solver was created on"); return PRL_ERR_ARG; }
-    if (s->streets || s->world > 1) { prl_set_error("prl_policy_table_from_solver: LEVELS engine or the single-deal fused engine, unsharded"); return PRL_ERR_UNSUPPORTED; }
+    if (s->world > 1) { prl_set_error("prl_policy_table_from_solver: an unsharded solve (a rank of a sharded one holds its share of the boards only)"); return PRL_ERR_UNSUPPORTED; }
     if (s->fused && s->user_strategy_f64 >= 0) { prl_set_error("prl_policy_table_from_solver: an explicit strategy is loaded; the table is made of a CFR run's average"); return PRL_ERR_STATE; }
     if (s->iter < 1 || (s->variant == PRL_CFR_PLUS && s->iter <= s->delay)) { prl_set_error("prl_policy_table_from_solver: no average strategy yet (iterate first; CFR+ starts averaging after `delay` iterations)"); return PRL_ERR_STATE; }
     if (s->fused) {  // a run of prl_solver_iterations leaves its last evaluation (and the Vanilla / Linear average update riding on it) pending
@@ -2610,6 +2612,46 @@ extern "C" int32_t prl_policy_table_from_solver(prl_solver_t* s, const prl_tree_
     int32_t* d_meta = nullptr;
     auto fail = [&](int code) { prl_policy_table_destroy(T); (void)hipFree(d_meta); return code; };
 #define PT_TRY(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); prl_set_error("HIP error in prl_policy_table_from_solver"); return fail(PRL_ERR_HIP); } } while (0)
+    if (s->streets) {
+        // the per-street engine: hand-order columns in the engine's INTERNAL column order (trunk, then group by group, instance by instance; a node's columns
+        // stay adjacent); the street columns' average may live in the float32 array (PRL_SOLVER_AVG_F32, CFR+)
+        std::vector<int32_t> inv(s->full_cols, -1), act(s->full_cols, 0);
+        for (int ci = 0; ci < s->full_cols; ++ci) {
+            const int c = s->col_dfs.empty() ? ci : s->col_dfs[ci];
+            inv[c] = ci;
+            act[ci] = full.col_action[c];
+        }
+        const bool street_f32 = s->avg_f32;  // (as prl_solver_get(AVG) reads them)
+        const int n_trunk_cols = s->T.n_cols;
+        for (int part = 0; part < 2; ++part) {  // 0: the trunk's rows (float64), 1: the streets' rows
+            std::vector<int32_t> col0, nch, rid;
+            for (int r = 0; r < n_rows; ++r) {
+                const int c0 = inv[full.first_col[rows[r]]];
+                if ((c0 >= n_trunk_cols) != (part == 1)) continue;
+                col0.push_back(c0); nch.push_back(full.n_children[rows[r]]); rid.push_back(r);
+            }
+            const int n = (int)col0.size();
+            if (n == 0) continue;
+            std::vector<int32_t> meta;
+            meta.insert(meta.end(), col0.begin(), col0.end());
+            meta.insert(meta.end(), nch.begin(), nch.end());
+            meta.insert(meta.end(), rid.begin(), rid.end());
+            meta.insert(meta.end(), act.begin(), act.end());
+            PT_TRY(hipMalloc((void**)&d_meta, meta.size() * 4 + 16));
+            PT_TRY(hipMemcpy(d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice));
+            PT_TRY(hipStreamSynchronize(s->stream));
+            const bool f32 = part == 1 && street_f32;
+            const long long items = (long long)n * s->R;
+            PRL_LAUNCH(prl_k_table_fill, (unsigned)((items + 255) / 256), 256, 0, s->stream, f32 ? (const void*)s->d_avg32 : (const void*)s->d_avg, f32 ? 4 : 8, s->R, n, n, 0,
+                       (const int32_t*)d_meta, (const int32_t*)(d_meta + n), (const int32_t*)(d_meta + 3 * (size_t)n), n_act, 0ll, T->probs, (const int32_t*)(d_meta + 2 * (size_t)n));
+            PT_TRY(hipGetLastError());
+            PT_TRY(hipStreamSynchronize(s->stream));
+            (void)hipFree(d_meta);
+            d_meta = nullptr;
+        }
+        *out = T;
+        return PRL_OK;
+    }
     // rows whose columns lie in hand order ([col][R] float64): every row of the LEVELS engine / an unsorted fused solve, the trunk's rows of the sorted one
     int n_plain = n_rows;
     if (s->sorted) {
@@ -2642,7 +2684,7 @@ extern "C" int32_t prl_policy_table_from_solver(prl_solver_t* s, const prl_tree_
         if (n_plain > 0) {
             const long long n = (long long)n_plain * s->R;
             PRL_LAUNCH(prl_k_table_fill, (unsigned)((n + 255) / 256), 256, 0, s->stream, (const void*)s->d_avg, 8, s->R, n_plain, n_plain, 0, (const int32_t*)d_meta,
-                       (const int32_t*)(d_meta + n_plain), (const int32_t*)(d_meta + 2 * n_plain), n_act, 0ll, T->probs);
+                       (const int32_t*)(d_meta + n_plain), (const int32_t*)(d_meta + 2 * n_plain), n_act, 0ll, T->probs, (const int32_t*)nullptr);
             PT_TRY(hipGetLastError());
         }
         if (s->sorted) {
@@ -2669,7 +2711,7 @@ extern "C" int32_t prl_policy_table_from_solver(prl_solver_t* s, const prl_tree_
                 PT_TRY(hipGetLastError());
                 const long long n = (long long)nb * n_dec * s->R;
                 PRL_LAUNCH(prl_k_table_fill, (unsigned)((n + 255) / 256), 256, 0, s->stream, (const void*)s->d_stage, elem, s->R, nb * n_dec, n_dec, s->ncb, m, m + n_dec,
-                           m + 2 * n_dec, n_act, (long long)n_plain + (long long)at * n_dec, T->probs);
+                           m + 2 * n_dec, n_act, (long long)n_plain + (long long)at * n_dec, T->probs, (const int32_t*)nullptr);
                 PT_TRY(hipGetLastError());
             }
         }

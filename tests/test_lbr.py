@@ -603,7 +603,7 @@ def check_solver_table_h2h_vs_host(L, tmp_path, n_classes, n_iters, n_hands):
     table.close()
 
 
-def check_solver_table_equals_tree_table(game_cls, agent_bets, n_iters, variant="plus", expect_twins=False, **cfr_kw):
+def check_solver_table_equals_tree_table(game_cls, agent_bets, n_iters, variant="plus", expect_twins=False, expect_engine=None, **cfr_kw):
     """prl_policy_table_from_solver on the LEVELS engine (columns already in hand order) = the host path PolicyTable.from_cfr: the same rows in the same
     order under the same keys, the same float32 probabilities; node keys by path = node keys by index; and on the device the look-ups hit.
     expect_twins: a bet set whose sizes the env turns into ONE amount (a size below the minimum raise is raised to it, the next size IS the minimum raise):
@@ -615,6 +615,7 @@ def check_solver_table_equals_tree_table(game_cls, agent_bets, n_iters, variant=
     cls = {"plus": CFRPlus, "linear": LinearCFR, "vanilla": VanillaCFR}[variant]
     kw = dict(delay=0) if variant == "plus" else {}
     cfr = cls(name="tab", chief_handle=_Chief(), game_cls=game_cls, agent_bet_set=agent_bets, **kw, **cfr_kw)
+    assert expect_engine is None or cfr._trees[0].solver.engine == expect_engine
     cfr.reset()
     for _ in range(n_iters):
         cfr.iteration()
@@ -640,6 +641,111 @@ def check_solver_table_equals_tree_table(game_cls, agent_bets, n_iters, variant=
 @pytest.mark.parametrize("game,bets,variant", [("StandardLeduc", None, "plus"), ("StandardLeduc", None, "linear"), ("DiscretizedNLLeduc", "B_3", "vanilla")])
 def test_solver_table_on_the_levels_engine_equals_the_tree_table_emu(emu_lib, game, bets, variant):
     check_solver_table_equals_tree_table({"StandardLeduc": StandardLeduc, "DiscretizedNLLeduc": DiscretizedNLLeduc}[game], getattr(bet_sets, bets) if bets else None, 4, variant)
+
+
+@pytest.mark.parametrize("game,bets,stack,outcomes,variant", [("DiscretizedNLHoldem", "POT_ONLY", 600, (1, 1, 1), "plus"), ("LimitHoldem", None, 6, (1, 2, 1), "linear")])
+def test_solver_table_on_the_per_street_engine_equals_the_tree_table_emu(emu_lib, game, bets, stack, outcomes, variant):
+    """prl_policy_table_from_solver on the per-street fused engine (round 6): columns gathered from the engine's internal order -- multi-street trees with mixed
+    street shapes and all-in run-out chains (no decision below an all-in call: the chains have no rows) = the host path, slot for slot, float for float"""
+    from pokerrl_amd.game.games import DiscretizedNLHoldem, LimitHoldem
+    check_solver_table_equals_tree_table({"DiscretizedNLHoldem": DiscretizedNLHoldem, "LimitHoldem": LimitHoldem}[game], getattr(bet_sets, bets) if bets else None, 2, variant,
+                                         starting_stack_sizes=[stack], max_outcomes=outcomes, expect_engine="fused")
+
+
+def check_street_table_float32_average(L, to_rows=None):
+    """the table of a per-street solver that keeps its street columns' average in float32 (PRL_SOLVER_AVG_F32): the trunk's rows from the float64 array, the
+    streets' rows from the float32 one -- every row = float32(prl_solver_get(AVG)) of its node's columns"""
+    import parity_cases as pc
+    from pokerrl_amd import _native
+    from pokerrl_amd.game.games import DiscretizedNLHoldem
+    from pokerrl_amd.rl.tabular_agent import PolicyTable
+    t, s, _o = pc.make_streets_pair(L, DiscretizedNLHoldem, 600, pc.multistreet_runouts(1, 2, 1), "plus", 0, bets=bet_sets.POT_ONLY, tape=_NoOracle(), avg_dtype="f32")
+    s.iterations(3)
+    tab = PolicyTable.from_solver(s)
+    avg, kind, fc, nch, ca = s.get("avg"), t.field("kind"), t.field("first_col"), t.field("n_children"), t.field("col_action")
+    dec = np.flatnonzero(kind == 0)
+    assert tab.n_rows == len(dec)
+    for r, n in enumerate(dec):
+        got = tab.row_probs(r)
+        want = np.zeros_like(got)
+        for j in range(nch[n]):
+            want[ca[fc[n] + j]] = avg[fc[n] + j].astype(np.float32)
+        assert np.array_equal(got, want), (r, n)
+    tab.close()
+
+
+class _NoOracle:
+    """make_streets_pair without the oracle (a 'replayed tape' that is never asked)"""
+    recording, live = False, False
+
+
+def test_solver_table_of_a_float32_average_on_the_per_street_engine_emu(emu_lib):
+    check_street_table_float32_average(emu_lib)
+
+
+@pytest.mark.gpu
+def test_gpu_solver_table_on_the_per_street_engine():
+    from pokerrl_amd.game.games import DiscretizedNLHoldem, LimitHoldem
+    L = _native.lib()
+    check_solver_table_equals_tree_table(DiscretizedNLHoldem, bet_sets.POT_ONLY, 4, "plus", starting_stack_sizes=[2500], max_outcomes=(2, 2, 2), expect_engine="fused")
+    check_solver_table_equals_tree_table(LimitHoldem, None, 3, "vanilla", max_outcomes=(2, 1, 2), expect_engine="fused")
+    check_street_table_float32_average(L)
+
+
+def check_street_solver_table_lbr_vs_host(L, tmp_path, stack, runouts, n_iters, n_hands, stranger_every=4):
+    """the evaluators pointed at a MULTI-STREET solution (round 6): CFR+ on DiscretizedNLHoldem with pot-sized raises over a few run-outs on the per-street
+    engine (mixed street shapes, run-out chains), its average strategy as a policy table built on the device, and BatchedLBR (LBR raises 0.5 / 1 / 2 pots:
+    sizes the agent's tree has and sizes it does not have) against it = the host LocalLBRWorker playing the same table, hand for hand -- on decks whose boards
+    are the tree's run-outs (flop in the tree's order: the history key hashes the cards as dealt) and on boards the tree never dealt (uniform play on both sides)"""
+    import parity_cases as pc
+    from pokerrl_amd.game.games import DiscretizedNLHoldem
+    from pokerrl_amd.rl.tabular_agent import PolicyTable, make_table_agent_cls
+    ro = pc.multistreet_runouts(*runouts)
+    t, s, _o = pc.make_streets_pair(L, DiscretizedNLHoldem, stack, ro, "plus", 0, bets=bet_sets.POT_ONLY, tape=_NoOracle())
+    s.iterations(n_iters)
+    table = PolicyTable.from_solver(s)
+    assert not table.suit_canon and table.n_actions == 3 and table.n_rows == int(np.sum(t.field("kind") == 0))
+    t_prof = make_t_prof(DiscretizedNLHoldem, bet_sets.POT_ONLY, dict(lbr_bet_set=[0.5, 1.0, 2.0], lbr_check_to_round=Poker.FLOP), n_hands, tmp_path)
+    b = BatchedLBR(t_prof, agent_kind="table", agent_seed=5, table=table)
+    b.set_stack_size([stack, stack])
+    rng = np.random.RandomState(3)
+    total_misses = 0
+    for seat in (0, 1):
+        decks = []
+        for i in range(n_hands):
+            if stranger_every and i % stranger_every == stranger_every - 1:
+                board = [int(c) for c in rng.choice(52, 5, replace=False)]
+            else:
+                board = [int(c) for c in ro[rng.randint(len(ro))]]
+            rest = [c for c in range(52) if c not in board]
+            decks.append([rest[j] for j in rng.choice(len(rest), 4, replace=False)] + board)
+        decks = np.asarray(decks, np.int8)
+        w = _DealtLBRWorker(t_prof=t_prof, chief_handle=None, eval_agent_cls=make_table_agent_cls(EvalAgentBase, table, seed=5))
+        w.DECKS = decks
+        misses, lookup = [], table.row_of
+        table.row_of = lambda hk, _f=lookup: (misses.append(1) if _f(hk) < 0 else None, _f(hk))[1]
+        try:
+            want = w.run(agent_seat_id=seat, n_iterations=n_hands, mode="TABLE", stack_size=[stack, stack])
+        finally:
+            del table.row_of
+        got = b.run(agent_seat_id=seat, n_hands=n_hands, decks=decks)
+        assert np.array_equal(got, want), "seat %d: %d of %d hands differ (first at %s): %s vs %s" % (seat, int(np.sum(got != want)), n_hands, np.flatnonzero(got != want)[:5], got[:8], want[:8])
+        total_misses += len(misses)
+        if seat == 0:
+            uni = BatchedLBR(t_prof, agent_kind="uniform")
+            uni.set_stack_size([stack, stack])
+            assert not np.array_equal(uni.run(agent_seat_id=seat, n_hands=n_hands, decks=decks), got)
+    assert total_misses > 0 and b.last_stats["lbr_lookaheads"] > 0
+    table.close()
+
+
+def test_batched_lbr_against_a_multi_street_solution_vs_host_worker_emu(emu_lib, tmp_path):
+    check_street_solver_table_lbr_vs_host(emu_lib, tmp_path, 600, (1, 2, 1), 2, 8)
+
+
+@pytest.mark.gpu
+def test_gpu_batched_lbr_against_a_multi_street_solution_vs_host_worker(tmp_path):
+    check_street_solver_table_lbr_vs_host(_native.lib(), tmp_path, 2500, (3, 3, 3), 20, 96)
 
 
 def test_solver_table_merges_children_the_env_turns_into_one_state_emu(emu_lib):
