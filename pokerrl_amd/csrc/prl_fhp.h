@@ -51,7 +51,7 @@ constexpr int prl_fhp_out_width(int mode) {
          : (prl_fhp_runs_seat(mode, 0) && prl_fhp_runs_seat(mode, 1) ? 2 : 1) * (prl_fhp_with_br(mode) ? 2 : 1);
 }
 
-#define PRL_FHP_MAX_NODES 32
+#define PRL_FHP_MAX_NODES 40
 #define PRL_FHP_MAX_DEC 12
 
 // the three arrays of a shape
@@ -82,6 +82,13 @@ struct PrlFhpSpec27 {
     static constexpr int K(int n) { constexpr int t[N_NODES] = {0, 0, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3}; return t[n]; }
     static constexpr int A(int n) { constexpr int t[N_NODES] = {1, 0, -1, 1, -1, -1, 0, -1, -1, 1, -1, -1, 0, -1, -1, 0, -1, -1, 1, -1, -1, 0, -1, -1, 1, -1, -1}; return t[n]; }
     static constexpr int C(int n) { constexpr int t[N_NODES] = {2, 2, 0, 3, 0, 0, 3, 0, 0, 3, 0, 0, 2, 0, 0, 3, 0, 0, 3, 0, 0, 3, 0, 0, 2, 0, 0}; return t[n]; }
+};
+// five raises per round: DiscretizedNLHoldem with pot-sized raises at its 200-big-blind default stacks (games.py:114-131) -- 100, 300, 900, 2700, 8100, all-in
+struct PrlFhpSpec33 {
+    static constexpr int N_NODES = 33;
+    static constexpr int K(int n) { constexpr int t[N_NODES] = {0, 0, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3, 0, 2, 3}; return t[n]; }
+    static constexpr int A(int n) { constexpr int t[N_NODES] = {1, 0, -1, 1, -1, -1, 0, -1, -1, 1, -1, -1, 0, -1, -1, 1, -1, -1, 0, -1, -1, 1, -1, -1, 0, -1, -1, 1, -1, -1, 0, -1, -1}; return t[n]; }
+    static constexpr int C(int n) { constexpr int t[N_NODES] = {2, 2, 0, 3, 0, 0, 3, 0, 0, 3, 0, 0, 3, 0, 0, 2, 0, 0, 3, 0, 0, 3, 0, 0, 3, 0, 0, 3, 0, 0, 2, 0, 0}; return t[n]; }
 };
 // everything the walk needs, derived from a spec (all constexpr: evaluated by the compiler for the template recursion)
 template <class S>

@@ -37,9 +37,9 @@
 // kid_base + k * n_leaves + j of the next street's buffer whatever it is. The decision-free subtrees (the chance outcomes below an all-in call) form a small
 // forest with two kernels of its own (prl_launch_st_chain_eval below): its showdowns read the reach of the all-in leaf in place and write their values into
 // the rows the parent's pass sums.
-enum { PRL_ST_SPEC_9 = 0, PRL_ST_SPEC_15 = 1, PRL_ST_SPEC_21 = 2, PRL_ST_SPEC_27 = 3, PRL_ST_N_SPECS = 4 };
+enum { PRL_ST_SPEC_9 = 0, PRL_ST_SPEC_15 = 1, PRL_ST_SPEC_21 = 2, PRL_ST_SPEC_27 = 3, PRL_ST_SPEC_33 = 4, PRL_ST_N_SPECS = 5 };
 #define PRL_ST_MAX_LEVELS 4   // dealing streets
-#define PRL_ST_MAX_GROUPS 16  // (street, shape) groups
+#define PRL_ST_MAX_GROUPS 20  // (street, shape) groups: PRL_ST_MAX_LEVELS x PRL_ST_N_SPECS
 
 // per street instance (uniform over the workgroup that walks it: read through scalar loads)
 struct PrlStInst {

@@ -11,7 +11,8 @@
 
 const PrlFhpShapeDesc& prl_st_spec_desc(int spec) {
     static const PrlFhpShapeDesc d[PRL_ST_N_SPECS] = {prl_fhp_describe<PrlFhpDerive<PrlFhpSpec9>>(), prl_fhp_describe<PrlFhpDerive<PrlFhpSpec15>>(),
-                                                      prl_fhp_describe<PrlFhpDerive<PrlFhpSpec21>>(), prl_fhp_describe<PrlFhpDerive<PrlFhpSpec27>>()};
+                                                      prl_fhp_describe<PrlFhpDerive<PrlFhpSpec21>>(), prl_fhp_describe<PrlFhpDerive<PrlFhpSpec27>>(),
+                                                      prl_fhp_describe<PrlFhpDerive<PrlFhpSpec33>>()};
     return d[spec];
 }
 
@@ -21,6 +22,7 @@ int prl_launch_st_down(int spec, const PrlStParams& prm, int src0, int src1, voi
         case PRL_ST_SPEC_15: return st_spec15::launch_down(prm, src0, src1, stream);
         case PRL_ST_SPEC_21: return st_spec21::launch_down(prm, src0, src1, stream);
         case PRL_ST_SPEC_27: return st_spec27::launch_down(prm, src0, src1, stream);
+        case PRL_ST_SPEC_33: return st_spec33::launch_down(prm, src0, src1, stream);
         default: return PRL_ERR_UNSUPPORTED;
     }
 }
@@ -31,6 +33,7 @@ int prl_launch_st_pass(int spec, bool last, const PrlStParams& prm, int mode, in
         case PRL_ST_SPEC_15: return st_spec15::launch_pass(last, prm, mode, src0, src1, stream);
         case PRL_ST_SPEC_21: return st_spec21::launch_pass(last, prm, mode, src0, src1, stream);
         case PRL_ST_SPEC_27: return st_spec27::launch_pass(last, prm, mode, src0, src1, stream);
+        case PRL_ST_SPEC_33: return st_spec33::launch_pass(last, prm, mode, src0, src1, stream);
         default: return PRL_ERR_UNSUPPORTED;
     }
 }

@@ -22,3 +22,4 @@ PRL_ST_DECLARE_SPEC(st_spec9)
 PRL_ST_DECLARE_SPEC(st_spec15)
 PRL_ST_DECLARE_SPEC(st_spec21)
 PRL_ST_DECLARE_SPEC(st_spec27)
+PRL_ST_DECLARE_SPEC(st_spec33)

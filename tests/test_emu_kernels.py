@@ -183,11 +183,12 @@ def test_emu_multistreet_limit_holdem_tree(L):
 
 
 @pytest.mark.parametrize("variant,runouts,max_raises,batched", [("plus", (2, 2, 1), (1, 1, 1, 1), False), ("vanilla", (1, 2, 2), (1, 1, 1, 1), True),
-                                                                ("linear", (1, 1, 2), (1, 2, 1, 1), True), ("plus", (1, 1, 1), (1, 2, 3, 1), True)])
+                                                                ("linear", (1, 1, 2), (1, 2, 1, 1), True), ("plus", (1, 1, 1), (1, 2, 3, 1), True),
+                                                                ("plus", (1, 1, 1), (1, 5, 1, 1), False), ("linear", (1, 1, 1), (1, 1, 1, 5), True)])  # (five raises: the 33-node street, not last / last)
 def test_emu_streets_engine_limit_holdem(L, variant, runouts, max_raises, batched):
     """the per-street fused engine (csrc/prl_st.h) on LimitHoldem trees with three dealing streets: engine=auto takes it, regrets /
     averages / exploitability history / average-strategy exploitability equal the oracle's bit for bit -- single iterations and the
-    batched steady state, 9-, 15- and 21-node street subtrees, several outcomes per chance node"""
+    batched steady state, 9-, 15-, 21- and 33-node street subtrees, several outcomes per chance node"""
     from pokerrl_amd.game import games as G
     pc.check_streets_vs_oracle(L, G.LimitHoldem, 48, pc.multistreet_runouts(*runouts), variant, 3 if batched else 2, max_raises=max_raises, batched=batched)
 

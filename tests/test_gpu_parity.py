@@ -229,11 +229,12 @@ def test_gpu_streets_engine_best_response_of_an_explicit_strategy_vs_oracle(L):
 
 
 @pytest.mark.parametrize("variant,stack,runouts,batched", [("plus", 1200, (2, 2, 1), False), ("vanilla", 2500, (2, 2, 2), True), ("linear", 600, (2, 3, 2), True),
-                                                           ("plus", 1200, (1, 34, 2), True)])
+                                                           ("plus", 1200, (1, 34, 2), True), ("linear", 20000, (2, 2, 2), True)])
 def test_gpu_streets_engine_discretized_nl_holdem_vs_oracle(L, variant, stack, runouts, batched):
     """MIXED STREETS (csrc/prl_st.h): DiscretizedNLHoldem (games.py:114-131) with pot-sized raises -- the subtrees of one street differ with the stacks
     behind (9-, 15-, 21-node shapes side by side: 6 to 9 (street, shape) groups) and every raise sequence that runs out of chips ends in an all-in call
-    whose hand is dealt out as a chain of chance nodes (a decision-free forest on the level kernels); 34 turn cards = two canonical blocks"""
+    whose hand is dealt out as a chain of chance nodes (the decision-free run-out forest); 34 turn cards = two canonical blocks; 20000 chips = the game's
+    200-big-blind default, where five raises fit on a street (the 33-node shape)"""
     from pokerrl_amd.game import bet_sets
     from pokerrl_amd.game import games as G
     pc.check_streets_vs_oracle(L, G.DiscretizedNLHoldem, stack, pc.multistreet_runouts(*runouts), variant, 4 if batched else 2, batched=batched, bets=bet_sets.POT_ONLY)
