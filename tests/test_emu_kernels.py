@@ -82,12 +82,14 @@ def test_emu_fused_engine_twentyone_node_board_subtree(L):
 
 
 def test_emu_unregistered_board_subtree_falls_back_to_levels(L):
-    """four post-flop raises = the 27-node shape, which only the per-street engine instantiates: a single-deal tree is one street to it;
-    five raises (with stacks that allow them) match no registered shape: level-synchronous engine, and asking for the fused one is an error"""
+    """four and five post-flop raises = the 27- and 33-node shapes, which only the per-street engine instantiates: a single-deal tree is one street to it;
+    six raises (with stacks that allow them) match no registered shape: level-synchronous engine, and asking for the fused one is an error"""
     from pokerrl_amd import _native
     from pokerrl_amd.game import games as G
     pc.check_fused_vs_oracle(L, 3, 2, flop_raises=4, nodes_per_board=27)
-    t = _native.NativeTree(pc.fhp_game(200000, flop_raises=5), G.Flop5Holdem.native_rules(), pc.fhp_boards(3), _lib=L)  # 33 nodes per board
+    pc.check_fused_vs_oracle(L, 2, 1, stack=200000, flop_raises=5, nodes_per_board=33)
+    t = _native.NativeTree(pc.fhp_game(2000000, flop_raises=6), G.Flop5Holdem.native_rules(), pc.fhp_boards(3), _lib=L)  # 39 nodes per board
+    assert t.n_nodes == 5 + 39 * 3
     assert _native.NativeSolver(t, "plus", 0, engine="auto", _lib=L).engine == "levels"
     with pytest.raises(_native.NativeError):
         _native.NativeSolver(t, "plus", 0, engine="fused", _lib=L)
@@ -222,7 +224,7 @@ def test_emu_streets_engine_checkpoint_resume(L):
     assert np.array_equal(s.eval_avg(), s2.eval_avg())
 
 
-@pytest.mark.parametrize("variant,stack,runouts,batched", [("plus", 4, (1, 1, 1), False), ("linear", 6, (2, 1, 2), True)])
+@pytest.mark.parametrize("variant,stack,runouts,batched", [("plus", 4, (1, 1, 1), False), ("linear", 6, (1, 2, 1), True)])
 def test_emu_streets_engine_all_in_run_outs(L, variant, stack, runouts, batched):
     """MIXED STREETS (csrc/prl_st.h): 4- and 6-chip stacks put all-in calls on every street, each dealt out as a chain of chance nodes down to showdown
     leaves (a decision-free forest on the level kernels, next to the street instances) -- engine=auto takes the per-street engine, results equal the
@@ -231,7 +233,7 @@ def test_emu_streets_engine_all_in_run_outs(L, variant, stack, runouts, batched)
     pc.check_streets_vs_oracle(L, G.LimitHoldem, stack, pc.multistreet_runouts(*runouts), variant, 3 if batched else 2, batched=batched)
 
 
-@pytest.mark.parametrize("variant,stack,runouts,batched,bundle", [("plus", 600, (1, 1, 1), False, 3), ("vanilla", 1200, (1, 1, 1), True, 0), ("linear", 600, (2, 1, 2), True, 2)])
+@pytest.mark.parametrize("variant,stack,runouts,batched,bundle", [("plus", 600, (1, 1, 1), False, 3), ("vanilla", 1200, (1, 1, 1), True, 0), ("linear", 600, (1, 2, 1), True, 2)])
 def test_emu_streets_engine_discretized_nl_holdem(L, monkeypatch, variant, stack, runouts, batched, bundle):
     """MIXED STREETS: DiscretizedNLHoldem (games.py:114-131) with pot-sized raises -- a street's subtrees differ with the stacks behind (9-, 15- and
     21-node shapes side by side on one street, 6 to 9 (street, shape) groups) and every raise sequence that runs out of chips ends in a run-out chain;
