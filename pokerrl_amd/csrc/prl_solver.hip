@@ -113,6 +113,8 @@ struct prl_solver {
     float* d_chain_ev = nullptr;       // [forest nodes][2][R]: values of the forest's inner nodes (its roots' values go straight to their streets' rows)
     PrlStChainTerm* d_chain_terms = nullptr;
     PrlStChainBundle* d_chain_bundles = nullptr;
+    hipStream_t chain_stream = nullptr;      // the run-out forest is evaluated beside the last street's passes (vector issue beside HBM streaming)
+    hipEvent_t chain_fork = nullptr, chain_join = nullptr;
     std::vector<int32_t> chain_level_start;  // the forest's chance nodes by level (Tc.level_nodes lists them, not the showdowns)
     int n_chain_term = 0, n_chain_bundles = 0, n_chain = 0;
     PrlStChainDev chain_dev{};
@@ -496,10 +498,23 @@ int street_sweep(prl_solver* s, const PrlDevState& st, int mode, int src0, int s
 #endif
         return q;
     };
-    for (int g = 0; g < NG; ++g) {  // reach down the streets
-        if (s->st.group[g].last) continue;
-        const int e = prl_launch_st_down(s->st.group[g].spec, level_params(g), src0, src1, s->stream);
-        if (e) { prl_set_error("street engine: unsupported strategy-source combination"); return e; }
+    // the groups [g0, g1) of one street, one launch after the other on the solver's stream (side by side on auxiliary streams was measured: the forks and
+    // joins cost more than the small launches gain, 87 -> 82 M node-updates/s on DiscretizedNLHoldem 16 x 8 x 8, profiles/r93_group_streams_ab.txt)
+    auto side_by_side = [&](int g0, int g1, auto&& launch) -> int {
+        for (int g = g0; g < g1; ++g) {
+            const int e = launch(g, s->stream);
+            if (e) return e;
+        }
+        return PRL_OK;
+    };
+    auto street_end = [&](int g0) { int g1 = g0; while (g1 < NG && s->st.group[g1].street == s->st.group[g0].street) ++g1; return g1; };
+    for (int g0 = 0; g0 < NG;) {  // reach down the streets
+        const int g1 = street_end(g0);
+        if (!s->st.group[g0].last) {
+            const int e = side_by_side(g0, g1, [&](int g, hipStream_t on) { return prl_launch_st_down(s->st.group[g].spec, level_params(g), src0, src1, on); });
+            if (e) { if (e != PRL_ERR_HIP) prl_set_error("street engine: unsupported strategy-source combination"); return e; }
+        }
+        g0 = g1;
     }
     if (s->n_chain) {  // the run-out chains below the all-in calls (prl_st.h): their values become rows of their streets before the passes read them
         PrlStChainIo io = {};
@@ -507,24 +522,46 @@ int street_sweep(prl_solver* s, const PrlDevState& st, int mode, int src0, int s
             io.src[v] = v == 0 ? st.reach : s->st_str[v - 1].leaf_reach;
             io.val[v] = s->st_str[v].val;
         }
-        prl_launch_st_chain_eval(s->Tc, s->d_chain_terms, s->d_chain_bundles, s->n_chain_bundles, io, s->chain_dev, s->d_chain_ev, s->chain_level_start.data(), mode, s->stream);
-    }
-    for (int g = NG - 1; g >= 0; --g) {
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        const bool timed = s->time_passes && s->st.group[g].last;  // the last street's pass is the dominant kernel
-        if (timed) {
-            PRL_HIP_TRY(hipEventCreate(&ev0));
-            PRL_HIP_TRY(hipEventCreate(&ev1));
-            PRL_HIP_TRY(hipEventRecord(ev0, s->stream));
+        if (s->chain_stream) {  // fork: the forest needs the leaf reach the DOWN launches left, nothing of the last street's passes
+            PRL_HIP_TRY(hipEventRecord(s->chain_fork, s->stream));
+            PRL_HIP_TRY(hipStreamWaitEvent(s->chain_stream, s->chain_fork, 0));
         }
-        const int e = prl_launch_st_pass(s->st.group[g].spec, s->st.group[g].last, level_params(g), mode, src0, src1, s->stream);
-        if (e) { prl_set_error("street engine: unsupported pass mode / strategy-source combination"); return e; }
-        if (timed) {
-            PRL_HIP_TRY(hipEventRecord(ev1, s->stream));
-            s->pass_events.push_back(ev0);
-            s->pass_events.push_back(ev1);
-        }
+        prl_launch_st_chain_eval(s->Tc, s->d_chain_terms, s->d_chain_bundles, s->n_chain_bundles, io, s->chain_dev, s->d_chain_ev, s->chain_level_start.data(), mode,
+                                 s->chain_stream ? s->chain_stream : s->stream);
+        if (s->chain_stream) PRL_HIP_TRY(hipEventRecord(s->chain_join, s->chain_stream));
     }
+    bool chain_joined = !(s->n_chain && s->chain_stream);
+    for (int g1 = NG; g1 > 0;) {  // the passes, street by street from the deepest one
+        int g0 = g1 - 1;
+        while (g0 > 0 && s->st.group[g0 - 1].street == s->st.group[g1 - 1].street) --g0;
+        if (s->st.group[g0].last) {  // the last street's passes: the dominant kernels, one after the other on the solver's stream (timed there)
+            for (int g = g1 - 1; g >= g0; --g) {
+                hipEvent_t ev0 = nullptr, ev1 = nullptr;
+                const bool timed = s->time_passes;
+                if (timed) {
+                    PRL_HIP_TRY(hipEventCreate(&ev0));
+                    PRL_HIP_TRY(hipEventCreate(&ev1));
+                    PRL_HIP_TRY(hipEventRecord(ev0, s->stream));
+                }
+                const int e = prl_launch_st_pass(s->st.group[g].spec, true, level_params(g), mode, src0, src1, s->stream);
+                if (e) { prl_set_error("street engine: unsupported pass mode / strategy-source combination"); return e; }
+                if (timed) {
+                    PRL_HIP_TRY(hipEventRecord(ev1, s->stream));
+                    s->pass_events.push_back(ev0);
+                    s->pass_events.push_back(ev1);
+                }
+            }
+        } else {
+            if (!chain_joined) {  // join: a pass that is not on the last street sums rows of the forest's roots
+                PRL_HIP_TRY(hipStreamWaitEvent(s->stream, s->chain_join, 0));
+                chain_joined = true;
+            }
+            const int e = side_by_side(g0, g1, [&](int g, hipStream_t on) { return prl_launch_st_pass(s->st.group[g].spec, false, level_params(g), mode, src0, src1, on); });
+            if (e) { if (e != PRL_ERR_HIP) prl_set_error("street engine: unsupported pass mode / strategy-source combination"); return e; }
+        }
+        g1 = g0;
+    }
+    if (!chain_joined) PRL_HIP_TRY(hipStreamWaitEvent(s->stream, s->chain_join, 0));
     // street-1 rows are outcome-major: [n_top][n_leaves][width][R] -> one canonical sum over the outcomes for all leaves at once
     const int W = NL0 * width * R, n_top = s->st.n_top;
     float* summed = s->d_row_sum;
@@ -1373,6 +1410,12 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             FAIL_IF(dev_upload(s, &s->chain_dev.street, k_street));
             FAIL_IF(dev_upload(s, &s->chain_dev.val_slot, k_val));
             FAIL_IF(dev_upload(s, &s->chain_dev.node_kid, node_kid));
+            const char* cs = getenv("PRL_ST_CHAIN_STREAM");
+            if (!cs || atoi(cs) != 0) {
+                PRL_HIP_TRY(hipStreamCreate(&s->chain_stream));
+                PRL_HIP_TRY(hipEventCreateWithFlags(&s->chain_fork, hipEventDisableTiming));
+                PRL_HIP_TRY(hipEventCreateWithFlags(&s->chain_join, hipEventDisableTiming));
+            }
         }
 #ifdef PRL_ST_TIMING
         FAIL_IF(dev_alloc(s, &s->sp.timing, (size_t)8));
@@ -1731,6 +1774,9 @@ void prl_solver_destroy(prl_solver_t* s) {
 #if !defined(PRL_EMU)
     for (void* r : s->vmm) { vmm_free(*(PrlVmmRange*)r); delete (PrlVmmRange*)r; }
 #endif
+    if (s->chain_fork) (void)hipEventDestroy(s->chain_fork);
+    if (s->chain_join) (void)hipEventDestroy(s->chain_join);
+    if (s->chain_stream) (void)hipStreamDestroy(s->chain_stream);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
