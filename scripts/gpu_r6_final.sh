@@ -13,10 +13,13 @@ timeout 600 python bench_lbr.py --game Flop5Holdem --agent table > gpurun_out/${
 timeout 300 python bench_env.py > gpurun_out/${TAG}_bench_env.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python bench_multistreet.py > gpurun_out/${TAG}_bench_multistreet.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python bench_multistreet.py --avg-f32 --no-cpu-baseline > gpurun_out/${TAG}_bench_multistreet_avg_f32.json 2>> gpurun_out/${TAG}_bench.err
+timeout 600 python bench_multistreet.py --game DiscretizedNLHoldem --flops 16 --turns 8 --rivers 8 --cpu-iters 2 > gpurun_out/${TAG}_bench_multistreet_nl.json 2>> gpurun_out/${TAG}_bench.err
+timeout 600 python bench_multistreet.py --game DiscretizedNLHoldem --stack 20000 --flops 8 --turns 4 --rivers 4 --no-cpu-baseline > gpurun_out/${TAG}_bench_multistreet_nl200bb.json 2>> gpurun_out/${TAG}_bench.err
+timeout 600 python bench_multistreet.py --game DiscretizedNLHoldem --stack 20000 --flops 8 --turns 4 --rivers 4 --no-cpu-baseline --engine levels > gpurun_out/${TAG}_bench_multistreet_nl200bb_levels.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python bench_leduc.py > gpurun_out/${TAG}_bench_leduc.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python bench_h2h.py > gpurun_out/${TAG}_bench_h2h.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python bench_handeval.py > gpurun_out/${TAG}_bench_handeval.json 2>> gpurun_out/${TAG}_bench.err
-for f in bench bench_linear bench_avg_f32 bench_br bench_lbr bench_lbr_fhp_table bench_env bench_multistreet bench_multistreet_avg_f32 bench_leduc bench_h2h bench_handeval; do python -c "
+for f in bench bench_linear bench_avg_f32 bench_br bench_lbr bench_lbr_fhp_table bench_env bench_multistreet bench_multistreet_avg_f32 bench_multistreet_nl bench_multistreet_nl200bb bench_multistreet_nl200bb_levels bench_leduc bench_h2h bench_handeval; do python -c "
 import json
 try:
     d=json.loads(open('gpurun_out/${TAG}_$f.json').read().strip().splitlines()[-1]); print('$f', '%.5g' % d['value'], d.get('unit'), 'ms/step %.4g' % d['ms_per_step'], 'frac', (d.get('roofline') or {}).get('frac'), 'with-eval', (d.get('roofline_with_avg_evaluation') or {}).get('frac'))
@@ -48,3 +51,4 @@ done
 grep "pass<[45], 0, 0, 1\|pass<2, 2, 2" $R/gpurun_out/${TAG}_${n}_pmc.txt | cut -c1-330
 rm -rf $R/gpurun_out/${TAG}_pmc_${n}?
 cd $R; bash scripts/gpu_r6_lbr.sh $TAG
+cd $R; bash scripts/gpu_r6_ms_traffic.sh $TAG
