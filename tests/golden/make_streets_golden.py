@@ -4,6 +4,7 @@ full betting, F flops x T turns x R rivers of bench_multistreet.runouts; default
 history, average-strategy exploitability, SHA-256 of the regret / average arrays in the flat tree's DFS column order.
 
     python tests/golden/make_streets_golden.py [flops] [turns] [rivers] [variant] [n_iters] [delay]
+    python tests/golden/make_streets_golden.py nl flops turns rivers variant n_iters stack     (DiscretizedNLHoldem, pot-sized raises: nl<stack>_..npz)
 
 (delay > 0: the file name carries _d<delay>_i<n_iters>; the averaging weights of several blends enter the fixture)
 
@@ -45,6 +46,27 @@ def main(flops=4, turns=2, rivers=2, variant="plus", n_iters=3, delay=0):
     print("wrote", out)
 
 
+def main_nl(flops=16, turns=8, rivers=8, variant="plus", n_iters=3, stack=2500):
+    """the same for bench_multistreet.py --game DiscretizedNLHoldem (pot-sized raises: mixed street shapes, all-in run-out chains; csrc/prl_st.h) ->
+    nl<stack>_<F>x<T>x<R>_<variant>.npz"""
+    from pokerrl_amd.game import bet_sets
+    ro = bench_multistreet.runouts(flops, turns, rivers)
+    t = _native.NativeTree.for_game(G.DiscretizedNLHoldem, stack, bet_sets.POT_ONLY, ro)
+    r = G.DiscretizedNLHoldem.RULES
+    o = oracle.Oracle({k: t.field(k) for k in oracle.Oracle.FIELDS}, t.board_rows, r.N_HOLE_CARDS, r.N_CARDS_IN_DECK, r.N_SUITS, r._RANK_RULE)
+    o.cfr_reset(pc.VARIANT_ID[variant], 0)
+    hist = [np.array(o.exploitability, np.float32)]
+    for it in range(n_iters):
+        o.cfr_iteration()
+        hist.append(np.array(o.exploitability, np.float32))
+        print("iteration", it + 1, hist[-1], flush=True)
+    out = os.path.join(HERE, "nl%d_%dx%dx%d_%s.npz" % (stack, flops, turns, rivers, variant))
+    np.savez(out, flops=flops, turns=turns, rivers=rivers, variant=variant, n_iters=n_iters, delay=0, stack=stack, runouts_sha256=h32(ro), n_nodes=t.n_nodes,
+             expl_history=np.stack(hist), eval_avg=o.eval_avg(), regret_sha256=h32(np.asarray(o.regret)), avg_sha256=h32(np.asarray(o.avg)),
+             numpy=np.__version__)
+    print("wrote", out)
+
+
 def seeded_strategy(t, seed):
     """float32 [n_cols][R] strategy in the flat tree's DFS column order, random and normalised per node and hand (fill_random_random semantics)"""
     kind, nch, fc = t.field("kind"), t.field("n_children"), t.field("first_col")
@@ -74,6 +96,9 @@ def main_br(flops=4, turns=2, rivers=2, seed=21):
 
 if __name__ == "__main__":
     a = sys.argv[1:]
+    if a and a[0] == "nl":  # nl flops turns rivers variant n_iters stack
+        main_nl(int(a[1]), int(a[2]), int(a[3]), a[4], int(a[5]), int(a[6]))
+        sys.exit(0)
     if a and a[0] == "br":
         main_br(*(int(x) for x in a[1:4]))
         sys.exit(0)

@@ -284,6 +284,36 @@ def test_gpu_streets_engine_bench_tree_vs_oracle_fixture(L, variant):
     assert h32(s.get("avg")) == str(g["avg_sha256"])
 
 
+@pytest.mark.parametrize("name", ["nl2500_16x8x8_plus", "nl20000_8x4x4_linear"])
+def test_gpu_streets_engine_nl_bench_trees_vs_oracle_fixture(L, name):
+    """bench_multistreet.py --game DiscretizedNLHoldem at its two benched sizes (16 x 8 x 8 run-outs at 50 big blinds: 340 742 nodes; 8 x 4 x 4 at the 200-big-
+    blind default: 257 754 nodes, five-raise streets) on the per-street engine -- mixed street shapes, ~39 k showdowns in run-out chains -- against the ORACLE's
+    own run (tests/golden/make_streets_golden.py nl): exploitability history, average-strategy exploitability, SHA-256 of the regrets / averages"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench_multistreet
+    from helpers import GOLDEN, h32
+    from pokerrl_amd import _native
+    from pokerrl_amd.game import bet_sets
+    from pokerrl_amd.game import games as G
+    path = os.path.join(GOLDEN, name + ".npz")
+    if not os.path.isfile(path):
+        pytest.skip("fixture not generated (tests/golden/make_streets_golden.py nl)")
+    g = np.load(path)
+    ro = bench_multistreet.runouts(int(g["flops"]), int(g["turns"]), int(g["rivers"]))
+    assert h32(ro) == str(g["runouts_sha256"])
+    t = _native.NativeTree.for_game(G.DiscretizedNLHoldem, int(g["stack"]), bet_sets.POT_ONLY, ro, _lib=L)
+    assert t.n_nodes == int(g["n_nodes"])
+    s = _native.NativeSolver(t, str(g["variant"]), 0, engine="auto", _lib=L)
+    assert s.engine == "fused"
+    s.iterations(int(g["n_iters"]))
+    assert np.array_equal(s.get("expl_history"), g["expl_history"]), (s.get("expl_history"), g["expl_history"])
+    assert np.array_equal(s.eval_avg(), g["eval_avg"])
+    assert h32(s.get("regret")) == str(g["regret_sha256"])
+    assert h32(s.get("avg")) == str(g["avg_sha256"])
+
+
 def test_gpu_streets_engine_bench_tree_best_response_vs_oracle_fixture(L):
     """exact best response of a seeded float32 strategy on bench_multistreet.py's tree: the per-street engine's evaluation pass against the
     oracle's exploitability of the same strategy (tests/golden/make_streets_golden.py br)"""
