@@ -146,14 +146,16 @@ def test_sharded_world2_gloo_emu(EMU):
     check_against_union(_native.bind(EMU), ranks, 2, 2, 3, 1, 21)
 
 
-def test_bench_multistreet_gpus_2_gloo_emu(EMU):
+@pytest.mark.parametrize("game_args", [["--max-raises", "1,1,1,1"], ["--game", "DiscretizedNLHoldem", "--stack", "600"]])
+def test_bench_multistreet_gpus_2_gloo_emu(EMU, game_args):
     """`python bench_multistreet.py --gpus 2`: two ranks, one flop each (with its turn / river run-outs), the per-street engine sharded over the
-    first deal's outcomes; the same exploitability as the one-rank solve of both flops, ONE JSON line from rank 0"""
+    first deal's outcomes; the same exploitability as the one-rank solve of both flops, ONE JSON line from rank 0. LimitHoldem with one raise per
+    round, and DiscretizedNLHoldem with pot-sized raises (mixed street shapes, all-in run-out chains: round 6)"""
     import json
     root = os.path.dirname(HERE)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["PRL_BENCH_EMU_LIB"] = EMU
-    common = ["--turns", "2", "--rivers", "1", "--steps", "1", "--warmup", "1", "--max-raises", "1,1,1,1", "--no-cpu-baseline"]
+    common = ["--turns", "2", "--rivers", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"] + game_args
     cmd = [sys.executable, os.path.join(root, "bench_multistreet.py")]
     two = subprocess.run(cmd + ["--gpus", "2", "--flops", "1"] + common, env=env, capture_output=True, text=True, timeout=900, check=True).stdout
     line = [x for x in two.splitlines() if x.startswith("{")]
