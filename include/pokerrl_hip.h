@@ -294,10 +294,11 @@ int32_t prl_solver_create(const prl_tree_t* tree, int32_t variant, int32_t delay
 /* engine selection: AUTO = FUSED where applicable, else LEVELS.
  *   LEVELS keeps every per-node vector in HBM (any supported tree; node.reach_probs / ev / ev_br readable);
  *   FUSED walks each board subtree on chip and only keeps regrets / averages / root values in HBM. It takes 2-hole-card trees whose betting
- *   after every deal matches a registered subtree shape (fold / call / one raise size, up to four raises per round: 9 / 15 / 21 / 27 nodes):
- *   one deal (Flop5Holdem: the board pass) or several (LimitHoldem 3 + 1 + 1: one pass per street and direction over its street instances,
- *   sharded over the first deal's outcomes). Trees it does not take (other bet sets, all-in run-out chains, 1-hole-card games) run on LEVELS;
- *   asking for FUSED on one of them is an error that says why. PRL_SF_ENGINE tells which engine a solver runs on. */
+ *   after every deal matches a registered subtree shape (fold / call / one raise size, up to five raises per round: 9 / 15 / 21 / 27 / 33 nodes):
+ *   one deal (Flop5Holdem: the board pass) or several (LimitHoldem, DiscretizedNLHoldem with pot-sized raises, 3 + 1 + 1: one pass per street, shape
+ *   and direction over its street instances, sharded over the first deal's outcomes). Since round 6 the subtrees of one street may have different
+ *   shapes and an all-in call may be dealt out without further decisions (run-out chains). Trees it does not take (several raise sizes, 1-hole-card
+ *   games) run on LEVELS; asking for FUSED on one of them is an error that says why. PRL_SF_ENGINE tells which engine a solver runs on. */
 enum { PRL_ENGINE_AUTO = 0, PRL_ENGINE_LEVELS = 1, PRL_ENGINE_FUSED = 2 };
 int32_t prl_solver_create_ex(const prl_tree_t* tree, int32_t variant, int32_t delay, int32_t engine, prl_solver_t** out_solver);
 /* Options. PRL_SOLVER_AVG_F32 (opt-in, NOT the reference's numerics): CFR+'s running average strategy of the board columns is STORED as
