@@ -1412,9 +1412,12 @@ static int32_t solver_create_impl(const prl_tree_t* tree, int32_t variant, int32
             FAIL_IF(dev_upload(s, &s->chain_dev.node_kid, node_kid));
             const char* cs = getenv("PRL_ST_CHAIN_STREAM");
             if (!cs || atoi(cs) != 0) {
-                PRL_HIP_TRY(hipStreamCreate(&s->chain_stream));
-                PRL_HIP_TRY(hipEventCreateWithFlags(&s->chain_fork, hipEventDisableTiming));
-                PRL_HIP_TRY(hipEventCreateWithFlags(&s->chain_join, hipEventDisableTiming));
+                if (hipStreamCreate(&s->chain_stream) != hipSuccess || hipEventCreateWithFlags(&s->chain_fork, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&s->chain_join, hipEventDisableTiming) != hipSuccess) {
+                    prl_set_error("street engine: could not create the stream of the run-out forest");
+                    prl_solver_destroy(s);
+                    return PRL_ERR_HIP;
+                }
             }
         }
 #ifdef PRL_ST_TIMING
