@@ -141,7 +141,13 @@ def main():
     t_tree = time.perf_counter() - t0
     exchange = None
     placement = None
-    if world > 1:
+    force = bool(os.environ.get("PRL_BENCH_FORCE_EXCHANGE")) and world == 1 and not emu_lib  # the all-gather path of a multi-GPU run on one GPU (tests)
+    if force:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    if world > 1 or force:
         if emu_lib:
             from pokerrl_amd.dist import TorchExchange
             exchange = TorchExchange("cpu")
@@ -210,7 +216,7 @@ def main():
                    "workload": "CFR+ (delay 0) on %s (%d-chip stacks%s), %d flops per GPU x %d turns x %d rivers of seeded run-outs, 1326-hand ranges"
                                % (args.game, stack, ", pot-sized raises" if nl else "", args.flops, args.turns, args.rivers),
                    "engine": s.engine + (" (per-street)" if s.engine == "fused" else ""), "nodes": tree.n_nodes, "nodes_whole_job": n_nodes_job,
-                   "placement_probe_ms_per_iteration": placement, "flops_per_gpu": args.flops, "exchanges": int(s.get("exchanges")[0]) if world > 1 else 0, "action_columns": tree.n_cols,
+                   "placement_probe_ms_per_iteration": placement, "flops_per_gpu": args.flops, "exchanges": int(s.get("exchanges")[0]) if (world > 1 or force) else 0, "action_columns": tree.n_cols,
                    "action_columns_last_street": cols_last, "board_rows": int(tree.n_boards), "tree_build_s": t_tree,
                    "device_ms_per_iteration": dev_ms / args.steps, "exploitability_chips": float(np.mean(expl)), "iterations_done": s.iter,
                    "hbm_bytes_allocated": int(s.get("bytes_allocated")[0])},

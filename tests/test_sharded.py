@@ -455,6 +455,26 @@ def test_gpu_bench_exchange_path_over_rccl_one_rank(how):
 
 
 @pytest.mark.gpu
+def test_gpu_bench_multistreet_exchange_path_over_rccl_one_rank_mixed_streets():
+    """bench_multistreet.py --game DiscretizedNLHoldem with the library's own exchange forced on, world_size 1 (ncclAllGather on the solver's stream while
+    the run-out forest runs on its own stream): the same exploitability as the plain run"""
+    import json
+    root = os.path.dirname(HERE)
+    base = [sys.executable, os.path.join(root, "bench_multistreet.py"), "--game", "DiscretizedNLHoldem", "--flops", "4", "--turns", "2", "--rivers", "2", "--steps", "3",
+            "--warmup", "1", "--no-cpu-baseline", "--placement-candidates", "1"]
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    def line(extra_env):
+        r = subprocess.run(base, env=dict(env, **extra_env), capture_output=True, text=True, timeout=600)
+        js = [x for x in r.stdout.splitlines() if x.startswith("{")]
+        assert r.returncode == 0 and len(js) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+        return json.loads(js[0])
+    a, b = line({}), line({"PRL_BENCH_FORCE_EXCHANGE": "1"})
+    assert b["config"]["exchanges"] > 0 and a["config"]["exchanges"] == 0
+    assert a["config"]["engine"].startswith("fused") and b["config"]["engine"].startswith("fused")
+    assert a["config"]["exploitability_chips"] == b["config"]["exploitability_chips"] and a["config"]["iterations_done"] == b["config"]["iterations_done"]
+
+
+@pytest.mark.gpu
 def test_gpu_rccl_world2_on_one_gpu_or_the_reason_it_cannot_run():
     """Two ranks of the library's own RCCL exchange (shuffled virtual-memory backing on, as every sharded solve has it) on the ONE GPU of
     the test box. RCCL refuses two ranks of a communicator on one device ("Duplicate GPU detected"); when it does, the test is skipped with
