@@ -27,11 +27,18 @@ sys.path.insert(0, ROOT)
 import bench_ref  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0
-# HBM bytes per launch of prl_k_ebf_random_step at 2^20 envs from the PMC counters (profiles/r08_env_pmc.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-# in separate runs; FETCH_SIZE 2.742e4 KB doubled as MI355X_MICROARCH.md prescribes = 54.8 MB -- the 13 state words + 9 cards of an env are 61 bytes --
-# WRITE_SIZE 5.289e5 KB = 528.9 MB): 583.7 MB against 593.5 MB algorithmic. Scales with the number of envs.
-PMC_TRAFFIC_BYTES_PER_ENV_STEP_FULL = 583.7e6 / (1 << 20)
-PMC_TRAFFIC_SOURCE = "profiles/r08_env_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+# HBM bytes per env step of prl_k_ebf_random_step from the PMC counters: profiles/env_counters.json, written by scripts/env_counters.py from
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench (separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+# Round 4's figure (profiles/r08_env_pmc.txt) was 583.7 MB per launch of 2^20 envs against 593.5 MB algorithmic.
+PMC_COUNTERS = os.path.join(ROOT, "profiles", "env_counters.json")
+
+
+def pmc_traffic_per_env_step():
+    try:
+        d = json.load(open(PMC_COUNTERS))
+        return float(d["hbm_bytes_per_env_step"]), "profiles/env_counters.json (%s)" % d["source"]
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def main():
@@ -60,6 +67,7 @@ def main():
     dt = time.perf_counter() - t0
     plain = _native.NativeEnvBatch(game, args.envs) if full else b
     r_steps, r_hands, _p, r_ms = plain.random_rollout(64, 3)
+    traffic_step, traffic_src = pmc_traffic_per_env_step()
     bytes_step = (104.0 + 4.0 * b.obs_dim + 16.0 + 1.0 + b.n_deal) if full else 104.0
     achieved = steps * bytes_step / (ms * 1e-3) / 1e9
     cfg = {"workload": "%d heads-up %s envs (stacks %d, bet set B_5), uniform-random legal play, one %s per env and launch, everything in HBM between "
@@ -74,8 +82,8 @@ def main():
            "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "int32", "data": "synthetic", "build_flavor": _native.build_flavor(), "config": cfg,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                        "traffic": PMC_TRAFFIC_BYTES_PER_ENV_STEP_FULL * args.envs if (full and args.game == "DiscretizedNLHoldem") else None,
-                        "traffic_source": PMC_TRAFFIC_SOURCE,
+                        "traffic": traffic_step * args.envs if (traffic_step is not None and full and args.game == "DiscretizedNLHoldem") else None,
+                        "traffic_source": traffic_src,
                         "kernel": "prl_k_ebf_random_step" if full else "prl_k_eb_random_step", "kernel_ms_per_launch": ms / args.steps,
                         "bytes_per_env_step_algorithmic": bytes_step}}
     if not args.no_cpu_baseline:

@@ -49,22 +49,53 @@ PRL_HD PRL_INLINE void prl_hand_cards(const PrlRules& r, int idx, int* c1, int* 
 
 // Counter-based decks for the batched engines (no reference counterpart: the reference shuffles with np.random, one hand at a time): the
 // first n_deal cards of hand `hand_id` depend on (seed, hand_id) only. A partial Fisher-Yates shuffle of 0 .. n_cards-1 driven by a
-// SplitMix-style hash; the deck as a sparse permutation (only the touched positions are remembered). n_deal <= 16.
+// SplitMix-style hash: card d = what lies at position j = d + hash_d % (n_cards - d), position j then takes what lay at position d.
+// n_deal <= 16, n_cards <= 65536.
+//
+// x % m of a 64-bit x without the 64-bit division (on the GPU a ~70-instruction scalar reciprocal chain and ~45 vector instructions per card):
+// with inv = floor((2^32 - 1) / m), q' = mulhi(v, inv) is floor(v / m) or one less for every 32-bit v (v / m - v inv / 2^32 =
+// v (2^32 - inv m) / (m 2^32) <= v / 2^32 < 1 because 2^32 - inv m <= m), so one conditional subtraction gives v % m; the two halves of x are
+// joined through 2^32 % m = (2^32 - inv m) % m. m <= 65536 keeps (hi % m)(2^32 % m) + lo % m inside 32 bits.
+struct PrlSmallMod { uint32_t m, inv, pow32; };
+PRL_HD PRL_INLINE PrlSmallMod prl_small_mod(uint32_t m) {
+    PrlSmallMod k;
+    k.m = m;
+    k.inv = 0xFFFFFFFFu / m;
+    const uint32_t t = 0u - k.inv * m;  // 2^32 - inv m, in 1 .. m
+    k.pow32 = t == m ? 0u : t;
+    return k;
+}
+PRL_HD PRL_INLINE uint32_t prl_mod32(uint32_t v, const PrlSmallMod& k) {
+    const uint32_t r = v - (uint32_t)(((unsigned long long)v * k.inv) >> 32) * k.m;
+    return r >= k.m ? r - k.m : r;
+}
+PRL_HD PRL_INLINE uint32_t prl_mod64(unsigned long long x, const PrlSmallMod& k) {
+    return prl_mod32(prl_mod32((uint32_t)(x >> 32), k) * k.pow32 + prl_mod32((uint32_t)x, k), k);
+}
+// The deck as a sparse permutation: step k leaves ONE remembered move (position j_k now holds what lay at position k; positions below the
+// current card are never looked at again), and "what lies at position p now" is the latest move onto p, else p itself. The moves live in two
+// fully unrolled register arrays scanned by selects -- no array indexed at run time, no loop whose trip count differs between lanes (round 6;
+// before: an in-place update list walked by a data-dependent loop, `s_set_gpr_idx` indexing on the GPU).
 PRL_HD PRL_INLINE void prl_deal_hand(int n_cards, int n_deal, unsigned long long seed, unsigned long long hand_id, int8_t* out) {
     const unsigned long long idx = (hand_id + 1ull) * 0x9E3779B97F4A7C15ull + seed;
     int pos[16], val[16];
-    int n_touched = 0;
-    for (int d = 0; d < n_deal; ++d) {
+#if defined(__clang__)
+#pragma unroll
+#endif
+    for (int d = 0; d < 16; ++d) {
+        if (d >= n_deal) continue;  // (not `break`: a loop with one exit unrolls)
         unsigned long long x = idx + (unsigned long long)(d + 1) * 0xBF58476D1CE4E5B9ull;
         x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
         x ^= x >> 27; x *= 0x94D049BB133111EBull;
         x ^= x >> 31;
-        const int j = d + (int)(x % (unsigned long long)(n_cards - d));
-        int a = d, b = j, ib = -1;
-        for (int k = 0; k < n_touched; ++k) { if (pos[k] == d) a = val[k]; if (pos[k] == j) { b = val[k]; ib = k; } }
-        // position d takes b (final: no later draw looks below d + 1, so it is not remembered), position j takes a: at most one new entry
-        // per card dealt -- 16 entries cover n_deal <= 16 (remembering position d as well overran the arrays from the 9th card on)
-        if (j != d) { if (ib >= 0) val[ib] = a; else { pos[n_touched] = j; val[n_touched] = a; ++n_touched; } }
+        const int j = d + (int)prl_mod64(x, prl_small_mod((uint32_t)(n_cards - d)));
+        int a = d, b = j;
+#if defined(__clang__)
+#pragma unroll
+#endif
+        for (int k = 0; k < d; ++k) { a = pos[k] == d ? val[k] : a; b = pos[k] == j ? val[k] : b; }
+        pos[d] = j != d ? j : -1;
+        val[d] = a;
         out[d] = (int8_t)b;
     }
 }

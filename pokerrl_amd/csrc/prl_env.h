@@ -265,8 +265,23 @@ PRL_HD PRL_INLINE int prl_legal_actions(const PrlGame& g, const PrlEnvState& s, 
     auto put = [&](int a) { out[k++] = a; };
     return prl_legal_actions_to(g, s, put);
 }
-// legal[r % n_legal] without the list (no array indexed at run time): one pass counts, one picks
+// legal[r % n_legal] without the list (no array indexed at run time). Up to 64 action ints: ONE enumeration into a bit mask, then the
+// (r % n)-th set bit (round 6; the enumeration -- a float64 pot fraction and the fixed-action rules per bet size -- was the random
+// player's main cost). More action ints: one pass counts, one picks.
 PRL_HD PRL_INLINE int prl_legal_action_pick(const PrlGame& g, const PrlEnvState& s, uint32_t r) {
+    if (g.game_type != PRL_GAME_DISCRETIZED || g.n_bet_sizes + 2 <= 64) {
+        uint32_t lo = 0u, hi = 0u;
+        auto mark = [&](int a) { lo |= a < 32 ? 1u << (a & 31) : 0u; hi |= a < 32 ? 0u : 1u << (a & 31); };
+        const int n = prl_legal_actions_to(g, s, mark);
+        const int want = (int)(r % (uint32_t)n);
+        for (int q = 0; q < want; ++q) {  // drop the lowest set bit
+            const uint32_t l2 = lo & (lo - 1u);
+            hi = lo ? hi : hi & (hi - 1u);
+            lo = l2;
+        }
+        if (!(lo | hi)) return -1;
+        return lo ? __builtin_ctz(lo) : 32 + __builtin_ctz(hi);
+    }
     auto nothing = [](int) {};
     const int n = prl_legal_actions_to(g, s, nothing);
     int want = (int)(r % (uint32_t)n), k = 0, picked = -1;

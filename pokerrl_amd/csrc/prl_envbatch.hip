@@ -16,6 +16,7 @@
 // seats), so a step moves 13 words in and 13 out per env.
 // Wave-level primitives: the list of still-running envs is compacted with ballot + popcount prefix (one atomic per wave), the
 // usual front half of an agent query over a ragged batch; legal actions come back as a 128-bit mask per env.
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -56,6 +57,7 @@ struct prl_envbatch {
     float* d_obs = nullptr;         // [n][obs_dim] staging for the host-pointer entry points
     double* d_rew = nullptr;        // [n][2]
     uint8_t* d_done = nullptr;      // [n]
+    int32_t full_cap = 0;           // workgroups of the kernels with observation rows the device holds at once (eb_grid_full)
 };
 
 PRL_DEV PRL_INLINE void eb_load(const int32_t* st, int n, int i, PrlEnvState& s, bool* done) {
@@ -267,19 +269,46 @@ PRL_HD PRL_INLINE int eb_hand_idx(const PrlRules& r, const int8_t* hc) {
     const int a = hc[0] < hc[1] ? hc[0] : hc[1], b = hc[0] < hc[1] ? hc[1] : hc[0];
     return prl_range_idx_2(a, b, r.n_cards);
 }
-// PokerEnv._payout_pots, heads-up (PokerEnv.py:468-481) + the rewards of PokerEnv.py:1069-1072: (stack after - starting stack) / REWARD_SCALAR
-PRL_HD PRL_INLINE void eb_payout(const PrlGame& g, const EbFull& F, const PrlEnvState& s, const int8_t* cards, double rew[2], bool* showdown) {
+// The cards of one env in registers (round 6): the flat [n_deal] row of d_cards -- seat 0's hole cards, seat 1's, the board in deal order -- read
+// ONCE, together with the state words (one memory round trip instead of one per consumer), every later index a compile-time constant
+// (an array indexed at run time would live in scratch memory). Entries past n_deal are -1.
+PRL_HD PRL_INLINE void eb_cards_load(const int8_t* p, int n_deal, int8_t (&c)[16]) {
+#if defined(__clang__)
+#pragma unroll
+#endif
+    for (int d = 0; d < 16; ++d) c[d] = d < n_deal ? p[d] : (int8_t)-1;
+}
+PRL_HD PRL_INLINE void eb_cards_store(int8_t* p, int n_deal, const int8_t (&c)[16]) {
+#if defined(__clang__)
+#pragma unroll
+#endif
+    for (int d = 0; d < 16; ++d)
+        if (d < n_deal) p[d] = c[d];
+}
+// board card i (a constant after unrolling) of a 1- or 2-hole-card game
+#define EB_BOARD(c, n_hole, i) ((n_hole) == 2 ? (c)[4 + (i)] : (c)[2 + (i)])
+// PokerEnv._payout_pots, heads-up (PokerEnv.py:468-481) + the rewards of PokerEnv.py:1069-1072: (stack after - starting stack) / REWARD_SCALAR.
+// The showdown ranks straight from the cards: what prl_lbr_rank(range index of the hole cards, board) returns (-1 for a hand that shares a
+// card with the board), without the trip through the range index and back.
+PRL_HD PRL_INLINE void eb_payout(const PrlGame& g, const EbFull& F, const PrlEnvState& s, const int8_t (&c)[16], double rew[2], bool* showdown) {
     const int pot = s.main_pot;
     double award0 = 0.0, award1 = 0.0;
     *showdown = false;
     if (s.folded[0]) award1 = (double)pot;
     else if (s.folded[1]) award0 = (double)pot;
     else {
-        PrlLbrGame hg;
-        hg.n_hole = F.rules.n_hole_cards; hg.n_cards = F.rules.n_cards; hg.n_suits = F.rules.n_suits; hg.rank_rule = F.rules.rank_rule; hg.R = F.rules.range_size;
-        hg.n_board_total = F.rules.n_board_cards;
-        const int8_t* board = cards + 2 * F.rules.n_hole_cards;
-        const int32_t r0 = prl_lbr_rank(hg, eb_hand_idx(F.rules, cards), board), r1 = prl_lbr_rank(hg, eb_hand_idx(F.rules, cards + F.rules.n_hole_cards), board);
+        int32_t r0, r1;
+        if (F.rules.n_hole_cards == 1) {
+            const int bonus = F.rules.rank_rule == 1 ? 10000 : 100;
+            r0 = prl_rank_leduc(c[0], c[2], F.rules.n_suits, bonus);
+            r1 = prl_rank_leduc(c[1], c[2], F.rules.n_suits, bonus);
+        } else {
+            const int8_t board[5] = {c[4], c[5], c[6], c[7], c[8]};
+            bool hit0 = false, hit1 = false;
+            for (int i = 0; i < 5; ++i) { hit0 |= board[i] == c[0] || board[i] == c[1]; hit1 |= board[i] == c[2] || board[i] == c[3]; }
+            r0 = hit0 ? -1 : prl_rank7_cards_52(board, c[0], c[1]);
+            r1 = hit1 ? -1 : prl_rank7_cards_52(board, c[2], c[3]);
+        }
         if (r0 > r1) award0 = (double)pot;
         else if (r0 < r1) award1 = (double)pot;
         else award0 = award1 = (double)pot / 2.0;
@@ -323,7 +352,8 @@ PRL_HD PRL_INLINE void eb_observation(const PrlGame& g, const EbFull& F, const P
 // belongs to env m / obs_dim, entry m % obs_dim, whose table entry says which word and which comparison.
 #define EB_OBS_ROW 29  // words per LDS row (odd: the lanes' row writes hit 64 different banks); [27] = 1: leave this env's vector alone
 #define EB_OBS_SKIP 27
-PRL_HD PRL_INLINE size_t eb_obs_smem(int obs_dim, int n_threads) { return (((size_t)obs_dim * 4 + 15) & ~(size_t)15) + (size_t)n_threads * EB_OBS_ROW * 4; }
+PRL_HD PRL_INLINE size_t eb_obs_tab_bytes(int obs_dim) { return (((size_t)obs_dim * 4 + 15) & ~(size_t)15) + 16; }  // the entry table + eb_obs_const(0..2)
+PRL_HD PRL_INLINE size_t eb_obs_smem(int obs_dim, int n_threads) { return eb_obs_tab_bytes(obs_dim) + (size_t)n_threads * EB_OBS_ROW * 4; }
 // table entry of element j: source word | (value + 1) << 8, value + 1 == 0 for a float that is copied. Source words: 0..6 the seven quotients of
 // eb_observation's first line, 7 last action, 8 who did it, 9 whose turn, 10 round, 11 + 3 p: stack, bet, all-in flag of seat p, 17 + 2 i: rank and
 // suit of board card i (-1: not dealt yet / suits do not matter)
@@ -344,8 +374,14 @@ PRL_HD PRL_INLINE int32_t eb_obs_entry(const EbFull& F, int j) {
     return q < F.rules.n_ranks ? ((17 + 2 * i) | ((q + 1) << 8)) : ((18 + 2 * i) | ((q - F.rules.n_ranks + 1) << 8));
 }
 PRL_HD PRL_INLINE uint32_t eb_f32_bits(double v) { const float f = (float)v; uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
-// the source words of one env (live = false: a finished episode, the reference's all-zero observation)
-PRL_HD PRL_INLINE void eb_obs_words(const PrlGame& g, const EbFull& F, const PrlEnvState& s, const int8_t* cards, bool live, uint32_t* w) {
+// the three quotients every vector starts with (ante, blinds): the game's, not the env's -- three lanes compute them once per workgroup
+// (eb_obs_setup), every lane copies them (round 6; they were three float64 divisions per env and step)
+PRL_HD PRL_INLINE uint32_t eb_obs_const(const PrlGame& g, int k) {
+    const double norm = (double)(g.start_stack[0] + g.start_stack[1]) / 2.0;
+    return eb_f32_bits((double)(k == 0 ? g.ante : (k == 1 ? g.small_blind : g.big_blind)) / norm);
+}
+// the source words of one env (live = false: a finished episode, the reference's all-zero observation); k3: eb_obs_const(0..2)
+PRL_HD PRL_INLINE void eb_obs_words(const PrlGame& g, const EbFull& F, const PrlEnvState& s, const int8_t (&c)[16], bool live, const uint32_t* k3, uint32_t* w) {
     w[EB_OBS_SKIP] = 0u;
     if (!live) {
         for (int k = 0; k < 7; ++k) w[k] = 0u;
@@ -357,34 +393,40 @@ PRL_HD PRL_INLINE void eb_obs_words(const PrlGame& g, const EbFull& F, const Prl
     const int small = s.bet[0] < s.bet[1] ? s.bet[0] : s.bet[1], big = s.bet[0] < s.bet[1] ? s.bet[1] : s.bet[0];
     const int min_raise = big + ((big - small) > g.big_blind ? (big - small) : g.big_blind);
     const bool have_la = s.last_action[0] >= 0;
-    w[0] = eb_f32_bits((double)g.ante / norm); w[1] = eb_f32_bits((double)g.small_blind / norm); w[2] = eb_f32_bits((double)g.big_blind / norm);
-    w[3] = eb_f32_bits((double)min_raise / norm); w[4] = eb_f32_bits((double)s.main_pot / norm); w[5] = eb_f32_bits((double)big / norm);
-    w[6] = eb_f32_bits(have_la ? (double)s.last_action[1] / norm : 0.0);
+    const uint32_t q_bet0 = eb_f32_bits((double)s.bet[0] / norm), q_bet1 = eb_f32_bits((double)s.bet[1] / norm);
+    w[0] = k3[0]; w[1] = k3[1]; w[2] = k3[2];
+    w[3] = eb_f32_bits((double)min_raise / norm); w[4] = eb_f32_bits((double)s.main_pot / norm);
+    w[5] = s.bet[0] < s.bet[1] ? q_bet1 : q_bet0;  // big / norm: the larger bet's quotient
+    w[6] = have_la ? eb_f32_bits((double)s.last_action[1] / norm) : 0u;
     w[7] = have_la ? (uint32_t)s.last_action[0] : 0xFFFFFFFFu;
     w[8] = have_la ? (uint32_t)s.last_action[2] : 0xFFFFFFFFu;
     w[9] = (uint32_t)s.cur;
     w[10] = (uint32_t)s.round;
-    for (int p = 0; p < 2; ++p) {
-        w[11 + 3 * p] = eb_f32_bits((double)s.stack[p] / norm); w[12 + 3 * p] = eb_f32_bits((double)s.bet[p] / norm); w[13 + 3 * p] = s.allin[p] ? 1u : 0u;
-    }
+    w[11] = eb_f32_bits((double)s.stack[0] / norm); w[12] = q_bet0; w[13] = s.allin[0] ? 1u : 0u;
+    w[14] = eb_f32_bits((double)s.stack[1] / norm); w[15] = q_bet1; w[16] = s.allin[1] ? 1u : 0u;
     const int n_out = eb_cards_out(F.rules, s.round);
-    const int8_t* board = cards + 2 * F.rules.n_hole_cards;
     for (int i = 0; i < 5; ++i) {
-        const int c = (i < F.rules.n_board_cards && i < n_out) ? board[i] : -1;
-        w[17 + 2 * i] = c >= 0 ? (uint32_t)(c / F.rules.n_suits) : 0xFFFFFFFFu;
-        w[18 + 2 * i] = (c >= 0 && F.suits_matter) ? (uint32_t)(c % F.rules.n_suits) : 0xFFFFFFFFu;
+        const int cb = EB_BOARD(c, F.rules.n_hole_cards, i);
+        const int cc = (i < F.rules.n_board_cards && i < n_out) ? cb : -1;
+        w[17 + 2 * i] = cc >= 0 ? (uint32_t)(cc / F.rules.n_suits) : 0xFFFFFFFFu;
+        w[18 + 2 * i] = (cc >= 0 && F.suits_matter) ? (uint32_t)(cc % F.rules.n_suits) : 0xFFFFFFFFu;
     }
 }
-// LDS: the entry table, then one row per lane
-PRL_DEV PRL_INLINE void eb_obs_setup(const EbFull& F, int32_t** tab, uint32_t** rows) {
+// LDS: the entry table, the game's three constant quotients, then one row per lane (valid after the next workgroup barrier)
+PRL_DEV PRL_INLINE void eb_obs_setup(const PrlGame& g, const EbFull& F, int32_t** tab, const uint32_t** k3, uint32_t** rows) {
     char* sm = prl_smem();
     *tab = (int32_t*)sm;
-    *rows = (uint32_t*)(sm + (((size_t)F.obs_dim * 4 + 15) & ~(size_t)15));
+    uint32_t* kc = (uint32_t*)(sm + eb_obs_tab_bytes(F.obs_dim) - 16);
+    *k3 = kc;
+    *rows = (uint32_t*)(sm + eb_obs_tab_bytes(F.obs_dim));
     for (int j = (int)prl_tid(); j < F.obs_dim; j += (int)prl_nthreads()) (*tab)[j] = eb_obs_entry(F, j);
+    if (prl_tid() < 3) kc[prl_tid()] = eb_obs_const(g, (int)prl_tid());
 }
-// after a workgroup barrier: the vectors of the n_rows envs whose rows the lanes filled, to out (= the first of these envs' vectors)
+// after a workgroup barrier: the vectors of the n_rows envs whose rows the lanes filled, to out (= the first of these envs' vectors).
+// The table-driven loop: element m of the piece by lane m % T -- any obs_dim, ~19 vector instructions per element (entry look-up, row look-up,
+// the running (env, entry) pair). Kept for vectors longer than the workgroup; the games of this package take eb_obs_emit_cols.
 template <bool SKIPPABLE>
-PRL_DEV PRL_INLINE void eb_obs_emit(const int32_t* tab, const uint32_t* rows, int obs_dim, int n_rows, float* out) {
+PRL_DEV PRL_INLINE void eb_obs_emit_any(const int32_t* tab, const uint32_t* rows, int obs_dim, int n_rows, float* out) {
     const int T = (int)prl_nthreads(), total = n_rows * obs_dim, de = T / obs_dim, dj = T % obs_dim;
     int e = (int)prl_tid() / obs_dim, j = (int)prl_tid() % obs_dim;
     for (int m = (int)prl_tid(); m < total; m += T) {
@@ -399,13 +441,94 @@ PRL_DEV PRL_INLINE void eb_obs_emit(const int32_t* tab, const uint32_t* rows, in
         if (j >= obs_dim) { j -= obs_dim; ++e; }
     }
 }
+// Round 6: a lane keeps ONE entry of the vector for the whole kernel. The emit loop above was 38 % of the step kernel's vector instructions
+// (19 per element x 109 elements per env; SQ_INSTS_VALU 5.4 k per wave, profiles/r07_env_pmc.txt) although an element is one LDS word, one
+// comparison and one store. With T / obs_dim envs side by side (2 for hold'em's 109 entries in a 256-lane workgroup) lane t owns entry
+// t % obs_dim of env t / obs_dim, + k envs every round: its table entry lives in registers as (source word, value to match, result on a match,
+// mask of the word otherwise) -- a copied float is "match 0 -> 0, else the word itself" -- and the row and output addresses advance by constants.
+// The stores of a round are still one linear piece of k vectors.
+// the lane id, opaque to the optimiser: what is derived from it is computed where it is asked for (after the step), not hoisted out of the
+// kernel's grid-stride loop to live in registers across the betting code (spills at the 128-register budget)
+PRL_DEV PRL_INLINE int eb_tid_here() {
+    int t = (int)prl_tid();
+#if !defined(PRL_EMU)
+    asm volatile("" : "+v"(t));
+#endif
+    return t;
+}
+struct EbObsLane {
+    int32_t src, e0, k, j;
+    uint32_t match, hit, keep;
+    bool on;
+};
+PRL_DEV PRL_INLINE EbObsLane eb_obs_lane(const EbFull& F) {
+    EbObsLane L;
+    const int T = (int)prl_nthreads(), D = F.obs_dim, t = eb_tid_here();
+    L.k = T / D;  // 0: vectors longer than the workgroup -> eb_obs_emit_any
+#if defined(PRL_EB_EMIT_ANY)  // A/B builds only (python -m pokerrl_amd.build --variant ...): round 4's loop for every game
+    L.k = 0;
+#endif
+    L.e0 = L.k ? t / D : 0;
+    L.j = L.k ? t % D : 0;
+    L.on = L.k != 0 && L.e0 < L.k;
+    const int32_t ent = eb_obs_entry(F, L.j);
+    const int c = ent >> 8;
+    L.src = ent & 255;
+    L.match = c ? (uint32_t)(c - 1) : 0u;
+    L.hit = c ? 0x3F800000u : 0u;
+    L.keep = c ? 0u : 0xFFFFFFFFu;
+    return L;
+}
+template <bool SKIPPABLE>
+PRL_DEV PRL_INLINE void eb_obs_emit_cols(const EbObsLane& L, const uint32_t* rows, int obs_dim, int n_rows, float* out) {
+    if (!L.on) return;
+    const uint32_t* r = rows + (size_t)L.e0 * EB_OBS_ROW;
+    float* o = out + (size_t)L.e0 * obs_dim + L.j;
+    const int dr = L.k * EB_OBS_ROW, dout = L.k * obs_dim;
+    auto put = [&](uint32_t w, uint32_t skip, float* dst) {
+        const uint32_t u = w == L.match ? L.hit : (w & L.keep);
+        float v;
+        __builtin_memcpy(&v, &u, 4);
+        if (!SKIPPABLE || skip == 0u) *dst = v;
+    };
+    int e = L.e0;
+    for (; e + 3 * L.k < n_rows; e += 4 * L.k) {  // four rounds' LDS words in flight, then four stores
+        uint32_t w[4], sk[4] = {0u, 0u, 0u, 0u};
+        for (int q = 0; q < 4; ++q) { w[q] = r[q * dr + L.src]; if (SKIPPABLE) sk[q] = r[q * dr + EB_OBS_SKIP]; }
+        for (int q = 0; q < 4; ++q) put(w[q], sk[q], o + (size_t)q * dout);
+        r += 4 * dr; o += (size_t)4 * dout;
+    }
+    for (; e < n_rows; e += L.k) {
+        put(r[L.src], SKIPPABLE ? r[EB_OBS_SKIP] : 0u, o);
+        r += dr; o += dout;
+    }
+}
+template <bool SKIPPABLE>
+PRL_DEV PRL_INLINE void eb_obs_emit(const EbFull& F, const int32_t* tab, const uint32_t* rows, int obs_dim, int n_rows, float* out) {
+    const EbObsLane L = eb_obs_lane(F);  // here, not ahead of the step: its registers would be live across the betting code (spills at 128 VGPRs)
+    if (L.k) eb_obs_emit_cols<SKIPPABLE>(L, rows, obs_dim, n_rows, out);
+    else eb_obs_emit_any<SKIPPABLE>(tab, rows, obs_dim, n_rows, out);
+}
 
+#if defined(PRL_EB_TIMELINE) && !defined(PRL_EMU)  // instrumented variant builds only: clocks of every workgroup's phases (scripts/r6_env_timeline.py)
+__device__ unsigned long long eb_timeline[4096 * 4];
+extern "C" int32_t prl_debug_eb_timeline(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(eb_timeline), sizeof(eb_timeline)) == hipSuccess ? 0 : -1;
+}
+#define EB_TL(slot) do { if (prl_tid() == 0 && prl_bid() < 4096u) eb_timeline[prl_bid() * 4 + (slot)] = (slot) == 3 ? (unsigned long long)__builtin_amdgcn_s_getreg(0xF804 /* HW_ID[15:0] */) : (unsigned long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define EB_TL(slot) do { } while (0)
+#endif
+#ifndef PRL_EB_KO
+#define PRL_EB_KO 0  // knock-out builds of prl_k_ebf_random_step for timing experiments: 1 no observation stores, 2 observation stores only
+#endif
 // reset of the masked envs: public state, a fresh hand from the env's counter-based deck, the observation of the new hand
 PRL_GLOBAL void prl_k_ebf_reset(const PrlGame* g, EbFull F, int32_t* st, int n, const uint8_t* mask, int8_t* cards, uint32_t* episode, uint64_t deck_seed,
                                 int deal, float* obs) {
     int32_t* tab;
+    const uint32_t* k3;
     uint32_t* rows;
-    eb_obs_setup(F, &tab, &rows);
+    eb_obs_setup(*g, F, &tab, &k3, &rows);
     const int T = (int)prl_nthreads();
     for (int i0 = (int)prl_bid() * T; i0 < n; i0 += (int)prl_nblocks() * T) {  // workgroup-uniform: the vectors of T consecutive envs leave together
         const int i = i0 + (int)prl_tid();
@@ -418,16 +541,18 @@ PRL_GLOBAL void prl_k_ebf_reset(const PrlGame* g, EbFull F, int32_t* st, int n, 
                 prl_env_reset(*g, s);
                 eb_store(st, n, i, s, false);
                 int8_t* c = cards + (size_t)i * F.n_deal;
+                int8_t cl[16];
                 if (deal) {
                     const uint32_t ep = episode[i];
                     episode[i] = ep + 1u;
-                    prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, c);
-                }
-                if (obs) eb_obs_words(*g, F, s, c, true, w);
+                    prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, cl);
+                    eb_cards_store(c, F.n_deal, cl);
+                } else eb_cards_load(c, F.n_deal, cl);
+                if (obs) eb_obs_words(*g, F, s, cl, true, k3, w);
             }
         }
         prl_sync();
-        if (obs) eb_obs_emit<true>(tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
+        if (obs) eb_obs_emit<true>(F, tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
     }
 }
 
@@ -436,8 +561,9 @@ PRL_GLOBAL void prl_k_ebf_reset(const PrlGame* g, EbFull F, int32_t* st, int n, 
 PRL_GLOBAL void prl_k_ebf_step(const PrlGame* g, EbFull F, int32_t* st, int n, const int32_t* a0, const int32_t* a1, int processed, const int8_t* cards,
                                float* obs, double* rew, uint8_t* done_out, int32_t* info) {
     int32_t* tab;
+    const uint32_t* k3;
     uint32_t* rows;
-    eb_obs_setup(F, &tab, &rows);
+    eb_obs_setup(*g, F, &tab, &k3, &rows);
     const int T = (int)prl_nthreads();
     for (int i0 = (int)prl_bid() * T; i0 < n; i0 += (int)prl_nblocks() * T) {
         const int i = i0 + (int)prl_tid();
@@ -445,6 +571,8 @@ PRL_GLOBAL void prl_k_ebf_step(const PrlGame* g, EbFull F, int32_t* st, int n, c
         if (i < n) {
             PrlEnvState s;
             bool done;
+            int8_t cl[16];
+            eb_cards_load(cards + (size_t)i * F.n_deal, F.n_deal, cl);
             eb_load(st, n, i, s, &done);
             const int act = a0[i];
             int o0 = -1, o1 = 0, o2 = 0, o3 = 0;
@@ -461,26 +589,27 @@ PRL_GLOBAL void prl_k_ebf_step(const PrlGame* g, EbFull F, int32_t* st, int n, c
                 o3 = si.is_terminal ? (si.terminal_is_fold ? 1 : (si.rundown ? 3 : 2)) : 0;
                 if (done) {
                     bool sd;
-                    eb_payout(*g, F, s, cards + (size_t)i * F.n_deal, r, &sd);
+                    eb_payout(*g, F, s, cl, r, &sd);
                 }
             }
             // PokerEnv.get_current_obs(is_terminal=True): zeros
-            eb_obs_words(*g, F, s, cards + (size_t)i * F.n_deal, stepped && !done, rows + (size_t)prl_tid() * EB_OBS_ROW);
+            eb_obs_words(*g, F, s, cl, stepped && !done, k3, rows + (size_t)prl_tid() * EB_OBS_ROW);
             rew[2 * (size_t)i] = r[0];
             rew[2 * (size_t)i + 1] = r[1];
             done_out[i] = done ? 1 : 0;
             if (info) { info[i] = o0; info[(size_t)n + i] = o1; info[(size_t)2 * n + i] = o2; info[(size_t)3 * n + i] = o3; }
         }
         prl_sync();
-        eb_obs_emit<false>(tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
+        eb_obs_emit<false>(F, tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
     }
 }
 
 // the observation of every env's CURRENT state (PokerEnv.get_current_obs; zeros for a finished episode)
 PRL_GLOBAL void prl_k_ebf_observe(const PrlGame* g, EbFull F, const int32_t* st, int n, const int8_t* cards, float* obs) {
     int32_t* tab;
+    const uint32_t* k3;
     uint32_t* rows;
-    eb_obs_setup(F, &tab, &rows);
+    eb_obs_setup(*g, F, &tab, &k3, &rows);
     const int T = (int)prl_nthreads();
     for (int i0 = (int)prl_bid() * T; i0 < n; i0 += (int)prl_nblocks() * T) {
         const int i = i0 + (int)prl_tid();
@@ -488,11 +617,13 @@ PRL_GLOBAL void prl_k_ebf_observe(const PrlGame* g, EbFull F, const int32_t* st,
         if (i < n) {
             PrlEnvState s;
             bool done;
+            int8_t cl[16];
+            eb_cards_load(cards + (size_t)i * F.n_deal, F.n_deal, cl);
             eb_load(st, n, i, s, &done);
-            eb_obs_words(*g, F, s, cards + (size_t)i * F.n_deal, !done, rows + (size_t)prl_tid() * EB_OBS_ROW);
+            eb_obs_words(*g, F, s, cl, !done, k3, rows + (size_t)prl_tid() * EB_OBS_ROW);
         }
         prl_sync();
-        eb_obs_emit<false>(tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
+        eb_obs_emit<false>(F, tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
     }
 }
 
@@ -502,6 +633,7 @@ PRL_HD PRL_INLINE void eb_play_full(const PrlGame& g, const EbFull& F, int n, in
     PrlEnvState s;
     prl_env_reset(g, s);
     int8_t cards[16];
+    for (int d = 0; d < 16; ++d) cards[d] = -1;
     uint32_t ep = 0;
     prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, cards);
     for (int k = 0; k < n_steps; ++k) {
@@ -547,22 +679,32 @@ PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* g, EbFull F, int32_t* st, i
                                       float* obs, double* rew, uint8_t* done_out, unsigned long long* stats) {
     unsigned long long hands = 0, pots = 0, steps = 0;
     int32_t* tab;
+    const uint32_t* k3;
     uint32_t* rows;
-    eb_obs_setup(F, &tab, &rows);
+    eb_obs_setup(*g, F, &tab, &k3, &rows);
     const int T = (int)prl_nthreads();
     for (int i0 = (int)prl_bid() * T; i0 < n; i0 += (int)prl_nblocks() * T) {
         const int i = i0 + (int)prl_tid();
         prl_sync();
+        EB_TL(0); EB_TL(3);
+#if PRL_EB_KO == 2
+        for (int q = 0; q < EB_OBS_ROW; ++q) rows[(size_t)prl_tid() * EB_OBS_ROW + q] = (uint32_t)(prl_tid() + q) & 3u;
+        if (false) {
+#else
         if (i < n) {
+#endif
             PrlEnvState s;
             bool done;
-            eb_load(st, n, i, s, &done);
             int8_t* c = cards + (size_t)i * F.n_deal;
+            int8_t cl[16];
+            eb_cards_load(c, F.n_deal, cl);  // cards, deck counter and state words: one memory round trip
+            const uint32_t ep = episode[i];
+            eb_load(st, n, i, s, &done);
             if (done) {
                 prl_env_reset(*g, s);
-                const uint32_t ep = episode[i];
                 episode[i] = ep + 1u;
-                prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, c);
+                prl_deal_hand(F.rules.n_cards, F.n_deal, deck_seed, (unsigned long long)ep * (unsigned long long)n + (unsigned long long)i, cl);
+                eb_cards_store(c, F.n_deal, cl);
             }
             const uint32_t r = eb_mix32(seed ^ eb_mix32((uint32_t)i * 0x9E3779B9u + (uint32_t)k));
             PrlStepInfo si;
@@ -573,18 +715,27 @@ PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* g, EbFull F, int32_t* st, i
             double rw[2] = {0.0, 0.0};
             if (si.is_terminal) {
                 bool sd;
-                eb_payout(*g, F, s, c, rw, &sd);
+                eb_payout(*g, F, s, cl, rw, &sd);
                 ++hands;
                 pots += (unsigned long long)si.pot_before_payout;
             }
-            eb_obs_words(*g, F, s, c, !si.is_terminal, rows + (size_t)prl_tid() * EB_OBS_ROW);
+            eb_obs_words(*g, F, s, cl, !si.is_terminal, k3, rows + (size_t)prl_tid() * EB_OBS_ROW);
             rew[2 * (size_t)i] = rw[0];
             rew[2 * (size_t)i + 1] = rw[1];
             done_out[i] = si.is_terminal ? 1 : 0;
             eb_store(st, n, i, s, si.is_terminal != 0);
         }
         prl_sync();
-        eb_obs_emit<false>(tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
+        EB_TL(1);
+#if PRL_EB_KO == 1
+        if (rows[prl_tid()] == 0x12345678u) obs[i0] = 1.f;
+#else
+        eb_obs_emit<false>(F, tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
+#endif
+#if defined(PRL_EB_TIMELINE) && !defined(PRL_EMU)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clock after the stores have left
+        EB_TL(2);
+#endif
     }
     eb_stats_add(stats, steps, hands, pots);
 }
@@ -592,6 +743,27 @@ PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* g, EbFull F, int32_t* st, i
 static int eb_grid(int n) {
     int g = (n + 255) / 256;
     return g < 1 ? 1 : (g > 4096 ? 4096 : g);
+}
+// The kernels with observation rows in LDS as PERSISTENT workgroups (round 6): as many as the device holds at once (4 per CU: 128 registers,
+// 30 KB of LDS), each walking its chunks of 256 envs -- a slot is not idle between a workgroup's last store and its successor's first load
+// (~3 us of a ~45 us workgroup life, profiles/r103_env_timeline.txt; 2.4 % of the step kernel). PRL_EB_GRID_CAP overrides (experiments).
+static int eb_grid_full(prl_envbatch* b) {
+    int& cap = b->full_cap;
+    if (!cap) {
+        const char* e = getenv("PRL_EB_GRID_CAP");
+        if (e && atoi(e) > 0) cap = atoi(e);
+        else {
+            int dev = 0, cus = 256, per_cu = 4;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+#if !defined(PRL_EMU)
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, prl_k_ebf_random_step, 256, eb_obs_smem(b->obs_dim, 256)) == hipSuccess && nb > 0) per_cu = nb;
+#endif
+            cap = cus * per_cu;
+        }
+    }
+    const int g = (b->n + 255) / 256;
+    return g < 1 ? 1 : (g > cap ? cap : g);
 }
 
 extern "C" {
@@ -666,7 +838,7 @@ int32_t prl_envbatch_reset_full(prl_envbatch_t* b, const uint8_t* mask, float* o
         d_m = (uint8_t*)b->d_mask;
         PRL_HIP_TRY(hipMemcpyAsync(d_m, mask, (size_t)b->n, hipMemcpyHostToDevice, b->stream));
     }
-    PRL_LAUNCH(prl_k_ebf_reset, eb_grid(b->n), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, (const uint8_t*)d_m, b->d_cards,
+    PRL_LAUNCH(prl_k_ebf_reset, eb_grid_full(b), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, (const uint8_t*)d_m, b->d_cards,
                b->d_episode, b->deck_seed, 1, b->d_obs);
     PRL_HIP_TRY(hipGetLastError());
     if (out_obs) PRL_HIP_TRY(hipMemcpyAsync(out_obs, b->d_obs, (size_t)b->n * b->obs_dim * sizeof(float), hipMemcpyDeviceToHost, b->stream));
@@ -690,7 +862,7 @@ int32_t prl_envbatch_get_cards(prl_envbatch_t* b, int8_t* out_cards) {
 
 int32_t prl_envbatch_observe(prl_envbatch_t* b, float* out_obs) {
     if (!b || !b->with_cards || !out_obs) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
-    PRL_LAUNCH(prl_k_ebf_observe, eb_grid(b->n), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), (const int32_t*)b->d_state, b->n, (const int8_t*)b->d_cards, b->d_obs);
+    PRL_LAUNCH(prl_k_ebf_observe, eb_grid_full(b), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), (const int32_t*)b->d_state, b->n, (const int8_t*)b->d_cards, b->d_obs);
     PRL_HIP_TRY(hipGetLastError());
     PRL_HIP_TRY(hipMemcpyAsync(out_obs, b->d_obs, (size_t)b->n * b->obs_dim * sizeof(float), hipMemcpyDeviceToHost, b->stream));
     PRL_HIP_TRY(hipStreamSynchronize(b->stream));
@@ -700,7 +872,7 @@ int32_t prl_envbatch_observe(prl_envbatch_t* b, float* out_obs) {
 int32_t prl_envbatch_step_full_device(prl_envbatch_t* b, const int32_t* d_actions, const int32_t* d_amounts, float* d_obs, double* d_reward2, uint8_t* d_done,
                                       int32_t* d_info4) {
     if (!b || !b->with_cards || !d_actions || !d_obs || !d_reward2 || !d_done) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
-    PRL_LAUNCH(prl_k_ebf_step, eb_grid(b->n), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, d_actions, d_amounts, d_amounts ? 1 : 0,
+    PRL_LAUNCH(prl_k_ebf_step, eb_grid_full(b), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, d_actions, d_amounts, d_amounts ? 1 : 0,
                (const int8_t*)b->d_cards, d_obs, d_reward2, d_done, d_info4);
     PRL_HIP_TRY(hipGetLastError());
     return PRL_OK;
@@ -755,7 +927,7 @@ int32_t prl_envbatch_random_steps_full(prl_envbatch_t* b, int32_t n_launches, ui
     PRL_HIP_TRY(hipEventCreate(&e1));
     PRL_HIP_TRY(hipEventRecord(e0, b->stream));
     for (int k = 0; k < n_launches; ++k)
-        PRL_LAUNCH(prl_k_ebf_random_step, eb_grid(b->n), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, k, seed, b->d_cards, b->d_episode,
+        PRL_LAUNCH(prl_k_ebf_random_step, eb_grid_full(b), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, k, seed, b->d_cards, b->d_episode,
                    b->deck_seed, b->d_obs, b->d_rew, b->d_done, d_stats);
     PRL_HIP_TRY(hipGetLastError());
     PRL_HIP_TRY(hipEventRecord(e1, b->stream));
