@@ -60,30 +60,43 @@ struct prl_envbatch {
     int32_t full_cap = 0;           // workgroups of the kernels with observation rows the device holds at once (eb_grid_full)
 };
 
-PRL_DEV PRL_INLINE void eb_load(const int32_t* st, int n, int i, PrlEnvState& s, bool* done) {
-    s.round = st[(size_t)EB_ROUND * n + i];
-    s.main_pot = st[(size_t)EB_POT * n + i];
-    s.bet[0] = st[(size_t)EB_BET0 * n + i];
-    s.bet[1] = st[(size_t)EB_BET1 * n + i];
-    s.stack[0] = st[(size_t)EB_STACK0 * n + i];
-    s.stack[1] = st[(size_t)EB_STACK1 * n + i];
-    const int f = st[(size_t)EB_FLAGS * n + i];
+// the 13 words of env i as they lie in HBM, and their unpacking: two steps, so that a persistent workgroup can have its NEXT chunk's words
+// in flight while it writes this chunk's observation vectors (prl_k_ebf_random_step)
+PRL_DEV PRL_INLINE void eb_load_raw(const int32_t* st, int n, int i, int32_t (&w)[PRL_EB_N_COLS]) {
+#if defined(__clang__)
+#pragma unroll
+#endif
+    for (int c = 0; c < PRL_EB_N_COLS; ++c) w[c] = st[(size_t)c * n + i];
+}
+PRL_HD PRL_INLINE void eb_unpack(const int32_t (&w)[PRL_EB_N_COLS], PrlEnvState& s, bool* done) {
+    s.round = w[EB_ROUND];
+    s.main_pot = w[EB_POT];
+    s.bet[0] = w[EB_BET0];
+    s.bet[1] = w[EB_BET1];
+    s.stack[0] = w[EB_STACK0];
+    s.stack[1] = w[EB_STACK1];
+    const int f = w[EB_FLAGS];
     s.allin[0] = f & 1; s.allin[1] = (f >> 1) & 1;
     s.folded[0] = (f >> 2) & 1; s.folded[1] = (f >> 3) & 1;
     s.acted[0] = (f >> 4) & 1; s.acted[1] = (f >> 5) & 1;
     s.cur = (int8_t)((f >> 6) & 1);
     s.capped_happened = (int8_t)((f >> 7) & 1);
     *done = ((f >> 8) & 1) != 0;
-    const int w = st[(size_t)EB_SEATS * n + i];
-    s.last_raiser = (int8_t)((w & 0xFF) - 1);
-    s.capped_raiser = (int8_t)(((w >> 8) & 0xFF) - 1);
-    s.capped_cant_reopen = (int8_t)(((w >> 16) & 0xFF) - 1);
+    const int x = w[EB_SEATS];
+    s.last_raiser = (int8_t)((x & 0xFF) - 1);
+    s.capped_raiser = (int8_t)(((x >> 8) & 0xFF) - 1);
+    s.capped_cant_reopen = (int8_t)(((x >> 16) & 0xFF) - 1);
     s.pad0 = 0;
-    s.n_actions_ep = st[(size_t)EB_NACT * n + i];
-    s.n_raises_round = st[(size_t)EB_NRAISES * n + i];
-    s.last_action[0] = st[(size_t)EB_LA_TYPE * n + i];
-    s.last_action[1] = st[(size_t)EB_LA_AMOUNT * n + i];
-    s.last_action[2] = st[(size_t)EB_LA_SEAT * n + i];
+    s.n_actions_ep = w[EB_NACT];
+    s.n_raises_round = w[EB_NRAISES];
+    s.last_action[0] = w[EB_LA_TYPE];
+    s.last_action[1] = w[EB_LA_AMOUNT];
+    s.last_action[2] = w[EB_LA_SEAT];
+}
+PRL_DEV PRL_INLINE void eb_load(const int32_t* st, int n, int i, PrlEnvState& s, bool* done) {
+    int32_t w[PRL_EB_N_COLS];
+    eb_load_raw(st, n, i, w);
+    eb_unpack(w, s, done);
 }
 
 PRL_DEV PRL_INLINE void eb_store(int32_t* st, int n, int i, const PrlEnvState& s, bool done) {
@@ -139,7 +152,7 @@ PRL_DEV PRL_INLINE void eb_stats_add(unsigned long long* stats, unsigned long lo
     }
 }
 
-PRL_GLOBAL void prl_k_eb_reset(const PrlGame* g, int32_t* st, int n, const uint8_t* mask) {
+PRL_GLOBAL void prl_k_eb_reset(const PrlGame* __restrict__ g, int32_t* __restrict__ st, int n, const uint8_t* __restrict__ mask) {
     for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) {
         if (mask && !mask[i]) continue;
         PrlEnvState s;
@@ -151,7 +164,7 @@ PRL_GLOBAL void prl_k_eb_reset(const PrlGame* g, int32_t* st, int n, const uint8
 // actions: env action ints (processed == 0) or (type, amount) pairs; an env whose episode is over, or whose action is < 0, is
 // left untouched and reports info = {-1, 0, 0, 0}. info[4][n]: is_terminal, chance_acts, pot_before_payout, terminal kind
 // (0 none, 1 fold, 2 showdown on the last street, 3 all-in run-out)
-PRL_GLOBAL void prl_k_eb_step(const PrlGame* g, int32_t* st, int n, const int32_t* a0, const int32_t* a1, int processed, int32_t* info) {
+PRL_GLOBAL void prl_k_eb_step(const PrlGame* __restrict__ g, int32_t* __restrict__ st, int n, const int32_t* __restrict__ a0, const int32_t* __restrict__ a1, int processed, int32_t* __restrict__ info) {
     for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) {
         PrlEnvState s;
         bool done;
@@ -174,7 +187,7 @@ PRL_GLOBAL void prl_k_eb_step(const PrlGame* g, int32_t* st, int n, const int32_
     }
 }
 
-PRL_GLOBAL void prl_k_eb_legal(const PrlGame* g, const int32_t* st, int n, uint32_t* mask4, int32_t* count) {
+PRL_GLOBAL void prl_k_eb_legal(const PrlGame* __restrict__ g, const int32_t* __restrict__ st, int n, uint32_t* __restrict__ mask4, int32_t* __restrict__ count) {
     for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) {
         PrlEnvState s;
         bool done;
@@ -188,7 +201,7 @@ PRL_GLOBAL void prl_k_eb_legal(const PrlGame* g, const int32_t* st, int n, uint3
 
 // ids of the envs whose episode is still running, ascending inside a wave's 64 envs, waves in arrival order: ballot of the
 // predicate, popcount of the lanes below = the lane's slot, one atomic per wave for the wave's base
-PRL_GLOBAL void prl_k_eb_active(const int32_t* st, int n, int32_t* out_idx, int32_t* out_count) {
+PRL_GLOBAL void prl_k_eb_active(const int32_t* __restrict__ st, int n, int32_t* __restrict__ out_idx, int32_t* __restrict__ out_count) {
     const int n_pad = (n + 63) & ~63;
     for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n_pad; i += (int)(prl_nblocks() * prl_nthreads())) {
         const bool live = i < n && ((st[(size_t)EB_FLAGS * n + i] >> 8) & 1) == 0;
@@ -204,7 +217,7 @@ PRL_GLOBAL void prl_k_eb_active(const int32_t* st, int n, int32_t* out_idx, int3
 
 // uniform-random legal play with a counter-based generator keyed by (seed, env, step): n_steps steps per env, an env that ends
 // its hand is reset and keeps playing. stats[0] += steps, [1] += finished hands, [2] += sum of terminal pots (a checksum).
-PRL_GLOBAL void prl_k_eb_rollout(const PrlGame* g, int32_t* st, int n, int n_steps, uint32_t seed, unsigned long long* stats) {
+PRL_GLOBAL void prl_k_eb_rollout(const PrlGame* __restrict__ g, int32_t* __restrict__ st, int n, int n_steps, uint32_t seed, unsigned long long* __restrict__ stats) {
     unsigned long long steps = 0, hands = 0, pots = 0;
     for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) {
         PrlEnvState s;
@@ -231,7 +244,7 @@ PRL_GLOBAL void prl_k_eb_rollout(const PrlGame* g, int32_t* st, int n, int n_ste
 
 // the same play with the state in HBM between steps: ONE step per env and launch (what a rollout driven by an external agent
 // costs per step: 13 words in, 13 out per env). Step k of env i draws the same number as step k of prl_k_eb_rollout.
-PRL_GLOBAL void prl_k_eb_random_step(const PrlGame* g, int32_t* st, int n, int k, uint32_t seed, unsigned long long* stats) {
+PRL_GLOBAL void prl_k_eb_random_step(const PrlGame* __restrict__ g, int32_t* __restrict__ st, int n, int k, uint32_t seed, unsigned long long* __restrict__ stats) {
     unsigned long long hands = 0, pots = 0, steps = 0;
     for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) {
         PrlEnvState s;
@@ -276,7 +289,10 @@ PRL_HD PRL_INLINE void eb_cards_load(const int8_t* p, int n_deal, int8_t (&c)[16
 #if defined(__clang__)
 #pragma unroll
 #endif
-    for (int d = 0; d < 16; ++d) c[d] = d < n_deal ? p[d] : (int8_t)-1;
+    for (int d = 0; d < 16; ++d) {  // no branch: the loads stay in one block with the state loads (a branch per card made the compiler drain them first)
+        const int8_t v = p[d < n_deal ? d : 0];
+        c[d] = d < n_deal ? v : (int8_t)-1;
+    }
 }
 PRL_HD PRL_INLINE void eb_cards_store(int8_t* p, int n_deal, const int8_t (&c)[16]) {
 #if defined(__clang__)
@@ -503,8 +519,74 @@ PRL_DEV PRL_INLINE void eb_obs_emit_cols(const EbObsLane& L, const uint32_t* row
         r += dr; o += dout;
     }
 }
+// ... and four entries per store: the vectors of four consecutive envs are obs_dim 16-byte pieces; a lane owns piece t % obs_dim of the group
+// t / obs_dim (+ k groups every round) = four (env of the group, entry) pairs with their table entries in registers: four LDS words, ONE
+// global_store_dwordx4. 32 stores per lane and chunk instead of 128 -- fewer than the 63 vector-memory operations a wave may have in flight, so
+// the next chunk's loads, issued ahead of them (prl_k_ebf_random_step), are not held up behind the stores. Needs a 16-byte aligned `out` (a
+// chunk's first vector lies 256 x 4 obs_dim bytes into the buffer); rows past the last whole group go through the per-entry loop.
+struct EbObsLane4 {
+    int32_t roff[4];  // word offset of piece entry q's source inside the group's four rows
+    uint32_t match[4], hit[4], keep[4];
+    int32_t g0, k, piece;
+    bool on;
+};
+PRL_DEV PRL_INLINE EbObsLane4 eb_obs_lane4(const EbFull& F) {
+    EbObsLane4 L;
+    const int T = (int)prl_nthreads(), D = F.obs_dim, t = eb_tid_here();
+    L.k = T / D;
+    L.g0 = L.k ? t / D : 0;
+    L.piece = L.k ? t % D : 0;
+    L.on = L.k != 0 && L.g0 < L.k;
+    for (int q = 0; q < 4; ++q) {
+        const int m = 4 * L.piece + q, e = m / D, j = m - e * D;
+        const int32_t ent = eb_obs_entry(F, j);
+        const int c = ent >> 8;
+        L.roff[q] = e * EB_OBS_ROW + (ent & 255);
+        L.match[q] = c ? (uint32_t)(c - 1) : 0u;
+        L.hit[q] = c ? 0x3F800000u : 0u;
+        L.keep[q] = c ? 0u : 0xFFFFFFFFu;
+    }
+    return L;
+}
+struct alignas(16) EbU4 { uint32_t x, y, z, w; };
+// returns the number of rows written (a multiple of 4)
+PRL_DEV PRL_INLINE int eb_obs_emit_vec4(const EbObsLane4& L, const uint32_t* rows, int obs_dim, int n_rows, float* out) {
+    const int n_groups = n_rows >> 2;
+    if (L.on) {
+        const uint32_t* r = rows + (size_t)L.g0 * 4 * EB_OBS_ROW;
+        EbU4* o = (EbU4*)out + (size_t)L.g0 * obs_dim + L.piece;
+        const int dr = L.k * 4 * EB_OBS_ROW, dout = L.k * obs_dim;
+        auto val = [&](uint32_t w, int q) { return w == L.match[q] ? L.hit[q] : (w & L.keep[q]); };
+        int g = L.g0;
+        for (; g + L.k < n_groups; g += 2 * L.k) {  // two rounds' LDS words in flight
+            uint32_t a[4], b[4];
+            for (int q = 0; q < 4; ++q) { a[q] = r[L.roff[q]]; b[q] = r[dr + L.roff[q]]; }
+            EbU4 va, vb;
+            va.x = val(a[0], 0); va.y = val(a[1], 1); va.z = val(a[2], 2); va.w = val(a[3], 3);
+            vb.x = val(b[0], 0); vb.y = val(b[1], 1); vb.z = val(b[2], 2); vb.w = val(b[3], 3);
+            o[0] = va; o[dout] = vb;
+            r += 2 * dr; o += (size_t)2 * dout;
+        }
+        for (; g < n_groups; g += L.k) {
+            EbU4 va;
+            va.x = val(r[L.roff[0]], 0); va.y = val(r[L.roff[1]], 1); va.z = val(r[L.roff[2]], 2); va.w = val(r[L.roff[3]], 3);
+            o[0] = va;
+            r += dr; o += dout;
+        }
+    }
+    return n_groups << 2;
+}
 template <bool SKIPPABLE>
 PRL_DEV PRL_INLINE void eb_obs_emit(const EbFull& F, const int32_t* tab, const uint32_t* rows, int obs_dim, int n_rows, float* out) {
+    int first = 0;
+#if !defined(PRL_EB_NO_VEC4)
+    if (!SKIPPABLE && (int)prl_nthreads() >= obs_dim && (((uintptr_t)out) & 15u) == 0) {
+        const EbObsLane4 L4 = eb_obs_lane4(F);
+        first = eb_obs_emit_vec4(L4, rows, obs_dim, n_rows, out);
+        if (first == n_rows) return;
+        rows += (size_t)first * EB_OBS_ROW; out += (size_t)first * obs_dim; n_rows -= first;
+    }
+#endif
     const EbObsLane L = eb_obs_lane(F);  // here, not ahead of the step: its registers would be live across the betting code (spills at 128 VGPRs)
     if (L.k) eb_obs_emit_cols<SKIPPABLE>(L, rows, obs_dim, n_rows, out);
     else eb_obs_emit_any<SKIPPABLE>(tab, rows, obs_dim, n_rows, out);
@@ -523,8 +605,8 @@ extern "C" int32_t prl_debug_eb_timeline(unsigned long long* out) {
 #define PRL_EB_KO 0  // knock-out builds of prl_k_ebf_random_step for timing experiments: 1 no observation stores, 2 observation stores only
 #endif
 // reset of the masked envs: public state, a fresh hand from the env's counter-based deck, the observation of the new hand
-PRL_GLOBAL void prl_k_ebf_reset(const PrlGame* g, EbFull F, int32_t* st, int n, const uint8_t* mask, int8_t* cards, uint32_t* episode, uint64_t deck_seed,
-                                int deal, float* obs) {
+PRL_GLOBAL void prl_k_ebf_reset(const PrlGame* __restrict__ g, EbFull F, int32_t* __restrict__ st, int n, const uint8_t* __restrict__ mask, int8_t* __restrict__ cards, uint32_t* __restrict__ episode, uint64_t deck_seed,
+                                int deal, float* __restrict__ obs) {
     int32_t* tab;
     const uint32_t* k3;
     uint32_t* rows;
@@ -558,30 +640,44 @@ PRL_GLOBAL void prl_k_ebf_reset(const PrlGame* g, EbFull F, int32_t* st, int n, 
 
 // PokerEnv.step of every env: (obs, reward, done, info). An env whose episode is over, or whose action is < 0, is skipped
 // (done = 1, zero observation, zero reward, info -1 as prl_k_eb_step).
-PRL_GLOBAL void prl_k_ebf_step(const PrlGame* g, EbFull F, int32_t* st, int n, const int32_t* a0, const int32_t* a1, int processed, const int8_t* cards,
-                               float* obs, double* rew, uint8_t* done_out, int32_t* info) {
+PRL_GLOBAL void prl_k_ebf_step(const PrlGame* __restrict__ g, EbFull F, int32_t* __restrict__ st, int n, const int32_t* __restrict__ a0, const int32_t* __restrict__ a1, int processed, const int8_t* __restrict__ cards,
+                               float* __restrict__ obs, double* __restrict__ rew, uint8_t* __restrict__ done_out, int32_t* __restrict__ info) {
     int32_t* tab;
     const uint32_t* k3;
     uint32_t* rows;
     eb_obs_setup(*g, F, &tab, &k3, &rows);
-    const int T = (int)prl_nthreads();
-    for (int i0 = (int)prl_bid() * T; i0 < n; i0 += (int)prl_nblocks() * T) {
+    const int T = (int)prl_nthreads(), stride = (int)prl_nblocks() * T;
+    // the raw words of a chunk -- state, cards, actions -- one chunk ahead, issued before the observation stores of the chunk in hand
+    // (as prl_k_ebf_random_step, where the scheme is described)
+    int32_t raw[PRL_EB_N_COLS], cw[16], act_in = -1, amt_in = -1;
+    auto fetch = [&](int i) {
+        eb_load_raw(st, n, i, raw);
+        act_in = a0[i];
+        if (processed) amt_in = a1[i];
+        const int8_t* p = cards + (size_t)i * F.n_deal;
+#if defined(__clang__)
+#pragma unroll
+#endif
+        for (int d = 0; d < 16; ++d) cw[d] = p[d < F.n_deal ? d : 0];
+    };
+    if ((int)prl_bid() * T + (int)prl_tid() < n) fetch((int)prl_bid() * T + (int)prl_tid());
+    for (int i0 = (int)prl_bid() * T; i0 < n; i0 += stride) {
         const int i = i0 + (int)prl_tid();
         prl_sync();
         if (i < n) {
             PrlEnvState s;
             bool done;
             int8_t cl[16];
-            eb_cards_load(cards + (size_t)i * F.n_deal, F.n_deal, cl);
-            eb_load(st, n, i, s, &done);
-            const int act = a0[i];
+            for (int d = 0; d < 16; ++d) cl[d] = d < F.n_deal ? (int8_t)cw[d] : (int8_t)-1;
+            eb_unpack(raw, s, &done);
+            const int act = act_in;
             int o0 = -1, o1 = 0, o2 = 0, o3 = 0;
             double r[2] = {0.0, 0.0};
             const int n_act = g->game_type == PRL_GAME_DISCRETIZED ? g->n_bet_sizes + 2 : 3;
             const bool stepped = !done && act >= 0 && act < (processed ? 3 : n_act);
             if (stepped) {
                 PrlStepInfo si;
-                if (processed) prl_env_step_processed(*g, s, act, a1[i], &si);
+                if (processed) prl_env_step_processed(*g, s, act, amt_in, &si);
                 else prl_env_step(*g, s, act, &si);
                 done = si.is_terminal != 0;
                 eb_store(st, n, i, s, done);
@@ -600,12 +696,13 @@ PRL_GLOBAL void prl_k_ebf_step(const PrlGame* g, EbFull F, int32_t* st, int n, c
             if (info) { info[i] = o0; info[(size_t)n + i] = o1; info[(size_t)2 * n + i] = o2; info[(size_t)3 * n + i] = o3; }
         }
         prl_sync();
+        if ((long long)i + stride < (long long)n) fetch(i + stride);
         eb_obs_emit<false>(F, tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
     }
 }
 
 // the observation of every env's CURRENT state (PokerEnv.get_current_obs; zeros for a finished episode)
-PRL_GLOBAL void prl_k_ebf_observe(const PrlGame* g, EbFull F, const int32_t* st, int n, const int8_t* cards, float* obs) {
+PRL_GLOBAL void prl_k_ebf_observe(const PrlGame* __restrict__ g, EbFull F, const int32_t* __restrict__ st, int n, const int8_t* __restrict__ cards, float* __restrict__ obs) {
     int32_t* tab;
     const uint32_t* k3;
     uint32_t* rows;
@@ -656,7 +753,7 @@ PRL_HD PRL_INLINE void eb_play_full(const PrlGame& g, const EbFull& F, int n, in
         }
     }
 }
-PRL_GLOBAL void prl_k_ebf_rollout(const PrlGame* g, EbFull F, int n, int n_steps, uint32_t seed, uint64_t deck_seed, unsigned long long* stats) {
+PRL_GLOBAL void prl_k_ebf_rollout(const PrlGame* __restrict__ g, EbFull F, int n, int n_steps, uint32_t seed, uint64_t deck_seed, unsigned long long* __restrict__ stats) {
     unsigned long long acc[4] = {0, 0, 0, 0};
     for (int i = (int)(prl_bid() * prl_nthreads() + prl_tid()); i < n; i += (int)(prl_nblocks() * prl_nthreads())) eb_play_full(*g, F, n, i, n_steps, seed, deck_seed, acc);
     // per wave: butterfly sums in 32-bit halves, one atomic per counter
@@ -675,15 +772,31 @@ PRL_GLOBAL void prl_k_ebf_rollout(const PrlGame* g, EbFull F, int n, int n_steps
 // one whole PokerEnv.step per env and launch with the state in HBM between the launches, driven by uniform-random legal actions: what an
 // agent-driven rollout costs per step -- 13 state words in and out, the observation vector, two rewards and the done flag out; a finished
 // hand is reset and dealt again at the next launch. Step k of env i draws the same number as step k of the other rollouts.
-PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* g, EbFull F, int32_t* st, int n, int k, uint32_t seed, int8_t* cards, uint32_t* episode, uint64_t deck_seed,
-                                      float* obs, double* rew, uint8_t* done_out, unsigned long long* stats) {
+PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* __restrict__ g, EbFull F, int32_t* __restrict__ st, int n, int k, uint32_t seed, int8_t* __restrict__ cards,
+                                      uint32_t* __restrict__ episode, uint64_t deck_seed, float* __restrict__ obs, double* __restrict__ rew, uint8_t* __restrict__ done_out,
+                                      unsigned long long* __restrict__ stats) {
     unsigned long long hands = 0, pots = 0, steps = 0;
     int32_t* tab;
     const uint32_t* k3;
     uint32_t* rows;
     eb_obs_setup(*g, F, &tab, &k3, &rows);
-    const int T = (int)prl_nthreads();
-    for (int i0 = (int)prl_bid() * T; i0 < n; i0 += (int)prl_nblocks() * T) {
+    const int T = (int)prl_nthreads(), stride = (int)prl_nblocks() * T;
+    // A chunk's raw words -- state, deck counter, cards -- are loaded ONE CHUNK AHEAD: issued after the step of the chunk before, ahead of that
+    // chunk's observation stores, which then drain while this chunk is stepped (a persistent workgroup walks n / (256 x grid) chunks).
+    int32_t raw[PRL_EB_N_COLS];
+    int32_t cw[16];  // a card per register while in flight (bytes carried around the loop get packed, and every load then waits for the one before)
+    uint32_t ep = 0u;
+    auto fetch = [&](int i) {
+        eb_load_raw(st, n, i, raw);
+        ep = episode[i];
+        const int8_t* p = cards + (size_t)i * F.n_deal;
+#if defined(__clang__)
+#pragma unroll
+#endif
+        for (int d = 0; d < 16; ++d) cw[d] = p[d < F.n_deal ? d : 0];
+    };
+    if ((int)prl_bid() * T + (int)prl_tid() < n) fetch((int)prl_bid() * T + (int)prl_tid());
+    for (int i0 = (int)prl_bid() * T; i0 < n; i0 += stride) {
         const int i = i0 + (int)prl_tid();
         prl_sync();
         EB_TL(0); EB_TL(3);
@@ -697,9 +810,8 @@ PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* g, EbFull F, int32_t* st, i
             bool done;
             int8_t* c = cards + (size_t)i * F.n_deal;
             int8_t cl[16];
-            eb_cards_load(c, F.n_deal, cl);  // cards, deck counter and state words: one memory round trip
-            const uint32_t ep = episode[i];
-            eb_load(st, n, i, s, &done);
+            for (int d = 0; d < 16; ++d) cl[d] = d < F.n_deal ? (int8_t)cw[d] : (int8_t)-1;
+            eb_unpack(raw, s, &done);
             if (done) {
                 prl_env_reset(*g, s);
                 episode[i] = ep + 1u;
@@ -727,6 +839,7 @@ PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* g, EbFull F, int32_t* st, i
         }
         prl_sync();
         EB_TL(1);
+        if ((long long)i + stride < (long long)n) fetch(i + stride);
 #if PRL_EB_KO == 1
         if (rows[prl_tid()] == 0x12345678u) obs[i0] = 1.f;
 #else

@@ -31,8 +31,4 @@ idx = idx[np.argsort(start[idx])]
 print("workgroups on the CU of workgroup 0 (n=%d): bid, wave slot, start, step_end, emit_end" % len(idx))
 for i in idx:
     print("  %5d slot %2d  %8d %8d %8d" % (i, hw[i] & 0xF, start[i], step_end[i], emit_end[i]))
-# how many workgroups are in their emit phase at a time (sampled)
-ts = np.linspace(0, emit_end.max(), 41)
-print("time: #in step, #in emit")
-for x in ts:
-    print("  %8d  %5d %5d" % (x, ((start <= x) & (x < step_end)).sum(), ((step_end <= x) & (x < emit_end)).sum()))
+# (the clocks of different XCDs do not share an origin: only one CU's workgroups are put side by side)
