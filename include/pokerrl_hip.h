@@ -273,6 +273,9 @@ int32_t prl_envbatch_random_rollout_full(prl_envbatch_t* batch, int32_t n_steps,
 /* the same play with the state in HBM between steps: n_launches launches of ONE whole step per env -- 13 state words in and out, the
  * observation vector, two rewards and the done flag out per env and step (what an agent-driven rollout moves); out_stats3 as random_steps */
 int32_t prl_envbatch_random_steps_full(prl_envbatch_t* batch, int32_t n_launches, uint32_t seed, uint64_t* out_stats3, float* out_device_ms);
+/* The observation vectors [n][obs_dim], rewards [n][2] and done flags [n] the last launch of prl_envbatch_random_steps_full left in the batch's own
+ * output buffers (any pointer may be NULL). Test / inspection entry point: an agent-driven rollout uses prl_envbatch_step_full_device. */
+int32_t prl_envbatch_last_outputs(prl_envbatch_t* batch, float* out_obs, double* out_reward2, uint8_t* out_done);
 int32_t prl_env_random_rollout_full_host(const PrlGame* game, const PrlRules* rules, int32_t n_envs, int32_t n_steps, uint32_t seed, uint64_t deck_seed,
                                          double reward_scalar, uint64_t* out_stats4);
 

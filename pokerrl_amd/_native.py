@@ -449,6 +449,14 @@ class NativeEnvBatch:
         check(self._L.prl_envbatch_step_full(self._h, _ptr(a), None if b is None else _ptr(b), _ptr(obs), _ptr(rew), _ptr(done), _ptr(info)), self._L)
         return obs, rew, done, info
 
+    def last_outputs(self):
+        """-> (obs, reward, done) of the last random_steps_full launch (the batch's own output buffers)"""
+        obs, rew, done = np.empty((self.n_envs, self.obs_dim), np.float32), np.empty((self.n_envs, 2), np.float64), np.empty(self.n_envs, np.uint8)
+        self._L.prl_envbatch_last_outputs.argtypes = [ctypes.c_void_p] * 4
+        self._L.prl_envbatch_last_outputs.restype = ctypes.c_int32
+        check(self._L.prl_envbatch_last_outputs(self._h, _ptr(obs), _ptr(rew), _ptr(done)), self._L)
+        return obs, rew, done
+
     def random_steps_full(self, n_launches, seed):
         """one WHOLE step (obs, rewards, done out) per env and launch, state in HBM between the launches -> (steps, hands, pots, device ms)"""
         st, ms = np.zeros(3, np.uint64), ctypes.c_float()

@@ -576,6 +576,44 @@ PRL_DEV PRL_INLINE int eb_obs_emit_vec4(const EbObsLane4& L, const uint32_t* row
     }
     return n_groups << 2;
 }
+// The same for the common case -- a whole chunk of 256 envs, 256 lanes, two groups of four envs per round (2 obs_dim <= 256 < 3 obs_dim: hold'em's
+// 109 entries) -- as STRAIGHT-LINE code: 16 x 2 stores every wave issues whatever its lanes are (the lanes past 2 obs_dim repeat the last piece:
+// same address, same value). That the stores are unconditional is the point: `vmcnt` counts loads and stores in order, and only when the compiler
+// can count 32 stores behind the next chunk's loads does its wait at the top of the next step let them drain underneath it
+// (prl_k_ebf_random_step<true>). LDS offsets and the rounds are compile-time constants.
+PRL_DEV PRL_INLINE void eb_obs_emit_whole_chunk_k2(const EbFull& F, const uint32_t* rows, float* out) {
+    const int D = F.obs_dim;
+    int t = eb_tid_here();
+    t = t < 2 * D ? t : 2 * D - 1;
+    const int g0 = t >= D ? 1 : 0, piece = t - g0 * D;
+    int32_t roff[4];
+    uint32_t match[4], hit[4], keep[4];
+    for (int q = 0; q < 4; ++q) {
+        const int m = 4 * piece + q, e = m / D, j = m - e * D;
+        const int32_t ent = eb_obs_entry(F, j);
+        const int c = ent >> 8;
+        roff[q] = (g0 * 4 + e) * EB_OBS_ROW + (ent & 255);
+        match[q] = c ? (uint32_t)(c - 1) : 0u;
+        hit[q] = c ? 0x3F800000u : 0u;
+        keep[q] = c ? 0u : 0xFFFFFFFFu;
+    }
+    EbU4* o = (EbU4*)out + (size_t)g0 * D + piece;
+    const int dout = 2 * D;
+    auto val = [&](uint32_t w, int q) { return w == match[q] ? hit[q] : (w & keep[q]); };
+    constexpr int DR = 8 * EB_OBS_ROW;  // two groups of four rows per round
+#if defined(__clang__)
+#pragma unroll
+#endif
+    for (int it = 0; it < 16; ++it) {
+        uint32_t a[4], b[4];
+        for (int q = 0; q < 4; ++q) { a[q] = rows[(2 * it) * DR + roff[q]]; b[q] = rows[(2 * it + 1) * DR + roff[q]]; }
+        EbU4 va, vb;
+        va.x = val(a[0], 0); va.y = val(a[1], 1); va.z = val(a[2], 2); va.w = val(a[3], 3);
+        vb.x = val(b[0], 0); vb.y = val(b[1], 1); vb.z = val(b[2], 2); vb.w = val(b[3], 3);
+        o[(size_t)(2 * it) * dout] = va;
+        o[(size_t)(2 * it + 1) * dout] = vb;
+    }
+}
 template <bool SKIPPABLE>
 PRL_DEV PRL_INLINE void eb_obs_emit(const EbFull& F, const int32_t* tab, const uint32_t* rows, int obs_dim, int n_rows, float* out) {
     int first = 0;
@@ -772,6 +810,9 @@ PRL_GLOBAL void prl_k_ebf_rollout(const PrlGame* __restrict__ g, EbFull F, int n
 // one whole PokerEnv.step per env and launch with the state in HBM between the launches, driven by uniform-random legal actions: what an
 // agent-driven rollout costs per step -- 13 state words in and out, the observation vector, two rewards and the done flag out; a finished
 // hand is reset and dealt again at the next launch. Step k of env i draws the same number as step k of the other rollouts.
+// WHOLE: every chunk is 256 envs (n % 256 == 0), 256 lanes, two groups of four observation vectors per store round, `obs` 16-byte aligned
+// (the host checks): the first chunk peeled and the straight-line emit, so that both ways into the loop carry "loads, then 32 stores"
+template <bool WHOLE>
 PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* __restrict__ g, EbFull F, int32_t* __restrict__ st, int n, int k, uint32_t seed, int8_t* __restrict__ cards,
                                       uint32_t* __restrict__ episode, uint64_t deck_seed, float* __restrict__ obs, double* __restrict__ rew, uint8_t* __restrict__ done_out,
                                       unsigned long long* __restrict__ stats) {
@@ -796,7 +837,7 @@ PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* __restrict__ g, EbFull F, i
         for (int d = 0; d < 16; ++d) cw[d] = p[d < F.n_deal ? d : 0];
     };
     if ((int)prl_bid() * T + (int)prl_tid() < n) fetch((int)prl_bid() * T + (int)prl_tid());
-    for (int i0 = (int)prl_bid() * T; i0 < n; i0 += stride) {
+    auto chunk = [&](int i0) __attribute__((always_inline)) {
         const int i = i0 + (int)prl_tid();
         prl_sync();
         EB_TL(0); EB_TL(3);
@@ -804,7 +845,7 @@ PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* __restrict__ g, EbFull F, i
         for (int q = 0; q < EB_OBS_ROW; ++q) rows[(size_t)prl_tid() * EB_OBS_ROW + q] = (uint32_t)(prl_tid() + q) & 3u;
         if (false) {
 #else
-        if (i < n) {
+        if (WHOLE || i < n) {
 #endif
             PrlEnvState s;
             bool done;
@@ -843,13 +884,20 @@ PRL_GLOBAL void prl_k_ebf_random_step(const PrlGame* __restrict__ g, EbFull F, i
 #if PRL_EB_KO == 1
         if (rows[prl_tid()] == 0x12345678u) obs[i0] = 1.f;
 #else
-        eb_obs_emit<false>(F, tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
+        if constexpr (WHOLE) eb_obs_emit_whole_chunk_k2(F, rows, obs + (size_t)i0 * F.obs_dim);
+        else eb_obs_emit<false>(F, tab, rows, F.obs_dim, n - i0 < T ? n - i0 : T, obs + (size_t)i0 * F.obs_dim);
 #endif
 #if defined(PRL_EB_TIMELINE) && !defined(PRL_EMU)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clock after the stores have left
         EB_TL(2);
 #endif
+    };
+    int i0 = (int)prl_bid() * T;
+    if constexpr (WHOLE) {  // (the grid never exceeds the number of chunks: every workgroup has a first one)
+        chunk(i0);
+        i0 += stride;
     }
+    for (; i0 < n; i0 += stride) chunk(i0);
     eb_stats_add(stats, steps, hands, pots);
 }
 
@@ -870,7 +918,7 @@ static int eb_grid_full(prl_envbatch* b) {
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 #if !defined(PRL_EMU)
             int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, prl_k_ebf_random_step, 256, eb_obs_smem(b->obs_dim, 256)) == hipSuccess && nb > 0) per_cu = nb;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, prl_k_ebf_random_step<false>, 256, eb_obs_smem(b->obs_dim, 256)) == hipSuccess && nb > 0) per_cu = nb;
 #endif
             cap = cus * per_cu;
         }
@@ -1031,6 +1079,16 @@ int32_t prl_envbatch_random_rollout_full(prl_envbatch_t* b, int32_t n_steps, uin
     return PRL_OK;
 }
 
+// what the LAST launch of prl_envbatch_random_steps_full (or prl_envbatch_step_full) left in the batch's own output buffers
+int32_t prl_envbatch_last_outputs(prl_envbatch_t* b, float* out_obs, double* out_reward2, uint8_t* out_done) {
+    if (!b || !b->with_cards) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
+    if (out_obs) PRL_HIP_TRY(hipMemcpyAsync(out_obs, b->d_obs, (size_t)b->n * b->obs_dim * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    if (out_reward2) PRL_HIP_TRY(hipMemcpyAsync(out_reward2, b->d_rew, (size_t)b->n * 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    if (out_done) PRL_HIP_TRY(hipMemcpyAsync(out_done, b->d_done, (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
+    PRL_HIP_TRY(hipStreamSynchronize(b->stream));
+    return PRL_OK;
+}
+
 int32_t prl_envbatch_random_steps_full(prl_envbatch_t* b, int32_t n_launches, uint32_t seed, uint64_t* out_stats3, float* out_device_ms) {
     if (!b || !b->with_cards || n_launches < 0 || !out_stats3) { prl_set_error("bad argument"); return PRL_ERR_ARG; }
     unsigned long long* d_stats = b->d_stats;
@@ -1039,9 +1097,14 @@ int32_t prl_envbatch_random_steps_full(prl_envbatch_t* b, int32_t n_launches, ui
     PRL_HIP_TRY(hipEventCreate(&e0));
     PRL_HIP_TRY(hipEventCreate(&e1));
     PRL_HIP_TRY(hipEventRecord(e0, b->stream));
+    const bool whole = b->n % 256 == 0 && 2 * b->obs_dim <= 256 && 3 * b->obs_dim > 256 && (((uintptr_t)b->d_obs) & 15u) == 0 && !getenv("PRL_EB_NO_WHOLE");
     for (int k = 0; k < n_launches; ++k)
-        PRL_LAUNCH(prl_k_ebf_random_step, eb_grid_full(b), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, k, seed, b->d_cards, b->d_episode,
-                   b->deck_seed, b->d_obs, b->d_rew, b->d_done, d_stats);
+        if (whole)
+            PRL_LAUNCH((prl_k_ebf_random_step<true>), eb_grid_full(b), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, k, seed, b->d_cards,
+                       b->d_episode, b->deck_seed, b->d_obs, b->d_rew, b->d_done, d_stats);
+        else
+            PRL_LAUNCH((prl_k_ebf_random_step<false>), eb_grid_full(b), 256, eb_obs_smem(b->obs_dim, 256), b->stream, (const PrlGame*)b->d_game, eb_full(b), b->d_state, b->n, k, seed, b->d_cards,
+                       b->d_episode, b->deck_seed, b->d_obs, b->d_rew, b->d_done, d_stats);
     PRL_HIP_TRY(hipGetLastError());
     PRL_HIP_TRY(hipEventRecord(e1, b->stream));
     PRL_HIP_TRY(hipEventSynchronize(e1));

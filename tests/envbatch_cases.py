@@ -153,3 +153,37 @@ def check_full_rollout_matches_host(L, cls, stack, bets, n_envs, n_steps, seed=5
     host = _native.env_random_rollout_full_host(game, rules, n_envs, n_steps, seed, deck_seed=77, reward_scalar=1.0, _lib=L)
     assert dev == host and dev[0] == n_envs * n_steps and dev[1] > 0 and dev[2] > 0, (dev, host)
     return dev
+
+
+def check_random_steps_outputs(L, cls, stack, bets, n_envs, n_launches, seed=3, grid_cap=None):
+    """prl_envbatch_random_steps_full: (a) its specialised kernel for whole chunks of 256 envs (straight-line 16-byte observation stores, next
+    chunk's loads ahead of them) = the general kernel, bit for bit -- observations, rewards, done flags, state; (b) the observation vectors it
+    leaves = prl_envbatch_observe of the state it leaves (zeros where the hand just ended)."""
+    import os
+    args = env_args(cls, stack, bets)
+    game, rules = cls.native_game(args), cls.native_rules()
+    outs = []
+    for general in (True, False):
+        if general:
+            os.environ["PRL_EB_NO_WHOLE"] = "1"
+        else:
+            os.environ.pop("PRL_EB_NO_WHOLE", None)
+        if grid_cap:
+            os.environ["PRL_EB_GRID_CAP"] = str(grid_cap)  # fewer workgroups than chunks: every workgroup walks several
+        try:
+            b = _native.NativeEnvBatch.with_cards(game, rules, n_envs, deck_seed=21, _lib=L)
+            stats = b.random_steps_full(n_launches, seed)[:3]
+            obs, rew, done = b.last_outputs()
+            cols = {k: v.copy() for k, v in b.state().items()}
+            now = b.observe()
+        finally:
+            os.environ.pop("PRL_EB_NO_WHOLE", None)
+            os.environ.pop("PRL_EB_GRID_CAP", None)
+        live = done == 0
+        assert live.any() and (~live).any()
+        assert np.array_equal(obs[live], now[live]) and not obs[~live].any() and not rew[live].any()
+        outs.append((stats, obs, rew, done, cols))
+    a, b2 = outs
+    assert a[0] == b2[0] and np.array_equal(a[1], b2[1]) and np.array_equal(a[2], b2[2]) and np.array_equal(a[3], b2[3])
+    for k in a[4]:
+        assert np.array_equal(a[4][k], b2[4][k]), k

@@ -84,3 +84,16 @@ def test_gpu_full_env_rollout_equals_host_rollout_and_steps_in_hbm():
     s_full = b.random_steps_full(48, 9)[:3]
     plain = _native.NativeEnvBatch(game, 30000)
     assert s_full == plain.random_steps(48, 9)[:3]
+
+
+def test_emu_random_steps_whole_chunk_kernel_equals_the_general_one(EMU):
+    cls, stack, bets = ENV_FUZZ["DiscretizedNLHoldem_B5"]
+    ec.check_random_steps_outputs(EMU, cls, stack, bets, n_envs=1536, n_launches=9, grid_cap=2)  # two workgroups, three chunks each
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_envs", [1 << 18, 65536 + 256, 70000])
+def test_gpu_random_steps_whole_chunk_kernel_equals_the_general_one(n_envs):
+    _native.require_device()
+    cls, stack, bets = ENV_FUZZ["DiscretizedNLHoldem_B5"]
+    ec.check_random_steps_outputs(_native.lib(), cls, stack, bets, n_envs=n_envs, n_launches=12)
